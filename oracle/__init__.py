@@ -1,0 +1,191 @@
+"""ctypes front end of the CPU oracle (oracle/ipx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by ``__graft_entry__.smoke()`` and by the
+``cpu_baseline`` leg of bench.py -- never by anything under ``imageprocessor_amd/``.
+
+PARITY UNPINNED: the reference holds no golden vectors for this path;
+the restatement is pinned only by the hand-derived known answers under tests/golden/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libipx_oracle.so")
+
+OP_OVER = 0
+OP_SRC = 1
+
+
+class Rect(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
+
+
+class Glyph(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("mw", C.c_int32), ("mh", C.c_int32),
+                ("mstride", C.c_int32), ("dr", Rect), ("mpx", C.c_int32), ("mpy", C.c_int32)]
+
+
+class Pipeline(C.Structure):
+    _fields_ = [("resize_w", C.c_int), ("resize_h", C.c_int), ("keep_aspect", C.c_int),
+                ("thumb_size", C.c_int), ("crop_to_fit", C.c_int),
+                ("glyphs", C.POINTER(Glyph)), ("n_glyphs", C.c_int), ("col", C.c_uint8 * 4)]
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ipx_oracle.c", "ipx_oracle.h"))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libipx_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.ipxo_scale_bilinear_rgba8.restype = C.c_int
+        L.ipxo_scale_bilinear_rgba8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect,
+                                                C.c_void_p, C.c_int, C.c_int, C.c_int, Rect,
+                                                C.c_int]
+        L.ipxo_draw_rgba8.restype = None
+        L.ipxo_draw_rgba8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int]
+        L.ipxo_composite_glyphs_rgba8.restype = None
+        L.ipxo_composite_glyphs_rgba8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                  C.POINTER(Glyph), C.c_int, C.c_void_p]
+        L.ipxo_process_rgba8.restype = C.c_int
+        L.ipxo_process_rgba8.argtypes = [C.POINTER(Pipeline), C.c_void_p, C.c_int, C.c_int,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ipxo_text_height_px.restype = C.c_int
+        L.ipxo_text_height_px.argtypes = [C.c_double]
+        L.ipxo_parse_color.restype = C.c_int
+        L.ipxo_parse_color.argtypes = [C.c_char_p, C.c_double, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    assert a.ndim == 3 and a.shape[2] == 4, "RGBA8 frame must be H x W x 4"
+    return a
+
+
+def _rect(r):
+    return r if isinstance(r, Rect) else Rect(*[int(v) for v in r])
+
+
+def resize_dims(ow, oh, w, h, keep_aspect):
+    nw, nh = C.c_int(), C.c_int()
+    lib().ipxo_resize_dims(ow, oh, w, h, int(bool(keep_aspect)), C.byref(nw), C.byref(nh))
+    return nw.value, nh.value
+
+
+def thumb_geometry(ow, oh, size, crop_to_fit):
+    r, nw, nh = Rect(), C.c_int(), C.c_int()
+    lib().ipxo_thumb_geometry(ow, oh, size, int(bool(crop_to_fit)), C.byref(r), C.byref(nw),
+                              C.byref(nh))
+    return (r.x0, r.y0, r.x1, r.y1), nw.value, nh.value
+
+
+def watermark_anchor(position, w, h, width_px, height_px):
+    px, py = C.c_int(), C.c_int()
+    lib().ipxo_watermark_anchor(position.encode(), w, h, width_px, height_px, C.byref(px),
+                                C.byref(py))
+    return px.value, py.value
+
+
+def text_height_px(font_size):
+    return lib().ipxo_text_height_px(float(font_size))
+
+
+def parse_color(s, opacity):
+    out = (C.c_uint8 * 4)()
+    err = lib().ipxo_parse_color(s.encode(), float(opacity), out)
+    return tuple(out), bool(err)
+
+
+def scale_bilinear(src, dw, dh, sr=None, dr=None, op=OP_OVER, dst=None):
+    """BiLinear.Scale(dst, dr, src, sr, op, nil); dst defaults to a zeroed dw x dh frame."""
+    src = _u8(src)
+    sh, sw = src.shape[:2]
+    if dst is None:
+        dst = np.zeros((dh, dw, 4), np.uint8)
+    dst = _u8(dst)
+    assert dst.shape[:2] == (dh, dw)
+    sr = _rect(sr if sr is not None else (0, 0, sw, sh))
+    dr = _rect(dr if dr is not None else (0, 0, dw, dh))
+    rc = lib().ipxo_scale_bilinear_rgba8(dst.ctypes.data, dw, dh, dw * 4, dr, src.ctypes.data, sw,
+                                         sh, sw * 4, sr, op)
+    if rc:
+        raise ValueError("source rectangle leaves the source image")
+    return dst
+
+
+def draw(dst, r, src, sp=(0, 0), op=OP_SRC):
+    """image/draw.DrawMask(dst, r, src, sp, nil, ZP, op) in place on dst."""
+    src = _u8(src)
+    assert dst.dtype == np.uint8 and dst.flags.c_contiguous
+    dh, dw = dst.shape[:2]
+    sh, sw = src.shape[:2]
+    lib().ipxo_draw_rgba8(dst.ctypes.data, dw, dh, dw * 4, _rect(r), src.ctypes.data, sw, sh,
+                          sw * 4, int(sp[0]), int(sp[1]), op)
+    return dst
+
+
+def _glyph_array(glyphs):
+    keep = []
+    arr = (Glyph * max(1, len(glyphs)))()
+    for i, g in enumerate(glyphs):
+        m = np.ascontiguousarray(g["mask"], dtype=np.uint8)
+        keep.append(m)
+        mp = g.get("mp", (0, 0))
+        arr[i] = Glyph(m.ctypes.data, m.shape[1], m.shape[0], m.shape[1], _rect(g["dr"]),
+                       int(mp[0]), int(mp[1]))
+    return arr, keep
+
+
+def composite_glyphs(dst, glyphs, col):
+    """DrawMask(dst, dr, Uniform(col), ZP, mask, mp, Over) per glyph, in order, in place."""
+    assert dst.dtype == np.uint8 and dst.flags.c_contiguous
+    dh, dw = dst.shape[:2]
+    arr, keep = _glyph_array(glyphs)
+    c = (C.c_uint8 * 4)(*[int(v) for v in col])
+    lib().ipxo_composite_glyphs_rgba8(dst.ctypes.data, dw, dh, dw * 4, arr, len(glyphs), c)
+    return dst
+
+
+def process(src, resize=(1024, 768, True), thumb=(200, True), glyphs=(), col=(255, 255, 255, 127),
+            want=("resize", "thumbnail", "watermark")):
+    """The three operators on the ORIGINAL frame (image_processor.go:64-65)."""
+    src = _u8(src)
+    sh, sw = src.shape[:2]
+    arr, keep = _glyph_array(list(glyphs))
+    p = Pipeline(resize[0], resize[1], int(bool(resize[2])), thumb[0], int(bool(thumb[1])),
+                 C.cast(arr, C.POINTER(Glyph)), len(glyphs), (C.c_uint8 * 4)(*col))
+    out = {}
+    ptr = {"resize": None, "thumbnail": None, "watermark": None}
+    if "resize" in want:
+        nw, nh = resize_dims(sw, sh, *resize)
+        out["resize"] = np.empty((nh, nw, 4), np.uint8)
+        ptr["resize"] = out["resize"].ctypes.data
+    if "thumbnail" in want:
+        _, nw, nh = thumb_geometry(sw, sh, *thumb)
+        out["thumbnail"] = np.empty((nh, nw, 4), np.uint8)
+        ptr["thumbnail"] = out["thumbnail"].ctypes.data
+    if "watermark" in want:
+        out["watermark"] = np.empty((sh, sw, 4), np.uint8)
+        ptr["watermark"] = out["watermark"].ctypes.data
+    rc = lib().ipxo_process_rgba8(C.byref(p), src.ctypes.data, sw, sh, sw * 4, ptr["resize"],
+                                  ptr["thumbnail"], ptr["watermark"])
+    if rc:
+        raise RuntimeError("oracle pipeline failed: %d" % rc)
+    return out

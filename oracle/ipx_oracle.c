@@ -1,0 +1,372 @@
+/*
+ * ipx_oracle.c -- CPU restatement of the reference's pixel hot path (plain C, scalar).
+ *
+ * TEST INFRASTRUCTURE ONLY (see ipx_oracle.h).  PARITY UNPINNED: the reference holds no
+ * golden vectors for this path and cannot be built here (Go; no toolchain, no module cache).
+ *
+ * Build with -ffp-contract=off: the reference is built for GOAMD64=v1 (dockerfile:12-13),
+ * where the Go compiler never fuses x*y+z, so every float64 product below is rounded
+ * before it is added.
+ *
+ * Reference call sites (under internal/usecase/processor/operations/):
+ *   resize.go:121-125      resizeImage      -> x/image/draw BiLinear.Scale(..., Over, nil)
+ *   thumbnail.go:114-132   cropAndResize    -> BiLinear.Scale (equal sizes => Copy) + resizeImage
+ *   watermark.go:90-92     draw.Draw(result, bounds, img, ZP, draw.Src)
+ *   watermark.go:151       freetype DrawString -> draw.DrawMask(dst, dr, Uniform, ZP, Alpha, mp, Over)
+ * Upstream routines restated: x/image@v0.33.0 draw/impl.go ablInterpolator.Scale and
+ * scale_RGBA_RGBA_{Src,Over}; draw/scale.go Copy, opaque; Go 1.24 image/draw/draw.go clip,
+ * DrawMask, drawCopyOver, drawCopySrc, drawGlyphOver; image/image.go (*RGBA).Opaque.
+ */
+#include "ipx_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- image.Rectangle helpers (image/geom.go) ---------------------------------------- */
+
+static int rect_empty(ipxo_rect r) { return r.x0 >= r.x1 || r.y0 >= r.y1; }
+
+static ipxo_rect rect_intersect(ipxo_rect r, ipxo_rect s)
+{
+    if (r.x0 < s.x0) r.x0 = s.x0;
+    if (r.y0 < s.y0) r.y0 = s.y0;
+    if (r.x1 > s.x1) r.x1 = s.x1;
+    if (r.y1 > s.y1) r.y1 = s.y1;
+    if (rect_empty(r)) { ipxo_rect z = {0, 0, 0, 0}; return z; }
+    return r;
+}
+
+static ipxo_rect rect_add(ipxo_rect r, int dx, int dy)
+{
+    r.x0 += dx; r.x1 += dx; r.y0 += dy; r.y1 += dy;
+    return r;
+}
+
+/* ---- geometry ------------------------------------------------------------------------ */
+
+/* resize.go:61-75.  Go's int(float64) truncates toward zero. */
+void ipxo_resize_dims(int ow, int oh, int w, int h, int keep_aspect, int *nw, int *nh)
+{
+    if (keep_aspect) {
+        double width_ratio = (double)w / (double)ow;
+        double height_ratio = (double)h / (double)oh;
+        double ratio = width_ratio < height_ratio ? width_ratio : height_ratio; /* math.Min */
+        *nw = (int)((double)ow * ratio);
+        *nh = (int)((double)oh * ratio);
+    } else {
+        *nw = w;
+        *nh = h;
+    }
+}
+
+/* thumbnail.go:48-65 and :114-127 */
+void ipxo_thumb_geometry(int ow, int oh, int size, int crop_to_fit, ipxo_rect *crop, int *nw,
+                         int *nh)
+{
+    if (crop_to_fit) {
+        int cx, cy, cs;
+        if (ow > oh) { cs = oh; cx = (ow - oh) / 2; cy = 0; }
+        else         { cs = ow; cx = 0; cy = (oh - ow) / 2; }
+        crop->x0 = cx; crop->y0 = cy; crop->x1 = cx + cs; crop->y1 = cy + cs;
+        *nw = size; *nh = size;
+    } else {
+        crop->x0 = 0; crop->y0 = 0; crop->x1 = ow; crop->y1 = oh;
+        if (ow > oh) {
+            *nh = size;
+            *nw = (int)((double)ow * (double)size / (double)oh);
+        } else {
+            *nw = size;
+            *nh = (int)((double)oh * (double)size / (double)ow);
+        }
+    }
+}
+
+/* watermark.go:116-118: fixed.Int26_6(fontSize*64*1.2).Ceil() */
+int ipxo_text_height_px(double font_size)
+{
+    int32_t h = (int32_t)(font_size * 64 * 1.2);
+    return (int)((h + 0x3f) >> 6);
+}
+
+/* watermark.go:121-148; freetype.Pt(x, y) keeps whole pixels, returned here as such */
+void ipxo_watermark_anchor(const char *position, int w, int h, int width_px, int height_px,
+                           int *px, int *py)
+{
+    const int margin = 20;
+    if (!strcmp(position, "top-left"))            { *px = margin;                 *py = margin + height_px; }
+    else if (!strcmp(position, "top-right"))      { *px = w - width_px - margin;  *py = margin + height_px; }
+    else if (!strcmp(position, "top-center"))     { *px = (w - width_px) / 2;     *py = margin + height_px; }
+    else if (!strcmp(position, "bottom-left"))    { *px = margin;                 *py = h - margin; }
+    else if (!strcmp(position, "bottom-right"))   { *px = w - width_px - margin;  *py = h - margin; }
+    else if (!strcmp(position, "bottom-center"))  { *px = (w - width_px) / 2;     *py = h - margin; }
+    else if (!strcmp(position, "center"))         { *px = (w - width_px) / 2;     *py = (h + height_px) / 2; }
+    else                                          { *px = w - width_px - margin;  *py = h - margin; }
+}
+
+/* strconv.Atoi: optional sign, decimal digits only, at least one digit */
+static int go_atoi(const char *s, size_t n, long *out)
+{
+    size_t i = 0;
+    int neg = 0;
+    long v = 0;
+    if (n == 0) return -1;
+    if (s[0] == '+' || s[0] == '-') { neg = s[0] == '-'; i = 1; if (n == 1) return -1; }
+    for (; i < n; i++) {
+        if (s[i] < '0' || s[i] > '9') return -1;
+        if (v > 900000000000000000L) return -1; /* Atoi reports a range error near 2^63 */
+        v = v * 10 + (s[i] - '0');
+    }
+    *out = neg ? -v : v;
+    return 0;
+}
+
+static int clampi(long v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); }
+
+/* watermark.go:159-186 with the fallback of :93-97 folded in */
+int ipxo_parse_color(const char *s, double opacity, uint8_t rgba[4])
+{
+    char buf[256];
+    const char *part[8];
+    size_t plen[8];
+    size_t n = 0, i;
+    int nparts = 0;
+    uint8_t oa = (uint8_t)(int32_t)(255 * opacity);
+    long r, g, b, a;
+
+    for (i = 0; s[i] && n + 1 < sizeof buf; i++)
+        if (s[i] != ' ') buf[n++] = s[i]; /* strings.ReplaceAll(colorStr, " ", "") */
+    buf[n] = 0;
+    part[0] = buf; nparts = 1;
+    for (i = 0; i < n; i++)
+        if (buf[i] == ',') {
+            plen[nparts - 1] = (size_t)(&buf[i] - part[nparts - 1]);
+            if (nparts == 8) goto bad;
+            part[nparts++] = &buf[i + 1];
+        }
+    plen[nparts - 1] = (size_t)(&buf[n] - part[nparts - 1]);
+    if (nparts != 3 && nparts != 4) goto bad;
+    if (go_atoi(part[0], plen[0], &r) || go_atoi(part[1], plen[1], &g) ||
+        go_atoi(part[2], plen[2], &b))
+        goto bad;
+    rgba[0] = (uint8_t)clampi(r, 0, 255);
+    rgba[1] = (uint8_t)clampi(g, 0, 255);
+    rgba[2] = (uint8_t)clampi(b, 0, 255);
+    if (nparts == 4 && go_atoi(part[3], plen[3], &a) == 0) rgba[3] = (uint8_t)clampi(a, 0, 255);
+    else rgba[3] = oa;
+    return 0;
+bad:
+    rgba[0] = rgba[1] = rgba[2] = 0; /* watermark.go:96: black with the opacity alpha */
+    rgba[3] = oa;
+    return 1;
+}
+
+/* ---- image/draw: DrawMask with a nil mask, *image.RGBA <- *image.RGBA ----------------- */
+
+void ipxo_draw_rgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r,
+                     const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op)
+{
+    const uint32_t m = 0xffff;
+    ipxo_rect db = {0, 0, dw, dh}, sb = {0, 0, sw, sh};
+    int ox = r.x0, oy = r.y0, x, y;
+    /* draw.clip */
+    r = rect_intersect(r, db);
+    r = rect_intersect(r, rect_add(sb, ox - spx, oy - spy));
+    if (rect_empty(r)) return;
+    spx += r.x0 - ox;
+    spy += r.y0 - oy;
+    for (y = 0; y < r.y1 - r.y0; y++) {
+        uint8_t *d = dst + (size_t)(r.y0 + y) * dstride + (size_t)r.x0 * 4;
+        const uint8_t *s = src + (size_t)(spy + y) * sstride + (size_t)spx * 4;
+        if (op == IPXO_OP_SRC) { /* drawCopySrc */
+            memmove(d, s, (size_t)(r.x1 - r.x0) * 4);
+            continue;
+        }
+        for (x = 0; x < r.x1 - r.x0; x++, d += 4, s += 4) { /* drawCopyOver */
+            uint32_t sr_ = (uint32_t)s[0] * 0x101;
+            uint32_t sg_ = (uint32_t)s[1] * 0x101;
+            uint32_t sb_ = (uint32_t)s[2] * 0x101;
+            uint32_t sa_ = (uint32_t)s[3] * 0x101;
+            uint32_t a = (m - sa_) * 0x101;
+            d[0] = (uint8_t)(((uint32_t)d[0] * a / m + sr_) >> 8);
+            d[1] = (uint8_t)(((uint32_t)d[1] * a / m + sg_) >> 8);
+            d[2] = (uint8_t)(((uint32_t)d[2] * a / m + sb_) >> 8);
+            d[3] = (uint8_t)(((uint32_t)d[3] * a / m + sa_) >> 8);
+        }
+    }
+}
+
+/* ---- x/image/draw: BiLinear.Scale ----------------------------------------------------- */
+
+/* image.(*RGBA).Opaque over the whole source image, as draw/scale.go opaque() asks */
+static int rgba_opaque(const uint8_t *src, int sw, int sh, int sstride)
+{
+    int x, y;
+    for (y = 0; y < sh; y++)
+        for (x = 0; x < sw; x++)
+            if (src[(size_t)y * sstride + (size_t)x * 4 + 3] != 0xff) return 0;
+    return 1;
+}
+
+int ipxo_scale_bilinear_rgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr,
+                              const uint8_t *src, int sw, int sh, int sstride, ipxo_rect sr,
+                              int op)
+{
+    ipxo_rect db = {0, 0, dw, dh};
+    ipxo_rect adr;
+    int32_t ssw, ssh, dx, dy;
+    double xscale, yscale;
+
+    /* ablInterpolator.Scale: equal sizes simplify to Copy -> image/draw.DrawMask */
+    if (dr.x1 - dr.x0 == sr.x1 - sr.x0 && dr.y1 - dr.y0 == sr.y1 - sr.y0) {
+        ipxo_draw_rgba8(dst, dw, dh, dstride, dr, src, sw, sh, sstride, sr.x0, sr.y0, op);
+        return 0;
+    }
+    adr = rect_intersect(db, dr);
+    if (rect_empty(adr) || rect_empty(sr)) return 0;
+    adr = rect_add(adr, -dr.x0, -dr.y0);
+    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) return -1; /* generic path */
+    if (op == IPXO_OP_OVER && rgba_opaque(src, sw, sh, sstride)) op = IPXO_OP_SRC;
+
+    ssw = sr.x1 - sr.x0;
+    ssh = sr.y1 - sr.y0;
+    yscale = (double)ssh / (double)(dr.y1 - dr.y0);
+    xscale = (double)ssw / (double)(dr.x1 - dr.x0);
+
+    for (dy = adr.y0; dy < adr.y1; dy++) {
+        double sy = ((double)dy + 0.5) * yscale - 0.5;
+        int32_t sy0 = (int32_t)sy;
+        double yf0 = sy - (double)sy0;
+        double yf1 = 1 - yf0;
+        int32_t sy1 = sy0 + 1;
+        uint8_t *d;
+        if (sy < 0) { sy0 = 0; sy1 = 0; yf0 = 0; yf1 = 1; }
+        else if (sy1 > ssh - 1) { sy0 = ssh - 1; sy1 = ssh - 1; yf0 = 1; yf1 = 0; }
+        d = dst + (size_t)(dr.y0 + dy) * dstride + (size_t)(dr.x0 + adr.x0) * 4;
+
+        for (dx = adr.x0; dx < adr.x1; dx++, d += 4) {
+            double sx = ((double)dx + 0.5) * xscale - 0.5;
+            int32_t sx0 = (int32_t)sx;
+            double xf0 = sx - (double)sx0;
+            double xf1 = 1 - xf0;
+            int32_t sx1 = sx0 + 1;
+            const uint8_t *p00, *p10, *p01, *p11;
+            uint32_t p[4];
+            int c;
+            if (sx < 0) { sx0 = 0; sx1 = 0; xf0 = 0; xf1 = 1; }
+            else if (sx1 > ssw - 1) { sx0 = ssw - 1; sx1 = ssw - 1; xf0 = 1; xf1 = 0; }
+            p00 = src + (size_t)(sr.y0 + sy0) * sstride + (size_t)(sr.x0 + sx0) * 4;
+            p10 = src + (size_t)(sr.y0 + sy0) * sstride + (size_t)(sr.x0 + sx1) * 4;
+            p01 = src + (size_t)(sr.y0 + sy1) * sstride + (size_t)(sr.x0 + sx0) * 4;
+            p11 = src + (size_t)(sr.y0 + sy1) * sstride + (size_t)(sr.x0 + sx1) * 4;
+            for (c = 0; c < 4; c++) {
+                double s00 = (double)((uint32_t)p00[c] * 0x101);
+                double s10 = (double)((uint32_t)p10[c] * 0x101);
+                double s01 = (double)((uint32_t)p01[c] * 0x101);
+                double s11 = (double)((uint32_t)p11[c] * 0x101);
+                s10 = xf1 * s00 + xf0 * s10;
+                s11 = xf1 * s01 + xf0 * s11;
+                s11 = yf1 * s10 + yf0 * s11;
+                p[c] = (uint32_t)s11;
+            }
+            if (op == IPXO_OP_SRC) {
+                d[0] = (uint8_t)(p[0] >> 8);
+                d[1] = (uint8_t)(p[1] >> 8);
+                d[2] = (uint8_t)(p[2] >> 8);
+                d[3] = (uint8_t)(p[3] >> 8);
+            } else {
+                uint32_t pa1 = (0xffff - p[3]) * 0x101;
+                d[0] = (uint8_t)(((uint32_t)d[0] * pa1 / 0xffff + p[0]) >> 8);
+                d[1] = (uint8_t)(((uint32_t)d[1] * pa1 / 0xffff + p[1]) >> 8);
+                d[2] = (uint8_t)(((uint32_t)d[2] * pa1 / 0xffff + p[2]) >> 8);
+                d[3] = (uint8_t)(((uint32_t)d[3] * pa1 / 0xffff + p[3]) >> 8);
+            }
+        }
+    }
+    return 0;
+}
+
+/* ---- image/draw: drawGlyphOver, one call per glyph in string order --------------------- */
+
+void ipxo_composite_glyphs_rgba8(uint8_t *dst, int dw, int dh, int dstride,
+                                 const ipxo_glyph *glyphs, int n, const uint8_t col[4])
+{
+    const uint32_t m = 0xffff;
+    /* color.RGBA.RGBA(): each 8-bit field widened with v |= v<<8; no premultiplication */
+    const uint32_t sr = (uint32_t)col[0] * 0x101, sg = (uint32_t)col[1] * 0x101,
+                   sb = (uint32_t)col[2] * 0x101, sa = (uint32_t)col[3] * 0x101;
+    ipxo_rect db = {0, 0, dw, dh};
+    int g, x, y;
+    for (g = 0; g < n; g++) {
+        const ipxo_glyph *gl = &glyphs[g];
+        ipxo_rect r = gl->dr, mb = {0, 0, gl->mw, gl->mh};
+        int ox = r.x0, oy = r.y0, mpx = gl->mpx, mpy = gl->mpy;
+        /* draw.clip; the Uniform source is unbounded */
+        r = rect_intersect(r, db);
+        r = rect_intersect(r, rect_add(mb, ox - mpx, oy - mpy));
+        if (rect_empty(r)) continue;
+        mpx += r.x0 - ox;
+        mpy += r.y0 - oy;
+        for (y = 0; y < r.y1 - r.y0; y++) {
+            uint8_t *d = dst + (size_t)(r.y0 + y) * dstride + (size_t)r.x0 * 4;
+            const uint8_t *mk = gl->mask + (size_t)(mpy + y) * gl->mstride + mpx;
+            for (x = 0; x < r.x1 - r.x0; x++, d += 4) {
+                uint32_t ma = mk[x];
+                uint32_t a;
+                if (ma == 0) continue;
+                ma |= ma << 8;
+                a = (m - (sa * ma / m)) * 0x101;
+                d[0] = (uint8_t)(((uint32_t)d[0] * a + sr * ma) / m >> 8);
+                d[1] = (uint8_t)(((uint32_t)d[1] * a + sg * ma) / m >> 8);
+                d[2] = (uint8_t)(((uint32_t)d[2] * a + sb * ma) / m >> 8);
+                d[3] = (uint8_t)(((uint32_t)d[3] * a + sa * ma) / m >> 8);
+            }
+        }
+    }
+}
+
+/* ---- image_processor.go:64-65,104-117: each operator applied to the original frame ----- */
+
+int ipxo_process_rgba8(const ipxo_pipeline *p, const uint8_t *src, int sw, int sh, int sstride,
+                       uint8_t *resize_out, uint8_t *thumb_out, uint8_t *wm_out)
+{
+    ipxo_rect full = {0, 0, sw, sh};
+    if (resize_out) { /* resize.go:61-75,121-125 */
+        int nw, nh;
+        ipxo_rect dr;
+        ipxo_resize_dims(sw, sh, p->resize_w, p->resize_h, p->keep_aspect, &nw, &nh);
+        if (nw < 0 || nh < 0) return -2; /* image.NewRGBA would panic */
+        memset(resize_out, 0, (size_t)nw * nh * 4);
+        dr.x0 = 0; dr.y0 = 0; dr.x1 = nw; dr.y1 = nh;
+        if (ipxo_scale_bilinear_rgba8(resize_out, nw, nh, nw * 4, dr, src, sw, sh, sstride, full,
+                                      IPXO_OP_OVER))
+            return -1;
+    }
+    if (thumb_out) { /* thumbnail.go:48-65,114-132 */
+        int nw, nh;
+        ipxo_rect crop, dr;
+        ipxo_thumb_geometry(sw, sh, p->thumb_size, p->crop_to_fit, &crop, &nw, &nh);
+        memset(thumb_out, 0, (size_t)nw * nh * 4);
+        dr.x0 = 0; dr.y0 = 0; dr.x1 = nw; dr.y1 = nh;
+        if (p->crop_to_fit) {
+            int cs = crop.x1 - crop.x0;
+            ipxo_rect cr = {0, 0, cs, cs};
+            uint8_t *cropped = (uint8_t *)calloc((size_t)cs * cs, 4);
+            if (!cropped) return -3;
+            ipxo_scale_bilinear_rgba8(cropped, cs, cs, cs * 4, cr, src, sw, sh, sstride, crop,
+                                      IPXO_OP_OVER);
+            ipxo_scale_bilinear_rgba8(thumb_out, nw, nh, nw * 4, dr, cropped, cs, cs, cs * 4, cr,
+                                      IPXO_OP_OVER);
+            free(cropped);
+        } else {
+            ipxo_scale_bilinear_rgba8(thumb_out, nw, nh, nw * 4, dr, src, sw, sh, sstride, full,
+                                      IPXO_OP_OVER);
+        }
+    }
+    if (wm_out) { /* watermark.go:90-92,151 */
+        memset(wm_out, 0, (size_t)sw * sh * 4);
+        ipxo_draw_rgba8(wm_out, sw, sh, sw * 4, full, src, sw, sh, sstride, 0, 0, IPXO_OP_SRC);
+        ipxo_composite_glyphs_rgba8(wm_out, sw, sh, sw * 4, p->glyphs, p->n_glyphs, p->col);
+    }
+    return 0;
+}

@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/kats.json: known answers for the pixel hot path.
+
+The reference (sj-shoff/ImageProcessor) has no tests or fixtures and cannot be run here
+(Go, no toolchain), so these vectors are NOT reference output -- PARITY UNPINNED.  They are
+derived two ways, both independent of oracle/ipx_oracle.c and of the HIP kernels:
+
+  * "hand": literal numbers worked out from the published formulas (SURVEY.md section 8c,
+    K1-K10) in integer / exact-fraction arithmetic;
+  * "model": a pure-Python loop model of the same routines (Python floats are IEEE doubles
+    and CPython never fuses a*b+c), run on small seeded inputs.
+
+The JSON layout takes real Go-generated vectors without change: every case is
+{"kind", inputs..., "expect"} with pixel data as flat byte lists.
+
+Run:  python tests/golden/make_kats.py
+"""
+import json
+import os
+import random
+from fractions import Fraction
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OVER, SRC = 0, 1
+M = 0xFFFF
+U32 = 0xFFFFFFFF
+
+
+# ---- pure-Python models ---------------------------------------------------------------------
+
+def trunc_i32(v):
+    return int(v)  # Go int32(float64): toward zero
+
+
+def model_opaque(src, sw, sh):
+    return all(src[(y * sw + x) * 4 + 3] == 0xFF for y in range(sh) for x in range(sw))
+
+
+def model_draw(dst, dw, dh, r, src, sw, sh, sp, op):
+    """image/draw.DrawMask, nil mask, RGBA <- RGBA (clip + drawCopyOver / drawCopySrc)."""
+    x0, y0, x1, y1 = r
+    ox, oy = x0, y0
+    spx, spy = sp
+    x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, dw), min(y1, dh)
+    if x0 >= x1 or y0 >= y1:
+        return
+    bx0, by0, bx1, by1 = ox - spx, oy - spy, sw + ox - spx, sh + oy - spy
+    x0, y0, x1, y1 = max(x0, bx0), max(y0, by0), min(x1, bx1), min(y1, by1)
+    if x0 >= x1 or y0 >= y1:
+        return
+    spx += x0 - ox
+    spy += y0 - oy
+    for y in range(y1 - y0):
+        for x in range(x1 - x0):
+            di = ((y0 + y) * dw + x0 + x) * 4
+            si = ((spy + y) * sw + spx + x) * 4
+            if op == SRC:
+                dst[di:di + 4] = src[si:si + 4]
+                continue
+            sa = src[si + 3] * 0x101
+            a = ((M - sa) * 0x101) & U32
+            for c in range(4):
+                s = src[si + c] * 0x101
+                dst[di + c] = ((((dst[di + c] * a) & U32) // M + s) >> 8) & 0xFF
+
+
+def model_scale(dst, dw, dh, dr, src, sw, sh, sr, op):
+    """x/image/draw ablInterpolator.Scale + scale_RGBA_RGBA_{Src,Over}."""
+    if dr[2] - dr[0] == sr[2] - sr[0] and dr[3] - dr[1] == sr[3] - sr[1]:
+        model_draw(dst, dw, dh, dr, src, sw, sh, (sr[0], sr[1]), op)
+        return
+    ax0, ay0, ax1, ay1 = max(dr[0], 0), max(dr[1], 0), min(dr[2], dw), min(dr[3], dh)
+    if ax0 >= ax1 or ay0 >= ay1 or sr[0] >= sr[2] or sr[1] >= sr[3]:
+        return
+    ax0, ax1, ay0, ay1 = ax0 - dr[0], ax1 - dr[0], ay0 - dr[1], ay1 - dr[1]
+    if op == OVER and model_opaque(src, sw, sh):
+        op = SRC
+    ssw, ssh = sr[2] - sr[0], sr[3] - sr[1]
+    yscale = float(ssh) / float(dr[3] - dr[1])
+    xscale = float(ssw) / float(dr[2] - dr[0])
+    for dy in range(ay0, ay1):
+        sy = (float(dy) + 0.5) * yscale - 0.5
+        sy0 = trunc_i32(sy)
+        yf0 = sy - float(sy0)
+        yf1 = 1 - yf0
+        sy1 = sy0 + 1
+        if sy < 0:
+            sy0, sy1, yf0, yf1 = 0, 0, 0.0, 1.0
+        elif sy1 > ssh - 1:
+            sy0, sy1, yf0, yf1 = ssh - 1, ssh - 1, 1.0, 0.0
+        for dx in range(ax0, ax1):
+            sx = (float(dx) + 0.5) * xscale - 0.5
+            sx0 = trunc_i32(sx)
+            xf0 = sx - float(sx0)
+            xf1 = 1 - xf0
+            sx1 = sx0 + 1
+            if sx < 0:
+                sx0, sx1, xf0, xf1 = 0, 0, 0.0, 1.0
+            elif sx1 > ssw - 1:
+                sx0, sx1, xf0, xf1 = ssw - 1, ssw - 1, 1.0, 0.0
+            p = []
+            for c in range(4):
+                def tap(xx, yy):
+                    return float(src[((sr[1] + yy) * sw + sr[0] + xx) * 4 + c] * 0x101)
+                s00, s10, s01, s11 = tap(sx0, sy0), tap(sx1, sy0), tap(sx0, sy1), tap(sx1, sy1)
+                s10 = xf1 * s00 + xf0 * s10
+                s11 = xf1 * s01 + xf0 * s11
+                s11 = yf1 * s10 + yf0 * s11
+                p.append(int(s11))
+            di = ((dr[1] + dy) * dw + dr[0] + dx) * 4
+            if op == SRC:
+                for c in range(4):
+                    dst[di + c] = (p[c] >> 8) & 0xFF
+            else:
+                pa1 = ((0xFFFF - p[3]) * 0x101) & U32
+                for c in range(4):
+                    dst[di + c] = ((((dst[di + c] * pa1) & U32) // 0xFFFF + p[c]) >> 8) & 0xFF
+
+
+def model_glyphs(dst, dw, dh, glyphs, col):
+    """image/draw drawGlyphOver per glyph, uint32 wrap-around kept."""
+    sr, sg, sb, sa = [v * 0x101 for v in col]
+    for g in glyphs:
+        x0, y0, x1, y1 = g["dr"]
+        ox, oy = x0, y0
+        mpx, mpy = g["mp"]
+        mw, mh = g["mw"], g["mh"]
+        x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, dw), min(y1, dh)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        bx0, by0, bx1, by1 = ox - mpx, oy - mpy, mw + ox - mpx, mh + oy - mpy
+        x0, y0, x1, y1 = max(x0, bx0), max(y0, by0), min(x1, bx1), min(y1, by1)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        mpx += x0 - ox
+        mpy += y0 - oy
+        for y in range(y1 - y0):
+            for x in range(x1 - x0):
+                ma = g["mask"][(mpy + y) * mw + mpx + x]
+                if ma == 0:
+                    continue
+                ma |= ma << 8
+                a = ((M - (sa * ma) // M) * 0x101) & U32
+                di = ((y0 + y) * dw + x0 + x) * 4
+                for c, s in enumerate((sr, sg, sb, sa)):
+                    dst[di + c] = ((((dst[di + c] * a + s * ma) & U32) // M) >> 8) & 0xFF
+
+
+# ---- cases ------------------------------------------------------------------------------------
+
+def rnd_frame(rng, w, h, opaque=False, premul=True):
+    out = []
+    for _ in range(w * h):
+        a = 255 if opaque else rng.randrange(256)
+        if premul:
+            out += [rng.randrange(a + 1), rng.randrange(a + 1), rng.randrange(a + 1), a]
+        else:
+            out += [rng.randrange(256), rng.randrange(256), rng.randrange(256), a]
+    return out
+
+
+def scale_case(name, origin, sw, sh, src, dw, dh, sr=None, dr=None, op=OVER, dst=None, expect=None):
+    sr = list(sr or (0, 0, sw, sh))
+    dr = list(dr or (0, 0, dw, dh))
+    dst0 = list(dst) if dst is not None else [0] * (dw * dh * 4)
+    if expect is None:
+        expect = list(dst0)
+        model_scale(expect, dw, dh, dr, src, sw, sh, sr, op)
+    return {"kind": "scale", "name": name, "origin": origin, "sw": sw, "sh": sh, "src": src,
+            "dw": dw, "dh": dh, "sr": sr, "dr": dr, "op": op, "dst": dst0, "expect": expect}
+
+
+def main():
+    rng = random.Random(0x1F00D)
+    cases = []
+
+    # K1: a constant frame scales to the same constant, any geometry (hand)
+    for (sw, sh, dw, dh, v) in [(7, 5, 3, 4, 200), (3, 3, 8, 8, 1), (27, 11, 5, 2, 255), (4, 4, 3, 3, 0)]:
+        src = [v] * (sw * sh * 4)
+        cases.append(scale_case("K1 constant %d %dx%d->%dx%d" % (v, sw, sh, dw, dh), "hand",
+                                sw, sh, src, dw, dh, expect=[v] * (dw * dh * 4)))
+
+    # K2: 2x2 -> 1x1, taps 10,20,30,41: 0.25*sum(tap*257) = 6489.25 -> 6489 >> 8 = 25 (hand)
+    src = [10] * 4 + [20] * 4 + [30] * 4 + [41] * 4
+    cases.append(scale_case("K2 2x2->1x1", "hand", 2, 2, src, 1, 1, expect=[25] * 4))
+
+    # K3: 1920 -> 1024 columns (xscale 1.875): every fraction is a multiple of 1/16, so the
+    # float64 arithmetic is exact and the answer follows in rationals (hand, via Fraction)
+    sw, dw = 1920, 1024
+    row = [(x * 7 + 3) & 0xFF for x in range(sw)]
+    src = []
+    for x in range(sw):
+        src += [row[x], (row[x] * 3) & 0xFF, 255 - row[x], 255]
+    exp = []
+    for dx in range(dw):
+        sx = (Fraction(dx) + Fraction(1, 2)) * Fraction(15, 8) - Fraction(1, 2)
+        sx0 = int(sx)
+        f0 = sx - sx0
+        if sx < 0:
+            sx0, sx1, f0 = 0, 0, Fraction(0)
+        elif sx0 + 1 > sw - 1:
+            sx0, sx1, f0 = sw - 1, sw - 1, Fraction(1)
+        else:
+            sx1 = sx0 + 1
+        for c in range(4):
+            v = (1 - f0) * (src[sx0 * 4 + c] * 257) + f0 * (src[sx1 * 4 + c] * 257)
+            exp.append(int(v) >> 8)
+    cases.append(scale_case("K3 1920x1->1024x1 ramp", "hand", sw, 1, src, dw, 1, expect=exp))
+    assert exp[0:1] == [(int((Fraction(9, 16) * row[0] + Fraction(7, 16) * row[1]) * 257)) >> 8]
+
+    # K4: upscale 2 -> 5 columns hits both clamp branches (hand, rationals: scale 0.4)
+    src = [0, 0, 0, 0, 200, 100, 50, 255]
+    exp = []
+    for dx in range(5):
+        sx = (Fraction(dx) + Fraction(1, 2)) * Fraction(2, 5) - Fraction(1, 2)
+        if sx < 0:
+            f0, a, b = Fraction(0), 0, 0
+        elif int(sx) + 1 > 1:
+            f0, a, b = Fraction(1), 1, 1
+        else:
+            f0, a, b = sx - int(sx), int(sx), int(sx) + 1
+        for c in range(4):
+            exp.append(int((1 - f0) * src[a * 4 + c] * 257 + f0 * src[b * 4 + c] * 257) >> 8)
+    cases.append(scale_case("K4 2x1->5x1 clamps", "hand~", 2, 1, src, 5, 1, expect=None))
+    # 0.4 is not dyadic: the rational answer can differ from float64 by one count only where a
+    # value sits within 1e-9 of an integer; none does here, so both derivations must agree.
+    assert cases[-1]["expect"] == exp, (cases[-1]["expect"], exp)
+
+    # model-derived scale cases
+    def add_model(name, sw, sh, dw, dh, opaque=False, **kw):
+        cases.append(scale_case(name, "model", sw, sh, rnd_frame(rng, sw, sh, opaque), dw, dh, **kw))
+
+    add_model("down 13x9->5x4 alpha", 13, 9, 5, 4)
+    add_model("down 27x27->5x5 (x5.4 as 1080->200)", 27, 27, 5, 5, opaque=True)
+    add_model("up 5x4->13x11", 5, 4, 13, 11)
+    add_model("crop sr 16x10 (3,2,11,10)->4x4", 16, 10, 4, 4, sr=(3, 2, 11, 10))
+    add_model("1-wide source 1x6->4x3", 1, 6, 4, 3)
+    add_model("1x1 source ->3x3", 1, 1, 3, 3)
+    add_model("down 32x18->17x10 src op", 32, 18, 17, 10, op=SRC)
+    add_model("dr inside dst", 9, 7, 12, 10, dr=(2, 1, 9, 8))
+    add_model("dr clipped by dst", 9, 7, 6, 6, dr=(-3, -2, 9, 8))
+    add_model("equal size -> Copy over", 6, 5, 6, 5, dst=rnd_frame(rng, 6, 5))
+    add_model("equal size crop -> Copy", 12, 9, 5, 5, sr=(4, 2, 9, 7))
+    add_model("over onto non-zero dst, translucent src", 11, 8, 6, 5, dst=rnd_frame(rng, 6, 5))
+    add_model("over onto non-zero dst, opaque src (switches to Src)", 11, 8, 6, 5, opaque=True,
+              dst=rnd_frame(rng, 6, 5))
+    add_model("src op onto non-zero dst", 11, 8, 6, 5, op=SRC, dst=rnd_frame(rng, 6, 5))
+
+    # draw (DrawMask without a mask)
+    for name, op, r, sp in [("draw src full", SRC, (0, 0, 8, 6), (0, 0)),
+                            ("draw over offset", OVER, (2, 1, 7, 6), (1, 0)),
+                            ("draw over clipped", OVER, (-2, -1, 12, 9), (0, 0)),
+                            ("draw src clipped by source", SRC, (3, 3, 8, 6), (5, 4))]:
+        sw, sh, dw, dh = 8, 6, 8, 6
+        src = rnd_frame(rng, sw, sh)
+        dst0 = rnd_frame(rng, dw, dh)
+        exp = list(dst0)
+        model_draw(exp, dw, dh, r, src, sw, sh, sp, op)
+        cases.append({"kind": "draw", "name": name, "origin": "model", "sw": sw, "sh": sh,
+                      "src": src, "dw": dw, "dh": dh, "r": list(r), "sp": list(sp), "op": op,
+                      "dst": dst0, "expect": exp})
+
+    # K5: geometry (hand)
+    for ow, oh, w, h, keep, nw, nh in [(854, 480, 1024, 768, 1, 1024, 575), (1080, 1920, 1024, 768, 1, 432, 768),
+                                       (333, 500, 1024, 768, 1, 511, 768), (1920, 1080, 1024, 768, 1, 1024, 576),
+                                       (640, 480, 1024, 768, 1, 1024, 768), (1920, 1080, 1024, 768, 0, 1024, 768),
+                                       (3840, 2160, 1024, 768, 1, 1024, 576), (7680, 4320, 1024, 768, 1, 1024, 576)]:
+        cases.append({"kind": "resize_dims", "origin": "hand", "ow": ow, "oh": oh, "w": w, "h": h,
+                      "keep_aspect": keep, "expect": [nw, nh]})
+    for ow, oh, size, crop, rect, nw, nh in [(640, 480, 200, 1, (80, 0, 560, 480), 200, 200),
+                                             (854, 480, 200, 1, (187, 0, 667, 480), 200, 200),
+                                             (1920, 1080, 200, 1, (420, 0, 1500, 1080), 200, 200),
+                                             (3840, 2160, 200, 1, (840, 0, 3000, 2160), 200, 200),
+                                             (7680, 4320, 200, 1, (1680, 0, 6000, 4320), 200, 200),
+                                             (1080, 1920, 200, 1, (0, 420, 1080, 1500), 200, 200),
+                                             (500, 500, 200, 1, (0, 0, 500, 500), 200, 200),
+                                             (1920, 1080, 200, 0, (0, 0, 1920, 1080), 355, 200),
+                                             (1080, 1920, 200, 0, (0, 0, 1080, 1920), 200, 355)]:
+        cases.append({"kind": "thumb_geometry", "origin": "hand", "ow": ow, "oh": oh, "size": size,
+                      "crop_to_fit": crop, "expect": {"crop": list(rect), "nw": nw, "nh": nh}})
+    # watermark.go:116-148 with width 300, 36 pt (height 44 = ceil(36*64*1.2 / 64)) on 1920x1080
+    cases.append({"kind": "text_height", "origin": "hand", "font_size": 36, "expect": 44})
+    cases.append({"kind": "text_height", "origin": "hand", "font_size": 12.5, "expect": 15})
+    for pos, x, y in [("top-left", 20, 64), ("top-right", 1600, 64), ("top-center", 810, 64),
+                      ("bottom-left", 20, 1060), ("bottom-right", 1600, 1060),
+                      ("bottom-center", 810, 1060), ("center", 810, 562), ("nonsense", 1600, 1060)]:
+        cases.append({"kind": "anchor", "origin": "hand", "position": pos, "w": 1920, "h": 1080,
+                      "width_px": 300, "height_px": 44, "expect": [x, y]})
+    for s, op_, rgba, err in [("255,255,255", 0.5, (255, 255, 255, 127), False),
+                              ("10, 20 ,30", 1.0, (10, 20, 30, 255), False),
+                              ("300,-5,7,64", 0.5, (255, 0, 7, 64), False),
+                              ("1,2,3,x", 0.25, (1, 2, 3, 63), False),
+                              ("1,2", 0.5, (0, 0, 0, 127), True),
+                              ("red,0,0", 0.5, (0, 0, 0, 127), True),
+                              ("", 0.5, (0, 0, 0, 127), True),
+                              ("1,2,3,4,5", 0.5, (0, 0, 0, 127), True)]:
+        cases.append({"kind": "parse_color", "origin": "hand", "s": s, "opacity": op_,
+                      "expect": {"rgba": list(rgba), "error": err}})
+
+    # K6-K10: drawGlyphOver with the default colour (255,255,255,127) (hand)
+    col = [255, 255, 255, 127]
+    ladder = [(0, 255), (1, 0), (2, 1), (3, 1), (4, 2), (128, 64), (254, 127), (255, 128)]
+    d = []
+    e = []
+    for dv, ev in ladder:
+        d += [dv, dv, dv, dv]
+        e += [ev, ev, ev, ev]
+    e[3] = 127  # K6: alpha of d=0 is 32639 >> 8
+    # alpha channel: (d*a + sa*ma)/m >> 8 with sa = 32639 -- worked by the model below, while the
+    # RGB ladder is the SURVEY's hand-derived K8 list
+    g = {"mask": [255] * len(ladder), "mw": len(ladder), "mh": 1, "dr": [0, 0, len(ladder), 1], "mp": [0, 0]}
+    chk = list(d)
+    model_glyphs(chk, len(ladder), 1, [g], col)
+    for i in range(len(ladder)):
+        assert chk[i * 4:i * 4 + 3] == e[i * 4:i * 4 + 3], (i, chk[i * 4:i * 4 + 4], e[i * 4:i * 4 + 4])
+        e[i * 4 + 3] = chk[i * 4 + 3]
+    assert e[3] == 127
+    cases.append({"kind": "glyphs", "name": "K6-K8 full-coverage ladder", "origin": "hand",
+                  "dw": len(ladder), "dh": 1, "dst": d, "glyphs": [g], "col": col, "expect": e})
+    # K9/K10 partial coverage, d in (0,100,255), RGB from SURVEY; alpha from the model
+    for mv, rgb in [(0, (0, 100, 255)), (1, (1, 101, 0)), (64, (64, 152, 32)), (128, (128, 203, 64)),
+                    (200, (200, 5, 100))]:
+        d = [0, 0, 0, 0, 100, 100, 100, 100, 255, 255, 255, 255]
+        g = {"mask": [mv] * 3, "mw": 3, "mh": 1, "dr": [0, 0, 3, 1], "mp": [0, 0]}
+        chk = list(d)
+        model_glyphs(chk, 3, 1, [g], col)
+        for i in range(3):
+            assert chk[i * 4:i * 4 + 3] == [rgb[i]] * 3, (mv, i, chk)
+        cases.append({"kind": "glyphs", "name": "K9 mask=%d" % mv, "origin": "hand", "dw": 3, "dh": 1,
+                      "dst": d, "glyphs": [g], "col": col, "expect": chk})
+
+    # model-derived glyph runs: clipping, mask points, overlapping glyphs applied in order
+    dw, dh = 24, 12
+    dst0 = rnd_frame(rng, dw, dh, opaque=True)
+    glyphs = []
+    for (mw, mh, dr, mp) in [(7, 9, (1, 2, 8, 11), (0, 0)), (6, 8, (6, 3, 12, 11), (0, 0)),
+                             (8, 8, (-3, -2, 5, 6), (0, 0)), (9, 7, (18, 8, 27, 15), (0, 0)),
+                             (10, 10, (10, 0, 16, 6), (2, 3)), (5, 5, (11, 1, 16, 6), (0, 2))]:
+        mask = [rng.choice([0, 0, 255, rng.randrange(256)]) for _ in range(mw * mh)]
+        glyphs.append({"mask": mask, "mw": mw, "mh": mh, "dr": list(dr), "mp": list(mp)})
+    for col_ in ([255, 255, 255, 127], [0, 0, 0, 127], [12, 200, 99, 255], [40, 30, 20, 64]):
+        exp = list(dst0)
+        model_glyphs(exp, dw, dh, glyphs, col_)
+        cases.append({"kind": "glyphs", "name": "clip+overlap col=%s" % col_, "origin": "model",
+                      "dw": dw, "dh": dh, "dst": dst0, "glyphs": glyphs, "col": col_, "expect": exp})
+
+    with open(os.path.join(HERE, "kats.json"), "w") as f:
+        json.dump({"note": "hand/model-derived known answers; NOT reference output (parity unpinned)",
+                   "cases": cases}, f, separators=(",", ":"))
+    print("wrote %d cases" % len(cases))
+
+
+if __name__ == "__main__":
+    main()
