@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec through resize + thumbnail + watermark on a batch of 1920x1080 RGBA
+frames resident in HBM (BASELINE.json configs[2]; --workload resize gives configs[1]).
+
+One process per GPU.  For N > 1 the driver launches this file under torch.distributed.run; the
+frames are independent, so every rank runs the same batch size on its own GPU with no data-path
+collective (weak scaling) and torch.distributed (gloo, CPU tensors) only carries the barrier and
+the max-over-ranks of the timed region.
+
+A "step" is one pass of the hot path over the whole batch (one fused launch).  Prints ONE JSON
+line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step")
+    ap.add_argument("--workload", choices=["full", "resize", "full-keepaspect"], default="full")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--pool", type=int, default=32, help="distinct seeded frames tiled over the batch")
+    ap.add_argument("--cpu-sample", type=int, default=384, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--check", action="store_true", help="compare frame 0 with the oracle after the run")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the ranks as children (no exec after
+    GPU init: nothing here has touched the GPU yet)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def cpu_baseline(pool, glyphs, col, resize, thumb, want, nsample):
+    """The CPU oracle (scalar C restatement of the reference's loops, one frame per thread, as Go's
+    loops are single-threaded per image) on a bounded sample of the same workload."""
+    import concurrent.futures as cf
+    import oracle
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+
+    def one(i):
+        oracle.process(pool[i % len(pool)], resize=resize or (1, 1, False), thumb=thumb or (1, False),
+                       glyphs=glyphs, col=col, want=want)
+
+    one(0)  # warm: page in the library
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        list(ex.map(one, range(nsample)))
+    dt = time.perf_counter() - t0
+    # the reference deploys WORKER_CONCURRENCY=3 goroutines (.env.example:38)
+    n3 = max(3, min(nsample, 24))
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(3) as ex:
+        list(ex.map(one, range(n3)))
+    dt3 = time.perf_counter() - t0
+    return {"value": round(nsample / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d frames of the same workload through oracle/ipx_oracle.c (C restatement of the "
+                      "Go loops, -O2, no FMA), %d threads, one frame per thread; %.1f s wall" % (nsample, cores, dt),
+            "at_reference_concurrency_3": round(n3 / dt3, 2)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        self_launch(args)
+
+    import numpy as np
+    import imageprocessor_amd as ipx
+    from helpers import DEFAULT_COL, rgba_frames, text_glyphs
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    sw, sh, F = args.width, args.height, args.frames
+    resize = {"full": (1024, 768, False), "resize": (1024, 768, False), "full-keepaspect": (1024, 768, True)}[args.workload]
+    thumb = None if args.workload == "resize" else (200, True)
+    do_wm = args.workload != "resize"
+
+    ctx = ipx.Context(device=local_rank % max(1, ipx.device_count()))
+    glyphs = text_glyphs(sw, sh) if do_wm else []
+    gs = ctx.glyphset(glyphs, DEFAULT_COL) if do_wm else None
+    plan = ctx.plan(sw, sh, resize=resize, thumbnail=thumb, watermark=gs)
+    info = plan.info
+
+    # synthetic batch: `pool` seeded opaque frames (seed 0x1F00D + rank), tiled over F slots in HBM
+    P = min(args.pool, F)
+    pool = rgba_frames(P, sw, sh, seed=0x1F00D + rank)
+    fbytes = sw * sh * 4
+    src = ctx.alloc(F * fbytes)
+    src.upload(pool)
+    for i in range(P, F, P):
+        m = min(P, F - i)
+        ctx.copy_d2d(src.ptr + i * fbytes, src.ptr, m * fbytes)
+    res = ctx.alloc(F * info.resize_bytes) if info.resize_bytes else None
+    th = ctx.alloc(F * info.thumb_bytes) if info.thumb_bytes else None
+    wm = ctx.alloc(F * info.wm_bytes) if info.wm_bytes else None
+
+    def step():
+        plan.run_dev(F, src.ptr, res.ptr if res else None, th.ptr if th else None, wm.ptr if wm else None)
+
+    L = ipx.lib()
+    for _ in range(args.warmup):
+        step()
+    ctx.device_sync()
+    if dist:
+        dist.barrier()
+    K = args.steps
+    evs = [(L.ipx_event_create(ctx.handle), L.ipx_event_create(ctx.handle)) for _ in range(K)]
+    t0 = time.perf_counter()
+    for k in range(K):
+        L.ipx_event_record(ctx.handle, evs[k][0], None)   # HIP events on the stream the kernel runs on
+        step()
+        L.ipx_event_record(ctx.handle, evs[k][1], None)
+    ctx.device_sync()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    import ctypes
+    launch_ms = []
+    for e0, e1 in evs:
+        ms = ctypes.c_float()
+        L.ipx_event_elapsed_ms(ctx.handle, e0, e1, ctypes.byref(ms))
+        launch_ms.append(ms.value)
+        L.ipx_event_destroy(ctx.handle, e0)
+        L.ipx_event_destroy(ctx.handle, e1)
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if args.check and rank == 0:
+        import oracle
+        want = oracle.process(pool[0], resize=resize, thumb=thumb or (1, False), glyphs=glyphs, col=DEFAULT_COL,
+                              want=[k for k, b in (("resize", res), ("thumbnail", th), ("watermark", wm)) if b])
+        if res:
+            assert np.array_equal(res.download((info.resize_h, info.resize_w, 4)), want["resize"])
+        if th:
+            assert np.array_equal(th.download((info.thumb_h, info.thumb_w, 4)), want["thumbnail"])
+        if wm:
+            assert np.array_equal(wm.download((sh, sw, 4)), want["watermark"])
+        print("check ok", file=sys.stderr)
+
+    if rank == 0:
+        avg_ms = sum(launch_ms) / len(launch_ms)
+        alg = info.algorithmic_bytes * F  # source read once + each output written once
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                key = "%s_%dx%d_%d" % (args.workload, sw, sh, F)
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "images/sec (resize+thumb+watermark) on 1080p batch at 1/2/4/8 MI355X",
+            "value": round(F * world * K / elapsed, 1),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 (taps interpolated in f64, composite in u32)",
+            "data": "synthetic: %d seeded opaque RGBA8 frames per GPU tiled over %d slots resident in HBM" % (P, F),
+            "config": {"workload": "%d x %dx%d RGBA8, %s" % (F, sw, sh, {
+                "full": "full pipeline: resize 1024x768 (keep_aspect=false) + thumbnail 200 crop + watermark 16 glyphs",
+                "resize": "resize to 1024x768 only",
+                "full-keepaspect": "full pipeline, product-default keep_aspect=true (1024x576)"}[args.workload]),
+                "frames_per_gpu": F, "sharding": "independent frames, round-robin by rank, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "band_kernel", "algorithmic_bytes_per_launch": alg,
+                         "avg_launch_ms": round(avg_ms, 4)},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(pool, glyphs, DEFAULT_COL, resize, thumb,
+                                               [k for k, b in (("resize", res), ("thumbnail", th), ("watermark", wm)) if b],
+                                               args.cpu_sample)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    plan.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,304 @@
+"""imageprocessor_amd -- MI355X-native pixel worker for ImageProcessor's resize / thumbnail /
+watermark path.  This module is a thin numpy/ctypes front end of the C ABI in include/ipx.h;
+all pixel work runs in the hand-written HIP kernels of csrc/ (there is no CPU fallback)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, Glyph, PlanInfo, PlanParams, Rect
+
+OP_OVER = 0
+OP_SRC = 1
+
+
+class IpxError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("ipx status %d: %s" % (status, text))
+        self.status = status
+        self.text = text
+
+
+def lib():
+    return _lib.load()
+
+
+def _check(rc):
+    if rc < 0:
+        raise IpxError(rc, lib().ipx_last_error().decode(errors="replace"))
+    return rc
+
+
+def _rect(r):
+    return r if isinstance(r, Rect) else Rect(*[int(v) for v in r])
+
+
+def _frame(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("RGBA8 frame must be H x W x 4")
+    return a
+
+
+# ---- host-only rules (no GPU needed) ------------------------------------------------------------
+
+def resize_dims(ow, oh, w, h, keep_aspect):
+    nw, nh = C.c_int(), C.c_int()
+    _check(lib().ipx_resize_dims(ow, oh, w, h, int(bool(keep_aspect)), C.byref(nw), C.byref(nh)))
+    return nw.value, nh.value
+
+
+def thumb_geometry(ow, oh, size, crop_to_fit):
+    r, nw, nh = Rect(), C.c_int(), C.c_int()
+    _check(lib().ipx_thumb_geometry(ow, oh, size, int(bool(crop_to_fit)), C.byref(r), C.byref(nw),
+                                    C.byref(nh)))
+    return (r.x0, r.y0, r.x1, r.y1), nw.value, nh.value
+
+
+def text_height_px(font_size):
+    return lib().ipx_text_height_px(float(font_size))
+
+
+def watermark_anchor(position, w, h, width_px, height_px):
+    px, py = C.c_int(), C.c_int()
+    _check(lib().ipx_watermark_anchor(position.encode(), w, h, width_px, height_px, C.byref(px),
+                                      C.byref(py)))
+    return px.value, py.value
+
+
+def parse_color(s, opacity):
+    out = (C.c_uint8 * 4)()
+    rc = _check(lib().ipx_parse_color(s.encode(), float(opacity), out))
+    return tuple(out), rc == 1
+
+
+def device_count():
+    return lib().ipx_device_count()
+
+
+def _glyph_array(glyphs):
+    keep = []
+    arr = (Glyph * max(1, len(glyphs)))()
+    for i, g in enumerate(glyphs):
+        m = np.ascontiguousarray(g["mask"], dtype=np.uint8)
+        if m.ndim != 2:
+            raise ValueError("glyph mask must be mh x mw")
+        keep.append(m)
+        mp = g.get("mp", (0, 0))
+        arr[i] = Glyph(m.ctypes.data, m.shape[1], m.shape[0], m.shape[1], _rect(g["dr"]), int(mp[0]),
+                       int(mp[1]))
+    return arr, keep
+
+
+# ---- GPU objects -------------------------------------------------------------------------------------
+
+class DevBuffer:
+    """hipMalloc'd bytes owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        self.ptr = lib().ipx_dev_alloc(ctx.handle, max(1, self.nbytes))
+        if not self.ptr:
+            raise IpxError(-2, lib().ipx_last_error().decode())
+
+    def upload(self, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        _check(lib().ipx_memcpy_h2d(self.ctx.handle, self.ptr + offset, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.uint8, offset=0):
+        out = np.empty(shape, dtype)
+        assert offset + out.nbytes <= self.nbytes
+        _check(lib().ipx_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().ipx_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class GlyphSet:
+    """Rasterised watermark text (A8 masks + DrawMask rectangles) resident in HBM."""
+
+    def __init__(self, ctx, glyphs, col):
+        self.ctx = ctx
+        arr, keep = _glyph_array(list(glyphs))
+        c = (C.c_uint8 * 4)(*[int(v) for v in col])
+        h = C.c_void_p()
+        _check(lib().ipx_glyphset_create(ctx.handle, arr, len(glyphs), c, C.byref(h)))
+        self.handle = h.value
+
+    def close(self):
+        if self.handle:
+            lib().ipx_glyphset_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """Fused resize + thumbnail + watermark for frames of one size (ipx_plan_*)."""
+
+    def __init__(self, ctx, sw, sh, resize=(1024, 768, True), thumbnail=(200, True), watermark=None):
+        """resize=(w, h, keep_aspect) | None; thumbnail=(size, crop_to_fit) | None;
+        watermark=None (operator absent) | False/GlyphSet-less copy (True) | GlyphSet."""
+        self.ctx = ctx
+        self._sw, self._sh = sw, sh
+        p = PlanParams()
+        p.sw, p.sh = sw, sh
+        if resize:
+            p.do_resize, p.resize_w, p.resize_h, p.keep_aspect = 1, resize[0], resize[1], int(bool(resize[2]))
+        if thumbnail:
+            p.do_thumbnail, p.thumb_size, p.crop_to_fit = 1, thumbnail[0], int(bool(thumbnail[1]))
+        self._gs = None
+        if watermark is not None and watermark is not False:
+            p.do_watermark = 1
+            if isinstance(watermark, GlyphSet):
+                self._gs = watermark
+                p.glyphs = watermark.handle
+        h = C.c_void_p()
+        _check(lib().ipx_plan_create(ctx.handle, C.byref(p), C.byref(h)))
+        self.handle = h.value
+        self.info = PlanInfo()
+        _check(lib().ipx_plan_query(self.handle, C.byref(self.info)))
+
+    def run_dev(self, n, src_ptr, resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None,
+                sstride=None, src_frame_stride=None, resize_frame_stride=None,
+                thumb_frame_stride=None, wm_frame_stride=None):
+        i = self.info
+        _check(lib().ipx_plan_run_dev(
+            self.ctx.handle, stream, self.handle, n, src_ptr,
+            sstride if sstride is not None else self._sw * 4,
+            src_frame_stride if src_frame_stride is not None else self._sw * self._sh * 4,
+            resize_ptr, resize_frame_stride if resize_frame_stride is not None else i.resize_bytes,
+            thumb_ptr, thumb_frame_stride if thumb_frame_stride is not None else i.thumb_bytes,
+            wm_ptr, wm_frame_stride if wm_frame_stride is not None else i.wm_bytes))
+
+    def run_host(self, frames, want=("resize", "thumbnail", "watermark")):
+        """frames: n x H x W x 4 uint8 (host).  Returns dict of output batches."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n = frames.shape[0]
+        i = self.info
+        out = {}
+        if "resize" in want and i.resize_bytes:
+            out["resize"] = np.empty((n, i.resize_h, i.resize_w, 4), np.uint8)
+        if "thumbnail" in want and i.thumb_bytes:
+            out["thumbnail"] = np.empty((n, i.thumb_h, i.thumb_w, 4), np.uint8)
+        if "watermark" in want and i.wm_bytes:
+            out["watermark"] = np.empty((n, i.wm_h, i.wm_w, 4), np.uint8)
+
+        def p(k):
+            return out[k].ctypes.data if k in out else None
+        _check(lib().ipx_plan_run_host(self.ctx.handle, self.handle, n, frames.ctypes.data,
+                                       self._sw * 4, self._sw * self._sh * 4,
+                                       p("resize"), i.resize_bytes, p("thumbnail"), i.thumb_bytes,
+                                       p("watermark"), i.wm_bytes))
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().ipx_plan_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per process and GPU (ipx_create)."""
+
+    def __init__(self, device=-1, lanes=0, lane_bytes=0):
+        cfg = Config(device, lanes, lane_bytes)
+        h = C.c_void_p()
+        _check(lib().ipx_create(C.byref(cfg), C.byref(h)))
+        self.handle = h.value
+
+    def close(self):
+        if self.handle:
+            lib().ipx_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def alloc(self, nbytes):
+        return DevBuffer(self, nbytes)
+
+    def sync(self, stream=None):
+        _check(lib().ipx_stream_sync(self.handle, stream))
+
+    def device_sync(self):
+        _check(lib().ipx_device_sync(self.handle))
+
+    def copy_d2d(self, dst_ptr, src_ptr, nbytes):
+        _check(lib().ipx_memcpy_d2d(self.handle, dst_ptr, src_ptr, nbytes))
+
+    def timed(self, fn, stream=None):
+        """Runs fn() bracketed by HIP events on `stream`; returns milliseconds (syncs)."""
+        L = lib()
+        e0, e1 = L.ipx_event_create(self.handle), L.ipx_event_create(self.handle)
+        try:
+            _check(L.ipx_event_record(self.handle, e0, stream))
+            fn()
+            _check(L.ipx_event_record(self.handle, e1, stream))
+            ms = C.c_float()
+            _check(L.ipx_event_elapsed_ms(self.handle, e0, e1, C.byref(ms)))
+            return ms.value
+        finally:
+            L.ipx_event_destroy(self.handle, e0)
+            L.ipx_event_destroy(self.handle, e1)
+
+    def glyphset(self, glyphs, col):
+        return GlyphSet(self, glyphs, col)
+
+    def plan(self, sw, sh, **kw):
+        return Plan(self, sw, sh, **kw)
+
+    # ---- per-operation seam on host arrays (synchronous) ----------------------------------------
+    def scale_bilinear(self, src, dw, dh, sr=None, dr=None, op=OP_OVER, dst=None):
+        """xdraw.BiLinear.Scale(dst, dr, src, sr, op, nil); dst defaults to a zeroed frame."""
+        src = _frame(src)
+        sh, sw = src.shape[:2]
+        if dst is None:
+            dst = np.zeros((dh, dw, 4), np.uint8)
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous and dst.shape == (dh, dw, 4)
+        _check(lib().ipx_scale_bilinear_rgba8(
+            self.handle, dst.ctypes.data, dw, dh, dw * 4, _rect(dr if dr is not None else (0, 0, dw, dh)),
+            src.ctypes.data, sw, sh, sw * 4, _rect(sr if sr is not None else (0, 0, sw, sh)), op))
+        return dst
+
+    def draw(self, dst, r, src, sp=(0, 0), op=OP_SRC):
+        src = _frame(src)
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous
+        dh, dw = dst.shape[:2]
+        sh, sw = src.shape[:2]
+        _check(lib().ipx_draw_rgba8(self.handle, dst.ctypes.data, dw, dh, dw * 4, _rect(r),
+                                    src.ctypes.data, sw, sh, sw * 4, int(sp[0]), int(sp[1]), op))
+        return dst
+
+    def composite_glyphs(self, dst, glyphs, col):
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous
+        dh, dw = dst.shape[:2]
+        arr, keep = _glyph_array(list(glyphs))
+        c = (C.c_uint8 * 4)(*[int(v) for v in col])
+        _check(lib().ipx_composite_glyphs_rgba8(self.handle, dst.ctypes.data, dw, dh, dw * 4, arr,
+                                                len(glyphs), c))
+        return dst

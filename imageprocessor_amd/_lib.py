@@ -1,0 +1,122 @@
+"""ctypes declarations for libipx.so (include/ipx.h).  Fails loudly when the HIP extension is
+missing: this package has no CPU fallback for the pixel path."""
+import ctypes as C
+import importlib.util
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libipx.so")
+
+
+class Rect(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32)]
+
+
+class Glyph(C.Structure):
+    _fields_ = [("mask", C.c_void_p), ("mw", C.c_int32), ("mh", C.c_int32), ("mstride", C.c_int32),
+                ("dr", Rect), ("mpx", C.c_int32), ("mpy", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("lanes", C.c_int32), ("lane_bytes", C.c_size_t)]
+
+
+class PlanParams(C.Structure):
+    _fields_ = [("sw", C.c_int32), ("sh", C.c_int32),
+                ("do_resize", C.c_int32), ("resize_w", C.c_int32), ("resize_h", C.c_int32),
+                ("keep_aspect", C.c_int32),
+                ("do_thumbnail", C.c_int32), ("thumb_size", C.c_int32), ("crop_to_fit", C.c_int32),
+                ("do_watermark", C.c_int32), ("glyphs", C.c_void_p)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("resize_w", C.c_int32), ("resize_h", C.c_int32),
+                ("thumb_w", C.c_int32), ("thumb_h", C.c_int32), ("thumb_crop", Rect),
+                ("wm_w", C.c_int32), ("wm_h", C.c_int32),
+                ("resize_bytes", C.c_size_t), ("thumb_bytes", C.c_size_t), ("wm_bytes", C.c_size_t),
+                ("algorithmic_bytes", C.c_size_t)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_Z = C.c_size_t
+
+# name -> (restype, argtypes); also the list of symbols the ABI test checks against the header
+SIGNATURES = {
+    "ipx_create": (_I, [C.POINTER(Config), C.POINTER(_P)]),
+    "ipx_destroy": (None, [_P]),
+    "ipx_last_error": (C.c_char_p, []),
+    "ipx_abi_version": (_I, []),
+    "ipx_device_count": (_I, []),
+    "ipx_resize_dims": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "ipx_thumb_geometry": (_I, [_I, _I, _I, _I, C.POINTER(Rect), C.POINTER(_I), C.POINTER(_I)]),
+    "ipx_text_height_px": (_I, [C.c_double]),
+    "ipx_watermark_anchor": (_I, [C.c_char_p, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "ipx_parse_color": (_I, [C.c_char_p, C.c_double, _P]),
+    "ipx_host_alloc": (_P, [_P, _Z]),
+    "ipx_host_free": (_I, [_P, _P]),
+    "ipx_dev_alloc": (_P, [_P, _Z]),
+    "ipx_dev_free": (_I, [_P, _P]),
+    "ipx_memcpy_h2d": (_I, [_P, _P, _P, _Z]),
+    "ipx_memcpy_d2h": (_I, [_P, _P, _P, _Z]),
+    "ipx_memcpy_d2d": (_I, [_P, _P, _P, _Z]),
+    "ipx_device_sync": (_I, [_P]),
+    "ipx_stream_sync": (_I, [_P, _P]),
+    "ipx_scale_bilinear_rgba8": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, Rect, _I]),
+    "ipx_draw_rgba8": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, _I, _I, _I]),
+    "ipx_composite_glyphs_rgba8": (_I, [_P, _P, _I, _I, _I, C.POINTER(Glyph), _I, _P]),
+    "ipx_dev_scale_bilinear_rgba8": (_I, [_P, _P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, Rect, _I]),
+    "ipx_dev_draw_rgba8": (_I, [_P, _P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, _I, _I, _I]),
+    "ipx_glyphset_create": (_I, [_P, C.POINTER(Glyph), _I, _P, C.POINTER(_P)]),
+    "ipx_glyphset_destroy": (None, [_P, _P]),
+    "ipx_dev_composite_glyphs_rgba8": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ipx_plan_create": (_I, [_P, C.POINTER(PlanParams), C.POINTER(_P)]),
+    "ipx_plan_destroy": (None, [_P, _P]),
+    "ipx_plan_query": (_I, [_P, C.POINTER(PlanInfo)]),
+    "ipx_plan_run_dev": (_I, [_P, _P, _P, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
+    "ipx_plan_run_host": (_I, [_P, _P, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
+    "ipx_event_create": (_P, [_P]),
+    "ipx_event_record": (_I, [_P, _P, _P]),
+    "ipx_event_elapsed_ms": (_I, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "ipx_event_destroy": (None, [_P, _P]),
+}
+
+_lib = None
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so (soname
+    libamdhip64.so.7, the same as /opt/rocm's).  If it is loaded first, libipx's NEEDED entry and a
+    later `import torch` both resolve to that one copy; loading them in the other order would put
+    two runtimes in the process.  IPX_SYSTEM_HIP=1 skips this (no torch in the process)."""
+    if os.environ.get("IPX_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def load():
+    """Loads libipx.so; raises if it has not been built (python -m imageprocessor_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "imageprocessor_amd: %s is missing -- build the HIP extension first "
+            "(python imageprocessor_amd/build.py, or __graft_entry__.build()). "
+            "There is no CPU fallback for the pixel path." % LIB_PATH)
+    _preload_hip_runtime()
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L

@@ -1,0 +1,112 @@
+// ipx_internal.h -- shared declarations of libipx (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/ipx.h"
+
+namespace ipx {
+
+// ---- error plumbing: every ABI entry returns a status, text goes to a thread-local buffer ----
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+void clear_error();
+
+#define IPX_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ipx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,  \
+                           __LINE__);                                                        \
+            return IPX_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+// ---- image.Rectangle arithmetic (image/geom.go semantics) ------------------------------------
+struct Rect {
+    int x0, y0, x1, y1;
+    int dx() const { return x1 - x0; }
+    int dy() const { return y1 - y0; }
+    bool empty() const { return x0 >= x1 || y0 >= y1; }
+    Rect shifted(int ox, int oy) const { return Rect{x0 + ox, y0 + oy, x1 + ox, y1 + oy}; }
+    Rect intersect(const Rect &s) const;
+};
+inline Rect to_rect(const ipx_rect &r) { return Rect{r.x0, r.y0, r.x1, r.y1}; }
+
+// image/draw.clip for DrawMask: narrows r to dst, to the source placed by sp and, when mask_w >= 0,
+// to the mask placed by mp; advances sp / mp by the amount r.Min moved.  has_src false = Uniform.
+bool draw_clip(Rect &r, int dw, int dh, bool has_src, int sw, int sh, int &spx, int &spy,
+               bool has_mask, int mw, int mh, int &mpx, int &mpy);
+
+// ---- one axis of ablInterpolator.Scale, tabulated -------------------------------------------
+// For destination index d: the pair of adjacent source indices (base, base+1), relative to the
+// source rectangle, and the float64 weights the reference multiplies them with.  At the clamped
+// edges the reference reads one index twice with weights (1,0) / (0,1); here the pair stays
+// adjacent and the zero weight lands on the neighbour, which yields the same bits
+// (1*a + 0*b == a for finite b).  Needs a source extent >= 2.
+struct AxisTap {
+    double w0;    // weight of src[base]     (xFrac1 / yFrac1 upstream)
+    double w1;    // weight of src[base + 1] (xFrac0 / yFrac0 upstream)
+    int32_t base;
+    int32_t pad;
+};
+void build_axis_taps(int src_extent, int dst_extent, int d_begin, int d_end, AxisTap *out);
+
+// ---- kernel launchers (ipx_kernels.hip) --------------------------------------------------------
+struct ScaleArgs {
+    uint8_t *dst; int dstride;      // dst pointer at (0,0)
+    const uint8_t *src; int sstride;
+    int dr_x0, dr_y0;               // dr.Min
+    int adr_x0, adr_y0, adr_x1, adr_y1; // affected rectangle, relative to dr.Min
+    int sr_x0, sr_y0, ssw, ssh;     // source rectangle origin and extent
+    double xscale, yscale;
+    int op;                         // IPX_OP_*
+    const int *opaque_flag;         // device int: nonzero when the whole source is opaque (Over only)
+};
+hipError_t launch_scale_generic(const ScaleArgs &a, hipStream_t s);
+hipError_t launch_opaque_scan(const uint8_t *src, int sw, int sh, int sstride, int *flag,
+                              hipStream_t s);
+hipError_t launch_draw(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h,
+                       int op, hipStream_t s);
+
+struct DevGlyph {           // one clipped DrawMask call, masks resident in HBM
+    const uint8_t *mask;    // points at mask(mpx, mpy) after clipping
+    int mstride;
+    int x0, y0, x1, y1;     // clipped destination rectangle
+};
+constexpr int kMaxGlyphs = 256;
+hipError_t launch_composite(uint8_t *dst, int dstride, size_t frame_stride, int nframes,
+                            const DevGlyph *glyphs_dev, int n, Rect bbox, uint32_t sr, uint32_t sg,
+                            uint32_t sb, uint32_t sa, hipStream_t s);
+
+// fused band kernel (resize + thumbnail + watermark copy in one pass over the source)
+struct ScaleOut {
+    uint8_t *out;              // frame 0
+    size_t frame_stride;
+    int ostride;               // bytes per output row
+    int dw, dh;
+    int sr_x0, sr_y0;          // source rectangle origin
+    const AxisTap *xt, *yt;    // dw / dh entries, device
+    const int *row_begin;      // nbands+1 entries: first output row owned by each band
+    const int *col_begin;      // ncolblk+1 entries
+};
+struct BandArgs {
+    const uint8_t *src; size_t src_frame_stride; int sstride;
+    int sw, sh;
+    int band_rows, nbands;     // owned source rows per workgroup
+    int blk_cols, ncolblk;     // owned source columns per workgroup (multiple of 4)
+    int nframes;
+    uint8_t *wm; size_t wm_frame_stride; int wm_stride;   // NULL = no watermark copy
+    int nscale;
+    ScaleOut sc[2];
+    // glyphs for the fused composite
+    const DevGlyph *glyphs; int nglyphs; Rect gbox;
+    uint32_t cr, cg, cb, ca;
+};
+hipError_t launch_band(const BandArgs &a, hipStream_t s);
+size_t band_lds_bytes(int band_rows, int blk_cols);
+
+}  // namespace ipx

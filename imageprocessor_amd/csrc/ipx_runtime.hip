@@ -1,0 +1,870 @@
+// ipx_runtime.hip -- context, staging lanes, glyph sets, plans and the C ABI of include/ipx.h.
+//
+// Threading model (worker.go:88-96: WORKER_CONCURRENCY goroutines share one processor): a
+// context is safe to call from any number of OS threads.  Host-pointer calls borrow one of
+// `lanes` staging lanes (stream + device scratch), blocking only when all lanes are busy;
+// device-pointer calls are plain asynchronous launches on the caller's stream.
+#include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <utility>
+#include <vector>
+
+#include "ipx_internal.h"
+
+using namespace ipx;
+
+// ---------------------------------------------------------------------------------------------
+struct Lane {
+    hipStream_t stream = nullptr;
+    uint8_t *dev = nullptr;   // device scratch
+    size_t dev_bytes = 0;
+    int *flag = nullptr;      // device int for the opaque() scan
+    bool busy = false;
+};
+
+struct ipx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;  // default stream for device-pointer calls
+    std::vector<Lane> lanes;
+    size_t lane_bytes = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+};
+
+struct GlyphHost {
+    size_t mask_off;  // offset of this glyph's mask in the packed blob
+    int mw, mh;
+    Rect dr;
+    int mpx, mpy;
+};
+
+struct ClippedGlyphs {
+    DevGlyph *dev = nullptr;
+    int n = 0;
+    Rect bbox{0, 0, 0, 0};
+};
+
+struct ipx_glyphset {
+    int device = 0;
+    std::vector<GlyphHost> g;
+    uint8_t *masks_dev = nullptr;
+    size_t masks_bytes = 0;
+    uint8_t col[4] = {0, 0, 0, 0};
+    mutable std::mutex mu;
+    mutable std::map<std::pair<int, int>, ClippedGlyphs> clipped;  // per frame size
+};
+
+struct PlanScale {
+    bool on = false;
+    int dw = 0, dh = 0;
+    Rect sr{0, 0, 0, 0};
+    AxisTap *xt = nullptr, *yt = nullptr;
+    int *row_begin = nullptr, *col_begin = nullptr;
+};
+
+struct ipx_plan {
+    ipx_plan_params p{};
+    ipx_plan_info info{};
+    bool fused = false;
+    int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0;
+    PlanScale sc[2];      // 0 = resize, 1 = thumbnail
+    uint8_t *blob = nullptr;
+    ClippedGlyphs glyphs;
+};
+
+namespace {
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+struct DeviceGuard {  // hipSetDevice is per-thread; callers may arrive on any OS thread
+    explicit DeviceGuard(int dev) { ok = hipSetDevice(dev) == hipSuccess; }
+    bool ok;
+};
+
+#define IPX_ENTER(ctx)                                                         \
+    clear_error();                                                             \
+    if (!(ctx)) { set_error("%s: null context", __func__); return IPX_ERR_INVALID; } \
+    DeviceGuard guard_((ctx)->device);                                         \
+    if (!guard_.ok) { set_error("hipSetDevice(%d) failed", (ctx)->device); return IPX_ERR_HIP; }
+
+class LaneLease {
+public:
+    explicit LaneLease(ipx_ctx *c) : c_(c)
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        c->cv.wait(lk, [&] {
+            for (auto &l : c->lanes) if (!l.busy) return true;
+            return false;
+        });
+        for (auto &l : c->lanes) if (!l.busy) { l.busy = true; lane_ = &l; break; }
+    }
+    ~LaneLease()
+    {
+        {
+            std::lock_guard<std::mutex> lk(c_->mu);
+            lane_->busy = false;
+        }
+        c_->cv.notify_one();
+    }
+    Lane *operator->() { return lane_; }
+    Lane &get() { return *lane_; }
+private:
+    ipx_ctx *c_;
+    Lane *lane_ = nullptr;
+};
+
+int lane_reserve(Lane &l, size_t bytes)
+{
+    if (bytes <= l.dev_bytes) return IPX_OK;
+    if (l.dev) { IPX_HIP(hipStreamSynchronize(l.stream)); IPX_HIP(hipFree(l.dev)); l.dev = nullptr; l.dev_bytes = 0; }
+    const size_t want = std::max(bytes, l.dev_bytes * 2);
+    hipError_t e = hipMalloc((void **)&l.dev, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("device allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return IPX_ERR_NOMEM;
+    }
+    l.dev_bytes = want;
+    return IPX_OK;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+bool frame_args_ok(const void *p, int w, int h, int stride)
+{
+    return p && w >= 0 && h >= 0 && (long long)stride >= (long long)w * 4;
+}
+
+// Scale's argument checks and dispatch decisions, shared by host- and device-pointer entries
+struct ScalePrep {
+    bool copy;      // equal sizes: Copy -> DrawMask
+    bool empty;
+    Rect adr;       // relative to dr.Min
+    double xscale, yscale;
+};
+
+int scale_prepare(int dw, int dh, const Rect &dr, int sw, int sh, const Rect &sr, int op, ScalePrep *o)
+{
+    if (op != IPX_OP_OVER && op != IPX_OP_SRC) { set_error("scale: unknown op %d", op); return IPX_ERR_INVALID; }
+    o->copy = dr.dx() == sr.dx() && dr.dy() == sr.dy();
+    o->empty = false;
+    if (o->copy) return IPX_OK;
+    Rect adr = Rect{0, 0, dw, dh}.intersect(dr);
+    if (adr.empty() || sr.empty()) { o->empty = true; return IPX_OK; }
+    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) {
+        set_error("scale: source rectangle (%d,%d)-(%d,%d) leaves the %dx%d source; the reference's "
+                  "generic Image path is not covered", sr.x0, sr.y0, sr.x1, sr.y1, sw, sh);
+        return IPX_ERR_UNSUPPORTED;
+    }
+    o->adr = adr.shifted(-dr.x0, -dr.y0);
+    o->yscale = (double)sr.dy() / (double)dr.dy();
+    o->xscale = (double)sr.dx() / (double)dr.dx();
+    return IPX_OK;
+}
+
+// dst / src are device pointers at pixel (0,0)
+int dev_draw(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect r, const uint8_t *src,
+             int sw, int sh, int sstride, int spx, int spy, int op)
+{
+    if (op != IPX_OP_OVER && op != IPX_OP_SRC) { set_error("draw: unknown op %d", op); return IPX_ERR_INVALID; }
+    int mx = 0, my = 0;
+    if (!draw_clip(r, dw, dh, true, sw, sh, spx, spy, false, 0, 0, mx, my)) return IPX_OK;
+    IPX_HIP(launch_draw(dst + (size_t)r.y0 * dstride + (size_t)r.x0 * 4, dstride,
+                        src + (size_t)spy * sstride + (size_t)spx * 4, sstride, r.dx(), r.dy(), op, s));
+    return IPX_OK;
+}
+
+int dev_scale(hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int dstride, const Rect &dr,
+              const uint8_t *src, int sw, int sh, int sstride, const Rect &sr, int op)
+{
+    ScalePrep pr;
+    int rc = scale_prepare(dw, dh, dr, sw, sh, sr, op, &pr);
+    if (rc) return rc;
+    if (pr.copy) return dev_draw(s, dst, dw, dh, dstride, dr, src, sw, sh, sstride, sr.x0, sr.y0, op);
+    if (pr.empty) return IPX_OK;
+    if (op == IPX_OP_OVER) IPX_HIP(launch_opaque_scan(src, sw, sh, sstride, flag, s));
+    ScaleArgs a;
+    a.dst = dst; a.dstride = dstride; a.src = src; a.sstride = sstride;
+    a.dr_x0 = dr.x0; a.dr_y0 = dr.y0;
+    a.adr_x0 = pr.adr.x0; a.adr_y0 = pr.adr.y0; a.adr_x1 = pr.adr.x1; a.adr_y1 = pr.adr.y1;
+    a.sr_x0 = sr.x0; a.sr_y0 = sr.y0; a.ssw = sr.dx(); a.ssh = sr.dy();
+    a.xscale = pr.xscale; a.yscale = pr.yscale;
+    a.op = op; a.opaque_flag = op == IPX_OP_OVER ? flag : nullptr;
+    IPX_HIP(launch_scale_generic(a, s));
+    return IPX_OK;
+}
+
+// clip every glyph against a dw x dh frame (image/draw.clip) and cache the device table
+int glyphs_for_frame(const ipx_glyphset *gs, int dw, int dh, ClippedGlyphs *out)
+{
+    std::lock_guard<std::mutex> lk(gs->mu);
+    auto it = gs->clipped.find({dw, dh});
+    if (it != gs->clipped.end()) { *out = it->second; return IPX_OK; }
+    std::vector<DevGlyph> tab;
+    Rect bb{0, 0, 0, 0};
+    for (const GlyphHost &g : gs->g) {
+        Rect r = g.dr;
+        int spx = 0, spy = 0, mpx = g.mpx, mpy = g.mpy;
+        if (!draw_clip(r, dw, dh, false, 0, 0, spx, spy, true, g.mw, g.mh, mpx, mpy)) continue;
+        DevGlyph d;
+        d.mask = gs->masks_dev + g.mask_off + (size_t)mpy * g.mw + mpx;
+        d.mstride = g.mw;
+        d.x0 = r.x0; d.y0 = r.y0; d.x1 = r.x1; d.y1 = r.y1;
+        if (tab.empty()) bb = r;
+        else {
+            bb.x0 = std::min(bb.x0, r.x0); bb.y0 = std::min(bb.y0, r.y0);
+            bb.x1 = std::max(bb.x1, r.x1); bb.y1 = std::max(bb.y1, r.y1);
+        }
+        tab.push_back(d);
+    }
+    ClippedGlyphs c;
+    c.n = (int)tab.size();
+    c.bbox = bb;
+    if (c.n) {
+        IPX_HIP(hipMalloc((void **)&c.dev, tab.size() * sizeof(DevGlyph)));
+        IPX_HIP(hipMemcpy(c.dev, tab.data(), tab.size() * sizeof(DevGlyph), hipMemcpyHostToDevice));
+    }
+    gs->clipped[{dw, dh}] = c;
+    *out = c;
+    return IPX_OK;
+}
+
+int dev_composite(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, size_t frame_stride,
+                  int nframes, const ipx_glyphset *gs)
+{
+    ClippedGlyphs c;
+    int rc = glyphs_for_frame(gs, dw, dh, &c);
+    if (rc) return rc;
+    IPX_HIP(launch_composite(dst, dstride, frame_stride, nframes, c.dev, c.n, c.bbox,
+                             gs->col[0] * 0x101u, gs->col[1] * 0x101u, gs->col[2] * 0x101u,
+                             gs->col[3] * 0x101u, s));
+    return IPX_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int ipx_device_count(void)
+{
+    clear_error();
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return IPX_ERR_NODEVICE; }
+    return n;
+}
+
+int ipx_create(const ipx_config *cfg, ipx_ctx **out)
+{
+    clear_error();
+    if (!out) { set_error("ipx_create: null out"); return IPX_ERR_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible: the pixel path has no CPU fallback");
+        return IPX_ERR_NODEVICE;
+    }
+    int dev = cfg ? cfg->device : -1;
+    if (dev < 0) dev = env_int("IPX_DEVICE", env_int("LOCAL_RANK", 0) % ndev);
+    if (dev >= ndev) { set_error("device %d out of range (%d visible)", dev, ndev); return IPX_ERR_INVALID; }
+    IPX_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    IPX_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libipx carries gfx950 code only", dev, prop.gcnArchName);
+        return IPX_ERR_NODEVICE;
+    }
+    ipx_ctx *c = new (std::nothrow) ipx_ctx;
+    if (!c) { set_error("out of memory"); return IPX_ERR_NOMEM; }
+    c->device = dev;
+    int lanes = cfg && cfg->lanes > 0 ? cfg->lanes : env_int("IPX_LANES", 3);
+    c->lane_bytes = cfg && cfg->lane_bytes ? cfg->lane_bytes : (size_t)64 << 20;
+    c->lanes.resize(lanes);
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (auto &l : c->lanes) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&l.flag, sizeof(int));
+    }
+    if (e != hipSuccess) {
+        set_error("context setup failed: %s", hipGetErrorString(e));
+        ipx_destroy(c);
+        return IPX_ERR_HIP;
+    }
+    *out = c;
+    return IPX_OK;
+}
+
+void ipx_destroy(ipx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (auto &l : c->lanes) {
+        if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+        if (l.dev) (void)hipFree(l.dev);
+        if (l.flag) (void)hipFree(l.flag);
+    }
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    delete c;
+}
+
+// ---- memory ------------------------------------------------------------------------------------
+void *ipx_host_alloc(ipx_ctx *ctx, size_t bytes)
+{
+    clear_error();
+    if (!ctx || !bytes) { set_error("ipx_host_alloc: bad argument"); return nullptr; }
+    (void)hipSetDevice(ctx->device);
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+int ipx_host_free(ipx_ctx *ctx, void *p)
+{
+    IPX_ENTER(ctx);
+    if (p) IPX_HIP(hipHostFree(p));
+    return IPX_OK;
+}
+
+void *ipx_dev_alloc(ipx_ctx *ctx, size_t bytes)
+{
+    clear_error();
+    if (!ctx || !bytes) { set_error("ipx_dev_alloc: bad argument"); return nullptr; }
+    (void)hipSetDevice(ctx->device);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+int ipx_dev_free(ipx_ctx *ctx, void *p)
+{
+    IPX_ENTER(ctx);
+    if (p) IPX_HIP(hipFree(p));
+    return IPX_OK;
+}
+
+int ipx_memcpy_h2d(ipx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    IPX_ENTER(ctx);
+    if (bytes) IPX_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return IPX_OK;
+}
+
+int ipx_memcpy_d2h(ipx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    IPX_ENTER(ctx);
+    if (bytes) IPX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return IPX_OK;
+}
+
+int ipx_memcpy_d2d(ipx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes)
+{
+    IPX_ENTER(ctx);
+    if (bytes) IPX_HIP(hipMemcpy(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice));
+    return IPX_OK;
+}
+
+int ipx_device_sync(ipx_ctx *ctx)
+{
+    IPX_ENTER(ctx);
+    IPX_HIP(hipDeviceSynchronize());
+    return IPX_OK;
+}
+
+int ipx_stream_sync(ipx_ctx *ctx, void *stream)
+{
+    IPX_ENTER(ctx);
+    IPX_HIP(hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    return IPX_OK;
+}
+
+void *ipx_event_create(ipx_ctx *ctx)
+{
+    clear_error();
+    if (!ctx) return nullptr;
+    (void)hipSetDevice(ctx->device);
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) { (void)hipGetLastError(); set_error("hipEventCreate failed"); return nullptr; }
+    return ev;
+}
+
+int ipx_event_record(ipx_ctx *ctx, void *event, void *stream)
+{
+    IPX_ENTER(ctx);
+    if (!event) { set_error("ipx_event_record: null event"); return IPX_ERR_INVALID; }
+    IPX_HIP(hipEventRecord((hipEvent_t)event, stream ? (hipStream_t)stream : ctx->stream));
+    return IPX_OK;
+}
+
+int ipx_event_elapsed_ms(ipx_ctx *ctx, void *start, void *stop, float *ms)
+{
+    IPX_ENTER(ctx);
+    if (!start || !stop || !ms) { set_error("ipx_event_elapsed_ms: bad argument"); return IPX_ERR_INVALID; }
+    IPX_HIP(hipEventSynchronize((hipEvent_t)stop));
+    IPX_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return IPX_OK;
+}
+
+void ipx_event_destroy(ipx_ctx *ctx, void *event)
+{
+    if (!ctx || !event) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipEventDestroy((hipEvent_t)event);
+}
+
+// ---- device-pointer operations ---------------------------------------------------------------------
+int ipx_dev_scale_bilinear_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int dw, int dh,
+                                 int dstride, ipx_rect dr, const uint8_t *src, int sw, int sh,
+                                 int sstride, ipx_rect sr, int op)
+{
+    IPX_ENTER(ctx);
+    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
+        set_error("ipx_dev_scale_bilinear_rgba8: bad frame arguments");
+        return IPX_ERR_INVALID;
+    }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int *flag = nullptr;
+    if (op == IPX_OP_OVER) {
+        // the opaque() flag must outlive the launch: one device int per call, freed stream-ordered
+        IPX_HIP(hipMallocAsync((void **)&flag, sizeof(int), s));
+    }
+    int rc = dev_scale(s, flag, dst, dw, dh, dstride, to_rect(dr), src, sw, sh, sstride, to_rect(sr), op);
+    if (flag) (void)hipFreeAsync(flag, s);
+    return rc;
+}
+
+int ipx_dev_draw_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int dw, int dh, int dstride,
+                       ipx_rect r, const uint8_t *src, int sw, int sh, int sstride, int spx, int spy,
+                       int op)
+{
+    IPX_ENTER(ctx);
+    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
+        set_error("ipx_dev_draw_rgba8: bad frame arguments");
+        return IPX_ERR_INVALID;
+    }
+    return dev_draw(stream ? (hipStream_t)stream : ctx->stream, dst, dw, dh, dstride, to_rect(r), src,
+                    sw, sh, sstride, spx, spy, op);
+}
+
+int ipx_glyphset_create(ipx_ctx *ctx, const ipx_glyph *glyphs, int n, const uint8_t col[4],
+                        ipx_glyphset **out)
+{
+    IPX_ENTER(ctx);
+    if (!out || n < 0 || (n && !glyphs) || !col) { set_error("ipx_glyphset_create: bad argument"); return IPX_ERR_INVALID; }
+    if (n > kMaxGlyphs) { set_error("ipx_glyphset_create: %d glyphs exceed the limit of %d", n, kMaxGlyphs); return IPX_ERR_UNSUPPORTED; }
+    *out = nullptr;
+    ipx_glyphset *gs = new (std::nothrow) ipx_glyphset;
+    if (!gs) { set_error("out of memory"); return IPX_ERR_NOMEM; }
+    gs->device = ctx->device;
+    memcpy(gs->col, col, 4);
+    std::vector<uint8_t> blob;
+    for (int i = 0; i < n; i++) {
+        const ipx_glyph &g = glyphs[i];
+        if (g.mw < 0 || g.mh < 0 || (g.mw && g.mh && (!g.mask || g.mstride < g.mw))) {
+            set_error("ipx_glyphset_create: glyph %d has a bad mask", i);
+            delete gs;
+            return IPX_ERR_INVALID;
+        }
+        GlyphHost h;
+        h.mask_off = blob.size();
+        h.mw = g.mw; h.mh = g.mh; h.dr = to_rect(g.dr); h.mpx = g.mpx; h.mpy = g.mpy;
+        for (int y = 0; y < g.mh; y++) blob.insert(blob.end(), g.mask + (size_t)y * g.mstride, g.mask + (size_t)y * g.mstride + g.mw);
+        gs->g.push_back(h);
+    }
+    gs->masks_bytes = blob.size();
+    if (!blob.empty()) {
+        hipError_t e = hipMalloc((void **)&gs->masks_dev, blob.size());
+        if (e == hipSuccess) e = hipMemcpy(gs->masks_dev, blob.data(), blob.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("glyph mask upload failed: %s", hipGetErrorString(e));
+            ipx_glyphset_destroy(ctx, gs);
+            return IPX_ERR_HIP;
+        }
+    }
+    *out = gs;
+    return IPX_OK;
+}
+
+void ipx_glyphset_destroy(ipx_ctx *ctx, ipx_glyphset *gs)
+{
+    if (!gs) return;
+    (void)hipSetDevice(ctx ? ctx->device : gs->device);
+    for (auto &kv : gs->clipped) if (kv.second.dev) (void)hipFree(kv.second.dev);
+    if (gs->masks_dev) (void)hipFree(gs->masks_dev);
+    delete gs;
+}
+
+int ipx_dev_composite_glyphs_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int dw, int dh,
+                                   int dstride, const ipx_glyphset *gs)
+{
+    IPX_ENTER(ctx);
+    if (!frame_args_ok(dst, dw, dh, dstride) || !gs) { set_error("ipx_dev_composite_glyphs_rgba8: bad argument"); return IPX_ERR_INVALID; }
+    return dev_composite(stream ? (hipStream_t)stream : ctx->stream, dst, dw, dh, dstride, 0, 1, gs);
+}
+
+// ---- host-pointer operations: stage through a lane ------------------------------------------------
+int ipx_scale_bilinear_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
+                             const uint8_t *src, int sw, int sh, int sstride, ipx_rect sr, int op)
+{
+    IPX_ENTER(ctx);
+    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
+        set_error("ipx_scale_bilinear_rgba8: bad frame arguments");
+        return IPX_ERR_INVALID;
+    }
+    ScalePrep pr;
+    int rc = scale_prepare(dw, dh, to_rect(dr), sw, sh, to_rect(sr), op, &pr);
+    if (rc) return rc;
+    if (pr.empty || dw == 0 || dh == 0) return IPX_OK;
+    LaneLease lane(ctx);
+    const size_t sbytes = align256((size_t)sw * sh * 4), dbytes = align256((size_t)dw * dh * 4);
+    rc = lane_reserve(lane.get(), sbytes + dbytes);
+    if (rc) return rc;
+    uint8_t *dsrc = lane->dev, *ddst = lane->dev + sbytes;
+    hipStream_t s = lane->stream;
+    if (sw && sh) IPX_HIP(hipMemcpy2DAsync(dsrc, (size_t)sw * 4, src, sstride, (size_t)sw * 4, sh, hipMemcpyHostToDevice, s));
+    // Over (and the Copy path's Over) reads the destination; Src leaves pixels outside adr untouched
+    IPX_HIP(hipMemcpy2DAsync(ddst, (size_t)dw * 4, dst, dstride, (size_t)dw * 4, dh, hipMemcpyHostToDevice, s));
+    rc = dev_scale(s, lane->flag, ddst, dw, dh, dw * 4, to_rect(dr), dsrc, sw, sh, sw * 4, to_rect(sr), op);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    IPX_HIP(hipMemcpy2DAsync(dst, dstride, ddst, (size_t)dw * 4, (size_t)dw * 4, dh, hipMemcpyDeviceToHost, s));
+    IPX_HIP(hipStreamSynchronize(s));
+    return IPX_OK;
+}
+
+int ipx_draw_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r,
+                   const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op)
+{
+    IPX_ENTER(ctx);
+    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
+        set_error("ipx_draw_rgba8: bad frame arguments");
+        return IPX_ERR_INVALID;
+    }
+    if (op != IPX_OP_OVER && op != IPX_OP_SRC) { set_error("draw: unknown op %d", op); return IPX_ERR_INVALID; }
+    if (!dw || !dh || !sw || !sh) return IPX_OK;
+    LaneLease lane(ctx);
+    const size_t sbytes = align256((size_t)sw * sh * 4), dbytes = align256((size_t)dw * dh * 4);
+    int rc = lane_reserve(lane.get(), sbytes + dbytes);
+    if (rc) return rc;
+    uint8_t *dsrc = lane->dev, *ddst = lane->dev + sbytes;
+    hipStream_t s = lane->stream;
+    IPX_HIP(hipMemcpy2DAsync(dsrc, (size_t)sw * 4, src, sstride, (size_t)sw * 4, sh, hipMemcpyHostToDevice, s));
+    IPX_HIP(hipMemcpy2DAsync(ddst, (size_t)dw * 4, dst, dstride, (size_t)dw * 4, dh, hipMemcpyHostToDevice, s));
+    rc = dev_draw(s, ddst, dw, dh, dw * 4, to_rect(r), dsrc, sw, sh, sw * 4, spx, spy, op);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    IPX_HIP(hipMemcpy2DAsync(dst, dstride, ddst, (size_t)dw * 4, (size_t)dw * 4, dh, hipMemcpyDeviceToHost, s));
+    IPX_HIP(hipStreamSynchronize(s));
+    return IPX_OK;
+}
+
+int ipx_composite_glyphs_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride,
+                               const ipx_glyph *glyphs, int n, const uint8_t col[4])
+{
+    IPX_ENTER(ctx);
+    if (!frame_args_ok(dst, dw, dh, dstride) || n < 0 || (n && !glyphs) || !col) {
+        set_error("ipx_composite_glyphs_rgba8: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    if (!n || !dw || !dh) return IPX_OK;
+    ipx_glyphset *gs = nullptr;
+    int rc = ipx_glyphset_create(ctx, glyphs, n, col, &gs);
+    if (rc) return rc;
+    {
+        LaneLease lane(ctx);
+        rc = lane_reserve(lane.get(), align256((size_t)dw * dh * 4));
+        hipStream_t s = lane->stream;
+        hipError_t e = hipSuccess;
+        if (!rc) {
+            e = hipMemcpy2DAsync(lane->dev, (size_t)dw * 4, dst, dstride, (size_t)dw * 4, dh, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) rc = dev_composite(s, lane->dev, dw, dh, dw * 4, 0, 1, gs);
+            if (e == hipSuccess && !rc)
+                e = hipMemcpy2DAsync(dst, dstride, lane->dev, (size_t)dw * 4, (size_t)dw * 4, dh, hipMemcpyDeviceToHost, s);
+            hipError_t e2 = hipStreamSynchronize(s);
+            if (e == hipSuccess) e = e2;
+            if (e != hipSuccess && !rc) { set_error("composite staging failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
+        }
+    }
+    ipx_glyphset_destroy(ctx, gs);
+    return rc;
+}
+
+// ---- plans -------------------------------------------------------------------------------------------
+int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
+{
+    IPX_ENTER(ctx);
+    if (!p || !out) { set_error("ipx_plan_create: bad argument"); return IPX_ERR_INVALID; }
+    *out = nullptr;
+    if (p->sw <= 0 || p->sh <= 0) { set_error("ipx_plan_create: frame size %dx%d", p->sw, p->sh); return IPX_ERR_INVALID; }
+    ipx_plan *pl = new (std::nothrow) ipx_plan;
+    if (!pl) { set_error("out of memory"); return IPX_ERR_NOMEM; }
+    pl->p = *p;
+    int rc = IPX_OK;
+    const int sw = p->sw, sh = p->sh;
+    if (p->do_resize) {
+        int nw, nh;
+        rc = ipx_resize_dims(sw, sh, p->resize_w, p->resize_h, p->keep_aspect, &nw, &nh);
+        if (rc) { delete pl; return rc; }
+        pl->sc[0].on = true; pl->sc[0].dw = nw; pl->sc[0].dh = nh; pl->sc[0].sr = Rect{0, 0, sw, sh};
+        pl->info.resize_w = nw; pl->info.resize_h = nh;
+        pl->info.resize_bytes = (size_t)nw * nh * 4;
+    }
+    if (p->do_thumbnail) {
+        int nw, nh;
+        ipx_rect crop;
+        rc = ipx_thumb_geometry(sw, sh, p->thumb_size, p->crop_to_fit, &crop, &nw, &nh);
+        if (rc) { delete pl; return rc; }
+        pl->sc[1].on = true; pl->sc[1].dw = nw; pl->sc[1].dh = nh; pl->sc[1].sr = to_rect(crop);
+        pl->info.thumb_w = nw; pl->info.thumb_h = nh; pl->info.thumb_crop = crop;
+        pl->info.thumb_bytes = (size_t)nw * nh * 4;
+    }
+    if (p->do_watermark) {
+        pl->info.wm_w = sw; pl->info.wm_h = sh;
+        pl->info.wm_bytes = (size_t)sw * sh * 4;
+        if (p->glyphs) {
+            rc = glyphs_for_frame(p->glyphs, sw, sh, &pl->glyphs);
+            if (rc) { delete pl; return rc; }
+        }
+    }
+    pl->info.algorithmic_bytes = (size_t)sw * sh * 4 + pl->info.resize_bytes + pl->info.thumb_bytes + pl->info.wm_bytes;
+
+    // The band kernel needs a tap pair per axis (source extents >= 2) and non-empty outputs; an
+    // output with a zero dimension (resize.go:70-72 has no guard) is simply empty.
+    pl->fused = true;
+    for (auto &s : pl->sc)
+        if (s.on && s.dw > 0 && s.dh > 0 && (s.sr.dx() < 2 || s.sr.dy() < 2)) pl->fused = false;
+    if (env_int("IPX_NO_FUSE", 0)) pl->fused = false;
+    if (!pl->fused) { *out = pl; return IPX_OK; }
+
+    // block shape: owned columns per workgroup (multiple of 4 pixels = 16 B) and owned rows
+    const int max_cols = std::max(64, env_int("IPX_BLK_COLS", 2048));
+    const int ncb = (sw + max_cols - 1) / max_cols;
+    int bc = ((sw + ncb - 1) / ncb + 3) & ~3;
+    const size_t lds_budget = (size_t)std::max(8, env_int("IPX_LDS_KB", 72)) << 10;
+    int br = (int)(lds_budget / ((size_t)(bc + 4) * 4)) - 1;
+    br = std::max(1, std::min(br, env_int("IPX_BAND_ROWS_MAX", 16)));
+    if (env_int("IPX_BAND_ROWS", 0) > 0) br = env_int("IPX_BAND_ROWS", 0);
+    br = std::min(br, sh);
+    pl->blk_cols = bc; pl->band_rows = br;
+    pl->ncolblk = (sw + bc - 1) / bc;
+    pl->nbands = (sh + br - 1) / br;
+
+    // host tables -> one device blob
+    std::vector<uint8_t> blob;
+    auto put = [&](const void *src, size_t bytes) {
+        const size_t off = (blob.size() + 15) & ~(size_t)15;
+        blob.resize(off + bytes);
+        memcpy(blob.data() + off, src, bytes);
+        return off;
+    };
+    size_t off_xt[2] = {0, 0}, off_yt[2] = {0, 0}, off_rb[2] = {0, 0}, off_cb[2] = {0, 0};
+    for (int k = 0; k < 2; k++) {
+        PlanScale &s = pl->sc[k];
+        if (!s.on || s.dw <= 0 || s.dh <= 0) continue;
+        std::vector<AxisTap> xt(s.dw), yt(s.dh);
+        build_axis_taps(s.sr.dx(), s.dw, 0, s.dw, xt.data());
+        build_axis_taps(s.sr.dy(), s.dh, 0, s.dh, yt.data());
+        std::vector<int> rb(pl->nbands + 1), cbv(pl->ncolblk + 1);
+        int d = 0;
+        for (int b = 0; b <= pl->nbands; b++) {  // first output row whose tap pair starts at or below band b
+            while (d < s.dh && s.sr.y0 + yt[d].base < b * br) d++;
+            rb[b] = b == pl->nbands ? s.dh : d;
+        }
+        d = 0;
+        for (int c = 0; c <= pl->ncolblk; c++) {
+            while (d < s.dw && s.sr.x0 + xt[d].base < c * bc) d++;
+            cbv[c] = c == pl->ncolblk ? s.dw : d;
+        }
+        off_xt[k] = put(xt.data(), xt.size() * sizeof(AxisTap));
+        off_yt[k] = put(yt.data(), yt.size() * sizeof(AxisTap));
+        off_rb[k] = put(rb.data(), rb.size() * sizeof(int));
+        off_cb[k] = put(cbv.data(), cbv.size() * sizeof(int));
+    }
+    if (!blob.empty()) {
+        hipError_t e = hipMalloc((void **)&pl->blob, blob.size());
+        if (e == hipSuccess) e = hipMemcpy(pl->blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("plan table upload failed: %s", hipGetErrorString(e));
+            ipx_plan_destroy(ctx, pl);
+            return IPX_ERR_HIP;
+        }
+        for (int k = 0; k < 2; k++) {
+            PlanScale &s = pl->sc[k];
+            if (!s.on || s.dw <= 0 || s.dh <= 0) continue;
+            s.xt = (AxisTap *)(pl->blob + off_xt[k]);
+            s.yt = (AxisTap *)(pl->blob + off_yt[k]);
+            s.row_begin = (int *)(pl->blob + off_rb[k]);
+            s.col_begin = (int *)(pl->blob + off_cb[k]);
+        }
+    }
+    *out = pl;
+    return IPX_OK;
+}
+
+void ipx_plan_destroy(ipx_ctx *ctx, ipx_plan *plan)
+{
+    if (!plan) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (plan->blob) (void)hipFree(plan->blob);
+    delete plan;
+}
+
+int ipx_plan_query(const ipx_plan *plan, ipx_plan_info *info)
+{
+    clear_error();
+    if (!plan || !info) { set_error("ipx_plan_query: bad argument"); return IPX_ERR_INVALID; }
+    *info = plan->info;
+    return IPX_OK;
+}
+
+int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *src,
+                     int sstride, size_t src_frame_stride, uint8_t *resize_out,
+                     size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride,
+                     uint8_t *wm_out, size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * 4) {
+        set_error("ipx_plan_run_dev: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    if (n == 0) return IPX_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    uint8_t *outs[2] = {pl->sc[0].on ? resize_out : nullptr, pl->sc[1].on ? thumb_out : nullptr};
+    const size_t ostr[2] = {resize_frame_stride, thumb_frame_stride};
+    uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
+    const uint32_t col[4] = {pl->p.glyphs ? pl->p.glyphs->col[0] * 0x101u : 0, pl->p.glyphs ? pl->p.glyphs->col[1] * 0x101u : 0,
+                             pl->p.glyphs ? pl->p.glyphs->col[2] * 0x101u : 0, pl->p.glyphs ? pl->p.glyphs->col[3] * 0x101u : 0};
+
+    if (pl->fused) {
+        BandArgs a{};
+        a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
+        a.sw = sw; a.sh = sh;
+        a.band_rows = pl->band_rows; a.nbands = pl->nbands;
+        a.blk_cols = pl->blk_cols; a.ncolblk = pl->ncolblk;
+        a.nframes = n;
+        a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
+        a.nscale = 0;
+        for (int k = 0; k < 2; k++) {
+            const PlanScale &ps = pl->sc[k];
+            if (!outs[k] || ps.dw <= 0 || ps.dh <= 0) continue;
+            ScaleOut &o = a.sc[a.nscale++];
+            o.out = outs[k]; o.frame_stride = ostr[k]; o.ostride = ps.dw * 4;
+            o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
+            o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
+        }
+        a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
+        a.cr = col[0]; a.cg = col[1]; a.cb = col[2]; a.ca = col[3];
+        if (!wm && a.nscale == 0) return IPX_OK;
+        IPX_HIP(launch_band(a, s));
+        return IPX_OK;
+    }
+
+    // unfused fallback (1-pixel-wide sources and the like): the per-operation kernels, frame by frame
+    for (int i = 0; i < n; i++) {
+        const uint8_t *f = src + (size_t)i * src_frame_stride;
+        for (int k = 0; k < 2; k++) {
+            const PlanScale &ps = pl->sc[k];
+            if (!outs[k] || ps.dw <= 0 || ps.dh <= 0) continue;
+            uint8_t *o = outs[k] + (size_t)i * ostr[k];
+            IPX_HIP(hipMemsetAsync(o, 0, (size_t)ps.dw * ps.dh * 4, s));  // image.NewRGBA
+            int rc = dev_scale(s, nullptr, o, ps.dw, ps.dh, ps.dw * 4, Rect{0, 0, ps.dw, ps.dh}, f, sw, sh,
+                               sstride, ps.sr, IPX_OP_SRC);  // Over on a zeroed frame == Src
+            if (rc) return rc;
+        }
+        if (wm) {
+            uint8_t *o = wm + (size_t)i * wm_frame_stride;
+            int rc = dev_draw(s, o, sw, sh, sw * 4, Rect{0, 0, sw, sh}, f, sw, sh, sstride, 0, 0, IPX_OP_SRC);
+            if (rc) return rc;
+        }
+    }
+    if (wm && pl->glyphs.n)
+        IPX_HIP(launch_composite(wm, sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox,
+                                 col[0], col[1], col[2], col[3], s));
+    return IPX_OK;
+}
+
+int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride,
+                      size_t src_frame_stride, uint8_t *resize_out, size_t resize_frame_stride,
+                      uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                      size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * 4) {
+        set_error("ipx_plan_run_host: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    if (n == 0) return IPX_OK;
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    const size_t fsrc = align256((size_t)sw * sh * 4);
+    const size_t fres = resize_out ? align256(pl->info.resize_bytes) : 0;
+    const size_t fth = thumb_out ? align256(pl->info.thumb_bytes) : 0;
+    const size_t fwm = wm_out ? align256(pl->info.wm_bytes) : 0;
+    const size_t per_frame = fsrc + fres + fth + fwm;
+    // chunk the batch so that copies of one chunk overlap kernels of another on a different lane
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ctx->lane_bytes / per_frame));
+    chunk = std::min(chunk, std::max(1, (n + (int)ctx->lanes.size() - 1) / (int)ctx->lanes.size()));
+
+    // take every lane: this call is the pipeline
+    std::vector<Lane *> lanes;
+    {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        ctx->cv.wait(lk, [&] { for (auto &l : ctx->lanes) if (l.busy) return false; return true; });
+        for (auto &l : ctx->lanes) { l.busy = true; lanes.push_back(&l); }
+    }
+    int rc = IPX_OK;
+    hipError_t e = hipSuccess;
+    for (auto *l : lanes) {
+        rc = lane_reserve(*l, per_frame * chunk);
+        if (rc) break;
+    }
+    for (int i0 = 0, c = 0; !rc && e == hipSuccess && i0 < n; i0 += chunk, c++) {
+        Lane &l = *lanes[c % lanes.size()];
+        const int m = std::min(chunk, n - i0);
+        uint8_t *dsrc = l.dev;
+        uint8_t *dres = fres ? dsrc + fsrc * chunk : nullptr;
+        uint8_t *dth = fth ? l.dev + (fsrc + fres) * chunk : nullptr;
+        uint8_t *dwm = fwm ? l.dev + (fsrc + fres + fth) * chunk : nullptr;
+        // the lane's stream serialises reuse of its scratch: chunk c waits for chunk c - lanes
+        for (int i = 0; i < m && e == hipSuccess; i++)
+            e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * 4, src + (size_t)(i0 + i) * src_frame_stride, sstride,
+                                 (size_t)sw * 4, sh, hipMemcpyHostToDevice, l.stream);
+        if (e != hipSuccess) break;
+        rc = ipx_plan_run_dev(ctx, l.stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm);
+        if (rc) break;
+        for (int i = 0; i < m && e == hipSuccess; i++) {
+            if (dres && pl->info.resize_bytes)
+                e = hipMemcpyAsync(resize_out + (size_t)(i0 + i) * resize_frame_stride, dres + fres * i,
+                                   pl->info.resize_bytes, hipMemcpyDeviceToHost, l.stream);
+            if (e == hipSuccess && dth && pl->info.thumb_bytes)
+                e = hipMemcpyAsync(thumb_out + (size_t)(i0 + i) * thumb_frame_stride, dth + fth * i,
+                                   pl->info.thumb_bytes, hipMemcpyDeviceToHost, l.stream);
+            if (e == hipSuccess && dwm && pl->info.wm_bytes)
+                e = hipMemcpyAsync(wm_out + (size_t)(i0 + i) * wm_frame_stride, dwm + fwm * i, pl->info.wm_bytes,
+                                   hipMemcpyDeviceToHost, l.stream);
+        }
+    }
+    for (auto *l : lanes) {
+        hipError_t e2 = hipStreamSynchronize(l->stream);
+        if (e == hipSuccess) e = e2;
+    }
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (auto *l : lanes) l->busy = false;
+    }
+    ctx->cv.notify_all();
+    if (!rc && e != hipSuccess) { set_error("ipx_plan_run_host: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
+    return rc;
+}
+
+}  // extern "C"

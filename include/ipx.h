@@ -1,0 +1,198 @@
+/*
+ * ipx.h -- C ABI of libipx, the MI355X (gfx950) pixel worker for ImageProcessor.
+ *
+ * This is the drop-in boundary for ONE path of the reference: the per-pixel work of
+ * internal/worker -> internal/usecase/processor.  The reference has no
+ * FFI today (dockerfile:12 builds with CGO_ENABLED=0); the seam is three private Go helpers
+ * plus the operator method set.  Every entry point below names the reference code it replaces.
+ * Plain pointers and sizes only; all functions are callable from any OS thread (goroutines
+ * migrate), return an ipx_status (0 = ok, negative = error) and never abort or throw.
+ * INTEGRATION.md holds the cgo binding that goes with this header.
+ *
+ * Pixel format everywhere: 8-bit premultiplied RGBA, as Go's image.RGBA (Pix, Stride, Rect
+ * with Min = (0,0)).  Strides are in bytes.
+ */
+#ifndef IPX_H
+#define IPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPX_ABI_VERSION 1
+
+typedef struct ipx_ctx ipx_ctx;           /* one per worker process and GPU            */
+typedef struct ipx_glyphset ipx_glyphset; /* rasterised watermark text resident in HBM */
+typedef struct ipx_plan ipx_plan;         /* fused resize+thumbnail+watermark geometry */
+
+typedef enum {
+    IPX_OK = 0,
+    IPX_ERR_INVALID = -1,     /* bad argument (the Go side returns an error, image_processor.go:66-75) */
+    IPX_ERR_NOMEM = -2,       /* host or device allocation failed                       */
+    IPX_ERR_HIP = -3,         /* a HIP call failed; text in ipx_last_error()            */
+    IPX_ERR_UNSUPPORTED = -4, /* valid in the reference but outside this library's path */
+    IPX_ERR_NODEVICE = -5     /* no gfx950 device visible                               */
+} ipx_status;
+
+/* draw.Op of image/draw and x/image/draw (resize.go:123 passes xdraw.Over, watermark.go:92 draw.Src) */
+enum { IPX_OP_OVER = 0, IPX_OP_SRC = 1 };
+
+/* image.Rectangle: [x0,x1) x [y0,y1) */
+typedef struct { int32_t x0, y0, x1, y1; } ipx_rect;
+
+/* One draw.DrawMask call of freetype.Context.DrawString (watermark.go:151): an *image.Alpha
+ * mask with bounds (0,0)-(mw,mh), the destination rectangle dr and the mask point mp that is
+ * aligned with dr.Min.  Clipping against the frame and the mask is done by the library exactly
+ * as image/draw does.  Glyphs are applied in array order; overlapping boxes are NOT merged. */
+typedef struct {
+    const uint8_t *mask;
+    int32_t mw, mh, mstride;
+    ipx_rect dr;
+    int32_t mpx, mpy;
+} ipx_glyph;
+
+typedef struct {
+    int32_t device;        /* HIP device ordinal; -1 = LOCAL_RANK / 0                          */
+    int32_t lanes;         /* concurrent host-pointer calls served without blocking; 0 = 3,
+                              the reference's WORKER_CONCURRENCY (.env.example:38, worker.go:90) */
+    size_t lane_bytes;     /* initial pinned+device staging per lane; grows on demand; 0 = 64 MiB */
+} ipx_config;
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+
+/* Replaces processor.NewImageProcessor (image_processor.go:29) as the owner of per-process state. */
+int ipx_create(const ipx_config *cfg, ipx_ctx **out);
+void ipx_destroy(ipx_ctx *ctx);
+/* Thread-local text of the last failure on the calling thread ("" if none). */
+const char *ipx_last_error(void);
+int ipx_abi_version(void);
+/* Number of gfx950 devices visible; a negative ipx_status on failure. */
+int ipx_device_count(void);
+
+/* ---- geometry and parameter rules (host only, no GPU needed) ------------------------------- */
+
+/* resize.go:61-75: aspect-fit in float64 with truncation, or (w,h) as given. */
+int ipx_resize_dims(int ow, int oh, int w, int h, int keep_aspect, int *nw, int *nh);
+/* thumbnail.go:48-65 (short side = size) and :114-127 (centre square crop). */
+int ipx_thumb_geometry(int ow, int oh, int size, int crop_to_fit, ipx_rect *crop, int *nw, int *nh);
+/* watermark.go:116-118: int(fixed.Int26_6(fontSize*64*1.2).Ceil()). */
+int ipx_text_height_px(double font_size);
+/* watermark.go:121-148: baseline point (whole pixels, as freetype.Pt) for a position string;
+ * unknown strings fall to bottom-right like the reference's default arm. */
+int ipx_watermark_anchor(const char *position, int w, int h, int width_px, int height_px,
+                         int *px, int *py);
+/* watermark.go:159-190 + :93-97: "r,g,b[,a]" -> color.RGBA bytes (NOT premultiplied, as the
+ * reference builds it).  Returns IPX_OK, or 1 when the string is malformed, in which case rgba
+ * holds the reference's fallback (black with alpha uint8(255*opacity)). */
+int ipx_parse_color(const char *s, double opacity, uint8_t rgba[4]);
+
+/* ---- memory the Go side may hand to asynchronous calls --------------------------------------- */
+
+/* hipHostMalloc'd staging (cgo: wrap with unsafe.Slice; C owns it, Go must not retain it past free). */
+void *ipx_host_alloc(ipx_ctx *ctx, size_t bytes);
+int ipx_host_free(ipx_ctx *ctx, void *p);
+void *ipx_dev_alloc(ipx_ctx *ctx, size_t bytes);
+int ipx_dev_free(ipx_ctx *ctx, void *p);
+int ipx_memcpy_h2d(ipx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int ipx_memcpy_d2h(ipx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int ipx_memcpy_d2d(ipx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
+/* Blocks until the device is idle (every stream). */
+int ipx_device_sync(ipx_ctx *ctx);
+/* Blocks until everything queued on `stream` (a hipStream_t, NULL = the context's stream) is done. */
+int ipx_stream_sync(ipx_ctx *ctx, void *stream);
+
+/* ---- per-operation seam, host pointers, synchronous ------------------------------------------
+ * Each call stages through a pinned lane, runs the HIP kernel and copies the result back. */
+
+/* xdraw.BiLinear.Scale(dst, dr, src, sr, op, nil) for *image.RGBA <- *image.RGBA:
+ * resizeImage (resize.go:121-125) and both Scale calls of cropAndResize (thumbnail.go:128-131).
+ * dst is read as well as written when op = IPX_OP_OVER.  sr must lie inside the source
+ * (IPX_ERR_UNSUPPORTED otherwise: the reference would leave its typed fast path). */
+int ipx_scale_bilinear_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
+                             const uint8_t *src, int sw, int sh, int sstride, ipx_rect sr, int op);
+/* draw.Draw / draw.DrawMask with a nil mask, *image.RGBA <- *image.RGBA: the full-frame copy of
+ * addTextWatermark (watermark.go:90-92) and the equal-size Scale of thumbnail.go:128-130. */
+int ipx_draw_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r,
+                   const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op);
+/* freetype.Context.DrawString's compositing (watermark.go:151): draw.DrawMask(dst, dr,
+ * image.Uniform{col}, ZP, mask, mp, draw.Over) per glyph, in order, in place on dst.
+ * col is the color.RGBA of watermark.go:93-97 (parseColor). */
+int ipx_composite_glyphs_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride,
+                               const ipx_glyph *glyphs, int n, const uint8_t col[4]);
+
+/* ---- same operations on frames already resident in HBM, asynchronous on `stream` -------------
+ * `stream` is a hipStream_t (NULL = the context's own stream).  Pointers are device pointers. */
+
+int ipx_dev_scale_bilinear_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int dw, int dh,
+                                 int dstride, ipx_rect dr, const uint8_t *src, int sw, int sh,
+                                 int sstride, ipx_rect sr, int op);
+int ipx_dev_draw_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int dw, int dh, int dstride,
+                       ipx_rect r, const uint8_t *src, int sw, int sh, int sstride, int spx,
+                       int spy, int op);
+/* Uploads the glyph masks once (host pointers in `glyphs`); clipping happens per frame size. */
+int ipx_glyphset_create(ipx_ctx *ctx, const ipx_glyph *glyphs, int n, const uint8_t col[4],
+                        ipx_glyphset **out);
+void ipx_glyphset_destroy(ipx_ctx *ctx, ipx_glyphset *gs);
+int ipx_dev_composite_glyphs_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int dw, int dh,
+                                   int dstride, const ipx_glyphset *gs);
+
+/* ---- the batched worker path -------------------------------------------------------------------
+ * Replaces (*ImageProcessor).Process (image_processor.go:39-102) between image.Decode (:47) and
+ * the encoders (resize.go:78-91, thumbnail.go:68-81, watermark.go:66-79) for a batch of decoded
+ * frames of one size: every operator is applied to the ORIGINAL frame (image_processor.go:64-65),
+ * so one pass over each source frame produces all requested outputs. */
+
+typedef struct {
+    int32_t sw, sh;                 /* frame size                                          */
+    int32_t do_resize;              /* operator present in task.Operations (domain/task.go) */
+    int32_t resize_w, resize_h, keep_aspect; /* resize.go:26-59                             */
+    int32_t do_thumbnail;
+    int32_t thumb_size, crop_to_fit;         /* thumbnail.go:25-47; size 0 = 200 (task.go:56) */
+    int32_t do_watermark;
+    const ipx_glyphset *glyphs;     /* rasterised text; may be NULL (copy only)             */
+} ipx_plan_params;
+
+typedef struct {
+    int32_t resize_w, resize_h;     /* actual output sizes after the aspect rules           */
+    int32_t thumb_w, thumb_h;
+    ipx_rect thumb_crop;
+    int32_t wm_w, wm_h;
+    size_t resize_bytes, thumb_bytes, wm_bytes; /* tightly packed bytes per frame             */
+    size_t algorithmic_bytes;       /* source read once + every output written once, per frame */
+} ipx_plan_info;
+
+int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out);
+void ipx_plan_destroy(ipx_ctx *ctx, ipx_plan *plan);
+int ipx_plan_query(const ipx_plan *plan, ipx_plan_info *info);
+
+/* n frames resident in HBM at src + i*src_frame_stride (row stride sstride); outputs tightly
+ * packed rows at out + i*out_frame_stride.  An output pointer may be NULL to skip it even when
+ * the plan has the operator.  Asynchronous on `stream`. */
+int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const uint8_t *src,
+                     int sstride, size_t src_frame_stride, uint8_t *resize_out,
+                     size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride,
+                     uint8_t *wm_out, size_t wm_frame_stride);
+
+/* Host-to-host variant for the worker: frames and outputs in pinned memory from ipx_host_alloc
+ * (or any host memory, slower); copies and kernels are pipelined over the context's lanes so
+ * H2D, kernels and D2H of consecutive chunks overlap.  Synchronous. */
+int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *plan, int n, const uint8_t *src, int sstride,
+                      size_t src_frame_stride, uint8_t *resize_out, size_t resize_frame_stride,
+                      uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                      size_t wm_frame_stride);
+
+/* Average duration in milliseconds of the last `ipx_plan_run_dev` launches on `stream` is a
+ * measurement concern of the caller: bracket calls with ipx_event_* below (HIP events on the
+ * stream the kernels run on). */
+void *ipx_event_create(ipx_ctx *ctx);
+int ipx_event_record(ipx_ctx *ctx, void *event, void *stream);
+int ipx_event_elapsed_ms(ipx_ctx *ctx, void *start, void *stop, float *ms); /* syncs on stop */
+void ipx_event_destroy(ipx_ctx *ctx, void *event);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPX_H */

@@ -1,0 +1,255 @@
+"""HIP path vs the CPU oracle, through the C ABI (include/ipx.h).  Bit-exact everywhere: the
+kernels restate the same float64 / uint32 arithmetic (the +-1 LSB allowance of the north star for
+the bilinear taps is not needed and not used).
+
+PARITY UNPINNED against the Go reference itself: see oracle/ipx_oracle.h.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import DEFAULT_COL, rgba_frames, text_glyphs
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "kats.json")) as f:
+    CASES = json.load(f)["cases"]
+
+
+@pytest.fixture(scope="module")
+def ipx():
+    import imageprocessor_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(ipx):
+    c = ipx.Context(lanes=2)
+    yield c
+    c.close()
+
+
+def _frame(flat, w, h):
+    return np.array(flat, np.uint8).reshape(h, w, 4)
+
+
+def _glyphs_from_case(c):
+    return [{"mask": np.array(g["mask"], np.uint8).reshape(g["mh"], g["mw"]), "dr": g["dr"],
+             "mp": g["mp"]} for g in c["glyphs"]]
+
+
+# ---- committed known answers through the per-operation seam ---------------------------------------
+
+def test_golden_scale(ctx):
+    for c in [c for c in CASES if c["kind"] == "scale"]:
+        dst = _frame(c["dst"], c["dw"], c["dh"]).copy()
+        ctx.scale_bilinear(_frame(c["src"], c["sw"], c["sh"]), c["dw"], c["dh"], sr=c["sr"], dr=c["dr"],
+                           op=c["op"], dst=dst)
+        np.testing.assert_array_equal(dst, _frame(c["expect"], c["dw"], c["dh"]), err_msg=c["name"])
+
+
+def test_golden_draw(ctx):
+    for c in [c for c in CASES if c["kind"] == "draw"]:
+        dst = _frame(c["dst"], c["dw"], c["dh"]).copy()
+        ctx.draw(dst, c["r"], _frame(c["src"], c["sw"], c["sh"]), c["sp"], c["op"])
+        np.testing.assert_array_equal(dst, _frame(c["expect"], c["dw"], c["dh"]), err_msg=c["name"])
+
+
+def test_golden_glyphs(ctx):
+    for c in [c for c in CASES if c["kind"] == "glyphs"]:
+        dst = _frame(c["dst"], c["dw"], c["dh"]).copy()
+        ctx.composite_glyphs(dst, _glyphs_from_case(c), c["col"])
+        np.testing.assert_array_equal(dst, _frame(c["expect"], c["dw"], c["dh"]), err_msg=c["name"])
+
+
+# ---- per-operation seam vs the oracle on seeded inputs ----------------------------------------------
+
+SCALE_GEOMS = [
+    # sw, sh, dw, dh, sr, dr, op, opaque, nonzero dst
+    (1920, 1080, 1024, 768, None, None, 0, True, False),    # BASELINE resize, dyadic scales
+    (1920, 1080, 1024, 576, None, None, 0, True, False),    # product default (keep_aspect)
+    (1920, 1080, 200, 200, (420, 0, 1500, 1080), None, 0, True, False),  # thumbnail: x5.4
+    (640, 480, 1024, 768, None, None, 0, True, False),      # upscale x1.6
+    (854, 480, 1024, 575, None, None, 0, False, False),     # odd width, translucent
+    (333, 500, 511, 768, None, None, 1, False, False),
+    (97, 61, 31, 200, None, None, 0, False, True),          # Over onto a used frame, translucent
+    (97, 61, 31, 200, None, None, 0, True, True),           # Over + opaque source => Src
+    (97, 61, 40, 40, (5, 7, 90, 55), (3, 2, 36, 39), 0, False, True),
+    (97, 61, 40, 40, None, (-7, -5, 50, 47), 1, False, True),  # dr clipped by dst
+    (2, 2, 9, 7, None, None, 0, False, False),
+    (1, 5, 4, 9, None, None, 0, False, False),              # 1-wide source: both taps clamp
+    (64, 64, 64, 64, None, None, 0, False, True),           # equal size => Copy (drawCopyOver)
+]
+
+
+@pytest.mark.parametrize("g", SCALE_GEOMS, ids=lambda g: "%dx%d->%dx%d" % g[:4])
+def test_scale_vs_oracle(ctx, g):
+    sw, sh, dw, dh, sr, dr, op, opaque, used = g
+    src = rgba_frames(1, sw, sh, seed=sw * 31 + dh, opaque=opaque)[0]
+    dst0 = rgba_frames(1, dw, dh, seed=7, opaque=False)[0] if used else np.zeros((dh, dw, 4), np.uint8)
+    want = oracle.scale_bilinear(src, dw, dh, sr=sr, dr=dr, op=op, dst=dst0.copy())
+    got = ctx.scale_bilinear(src, dw, dh, sr=sr, dr=dr, op=op, dst=dst0.copy())
+    np.testing.assert_array_equal(got, want)
+
+
+def test_scale_rejects_source_rect_outside(ctx, ipx):
+    src = rgba_frames(1, 8, 8)[0]
+    with pytest.raises(ipx.IpxError) as e:
+        ctx.scale_bilinear(src, 4, 4, sr=(-1, 0, 7, 8))
+    assert e.value.status == -4
+
+
+def test_draw_and_glyphs_vs_oracle(ctx):
+    src = rgba_frames(1, 300, 120, seed=3, opaque=False)[0]
+    for op in (0, 1):
+        for r, sp in [((0, 0, 300, 120), (0, 0)), ((10, 5, 280, 100), (3, 9)), ((-5, -5, 400, 400), (0, 0))]:
+            d0 = rgba_frames(1, 300, 120, seed=4, opaque=False)[0]
+            want = oracle.draw(d0.copy(), r, src, sp, op)
+            got = ctx.draw(d0.copy(), r, src, sp, op)
+            np.testing.assert_array_equal(got, want)
+    frame = rgba_frames(1, 640, 360, seed=5)[0]
+    for pos in ("bottom-right", "top-left", "center"):
+        gl = text_glyphs(640, 360, position=pos)
+        gl.append({"mask": gl[0]["mask"], "dr": (630, 350, 660, 380), "mp": (2, 1)})   # clipped by the frame
+        gl.append({"mask": gl[1]["mask"], "dr": (-4, -6, 12, 20), "mp": (0, 0)})
+        for col in (DEFAULT_COL, (0, 0, 0, 127), (200, 10, 90, 255)):
+            want = oracle.composite_glyphs(frame.copy(), gl, col)
+            got = ctx.composite_glyphs(frame.copy(), gl, col)
+            np.testing.assert_array_equal(got, want)
+
+
+# ---- the fused batched path (band kernel) vs the oracle -----------------------------------------------
+
+PLAN_CASES = [
+    # sw, sh, n, resize, thumbnail, env
+    (1920, 1080, 2, (1024, 768, False), (200, True), {}),
+    (1920, 1080, 1, (1024, 768, True), (200, True), {}),
+    (1920, 1080, 1, (1024, 768, True), (200, False), {"IPX_BLK_COLS": "512"}),
+    (640, 480, 3, (1024, 768, True), (200, True), {}),
+    (854, 480, 2, (1024, 768, True), (200, True), {}),                  # rows not 16-byte aligned
+    (1080, 1920, 1, (1024, 768, True), (200, True), {"IPX_BAND_ROWS": "5"}),
+    (3840, 2160, 1, (1024, 768, False), (200, True), {}),
+    (333, 500, 2, (1024, 768, True), (64, True), {"IPX_BLK_COLS": "64", "IPX_BAND_ROWS": "3"}),
+    (200, 200, 1, (200, 200, False), (200, True), {}),                  # scale 1: reference takes Copy
+    (1280, 720, 2, (100, 30, False), (200, False), {"IPX_BAND_ROWS": "16"}),
+    (37, 23, 2, (64, 64, True), (10, True), {}),
+    (7680, 4320, 1, (1024, 768, True), (200, True), {}),
+]
+
+
+@pytest.mark.parametrize("case", PLAN_CASES, ids=lambda c: "%dx%dx%d" % c[:3])
+def test_plan_vs_oracle(ctx, case, monkeypatch):
+    sw, sh, n, resize, thumb, env = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    frames = rgba_frames(n, sw, sh, seed=sw + sh)
+    glyphs = text_glyphs(sw, sh)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(sw, sh, resize=resize, thumbnail=thumb, watermark=gs)
+    got = plan.run_host(frames)
+    for i in range(n):
+        want = oracle.process(frames[i], resize=resize, thumb=thumb, glyphs=glyphs, col=DEFAULT_COL)
+        for k in ("resize", "thumbnail", "watermark"):
+            np.testing.assert_array_equal(got[k][i], want[k], err_msg="%s frame %d" % (k, i))
+    plan.close()
+    gs.close()
+
+
+def test_plan_subsets_and_unfused(ctx, monkeypatch):
+    frames = rgba_frames(2, 320, 200, seed=9, opaque=False)
+    glyphs = text_glyphs(320, 200, n=6, width_px=120, height_px=30)
+    gs = ctx.glyphset(glyphs, (10, 20, 30, 200))
+    want = [oracle.process(f, resize=(100, 100, True), thumb=(50, True), glyphs=glyphs, col=(10, 20, 30, 200))
+            for f in frames]
+    for env in ({}, {"IPX_NO_FUSE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for kw in (dict(resize=(100, 100, True), thumbnail=None, watermark=None),
+                   dict(resize=None, thumbnail=(50, True), watermark=None),
+                   dict(resize=None, thumbnail=None, watermark=gs),
+                   dict(resize=(100, 100, True), thumbnail=(50, True), watermark=gs),
+                   dict(resize=None, thumbnail=None, watermark=True)):
+            plan = ctx.plan(320, 200, **kw)
+            got = plan.run_host(frames)
+            for i in range(2):
+                for k, v in got.items():
+                    exp = want[i][k] if not (k == "watermark" and kw["watermark"] is True) else frames[i]
+                    np.testing.assert_array_equal(v[i], exp, err_msg="%s %s" % (k, kw))
+            plan.close()
+    gs.close()
+
+
+def test_one_pixel_wide_source_takes_unfused_path(ctx):
+    frames = rgba_frames(2, 1, 40, seed=11, opaque=False)
+    plan = ctx.plan(1, 40, resize=(8, 8, False), thumbnail=(4, True), watermark=True)
+    got = plan.run_host(frames)
+    for i in range(2):
+        want = oracle.process(frames[i], resize=(8, 8, False), thumb=(4, True))
+        for k in ("resize", "thumbnail", "watermark"):
+            np.testing.assert_array_equal(got[k][i], want[k])
+
+
+# ---- BASELINE-size batch: size-independent properties + sampled frames vs the oracle ----------------
+
+def test_full_size_batch_properties(ctx):
+    n, sw, sh = 64, 1920, 1080
+    rng = np.random.default_rng(1)
+    frames = rgba_frames(n, sw, sh, seed=21)
+    frames[0][...] = 173            # constant frame: every scaled output equals the constant (K1)
+    glyphs = text_glyphs(sw, sh)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(sw, sh, resize=(1024, 768, False), thumbnail=(200, True), watermark=gs)
+    assert plan.info.algorithmic_bytes == 19894528
+    src = ctx.alloc(frames.nbytes).upload(frames)
+    i = plan.info
+    res, th, wm = ctx.alloc(n * i.resize_bytes), ctx.alloc(n * i.thumb_bytes), ctx.alloc(n * i.wm_bytes)
+    plan.run_dev(n, src.ptr, res.ptr, th.ptr, wm.ptr)
+    ctx.sync()
+    r = res.download((n, 768, 1024, 4))
+    t = th.download((n, 200, 200, 4))
+    w = wm.download((n, sh, sw, 4))
+    assert (r[0] == 173).all() and (t[0] == 173).all()
+    # the watermark frame is the source outside the glyph boxes, in every frame
+    box = np.zeros((sh, sw), bool)
+    for g in glyphs:
+        x0, y0, x1, y1 = g["dr"]
+        box[max(y0, 0):y1, max(x0, 0):x1] = True
+    assert (w[:, ~box] == frames[:, ~box]).all()
+    # opaque sources give opaque outputs
+    assert (r[1:, ..., 3] == 255).all() and (t[1:, ..., 3] == 255).all()
+    # running the batch again is idempotent (no state carried between launches)
+    plan.run_dev(n, src.ptr, res.ptr, th.ptr, wm.ptr)
+    ctx.sync()
+    assert (res.download((n, 768, 1024, 4)) == r).all()
+    # sampled frames, bit for bit against the oracle
+    for k in (0, 1, int(rng.integers(2, n)), n - 1):
+        want = oracle.process(frames[k], resize=(1024, 768, False), thumb=(200, True), glyphs=glyphs,
+                              col=DEFAULT_COL)
+        np.testing.assert_array_equal(r[k], want["resize"])
+        np.testing.assert_array_equal(t[k], want["thumbnail"])
+        np.testing.assert_array_equal(w[k], want["watermark"])
+    for b in (src, res, th, wm):
+        b.free()
+
+
+def test_concurrent_callers(ctx):
+    """worker.go:90-96: several goroutines share one processor; lanes=2 forces waiting."""
+    import threading
+    src = rgba_frames(1, 400, 300, seed=2)[0]
+    want = oracle.scale_bilinear(src, 123, 77)
+    errs = []
+
+    def work():
+        try:
+            for _ in range(5):
+                np.testing.assert_array_equal(ctx.scale_bilinear(src, 123, 77), want)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work) for _ in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
