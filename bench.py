@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step")
-    ap.add_argument("--workload", choices=["full", "resize", "full-keepaspect"], default="full")
+    ap.add_argument("--workload", choices=["full", "resize", "full-keepaspect", "wm"], default="full")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pool", type=int, default=32, help="distinct seeded frames tiled over the batch")
@@ -96,8 +96,9 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     sw, sh, F = args.width, args.height, args.frames
-    resize = {"full": (1024, 768, False), "resize": (1024, 768, False), "full-keepaspect": (1024, 768, True)}[args.workload]
-    thumb = None if args.workload == "resize" else (200, True)
+    resize = {"full": (1024, 768, False), "resize": (1024, 768, False), "full-keepaspect": (1024, 768, True),
+              "wm": None}[args.workload]
+    thumb = None if args.workload in ("resize", "wm") else (200, True)
     do_wm = args.workload != "resize"
 
     ctx = ipx.Context(device=local_rank % max(1, ipx.device_count()))
@@ -154,7 +155,7 @@ def main():
 
     if args.check and rank == 0:
         import oracle
-        want = oracle.process(pool[0], resize=resize, thumb=thumb or (1, False), glyphs=glyphs, col=DEFAULT_COL,
+        want = oracle.process(pool[0], resize=resize or (1, 1, False), thumb=thumb or (1, False), glyphs=glyphs, col=DEFAULT_COL,
                               want=[k for k, b in (("resize", res), ("thumbnail", th), ("watermark", wm)) if b])
         if res:
             assert np.array_equal(res.download((info.resize_h, info.resize_w, 4)), want["resize"])
@@ -194,7 +195,8 @@ def main():
             "config": {"workload": "%d x %dx%d RGBA8, %s" % (F, sw, sh, {
                 "full": "full pipeline: resize 1024x768 (keep_aspect=false) + thumbnail 200 crop + watermark 16 glyphs",
                 "resize": "resize to 1024x768 only",
-                "full-keepaspect": "full pipeline, product-default keep_aspect=true (1024x576)"}[args.workload]),
+                "full-keepaspect": "full pipeline, product-default keep_aspect=true (1024x576)",
+                "wm": "watermark only (copy + 16 glyphs)"}[args.workload]),
                 "frames_per_gpu": F, "sharding": "independent frames, round-robin by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -1,0 +1,554 @@
+// ipx_band.hip -- the fused band kernels: one pass over each source frame produces the watermark
+// frame (copy + glyph composite) and every scaled output (resize, thumbnail).
+//
+// Reference semantics: every operator of image_processor.go:64-65 reads the ORIGINAL decoded
+// frame, so resizeImage (resize.go:121-125), cropAndResize (thumbnail.go:114-132) and the
+// draw.Draw + DrawString of addTextWatermark (watermark.go:90-92,151) are independent functions of
+// one source and can share its single trip through HBM.
+//
+// Decomposition: a work item is source rows [r0, r1) x columns [c0, c1) of one frame.  For it
+//   1. those pixels plus one halo row and one halo column go to LDS with 16-byte coalesced row
+//      loads, and the owned pixels go to the watermark frame on the way;
+//   2. every destination pixel of each scaled output whose tap pair STARTS inside the owned block
+//      (its second row / column is at most the halo) is produced from LDS;
+//   3. where the block meets the text box, the glyphs are composited over the block's pixels (from
+//      LDS) and those watermark pixels written (step 1 skipped them).
+// Which destination rows / columns start in which block, and the taps themselves, are tabulated on
+// the host with the reference's float64 arithmetic (ipx_runtime.hip, build_axis_taps).
+//
+// Two kernels share these steps:
+//   band_pipe_kernel  persistent: a workgroup walks a contiguous run of items and keeps the NEXT
+//                     item's tile in flight (global -> registers) while it computes the current one
+//                     from LDS, so HBM never idles behind the float64 lerp.  Needs 16-byte aligned
+//                     rows.  This is the throughput path.
+//   band_kernel       one workgroup per item, any alignment or width; the fallback.
+//
+// Bound: HBM.  Per 1080p frame 8.29 MB in, 11.6 MB out; the lerp is ~0.1 flop/B.
+//
+// Code-shape rule used throughout: NO global load or store sits under a lane-divergent condition.
+// hipcc (ROCm 7.2) ends such a branch with s_waitcnt vmcnt(0), which serialises a wave's memory
+// operations (measured: a tile copy drops from 5.9 to 3.5 TB/s).  Frames are addressed through
+// buffer descriptors instead and an idle lane gets an out-of-range offset (load returns 0, store
+// is dropped), so the instruction stream is straight-line and vmcnt can be counted.
+#include <algorithm>
+
+#include "ipx_internal.h"
+
+#pragma clang fp contract(off)
+
+#include "ipx_device.h"
+
+namespace ipx {
+
+namespace {
+
+constexpr int kYChunk = 64;  // destination rows whose y taps sit in LDS at a time
+constexpr int kLoadU = 4;    // 16-byte loads in flight per lane in band_kernel's phase 1
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+constexpr int kOOB = 0x7fffffff;  // a byte offset beyond any frame
+
+// Exact lerp for dyadic weights: x0+x1 = 2^kx, y0+y1 = 2^ky (small integers held in floats), taps
+// as plain bytes.  sum = y0*(x0*t00 + x1*t10) + y1*(x0*t01 + x1*t11) < 2^(8+kx+ky) <= 2^24, so fp32
+// (fused or not) is exact; the reference's float64 value is 257*sum / 2^(kx+ky), truncated, >> 8.
+// sh = kx + ky + 8.
+__device__ __forceinline__ uint32_t lerp_dyadic(uint32_t p00, uint32_t p10, uint32_t p01,
+                                                uint32_t p11, float x0, float x1, float y0, float y1,
+                                                int sh)
+{
+    const v2f X0 = {x0, x0}, X1 = {x1, x1}, Y0 = {y0, y0}, Y1 = {y1, y1};
+    auto lo = [](uint32_t p) { return v2f{(float)(p & 0xffu), (float)((p >> 8) & 0xffu)}; };
+    auto hi = [](uint32_t p) { return v2f{(float)((p >> 16) & 0xffu), (float)(p >> 24)}; };
+    const v2f top_l = __builtin_elementwise_fma(X1, lo(p10), X0 * lo(p00));
+    const v2f bot_l = __builtin_elementwise_fma(X1, lo(p11), X0 * lo(p01));
+    const v2f top_h = __builtin_elementwise_fma(X1, hi(p10), X0 * hi(p00));
+    const v2f bot_h = __builtin_elementwise_fma(X1, hi(p11), X0 * hi(p01));
+    const v2f vl = __builtin_elementwise_fma(Y1, bot_l, Y0 * top_l);
+    const v2f vh = __builtin_elementwise_fma(Y1, bot_h, Y0 * top_h);
+    const uint32_t r = (uint32_t)vl.x, g = (uint32_t)vl.y, b = (uint32_t)vh.x, a = (uint32_t)vh.y;
+    return ((r * 257u) >> sh) | (((g * 257u) >> sh) << 8) | (((b * 257u) >> sh) << 16) |
+           (((a * 257u) >> sh) << 24);
+}
+
+__device__ __forceinline__ uint32_t lds_u32(const uint8_t *lds, int off)
+{
+    return *(const uint32_t *)(lds + off);
+}
+
+// the part of an AxisTap a thread keeps in registers for its destination column
+struct XTap {
+    double w0, w1;
+    float f0, f1;
+    int base;
+};
+
+struct Tile {
+    int r0, r1, c0, c1;          // owned rows / columns
+    int rows_ld, cols_ld;        // with the halo row / column
+    int own_rows, own_cols, pitch, nchunk;
+};
+
+__device__ __forceinline__ Tile make_tile(const BandArgs &a, int b, int cb)
+{
+    Tile t;
+    t.r0 = b * a.band_rows;
+    t.r1 = min(t.r0 + a.band_rows, a.sh);
+    t.c0 = cb * a.blk_cols;
+    t.c1 = min(t.c0 + a.blk_cols, a.sw);
+    t.rows_ld = min(t.r1 + 1, a.sh) - t.r0;
+    t.cols_ld = min(t.c1 + 1, a.sw) - t.c0;
+    t.pitch = (a.blk_cols + 4) * 4;                // LDS bytes per tile row
+    t.nchunk = (t.cols_ld + 3) >> 2;               // 16-byte chunks per tile row
+    t.own_rows = t.r1 - t.r0;
+    t.own_cols = t.c1 - t.c0;
+    return t;
+}
+
+__device__ __forceinline__ bool chunk_in_textbox(const BandArgs &a, int x, int y)
+{
+    return y >= a.gbox.y0 && y < a.gbox.y1 && x + 4 > a.gbox.x0 && x < a.gbox.x1;
+}
+
+// x taps of column block cb for this thread: destination columns dxA + tid + 256*i.
+// (a.sc[1] mirrors a.sc[0] when only one output is scaled, so both loads are always legal.)
+template <int NX>
+__device__ __forceinline__ void load_xtaps(const BandArgs &a, int cb, int tid, XTap (&tx)[2][NX],
+                                           int (&dxA)[2], int (&dxB)[2])
+{
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const ScaleOut &S = a.sc[k];
+        dxA[k] = S.col_begin[cb];
+        dxB[k] = k < a.nscale ? S.col_begin[cb + 1] : dxA[k];
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            const AxisTap xt = S.xt[min(dxA[k] + tid + 256 * i, S.dw - 1)];
+            tx[k][i].w0 = xt.w0; tx[k][i].w1 = xt.w1; tx[k][i].f0 = xt.f0; tx[k][i].f1 = xt.f1;
+            tx[k][i].base = xt.base;
+        }
+    }
+}
+
+// Step 3: glyph composite over the block's share of the text box, source pixels from LDS.
+__device__ __forceinline__ void glyph_phase(const BandArgs &a, const Tile &t, uint8_t *wframe,
+                                            const uint8_t *lds, int tid)
+{
+    const int gy0 = max(a.gbox.y0, t.r0), gy1 = min(a.gbox.y1, t.r1);
+    const int gx0 = max(a.gbox.x0 & ~3, t.c0), gx1 = min((a.gbox.x1 + 3) & ~3, t.c1);  // whole skipped chunks
+    const int gw = gx1 - gx0, gn = gw * (gy1 - gy0);
+    for (int i = tid; i < gn; i += 256) {
+        const int yy = i / gw, x = gx0 + (i - yy * gw), y = gy0 + yy;
+        uint32_t d = lds_u32(lds, (y - t.r0) * t.pitch + (x - t.c0) * 4);
+        d = glyph_run(d, x, y, a.glyphs, a.nglyphs, a.cr, a.cg, a.cb, a.ca);
+        *(uint32_t *)(wframe + (size_t)y * a.wm_stride + (size_t)x * 4) = d;
+    }
+}
+
+__device__ __forceinline__ bool tile_meets_textbox(const BandArgs &a, const Tile &t)
+{
+    return t.r0 < a.gbox.y1 && t.r1 > a.gbox.y0 && t.c0 < a.gbox.x1 && t.c1 > a.gbox.x0;
+}
+
+// Step 2: scaled outputs from the LDS tile.  Global memory is touched with stores only: on gfx9
+// loads and stores share vmcnt in issue order, and a load in here would wait for every pixel store
+// before it.  The y taps of the block's destination rows sit in LDS (wave-uniform reads).
+template <int NX>
+__device__ __forceinline__ void scale_phase(const BandArgs &a, const Tile &t, int f, const uint8_t *lds,
+                                            AxisTap *ytap, int tid, const XTap (&tx)[2][NX],
+                                            const int (&dxA)[2], const int (&dxB)[2],
+                                            const int (&dyA)[2], const int (&dyB)[2])
+{
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (k >= a.nscale || dyA[k] >= dyB[k]) continue;
+        const ScaleOut &S = a.sc[k];
+        uint8_t *oframe = S.out + (size_t)f * S.frame_stride;
+        const int ybias = S.sr_y0 - t.r0, xbias = S.sr_x0 - t.c0;
+        for (int chunk = dyA[k]; chunk < dyB[k]; chunk += kYChunk) {
+            const int rows = min(kYChunk, dyB[k] - chunk);
+            if (chunk != dyA[k]) {  // more destination rows than one chunk: refill the y taps
+                __syncthreads();
+                ytap[k * kYChunk + (tid & (kYChunk - 1))] = S.yt[min(chunk + (tid & (kYChunk - 1)), S.dh - 1)];
+                __syncthreads();
+            }
+            const AxisTap *yt = ytap + k * kYChunk;
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                const int dx = dxA[k] + tid + 256 * i;
+                if (dx >= dxB[k]) continue;
+                const XTap &X = tx[k][i];
+                const int lx = (xbias + X.base) * 4;
+                uint32_t *op = (uint32_t *)(oframe + (size_t)chunk * S.ostride + (size_t)dx * 4);
+                if (S.dyadic_shift >= 0) {
+                    // both axes dyadic: every product and sum is exact in fp32 (8 + kx + ky <= 24
+                    // bits) and 257 * sum / 2^(kx+ky) is the reference's float64 value
+                    const int sh = S.dyadic_shift + 8;
+                    for (int r = 0; r < rows; r++, op = (uint32_t *)((uint8_t *)op + S.ostride)) {
+                        const int ybase = yt[r].base;
+                        const float yf0 = yt[r].f0, yf1 = yt[r].f1;
+                        const int off = (ybias + ybase) * t.pitch + lx;
+                        const uint32_t p00 = lds_u32(lds, off), p10 = lds_u32(lds, off + 4);
+                        const uint32_t p01 = lds_u32(lds, off + t.pitch), p11 = lds_u32(lds, off + t.pitch + 4);
+                        *op = lerp_dyadic(p00, p10, p01, p11, X.f0, X.f1, yf0, yf1, sh);
+                    }
+                } else {
+                    for (int r = 0; r < rows; r++, op = (uint32_t *)((uint8_t *)op + S.ostride)) {
+                        const int ybase = yt[r].base;
+                        const double yw0 = yt[r].w0, yw1 = yt[r].w1;
+                        const int off = (ybias + ybase) * t.pitch + lx;
+                        const uint32_t p00 = lds_u32(lds, off), p10 = lds_u32(lds, off + 4);
+                        const uint32_t p01 = lds_u32(lds, off + t.pitch), p11 = lds_u32(lds, off + t.pitch + 4);
+                        const uint32_t pr = lerp_channel<0>(p00, p10, p01, p11, X.w0, X.w1, yw0, yw1);
+                        const uint32_t pg = lerp_channel<1>(p00, p10, p01, p11, X.w0, X.w1, yw0, yw1);
+                        const uint32_t pb = lerp_channel<2>(p00, p10, p01, p11, X.w0, X.w1, yw0, yw1);
+                        const uint32_t pa = lerp_channel<3>(p00, p10, p01, p11, X.w0, X.w1, yw0, yw1);
+                        *op = pack_src(pr, pg, pb, pa);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// band_kernel: one workgroup per item.  Step 1 here: wave w takes tile rows w, w+4, ...; a "slot"
+// is one 1 KiB wave-load (64 lanes x 16 B) of such a row; kLoadU slots are issued back to back
+// before any is consumed.  FAST: 16-byte aligned rows and a frame width that is a multiple of 4.
+// ---------------------------------------------------------------------------------------------
+template <bool FAST>
+__device__ __forceinline__ void stage_tile(const BandArgs &a, const Tile &t, const uint8_t *sframe,
+                                           uint8_t *wframe, uint8_t *lds, int lane, int wave,
+                                           bool any_glyph)
+{
+    const int frame_bytes = (a.sh - 1) * a.sstride + a.sw * 4;
+    const int wm_bytes = wframe ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)sframe, 0, frame_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wframe, 0, wm_bytes, 0x00020000);
+    const int cpl = (t.nchunk + 63) >> 6;                 // slots per row
+    const int nrow_w = (t.rows_ld - wave + 3) >> 2;       // rows of this wave (may be <= 0)
+    int ri = 0, ci = 0;
+    while (ri < nrow_w) {
+        v4u v[kLoadU];
+        int rr[kLoadU], cc[kLoadU];
+#pragma unroll
+        for (int u = 0; u < kLoadU; u++) {
+            rr[u] = ri; cc[u] = ci;
+            const int ry = wave + 4 * ri;
+            const int px = (ci * 64 + lane) * 4;
+            const bool ok = ry < t.rows_ld && px < t.cols_ld;
+            const int off = (t.r0 + ry) * a.sstride + (t.c0 + px) * 4;
+            if (FAST) {
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(srs, ok ? off : kOOB, 0, 0);
+            } else {
+                v[u].x = __builtin_amdgcn_raw_buffer_load_b32(srs, ok ? off : kOOB, 0, 0);
+                v[u].y = __builtin_amdgcn_raw_buffer_load_b32(srs, ok && px + 1 < t.cols_ld ? off + 4 : kOOB, 0, 0);
+                v[u].z = __builtin_amdgcn_raw_buffer_load_b32(srs, ok && px + 2 < t.cols_ld ? off + 8 : kOOB, 0, 0);
+                v[u].w = __builtin_amdgcn_raw_buffer_load_b32(srs, ok && px + 3 < t.cols_ld ? off + 12 : kOOB, 0, 0);
+            }
+            if (++ci == cpl) { ci = 0; ++ri; }
+        }
+#pragma unroll
+        for (int u = 0; u < kLoadU; u++) {
+            const int ry = wave + 4 * rr[u];
+            const int px = (cc[u] * 64 + lane) * 4;
+            const bool ok = ry < t.rows_ld && px < t.cols_ld;
+            const int y = t.r0 + ry, x = t.c0 + px;
+            if (ok) *(v4u *)(lds + ry * t.pitch + px * 4) = v[u];
+            // owned pixels go to the watermark frame, except chunks that meet the text box: those
+            // are written by the composite step
+            bool w = ok && wframe && ry < t.own_rows && px < t.own_cols;
+            if (any_glyph && chunk_in_textbox(a, x, y)) w = false;
+            const int woff = y * a.wm_stride + x * 4;
+            if (FAST) {
+                __builtin_amdgcn_raw_buffer_store_b128(v[u], wrs, w ? woff : kOOB, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(v[u].x, wrs, w ? woff : kOOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(v[u].y, wrs, w && px + 1 < t.own_cols ? woff + 4 : kOOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(v[u].z, wrs, w && px + 2 < t.own_cols ? woff + 8 : kOOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(v[u].w, wrs, w && px + 3 < t.own_cols ? woff + 12 : kOOB, 0, 0);
+            }
+        }
+    }
+}
+
+template <int NX>
+__global__ __launch_bounds__(256) void band_kernel(BandArgs a)
+{
+    extern __shared__ uint4 lds_raw[];
+    uint8_t *lds = (uint8_t *)lds_raw;
+
+    // XCD-aware order: workgroups that share blockIdx % 8 share an XCD (and its L2); give each XCD
+    // a contiguous run of (frame, band) blocks so a band's halo row is the neighbour's L2 line.
+    const int per_frame = a.nbands * a.ncolblk;
+    const int total = per_frame * a.nframes;
+    int bid = blockIdx.x;
+    {
+        const int per_xcd = total >> 3;
+        const int body = per_xcd << 3;
+        if (bid < body) bid = (bid & 7) * per_xcd + (bid >> 3);
+    }
+    const int f = bid / per_frame;
+    const int rem = bid - f * per_frame;
+    const int b = rem / a.ncolblk;
+    const int cb = rem - b * a.ncolblk;
+
+    const int tid = threadIdx.x;
+    const Tile t = make_tile(a, b, cb);
+
+    // taps first: the oldest loads of the wave, so nothing later waits behind a store
+    AxisTap *ytap = (AxisTap *)(lds + (a.band_rows + 1) * t.pitch);  // [2][kYChunk]
+    int dyA[2] = {0, 0}, dyB[2] = {0, 0}, dxA[2] = {0, 0}, dxB[2] = {0, 0};
+    XTap tx[2][NX];
+    v4u ty_stage[2][2];  // an AxisTap as two 16-byte words
+    if (a.nscale > 0) {
+        load_xtaps<NX>(a, cb, tid, tx, dxA, dxB);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const ScaleOut &S = a.sc[k];
+            dyA[k] = S.row_begin[b];
+            dyB[k] = k < a.nscale ? S.row_begin[b + 1] : dyA[k];
+            const v4u *yp = (const v4u *)&S.yt[min(dyA[k] + tid, S.dh - 1)];
+            ty_stage[k][0] = yp[0]; ty_stage[k][1] = yp[1];
+        }
+    }
+
+    const uint8_t *sframe = a.src + (size_t)f * a.src_frame_stride;
+    uint8_t *wframe = a.wm ? a.wm + (size_t)f * a.wm_frame_stride : nullptr;
+    const bool any_glyph = a.nglyphs > 0 && wframe;
+    const bool fast = (a.sw & 3) == 0 && ((((uintptr_t)sframe) | (uintptr_t)a.sstride) & 15) == 0 &&
+                      (!wframe || ((((uintptr_t)wframe) | (uintptr_t)a.wm_stride) & 15) == 0);
+
+    if (fast) stage_tile<true>(a, t, sframe, wframe, lds, tid & 63, tid >> 6, any_glyph);
+    else stage_tile<false>(a, t, sframe, wframe, lds, tid & 63, tid >> 6, any_glyph);
+
+    const bool glyph_tile = any_glyph && tile_meets_textbox(a, t);
+    if (a.nscale == 0 && !glyph_tile) return;
+    if (a.nscale > 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (tid < min(dyB[k] - dyA[k], kYChunk)) {
+                v4u *yl = (v4u *)&ytap[k * kYChunk + tid];
+                yl[0] = ty_stage[k][0]; yl[1] = ty_stage[k][1];
+            }
+    }
+    __syncthreads();
+    // the composite goes first so that its few loads are not queued behind the pixel stores
+    if (glyph_tile) glyph_phase(a, t, wframe, lds, tid);
+    if (a.nscale > 0) scale_phase<NX>(a, t, f, lds, ytap, tid, tx, dxA, dxB, dyA, dyB);
+}
+
+// ---------------------------------------------------------------------------------------------
+// band_pipe_kernel: persistent, software-pipelined.  Items are ordered (column block, frame, band)
+// and each workgroup walks a contiguous run of them, so consecutive items are consecutive bands of
+// one frame (the halo row of one is the first row of the next: an L2 hit) and the x taps rarely
+// change.  Per item:
+//     A  the staged tile (registers, loaded during the previous item's compute) -> LDS, and the
+//        owned chunks -> watermark frame;                                   barrier
+//     B  issue the NEXT item's tile loads into the same registers (S x 16 B per thread in flight)
+//     C  composite + scale the current item from LDS, pixel stores;         barrier
+// The tile is spread over the workgroup as a flat list of 16-byte chunks: thread t holds chunks
+// t, t+256, ... (S of them), each mapped to (row, chunk-in-row) with a multiply-high division.
+// ---------------------------------------------------------------------------------------------
+struct Item {
+    int f, b, cb;
+    Tile t;
+    int nq;            // chunks of the tile (0 = no item: every offset out of range)
+    uint32_t magic;    // ceil(2^32 / nchunk): q / nchunk == umulhi(q, magic) for q < 2^16
+    int dyA[2], dyB[2];
+};
+
+__device__ __forceinline__ void item_setup(const BandArgs &a, Item &it, bool valid)
+{
+    it.t = make_tile(a, it.b, it.cb);
+    it.nq = valid ? it.t.rows_ld * it.t.nchunk : 0;
+    it.magic = 0xffffffffu / (uint32_t)it.t.nchunk + 1u;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        it.dyA[k] = a.nscale > 0 ? a.sc[k].row_begin[it.b] : 0;
+        it.dyB[k] = valid && k < a.nscale ? a.sc[k].row_begin[it.b + 1] : it.dyA[k];
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, int tid, v4u (&stage)[S],
+                                           v4u (&ty_stage)[2][2])
+{
+    const int frame_bytes = (a.sh - 1) * a.sstride + a.sw * 4;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.src + (size_t)it.f * a.src_frame_stride), 0, frame_bytes, 0x00020000);
+    const int base = it.t.r0 * a.sstride + it.t.c0 * 4;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const int q = tid + 256 * s;
+        const int row = (int)__umulhi((uint32_t)q, it.magic);
+        const int ch = q - row * it.t.nchunk;
+        stage[s] = __builtin_amdgcn_raw_buffer_load_b128(srs, q < it.nq ? base + row * a.sstride + ch * 16 : kOOB, 0, 0);
+    }
+    if (a.nscale > 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const v4u *yp = (const v4u *)&a.sc[k].yt[min(it.dyA[k] + tid, a.sc[k].dh - 1)];
+            ty_stage[k][0] = yp[0]; ty_stage[k][1] = yp[1];
+        }
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, int tid, const v4u (&stage)[S],
+                                           const v4u (&ty_stage)[2][2], uint8_t *lds, AxisTap *ytap,
+                                           bool any_glyph)
+{
+    uint8_t *wframe = a.wm ? a.wm + (size_t)it.f * a.wm_frame_stride : nullptr;
+    const int wm_bytes = wframe ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wframe, 0, wm_bytes, 0x00020000);
+    const int wbase = it.t.r0 * a.wm_stride + it.t.c0 * 4;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const int q = tid + 256 * s;
+        const int row = (int)__umulhi((uint32_t)q, it.magic);
+        const int ch = q - row * it.t.nchunk;
+        const bool ok = q < it.nq;
+        if (ok) *(v4u *)(lds + row * it.t.pitch + ch * 16) = stage[s];
+        bool w = ok && wframe && row < it.t.own_rows && ch * 4 < it.t.own_cols;
+        if (any_glyph && chunk_in_textbox(a, it.t.c0 + ch * 4, it.t.r0 + row)) w = false;
+        __builtin_amdgcn_raw_buffer_store_b128(stage[s], wrs, w ? wbase + row * a.wm_stride + ch * 16 : kOOB, 0, 0);
+    }
+    if (a.nscale > 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (tid < min(it.dyB[k] - it.dyA[k], kYChunk)) {
+                v4u *yl = (v4u *)&ytap[k * kYChunk + tid];
+                yl[0] = ty_stage[k][0]; yl[1] = ty_stage[k][1];
+            }
+    }
+}
+
+template <int NX, int S>
+__global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
+{
+    extern __shared__ uint4 lds_raw[];
+    uint8_t *lds = (uint8_t *)lds_raw;
+    const int tid = threadIdx.x;
+
+    const int per_cb = a.nframes * a.nbands;
+    const int items = per_cb * a.ncolblk;
+    const int per = (items + (int)gridDim.x - 1) / (int)gridDim.x;
+    int idx = blockIdx.x * per;
+    const int idx_end = min(items, idx + per);
+    if (idx >= idx_end) return;
+
+    AxisTap *ytap = (AxisTap *)(lds + (a.band_rows + 1) * ((a.blk_cols + 4) * 4));  // [2][kYChunk]
+    const bool any_glyph = a.nglyphs > 0 && a.wm;
+
+    Item cur;
+    cur.cb = idx / per_cb;
+    cur.f = (idx - cur.cb * per_cb) / a.nbands;
+    cur.b = idx - cur.cb * per_cb - cur.f * a.nbands;
+    item_setup(a, cur, true);
+
+    XTap tx[2][NX];
+    int dxA[2] = {0, 0}, dxB[2] = {0, 0};
+    if (a.nscale > 0) load_xtaps<NX>(a, cur.cb, tid, tx, dxA, dxB);
+
+    v4u stage[S];
+    v4u ty_stage[2][2];
+    issue_tile<S>(a, cur, tid, stage, ty_stage);
+
+    for (;;) {
+        // A: staged tile -> LDS (+ watermark copy)
+        drain_tile<S>(a, cur, tid, stage, ty_stage, lds, ytap, any_glyph);
+        __syncthreads();
+
+        // B: the next item's loads go out now and land while C computes.  Past the end of the run
+        // the "item" has no chunks: the same loads are issued with out-of-range offsets, which
+        // keeps this block free of branches around memory operations.
+        Item nxt;
+        nxt.b = cur.b + 1; nxt.f = cur.f; nxt.cb = cur.cb;
+        if (nxt.b == a.nbands) { nxt.b = 0; if (++nxt.f == a.nframes) { nxt.f = 0; ++nxt.cb; } }
+        const bool has_next = idx + 1 < idx_end;
+        if (!has_next) { nxt.b = cur.b; nxt.f = cur.f; nxt.cb = cur.cb; }
+        item_setup(a, nxt, has_next);
+        issue_tile<S>(a, nxt, tid, stage, ty_stage);
+
+        // C: the current item from LDS
+        if (any_glyph && tile_meets_textbox(a, cur.t))
+            glyph_phase(a, cur.t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
+        if (a.nscale > 0) scale_phase<NX>(a, cur.t, cur.f, lds, ytap, tid, tx, dxA, dxB, cur.dyA, cur.dyB);
+        __syncthreads();
+
+        if (!has_next) break;
+        if (nxt.cb != cur.cb && a.nscale > 0) load_xtaps<NX>(a, nxt.cb, tid, tx, dxA, dxB);
+        cur = nxt;
+        ++idx;
+    }
+}
+
+template <int NX>
+hipError_t launch_nx(const BandArgs &a, unsigned total, size_t lds, hipStream_t s)
+{
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)band_kernel<NX>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(band_kernel<NX>, dim3(total), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int NX, int S>
+hipError_t launch_pipe(const BandArgs &a, unsigned grid, size_t lds, hipStream_t s)
+{
+    static thread_local size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)band_pipe_kernel<NX, S>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL((band_pipe_kernel<NX, S>), dim3(grid), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int NX>
+hipError_t launch_pipe_s(const BandArgs &a, int slots, unsigned grid, size_t lds, hipStream_t s)
+{
+    if (slots <= 5) return launch_pipe<NX, 5>(a, grid, lds, s);
+    if (slots <= 9) return launch_pipe<NX, 9>(a, grid, lds, s);
+    if (slots <= 13) return launch_pipe<NX, 13>(a, grid, lds, s);
+    return launch_pipe<NX, kPipeMaxSlots>(a, grid, lds, s);
+}
+
+}  // namespace
+
+size_t band_lds_bytes(int band_rows, int blk_cols)
+{
+    return (size_t)(band_rows + 1) * (size_t)(blk_cols + 4) * 4 + 2 * kYChunk * sizeof(AxisTap);
+}
+
+int band_tile_slots(int band_rows, int blk_cols)
+{
+    return ((band_rows + 1) * (blk_cols / 4 + 1) + 255) / 256;
+}
+
+hipError_t launch_band(const BandArgs &a, hipStream_t s)
+{
+    const long long total = (long long)a.nbands * a.ncolblk * a.nframes;
+    if (total <= 0) return hipSuccess;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    const size_t lds = band_lds_bytes(a.band_rows, a.blk_cols);
+    if (a.pipe_grid > 0) {
+        const int slots = band_tile_slots(a.band_rows, a.blk_cols);
+        const unsigned grid = (unsigned)std::min<long long>(total, a.pipe_grid);
+        if (a.nx <= 1) return launch_pipe_s<1>(a, slots, grid, lds, s);
+        if (a.nx <= 2) return launch_pipe_s<2>(a, slots, grid, lds, s);
+        return launch_pipe_s<kBandNX>(a, slots, grid, lds, s);
+    }
+    if (a.nx <= 1) return launch_nx<1>(a, (unsigned)total, lds, s);
+    if (a.nx <= 2) return launch_nx<2>(a, (unsigned)total, lds, s);
+    return launch_nx<kBandNX>(a, (unsigned)total, lds, s);
+}
+
+}  // namespace ipx

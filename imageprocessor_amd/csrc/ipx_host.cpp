@@ -62,7 +62,7 @@ void build_axis_taps(int src_extent, int dst_extent, int d_begin, int d_end, Axi
         double f0 = s - (double)s0;
         double f1 = 1 - f0;
         AxisTap t;
-        t.pad = 0;
+        t.pad = 0; t.f0 = 0; t.f1 = 0;
         if (s < 0) {                 // both taps index 0, weights (1, 0)
             t.base = 0; t.w0 = 1; t.w1 = 0;
         } else if (s0 + 1 > last) {  // both taps index last, weights (0, 1)
@@ -72,6 +72,25 @@ void build_axis_taps(int src_extent, int dst_extent, int d_begin, int d_end, Axi
         }
         out[d - d_begin] = t;
     }
+}
+
+int axis_dyadic_bits(AxisTap *taps, int n, int max_k)
+{
+    for (int k = 0; k <= max_k; k++) {
+        const double unit = (double)(1 << k);
+        bool ok = true;
+        for (int i = 0; i < n && ok; i++) {
+            const double a = taps[i].w0 * unit, b = taps[i].w1 * unit;  // exact: power-of-two scaling
+            ok = a == std::floor(a) && b == std::floor(b) && a + b == unit && a >= 0 && b >= 0;
+        }
+        if (!ok) continue;
+        for (int i = 0; i < n; i++) {
+            taps[i].f0 = (float)(taps[i].w0 * unit);
+            taps[i].f1 = (float)(taps[i].w1 * unit);
+        }
+        return k;
+    }
+    return -1;
 }
 
 }  // namespace ipx

@@ -51,9 +51,16 @@ struct AxisTap {
     double w0;    // weight of src[base]     (xFrac1 / yFrac1 upstream)
     double w1;    // weight of src[base + 1] (xFrac0 / yFrac0 upstream)
     int32_t base;
+    float f0, f1; // w0 * 2^k, w1 * 2^k as exact small integers when the axis is dyadic (see below)
     int32_t pad;
 };
+static_assert(sizeof(AxisTap) == 32, "AxisTap is loaded as two 16-byte words");
 void build_axis_taps(int src_extent, int dst_extent, int d_begin, int d_end, AxisTap *out);
+// Smallest k <= max_k such that every weight of the axis is an exact multiple of 2^-k and each
+// pair sums to exactly 1; -1 if there is none.  On such an axis every float64 product and sum of
+// the reference's lerp is exact (weights k bits, taps 16 bits), so the result equals the rational
+// value and can be computed in narrower exact arithmetic.  Fills f0 / f1 for that k.
+int axis_dyadic_bits(AxisTap *taps, int n, int max_k);
 
 // ---- kernel launchers (ipx_kernels.hip) --------------------------------------------------------
 struct ScaleArgs {
@@ -83,6 +90,8 @@ hipError_t launch_composite(uint8_t *dst, int dstride, size_t frame_stride, int 
                             uint32_t sb, uint32_t sa, hipStream_t s);
 
 // fused band kernel (resize + thumbnail + watermark copy in one pass over the source)
+constexpr int kPipeMaxSlots = 17;  // 16-byte chunks a thread stages per tile in the pipelined kernel
+constexpr int kBandNX = 4;  // a column block holds at most 256 * kBandNX destination columns per output
 struct ScaleOut {
     uint8_t *out;              // frame 0
     size_t frame_stride;
@@ -90,6 +99,7 @@ struct ScaleOut {
     int dw, dh;
     int sr_x0, sr_y0;          // source rectangle origin
     const AxisTap *xt, *yt;    // dw / dh entries, device
+    int dyadic_shift;          // kx + ky when both axes are dyadic (exact fp32 path), else -1
     const int *row_begin;      // nbands+1 entries: first output row owned by each band
     const int *col_begin;      // ncolblk+1 entries
 };
@@ -99,6 +109,8 @@ struct BandArgs {
     int band_rows, nbands;     // owned source rows per workgroup
     int blk_cols, ncolblk;     // owned source columns per workgroup (multiple of 4)
     int nframes;
+    int nx;                    // destination columns per thread: 1, 2 or kBandNX
+    int pipe_grid;             // > 0: persistent pipelined kernel with this many workgroups
     uint8_t *wm; size_t wm_frame_stride; int wm_stride;   // NULL = no watermark copy
     int nscale;
     ScaleOut sc[2];
@@ -108,5 +120,6 @@ struct BandArgs {
 };
 hipError_t launch_band(const BandArgs &a, hipStream_t s);
 size_t band_lds_bytes(int band_rows, int blk_cols);
+int band_tile_slots(int band_rows, int blk_cols);
 
 }  // namespace ipx

@@ -29,6 +29,7 @@ struct Lane {
 
 struct ipx_ctx {
     int device = 0;
+    int cus = 256;                 // compute units of the device
     hipStream_t stream = nullptr;  // default stream for device-pointer calls
     std::vector<Lane> lanes;
     size_t lane_bytes = 0;
@@ -65,13 +66,14 @@ struct PlanScale {
     Rect sr{0, 0, 0, 0};
     AxisTap *xt = nullptr, *yt = nullptr;
     int *row_begin = nullptr, *col_begin = nullptr;
+    int dyadic_shift = -1;
 };
 
 struct ipx_plan {
     ipx_plan_params p{};
     ipx_plan_info info{};
     bool fused = false;
-    int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0;
+    int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0, nx = kBandNX;
     PlanScale sc[2];      // 0 = resize, 1 = thumbnail
     uint8_t *blob = nullptr;
     ClippedGlyphs glyphs;
@@ -288,6 +290,7 @@ int ipx_create(const ipx_config *cfg, ipx_ctx **out)
     ipx_ctx *c = new (std::nothrow) ipx_ctx;
     if (!c) { set_error("out of memory"); return IPX_ERR_NOMEM; }
     c->device = dev;
+    c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int lanes = cfg && cfg->lanes > 0 ? cfg->lanes : env_int("IPX_LANES", 3);
     c->lane_bytes = cfg && cfg->lane_bytes ? cfg->lane_bytes : (size_t)64 << 20;
     c->lanes.resize(lanes);
@@ -646,18 +649,61 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
     if (env_int("IPX_NO_FUSE", 0)) pl->fused = false;
     if (!pl->fused) { *out = pl; return IPX_OK; }
 
-    // block shape: owned columns per workgroup (multiple of 4 pixels = 16 B) and owned rows
-    const int max_cols = std::max(64, env_int("IPX_BLK_COLS", 2048));
-    const int ncb = (sw + max_cols - 1) / max_cols;
-    int bc = ((sw + ncb - 1) / ncb + 3) & ~3;
-    const size_t lds_budget = (size_t)std::max(8, env_int("IPX_LDS_KB", 72)) << 10;
-    int br = (int)(lds_budget / ((size_t)(bc + 4) * 4)) - 1;
-    br = std::max(1, std::min(br, env_int("IPX_BAND_ROWS_MAX", 16)));
-    if (env_int("IPX_BAND_ROWS", 0) > 0) br = env_int("IPX_BAND_ROWS", 0);
-    br = std::min(br, sh);
-    pl->blk_cols = bc; pl->band_rows = br;
-    pl->ncolblk = (sw + bc - 1) / bc;
-    pl->nbands = (sh + br - 1) / br;
+    // taps per axis, with the reference's float64 arithmetic; dyadic axes get the exact fp32 path
+    std::vector<AxisTap> xt[2], yt[2];
+    for (int k = 0; k < 2; k++) {
+        PlanScale &s = pl->sc[k];
+        s.dyadic_shift = -1;
+        if (!s.on || s.dw <= 0 || s.dh <= 0) continue;
+        xt[k].resize(s.dw); yt[k].resize(s.dh);
+        build_axis_taps(s.sr.dx(), s.dw, 0, s.dw, xt[k].data());
+        build_axis_taps(s.sr.dy(), s.dh, 0, s.dh, yt[k].data());
+        if (!env_int("IPX_NO_DYADIC", 0)) {
+            const int kx = axis_dyadic_bits(xt[k].data(), s.dw, 12);
+            const int ky = axis_dyadic_bits(yt[k].data(), s.dh, 12);
+            if (kx >= 0 && ky >= 0 && kx + ky <= 16) s.dyadic_shift = kx + ky;  // 8 + kx + ky <= 24 bits
+        }
+    }
+
+    // block shape: owned columns per workgroup (multiple of 4 pixels = 16 B) and owned rows; a
+    // column block may hold at most 256 * kBandNX destination columns of any scaled output
+    int max_cols = std::max(4, env_int("IPX_BLK_COLS", 2048)) & ~3;
+    const size_t lds_budget = ((size_t)std::max(8, env_int("IPX_LDS_KB", 72)) << 10) - band_lds_bytes(-1, -4);
+    int bc = 0, br = 0;
+    std::vector<int> rb[2], cbv[2];
+    for (;;) {
+        const int ncb = (sw + max_cols - 1) / max_cols;
+        bc = std::max(4, ((sw + ncb - 1) / ncb + 3) & ~3);
+        br = (int)(lds_budget / ((size_t)(bc + 4) * 4)) - 1;
+        br = std::max(1, std::min(br, env_int("IPX_BAND_ROWS_MAX", 16)));
+        if (env_int("IPX_BAND_ROWS", 0) > 0) br = env_int("IPX_BAND_ROWS", 0);
+        br = std::min(br, sh);
+        pl->blk_cols = bc; pl->band_rows = br;
+        pl->ncolblk = (sw + bc - 1) / bc;
+        pl->nbands = (sh + br - 1) / br;
+        int widest = 0;
+        for (int k = 0; k < 2; k++) {
+            PlanScale &s = pl->sc[k];
+            if (xt[k].empty()) continue;
+            rb[k].assign(pl->nbands + 1, 0); cbv[k].assign(pl->ncolblk + 1, 0);
+            int d = 0;
+            for (int b = 0; b <= pl->nbands; b++) {  // first output row whose tap pair starts in band b or below
+                while (d < s.dh && s.sr.y0 + yt[k][d].base < b * br) d++;
+                rb[k][b] = b == pl->nbands ? s.dh : d;
+            }
+            d = 0;
+            for (int c = 0; c <= pl->ncolblk; c++) {
+                while (d < s.dw && s.sr.x0 + xt[k][d].base < c * bc) d++;
+                cbv[k][c] = c == pl->ncolblk ? s.dw : d;
+            }
+            for (int c = 0; c < pl->ncolblk; c++) widest = std::max(widest, cbv[k][c + 1] - cbv[k][c]);
+        }
+        pl->nx = widest <= 256 ? 1 : widest <= 512 ? 2 : kBandNX;
+        if (widest <= 256 * kBandNX) break;
+        if (bc <= 4) { pl->fused = false; *out = pl; return IPX_OK; }  // enormous upscale: per-operation kernels
+        max_cols = std::max(4, (int)((long long)bc * 256 * kBandNX / widest) & ~3);
+        if (max_cols >= bc) max_cols = bc - 4;
+    }
 
     // host tables -> one device blob
     std::vector<uint8_t> blob;
@@ -669,26 +715,11 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
     };
     size_t off_xt[2] = {0, 0}, off_yt[2] = {0, 0}, off_rb[2] = {0, 0}, off_cb[2] = {0, 0};
     for (int k = 0; k < 2; k++) {
-        PlanScale &s = pl->sc[k];
-        if (!s.on || s.dw <= 0 || s.dh <= 0) continue;
-        std::vector<AxisTap> xt(s.dw), yt(s.dh);
-        build_axis_taps(s.sr.dx(), s.dw, 0, s.dw, xt.data());
-        build_axis_taps(s.sr.dy(), s.dh, 0, s.dh, yt.data());
-        std::vector<int> rb(pl->nbands + 1), cbv(pl->ncolblk + 1);
-        int d = 0;
-        for (int b = 0; b <= pl->nbands; b++) {  // first output row whose tap pair starts at or below band b
-            while (d < s.dh && s.sr.y0 + yt[d].base < b * br) d++;
-            rb[b] = b == pl->nbands ? s.dh : d;
-        }
-        d = 0;
-        for (int c = 0; c <= pl->ncolblk; c++) {
-            while (d < s.dw && s.sr.x0 + xt[d].base < c * bc) d++;
-            cbv[c] = c == pl->ncolblk ? s.dw : d;
-        }
-        off_xt[k] = put(xt.data(), xt.size() * sizeof(AxisTap));
-        off_yt[k] = put(yt.data(), yt.size() * sizeof(AxisTap));
-        off_rb[k] = put(rb.data(), rb.size() * sizeof(int));
-        off_cb[k] = put(cbv.data(), cbv.size() * sizeof(int));
+        if (xt[k].empty()) continue;
+        off_xt[k] = put(xt[k].data(), xt[k].size() * sizeof(AxisTap));
+        off_yt[k] = put(yt[k].data(), yt[k].size() * sizeof(AxisTap));
+        off_rb[k] = put(rb[k].data(), rb[k].size() * sizeof(int));
+        off_cb[k] = put(cbv[k].data(), cbv[k].size() * sizeof(int));
     }
     if (!blob.empty()) {
         hipError_t e = hipMalloc((void **)&pl->blob, blob.size());
@@ -753,6 +784,17 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         a.band_rows = pl->band_rows; a.nbands = pl->nbands;
         a.blk_cols = pl->blk_cols; a.ncolblk = pl->ncolblk;
         a.nframes = n;
+        a.nx = pl->nx;
+        // the persistent pipelined kernel needs 16-byte aligned rows on both frames and a tile of at
+        // most kPipeMaxSlots chunks per thread; otherwise one workgroup per item
+        a.pipe_grid = 0;
+        const bool aligned = (sw & 3) == 0 && ((((uintptr_t)src) | (uintptr_t)sstride | src_frame_stride) & 15) == 0 &&
+                             (!wm || ((((uintptr_t)wm) | wm_frame_stride) & 15) == 0);
+        if (aligned && env_int("IPX_PIPE", 1) && band_tile_slots(pl->band_rows, pl->blk_cols) <= kPipeMaxSlots) {
+            const int by_lds = (int)((160u << 10) / band_lds_bytes(pl->band_rows, pl->blk_cols));
+            const int wgs = std::max(1, std::min(by_lds, env_int("IPX_PIPE_WGS", 2)));
+            a.pipe_grid = ctx->cus * wgs;
+        }
         a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
         a.nscale = 0;
         for (int k = 0; k < 2; k++) {
@@ -762,7 +804,9 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
             o.out = outs[k]; o.frame_stride = ostr[k]; o.ostride = ps.dw * 4;
             o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
             o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
+            o.dyadic_shift = ps.dyadic_shift;
         }
+        if (a.nscale == 1) a.sc[1] = a.sc[0];  // keeps the kernel's unconditional tap loads legal
         a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
         a.cr = col[0]; a.cg = col[1]; a.cb = col[2]; a.ca = col[3];
         if (!wm && a.nscale == 0) return IPX_OK;
