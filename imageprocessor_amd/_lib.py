@@ -37,6 +37,39 @@ class PlanInfo(C.Structure):
                 ("algorithmic_bytes", C.c_size_t)]
 
 
+class Param(C.Structure):
+    _fields_ = [("key", C.c_char_p), ("type", C.c_int32), ("f64", C.c_double), ("i64", C.c_int64),
+                ("str", C.c_char_p)]
+
+
+class Image(C.Structure):
+    _fields_ = [("pix", C.c_void_p), ("w", C.c_int32), ("h", C.c_int32), ("stride", C.c_int32)]
+
+
+MEASURE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_double, C.POINTER(C.c_int))
+GLYPHS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_double, C.c_int, C.c_int,
+                        C.POINTER(C.POINTER(Glyph)), C.POINTER(C.c_int))
+RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class TextRasterizer(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("measure", MEASURE_FN), ("glyphs", GLYPHS_FN), ("release", RELEASE_FN)]
+
+
+class Operation(C.Structure):
+    _fields_ = [("type", C.c_char_p), ("params", C.POINTER(Param)), ("nparams", C.c_int32)]
+
+
+class Task(C.Structure):
+    _fields_ = [("id", C.c_char_p), ("image_id", C.c_char_p), ("ops", C.POINTER(Operation)),
+                ("nops", C.c_int32), ("format", C.c_char_p)]
+
+
+class Processed(C.Structure):
+    _fields_ = [("operation", C.c_char * 16), ("path", C.c_char * 320), ("content_type", C.c_char * 32),
+                ("format", C.c_char * 8), ("image", Image)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _Z = C.c_size_t
@@ -79,6 +112,13 @@ SIGNATURES = {
     "ipx_event_record": (_I, [_P, _P, _P]),
     "ipx_event_elapsed_ms": (_I, [_P, _P, _P, C.POINTER(C.c_float)]),
     "ipx_event_destroy": (None, [_P, _P]),
+    "ipx_image_free": (None, [C.POINTER(Image)]),
+    "ipx_resizer_process": (_I, [_P, C.POINTER(Image), C.c_char_p, C.POINTER(Param), _I, C.POINTER(Image), _P]),
+    "ipx_thumbnailer_process": (_I, [_P, C.POINTER(Image), C.c_char_p, C.POINTER(Param), _I, C.POINTER(Image), _P]),
+    "ipx_watermarker_process": (_I, [_P, C.POINTER(Image), C.c_char_p, C.POINTER(Param), _I,
+                                     C.POINTER(TextRasterizer), C.POINTER(Image), _P]),
+    "ipx_processor_process": (_I, [_P, C.POINTER(Task), C.POINTER(Image), C.c_char_p, C.POINTER(TextRasterizer),
+                                   C.POINTER(Processed), C.POINTER(_I)]),
 }
 
 _lib = None

@@ -31,6 +31,7 @@
 // buffer descriptors instead and an idle lane gets an out-of-range offset (load returns 0, store
 // is dropped), so the instruction stream is straight-line and vmcnt can be counted.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ipx_internal.h"
 
@@ -499,26 +500,40 @@ hipError_t launch_nx(const BandArgs &a, unsigned total, size_t lds, hipStream_t 
 }
 
 template <int NX, int S>
-hipError_t launch_pipe(const BandArgs &a, unsigned grid, size_t lds, hipStream_t s)
+hipError_t launch_pipe(const BandArgs &a, long long items, size_t lds, hipStream_t s)
 {
+    // a persistent grid must be fully resident: size it from the occupancy the runtime reports for
+    // this instantiation and LDS size, not from the LDS arithmetic alone (VGPRs may bind first)
     static thread_local size_t lds_set = 0;
-    if (lds > lds_set) {
+    static thread_local int resident = 0;
+    if (lds != lds_set) {
         hipError_t e = hipFuncSetAttribute((const void *)band_pipe_kernel<NX, S>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        int n = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)band_pipe_kernel<NX, S>, 256, lds);
+        if (e != hipSuccess) return e;
+        resident = std::max(1, n);
         lds_set = lds;
     }
-    hipLaunchKernelGGL((band_pipe_kernel<NX, S>), dim3(grid), dim3(256), lds, s, a);
+    const long long grid = std::min<long long>(items, (long long)a.cus * std::min(a.pipe_wgs, resident));
+    static thread_local bool said = false;
+    if (!said && getenv("IPX_DEBUG")) {
+        said = true;
+        fprintf(stderr, "[ipx] band_pipe_kernel<%d,%d>: tile %d rows x %d cols, lds %zu B, resident %d/CU, grid %lld, items %lld\n",
+                NX, S, a.band_rows, a.blk_cols, lds, resident, grid, items);
+    }
+    hipLaunchKernelGGL((band_pipe_kernel<NX, S>), dim3((unsigned)grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
 template <int NX>
-hipError_t launch_pipe_s(const BandArgs &a, int slots, unsigned grid, size_t lds, hipStream_t s)
+hipError_t launch_pipe_s(const BandArgs &a, int slots, long long items, size_t lds, hipStream_t s)
 {
-    if (slots <= 5) return launch_pipe<NX, 5>(a, grid, lds, s);
-    if (slots <= 9) return launch_pipe<NX, 9>(a, grid, lds, s);
-    if (slots <= 13) return launch_pipe<NX, 13>(a, grid, lds, s);
-    return launch_pipe<NX, kPipeMaxSlots>(a, grid, lds, s);
+    if (slots <= 5) return launch_pipe<NX, 5>(a, items, lds, s);
+    if (slots <= 9) return launch_pipe<NX, 9>(a, items, lds, s);
+    if (slots <= 13) return launch_pipe<NX, 13>(a, items, lds, s);
+    return launch_pipe<NX, kPipeMaxSlots>(a, items, lds, s);
 }
 
 }  // namespace
@@ -539,12 +554,11 @@ hipError_t launch_band(const BandArgs &a, hipStream_t s)
     if (total <= 0) return hipSuccess;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds = band_lds_bytes(a.band_rows, a.blk_cols);
-    if (a.pipe_grid > 0) {
+    if (a.pipe_wgs > 0) {
         const int slots = band_tile_slots(a.band_rows, a.blk_cols);
-        const unsigned grid = (unsigned)std::min<long long>(total, a.pipe_grid);
-        if (a.nx <= 1) return launch_pipe_s<1>(a, slots, grid, lds, s);
-        if (a.nx <= 2) return launch_pipe_s<2>(a, slots, grid, lds, s);
-        return launch_pipe_s<kBandNX>(a, slots, grid, lds, s);
+        if (a.nx <= 1) return launch_pipe_s<1>(a, slots, total, lds, s);
+        if (a.nx <= 2) return launch_pipe_s<2>(a, slots, total, lds, s);
+        return launch_pipe_s<kBandNX>(a, slots, total, lds, s);
     }
     if (a.nx <= 1) return launch_nx<1>(a, (unsigned)total, lds, s);
     if (a.nx <= 2) return launch_nx<2>(a, (unsigned)total, lds, s);

@@ -110,7 +110,8 @@ struct BandArgs {
     int blk_cols, ncolblk;     // owned source columns per workgroup (multiple of 4)
     int nframes;
     int nx;                    // destination columns per thread: 1, 2 or kBandNX
-    int pipe_grid;             // > 0: persistent pipelined kernel with this many workgroups
+    int pipe_wgs;              // > 0: persistent pipelined kernel, this many workgroups per CU wanted
+    int cus;                   // compute units of the device
     uint8_t *wm; size_t wm_frame_stride; int wm_stride;   // NULL = no watermark copy
     int nscale;
     ScaleOut sc[2];

@@ -787,13 +787,12 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         a.nx = pl->nx;
         // the persistent pipelined kernel needs 16-byte aligned rows on both frames and a tile of at
         // most kPipeMaxSlots chunks per thread; otherwise one workgroup per item
-        a.pipe_grid = 0;
+        a.pipe_wgs = 0;
+        a.cus = ctx->cus;
         const bool aligned = (sw & 3) == 0 && ((((uintptr_t)src) | (uintptr_t)sstride | src_frame_stride) & 15) == 0 &&
                              (!wm || ((((uintptr_t)wm) | wm_frame_stride) & 15) == 0);
         if (aligned && env_int("IPX_PIPE", 1) && band_tile_slots(pl->band_rows, pl->blk_cols) <= kPipeMaxSlots) {
-            const int by_lds = (int)((160u << 10) / band_lds_bytes(pl->band_rows, pl->blk_cols));
-            const int wgs = std::max(1, std::min(by_lds, env_int("IPX_PIPE_WGS", 2)));
-            a.pipe_grid = ctx->cus * wgs;
+            a.pipe_wgs = std::max(1, env_int("IPX_PIPE_WGS", 8));  // clamped to what is resident at launch
         }
         a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
         a.nscale = 0;

@@ -192,6 +192,76 @@ int ipx_event_record(ipx_ctx *ctx, void *event, void *stream);
 int ipx_event_elapsed_ms(ipx_ctx *ctx, void *start, void *stop, float *ms); /* syncs on stop */
 void ipx_event_destroy(ipx_ctx *ctx, void *event);
 
+/* ---- operator seam: the reference's own method set on decoded frames ---------------------------
+ * Resizer / Thumbnailer / Watermarker .Process(ctx, img, format, params) (resize.go:26,
+ * thumbnail.go:25, watermark.go:40) and ImageProcessor.Process (image_processor.go:39) with the
+ * codecs cut off: the input is the decoded frame (image_processor.go:47 stays on the Go side) and
+ * each result is the *image.RGBA the reference would hand to its encoder, plus the format string
+ * and object key it would use.  Parameter parsing, defaults and error texts follow the reference. */
+
+/* one entry of Go's map[string]interface{}; the type tag reproduces the reference's type switches
+ * (after the JSON round trip of a task every number is float64, domain/task.go:17-20) */
+typedef enum {
+    IPX_PT_FLOAT64 = 1, IPX_PT_INT = 2, IPX_PT_INT64 = 3, IPX_PT_INT32 = 4, IPX_PT_BOOL = 5, IPX_PT_STRING = 6
+} ipx_param_type;
+typedef struct {
+    const char *key;
+    int32_t type;      /* ipx_param_type */
+    double f64;        /* FLOAT64 */
+    int64_t i64;       /* INT / INT64 / INT32 / BOOL */
+    const char *str;   /* STRING */
+} ipx_param;
+
+/* *image.RGBA with Rect.Min = (0,0).  Outputs are allocated by the library (ipx_image_free). */
+typedef struct { uint8_t *pix; int32_t w, h, stride; } ipx_image;
+void ipx_image_free(ipx_image *img);
+
+/* The text rasteriser stays on the host side of the boundary (the reference uses golang/freetype
+ * with the Go Regular face, watermark.go:29-38,98-118,151).  measure() returns
+ * int(textWidth.Ceil()) of watermark.go:109-117; glyphs() returns, for the baseline point (px, py),
+ * the DrawMask calls DrawString would make (valid until release()).  A NULL rasteriser makes
+ * Watermarker.Process fail with "font not loaded" like a nil font (watermark.go:87-89). */
+typedef struct {
+    void *user;
+    int (*measure)(void *user, const char *text, double font_size, int *width_px);
+    int (*glyphs)(void *user, const char *text, double font_size, int px, int py,
+                  const ipx_glyph **out, int *n);
+    void (*release)(void *user);
+} ipx_text_rasterizer;
+
+/* out_format receives "jpeg" / "png" / "gif" as the reference's encoder switch would name it
+ * (resize.go:78-91, thumbnail.go:68-81, watermark.go:66-79: a GIF watermark becomes JPEG). */
+int ipx_resizer_process(ipx_ctx *ctx, const ipx_image *img, const char *format,
+                        const ipx_param *params, int nparams, ipx_image *out, char out_format[8]);
+int ipx_thumbnailer_process(ipx_ctx *ctx, const ipx_image *img, const char *format,
+                            const ipx_param *params, int nparams, ipx_image *out, char out_format[8]);
+int ipx_watermarker_process(ipx_ctx *ctx, const ipx_image *img, const char *format,
+                            const ipx_param *params, int nparams, const ipx_text_rasterizer *font,
+                            ipx_image *out, char out_format[8]);
+
+/* domain.OperationParams / domain.ProcessingTask (domain/task.go:3-20) */
+typedef struct { const char *type; const ipx_param *params; int32_t nparams; } ipx_operation;
+typedef struct {
+    const char *id, *image_id;
+    const ipx_operation *ops; int32_t nops;
+    const char *format;            /* task.Format; "" = the decoded format (image_processor.go:55-58) */
+} ipx_task;
+typedef struct {
+    char operation[16];            /* key of ProcessingResult.ProcessedPaths                    */
+    char path[320];                /* generatePath (image_processor.go:129-162)                 */
+    char content_type[32];         /* getContentType (image_processor.go:164-182)               */
+    char format[8];
+    ipx_image image;
+} ipx_processed;
+/* (*ImageProcessor).Process (image_processor.go:39-102) from the decoded frame on: every operator
+ * is applied to the ORIGINAL frame (:64-65), in one fused GPU pass when each type occurs at most
+ * once.  `out` has room for task->nops entries; *n_out of them are filled.  On an operator failure
+ * the status is negative, *n_out counts the operators that had succeeded before it, and
+ * ipx_last_error() holds "operation <type> failed: ..." as the reference formats it (:66-75). */
+int ipx_processor_process(ipx_ctx *ctx, const ipx_task *task, const ipx_image *decoded,
+                          const char *decoded_format, const ipx_text_rasterizer *font,
+                          ipx_processed *out, int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

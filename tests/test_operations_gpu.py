@@ -1,0 +1,193 @@
+"""The reference's operator interface (Resizer / Thumbnailer / Watermarker .Process and
+ImageProcessor.Process) on the HIP path, against expectations assembled from the CPU oracle and
+the parameter / error rules of operations/*.go and image_processor.go."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import rgba_frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ipx():
+    import imageprocessor_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def ops(ipx):
+    from imageprocessor_amd import operations
+    return operations
+
+
+@pytest.fixture(scope="module")
+def ctx(ipx):
+    c = ipx.Context(lanes=2)
+    yield c
+    c.close()
+
+
+# a deterministic stand-in for golang/freetype + Go Regular (the glyph producer is outside the path)
+def fake_measure(text, size):
+    return int(len(text) * size * 0.52) + 1
+
+
+def fake_glyphs(text, size, px, py):
+    out = []
+    x = px
+    for i, ch in enumerate(text):
+        rng = np.random.default_rng(ord(ch) * 131 + int(size * 8))
+        mw, mh = max(2, int(size * 0.6)), max(2, int(size * (0.6 + 0.4 * rng.random())))
+        m = rng.integers(0, 256, (mh, mw), dtype=np.uint8)
+        m[rng.random((mh, mw)) < 0.4] = 0
+        out.append({"mask": m, "dr": (x - 1, py - mh + (i % 3), x - 1 + mw, py + (i % 3)), "mp": (0, 0)})
+        x += int(size * 0.52)
+    return out
+
+
+@pytest.fixture(scope="module")
+def font(ops):
+    return ops.Font(fake_measure, fake_glyphs)
+
+
+def expect_watermark(src, text, position, opacity, size, color):
+    h, w = src.shape[:2]
+    col, _ = oracle.parse_color(color, opacity)
+    px, py = oracle.watermark_anchor(position, w, h, fake_measure(text, size), oracle.text_height_px(size))
+    out = src.copy()
+    oracle.composite_glyphs(out, fake_glyphs(text, size, px, py), col)
+    return out
+
+
+SRC = rgba_frames(1, 640, 360, seed=77)[0]
+
+
+def test_resizer_parameter_ladder_and_formats(ctx, ops):
+    r = ops.Resizer()
+    want_fit = oracle.scale_bilinear(SRC, *oracle.resize_dims(640, 360, 300, 300, True))
+    for params in ({"width": 300.0, "height": 300.0, "keep_aspect": True},          # after the JSON round trip
+                   {"width": 300, "height": 300, "keep_aspect": True},
+                   {"width": ops.Int64(300), "height": ops.Int32(300), "keep_aspect": True},
+                   {"width": 300.9, "height": 300.2, "keep_aspect": True}):           # int(w) truncates
+        got, fmt = r.Process(ctx, SRC, "jpeg", params)
+        np.testing.assert_array_equal(got, want_fit)
+        assert fmt == "jpeg"
+    got, _ = r.Process(ctx, SRC, "png", {"width": 300, "height": 300})               # keep_aspect absent = false
+    np.testing.assert_array_equal(got, oracle.scale_bilinear(SRC, 300, 300))
+    got, _ = r.Process(ctx, SRC, "png", {"width": 300, "height": 300, "keep_aspect": "true"})  # not a bool = false
+    assert got.shape == (300, 300, 4)
+    for f, want in (("JPG", "jpeg"), ("jpeg", "jpeg"), ("png", "png"), ("GIF", "gif"), ("webp", "jpeg"), ("", "jpeg")):
+        assert r.Process(ctx, SRC, f, {"width": 8, "height": 8})[1] == want
+
+
+def test_resizer_errors(ctx, ops, ipx):
+    r = ops.Resizer()
+    for params, text in (({"height": 5}, "width parameter is required and must be a number"),
+                         ({"width": "5", "height": 5}, "width parameter is required and must be a number"),
+                         ({"width": 5}, "height parameter is required and must be a number"),
+                         ({"width": 5, "height": True}, "height parameter is required and must be a number"),
+                         ({"width": 0, "height": 5}, "width and height must be positive numbers"),
+                         ({"width": 5, "height": -1.0}, "width and height must be positive numbers")):
+        with pytest.raises(ipx.IpxError) as e:
+            r.Process(ctx, SRC, "jpeg", params)
+        assert e.value.text == text
+
+
+def test_thumbnailer(ctx, ops, ipx):
+    t = ops.Thumbnailer()
+    crop, nw, nh = oracle.thumb_geometry(640, 360, 200, True)
+    want = oracle.scale_bilinear(SRC, nw, nh, sr=crop)
+    for params in ({"crop_to_fit": True}, {"size": "big", "crop_to_fit": True}, {"size": 200.0, "crop_to_fit": True}):
+        got, fmt = t.Process(ctx, SRC, "jpg", params)       # size absent / not a number -> 200 (task.go:56)
+        np.testing.assert_array_equal(got, want)
+        assert fmt == "jpeg"
+    _, nw, nh = oracle.thumb_geometry(640, 360, 50, False)
+    got, _ = t.Process(ctx, SRC, "png", {"size": 50})
+    assert (nw, nh) == (88, 50)
+    np.testing.assert_array_equal(got, oracle.scale_bilinear(SRC, nw, nh))
+    tall = np.ascontiguousarray(SRC.transpose(1, 0, 2))
+    got, _ = t.Process(ctx, tall, "png", {"size": 50, "crop_to_fit": False})
+    np.testing.assert_array_equal(got, oracle.scale_bilinear(tall, 50, 88))
+    for bad in (0, -3, -1.5):
+        with pytest.raises(ipx.IpxError) as e:
+            t.Process(ctx, SRC, "png", {"size": bad})
+        assert e.value.text == "size must be a positive number"
+    assert t.Process(ctx, SRC, "gif", {})[1] == "gif"
+
+
+def test_watermarker(ctx, ops, ipx, font):
+    w = ops.Watermarker(font)
+    got, fmt = w.Process(ctx, SRC, "jpeg", {})               # every default of watermark.go:41-60
+    np.testing.assert_array_equal(got, expect_watermark(SRC, "© ImageProcessor", "bottom-right", 0.5, 36, "255,255,255"))
+    assert fmt == "jpeg"
+    cases = [
+        ({"text": "hello", "opacity": 0.8, "position": "top-left", "font_size": 20.0, "font_color": "10,200,30"},
+         ("hello", "top-left", 0.8, 20.0, "10,200,30")),
+        ({"text": "", "opacity": -1.0, "position": "center", "font_size": 0.0, "font_color": "1,2,3,200"},
+         ("© ImageProcessor", "center", 0.5, 36, "1,2,3,200")),          # empty / non-positive -> defaults
+        ({"text": "x y", "opacity": 1, "position": "nowhere", "font_size": 24, "font_color": "red"},
+         ("x y", "nowhere", 0.5, 36, "red")),                                 # ints are not float64 -> defaults; bad colour -> black
+        ({"position": 7}, ("© ImageProcessor", "bottom-right", 0.5, 36, "255,255,255")),
+    ]
+    for params, exp in cases:
+        got, _ = w.Process(ctx, SRC, "png", params)
+        np.testing.assert_array_equal(got, expect_watermark(SRC, *exp), err_msg=str(params))
+    for f, want in (("png", "png"), ("gif", "jpeg"), ("jpg", "jpeg"), ("bmp", "jpeg")):   # watermark.go:66-79
+        assert w.Process(ctx, SRC, f, {"text": "a"})[1] == want
+    with pytest.raises(ipx.IpxError) as e:
+        ops.Watermarker(None).Process(ctx, SRC, "png", {})
+    assert e.value.text == "failed to add watermark: font not loaded"           # watermark.go:87-89,61-64
+
+
+def _task(ops_list, fmt=""):
+    return {"ID": "task-1", "ImageID": "img-42", "OriginalPath": "original/img-42.jpg", "Bucket": "original",
+            "Operations": ops_list, "Format": fmt}
+
+
+def test_image_processor_standard_task(ctx, ops, font):
+    # parseOperationsFromForm (handler/image/image.go:222-256) after json.Marshal / Unmarshal
+    task = _task([{"Type": "thumbnail", "Parameters": {"size": 200.0, "crop_to_fit": True}},
+                  {"Type": "resize", "Parameters": {"width": 1024.0, "height": 768.0, "keep_aspect": True}},
+                  {"Type": "watermark", "Parameters": {"text": "© ImageProcessor", "opacity": 0.5, "position": "bottom-right"}}])
+    res, err = ops.ImageProcessor(ctx, font).Process(task, SRC, "jpeg")
+    assert err is None and res["Status"] == "completed" and res["Error"] == ""
+    assert res["ProcessedPaths"] == {"thumbnail": "processed/thumbnails/img-42/200.jpeg",
+                                     "resize": "processed/resize/img-42/1024x768.jpeg",       # requested, not actual, size
+                                     "watermark": "processed/watermarked/img-42/watermarked.jpeg"}
+    crop, tw, th = oracle.thumb_geometry(640, 360, 200, True)
+    np.testing.assert_array_equal(res["Outputs"]["thumbnail"][0], oracle.scale_bilinear(SRC, tw, th, sr=crop))
+    np.testing.assert_array_equal(res["Outputs"]["resize"][0], oracle.scale_bilinear(SRC, *oracle.resize_dims(640, 360, 1024, 768, True)))
+    np.testing.assert_array_equal(res["Outputs"]["watermark"][0],
+                                  expect_watermark(SRC, "© ImageProcessor", "bottom-right", 0.5, 36, "255,255,255"))
+    assert all(v[1] == "image/jpeg" for v in res["Outputs"].values())
+    # task.Format overrides the decoded format (image_processor.go:55-58); a PNG task keeps PNG everywhere
+    res, _ = ops.ImageProcessor(ctx, font).Process(_task(task["Operations"], "png"), SRC, "jpeg")
+    assert res["ProcessedPaths"]["watermark"].endswith(".png") and res["Outputs"]["resize"][1] == "image/png"
+
+
+def test_image_processor_failures_and_quirks(ctx, ops, font):
+    ip = ops.ImageProcessor(ctx, font)
+    res, err = ip.Process(_task([{"Type": "thumbnail", "Parameters": {}},
+                                 {"Type": "resize", "Parameters": {"height": 10.0}},
+                                 {"Type": "watermark", "Parameters": {}}]), SRC)
+    assert err == "operation resize failed: failed to process operation resize: width parameter is required and must be a number"
+    assert res["Status"] == "failed" and res["Error"].startswith("Operation resize failed: ")
+    assert list(res["ProcessedPaths"]) == ["thumbnail"]          # stored before the failure (image_processor.go:76-92)
+    res, err = ip.Process(_task([{"Type": "rotate", "Parameters": {"angle": 90.0}}]), SRC)
+    assert err == "operation rotate failed: unsupported operation type: rotate" and not res["ProcessedPaths"]
+    res, err = ops.ImageProcessor(ctx, None).Process(_task([{"Type": "watermark", "Parameters": {}}]), SRC)
+    assert err == "operation watermark failed: failed to process operation watermark: failed to add watermark: font not loaded"
+    # generatePath reads width / height with the short ladder only (float64, int): int64 prints as 0
+    res, err = ip.Process(_task([{"Type": "resize", "Parameters": {"width": ops.Int64(64), "height": ops.Int64(48)}}], "gif"), SRC)
+    assert err is None and res["ProcessedPaths"]["resize"] == "processed/resize/img-42/0x0.gif"
+    assert res["Outputs"]["resize"][0].shape == (48, 64, 4) and res["Outputs"]["resize"][1] == "image/gif"
+    # the same operator twice: last path wins in ProcessedPaths, both run on the ORIGINAL frame
+    res, err = ip.Process(_task([{"Type": "resize", "Parameters": {"width": 32, "height": 32}},
+                                 {"Type": "resize", "Parameters": {"width": 16, "height": 16}}]), SRC)
+    assert err is None and res["ProcessedPaths"]["resize"] == "processed/resize/img-42/16x16.jpeg"
+    np.testing.assert_array_equal(res["Outputs"]["resize"][0], oracle.scale_bilinear(SRC, 16, 16))
+    # an empty operator list is a completed task with no outputs
+    res, err = ip.Process(_task([]), SRC)
+    assert err is None and res["Status"] == "completed" and not res["Outputs"]
