@@ -165,6 +165,8 @@ def main():
             assert np.array_equal(wm.download((sh, sw, 4)), want["watermark"])
         print("check ok", file=sys.stderr)
 
+    if rank == 0 and os.environ.get("IPX_BENCH_TRACE"):
+        print("launch_ms:", " ".join("%.3f" % m for m in launch_ms), file=sys.stderr)
     if rank == 0:
         avg_ms = sum(launch_ms) / len(launch_ms)
         alg = info.algorithmic_bytes * F  # source read once + each output written once

@@ -186,17 +186,18 @@ class Plan:
             thumb_ptr, thumb_frame_stride if thumb_frame_stride is not None else i.thumb_bytes,
             wm_ptr, wm_frame_stride if wm_frame_stride is not None else i.wm_bytes))
 
-    def run_host(self, frames, want=("resize", "thumbnail", "watermark")):
-        """frames: n x H x W x 4 uint8 (host).  Returns dict of output batches."""
+    def run_host(self, frames, want=("resize", "thumbnail", "watermark"), out=None):
+        """frames: n x H x W x 4 uint8 (host).  Returns dict of output batches (`out` may supply
+        preallocated, e.g. pinned, arrays)."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         n = frames.shape[0]
         i = self.info
-        out = {}
-        if "resize" in want and i.resize_bytes:
+        out = dict(out) if out else {}
+        if "resize" in want and i.resize_bytes and "resize" not in out:
             out["resize"] = np.empty((n, i.resize_h, i.resize_w, 4), np.uint8)
-        if "thumbnail" in want and i.thumb_bytes:
+        if "thumbnail" in want and i.thumb_bytes and "thumbnail" not in out:
             out["thumbnail"] = np.empty((n, i.thumb_h, i.thumb_w, 4), np.uint8)
-        if "watermark" in want and i.wm_bytes:
+        if "watermark" in want and i.wm_bytes and "watermark" not in out:
             out["watermark"] = np.empty((n, i.wm_h, i.wm_w, 4), np.uint8)
 
         def p(k):
@@ -241,6 +242,22 @@ class Context:
 
     def alloc(self, nbytes):
         return DevBuffer(self, nbytes)
+
+    def host_alloc(self, shape, dtype=np.uint8):
+        """Pinned (hipHostMalloc) staging as a numpy array; free with host_free(arr)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = lib().ipx_host_alloc(self.handle, max(1, n))
+        if not p:
+            raise IpxError(-2, lib().ipx_last_error().decode())
+        arr = np.frombuffer((C.c_uint8 * n).from_address(p), dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            lib().ipx_host_free(self.handle, p)
 
     def sync(self, stream=None):
         _check(lib().ipx_stream_sync(self.handle, stream))

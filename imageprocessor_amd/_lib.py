@@ -5,7 +5,7 @@ import importlib.util
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libipx.so")
+LIB_PATH = os.environ.get("IPX_LIB") or os.path.join(HERE, "libipx.so")  # IPX_LIB: an experimental build
 
 
 class Rect(C.Structure):

@@ -49,6 +49,22 @@ constexpr int kLoadU = 4;    // 16-byte loads in flight per lane in band_kernel'
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 constexpr int kOOB = 0x7fffffff;  // a byte offset beyond any frame
+#ifndef IPX_AUX_LOAD
+#define IPX_AUX_LOAD 0
+#endif
+#ifndef IPX_AUX_WM
+#define IPX_AUX_WM 0
+#endif
+#ifndef IPX_NT_PX
+#define IPX_NT_PX 0
+#endif
+#ifndef IPX_WM_FROM_LDS
+#define IPX_WM_FROM_LDS 0
+#endif
+__device__ __forceinline__ void store_px(uint32_t *p, uint32_t v)
+{
+    if (IPX_NT_PX) __builtin_nontemporal_store(v, p); else *p = v;
+}
 
 // Exact lerp for dyadic weights: x0+x1 = 2^kx, y0+y1 = 2^ky (small integers held in floats), taps
 // as plain bytes.  sum = y0*(x0*t00 + x1*t10) + y1*(x0*t01 + x1*t11) < 2^(8+kx+ky) <= 2^24, so fp32
@@ -191,7 +207,7 @@ __device__ __forceinline__ void scale_phase(const BandArgs &a, const Tile &t, in
                         const int off = (ybias + ybase) * t.pitch + lx;
                         const uint32_t p00 = lds_u32(lds, off), p10 = lds_u32(lds, off + 4);
                         const uint32_t p01 = lds_u32(lds, off + t.pitch), p11 = lds_u32(lds, off + t.pitch + 4);
-                        *op = lerp_dyadic(p00, p10, p01, p11, X.f0, X.f1, yf0, yf1, sh);
+                        store_px(op, lerp_dyadic(p00, p10, p01, p11, X.f0, X.f1, yf0, yf1, sh));
                     }
                 } else {
                     for (int r = 0; r < rows; r++, op = (uint32_t *)((uint8_t *)op + S.ostride)) {
@@ -204,7 +220,7 @@ __device__ __forceinline__ void scale_phase(const BandArgs &a, const Tile &t, in
                         const uint32_t pg = lerp_channel<1>(p00, p10, p01, p11, X.w0, X.w1, yw0, yw1);
                         const uint32_t pb = lerp_channel<2>(p00, p10, p01, p11, X.w0, X.w1, yw0, yw1);
                         const uint32_t pa = lerp_channel<3>(p00, p10, p01, p11, X.w0, X.w1, yw0, yw1);
-                        *op = pack_src(pr, pg, pb, pa);
+                        store_px(op, pack_src(pr, pg, pb, pa));
                     }
                 }
             }
@@ -384,7 +400,7 @@ __device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, in
         const int q = tid + 256 * s;
         const int row = (int)__umulhi((uint32_t)q, it.magic);
         const int ch = q - row * it.t.nchunk;
-        stage[s] = __builtin_amdgcn_raw_buffer_load_b128(srs, q < it.nq ? base + row * a.sstride + ch * 16 : kOOB, 0, 0);
+        stage[s] = __builtin_amdgcn_raw_buffer_load_b128(srs, q < it.nq ? base + row * a.sstride + ch * 16 : kOOB, 0, IPX_AUX_LOAD);
     }
     if (a.nscale > 0) {
 #pragma unroll
@@ -411,10 +427,13 @@ __device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, in
         const int ch = q - row * it.t.nchunk;
         const bool ok = q < it.nq;
         if (ok) *(v4u *)(lds + row * it.t.pitch + ch * 16) = stage[s];
+#if !IPX_WM_FROM_LDS
         bool w = ok && wframe && row < it.t.own_rows && ch * 4 < it.t.own_cols;
         if (any_glyph && chunk_in_textbox(a, it.t.c0 + ch * 4, it.t.r0 + row)) w = false;
-        __builtin_amdgcn_raw_buffer_store_b128(stage[s], wrs, w ? wbase + row * a.wm_stride + ch * 16 : kOOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(stage[s], wrs, w ? wbase + row * a.wm_stride + ch * 16 : kOOB, 0, IPX_AUX_WM);
+#endif
     }
+    (void)wrs; (void)wbase;
     if (a.nscale > 0) {
 #pragma unroll
         for (int k = 0; k < 2; k++)
@@ -422,6 +441,29 @@ __device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, in
                 v4u *yl = (v4u *)&ytap[k * kYChunk + tid];
                 yl[0] = ty_stage[k][0]; yl[1] = ty_stage[k][1];
             }
+    }
+}
+
+// Variant (IPX_WM_FROM_LDS): the watermark copy of the current item is stored from LDS AFTER the next
+// item's loads have been issued, so that the loads are in flight during the store burst as well.
+template <int S>
+__device__ __forceinline__ void wm_from_lds(const BandArgs &a, const Item &it, int tid, const uint8_t *lds,
+                                            bool any_glyph)
+{
+    uint8_t *wframe = a.wm ? a.wm + (size_t)it.f * a.wm_frame_stride : nullptr;
+    const int wm_bytes = wframe ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wframe, 0, wm_bytes, 0x00020000);
+    const int wbase = it.t.r0 * a.wm_stride + it.t.c0 * 4;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const int q = tid + 256 * s;
+        const int qc = min(q, it.nq - 1);
+        const int row = (int)__umulhi((uint32_t)qc, it.magic);
+        const int ch = qc - row * it.t.nchunk;
+        const v4u v = *(const v4u *)(lds + row * it.t.pitch + ch * 16);
+        bool w = q < it.nq && wframe && row < it.t.own_rows && ch * 4 < it.t.own_cols;
+        if (any_glyph && chunk_in_textbox(a, it.t.c0 + ch * 4, it.t.r0 + row)) w = false;
+        __builtin_amdgcn_raw_buffer_store_b128(v, wrs, w ? wbase + row * a.wm_stride + ch * 16 : kOOB, 0, IPX_AUX_WM);
     }
 }
 
@@ -471,6 +513,9 @@ __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
         if (!has_next) { nxt.b = cur.b; nxt.f = cur.f; nxt.cb = cur.cb; }
         item_setup(a, nxt, has_next);
         issue_tile<S>(a, nxt, tid, stage, ty_stage);
+#if IPX_WM_FROM_LDS
+        if (a.wm) wm_from_lds<S>(a, cur, tid, lds, any_glyph);
+#endif
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, cur.t))

@@ -849,14 +849,20 @@ int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *sr
     }
     if (n == 0) return IPX_OK;
     const int sw = pl->p.sw, sh = pl->p.sh;
-    const size_t fsrc = align256((size_t)sw * sh * 4);
-    const size_t fres = resize_out ? align256(pl->info.resize_bytes) : 0;
-    const size_t fth = thumb_out ? align256(pl->info.thumb_bytes) : 0;
-    const size_t fwm = wm_out ? align256(pl->info.wm_bytes) : 0;
+    // device-side frame strides: tight when that keeps rows 16-byte aligned (then a whole chunk moves
+    // with one copy per direction and buffer), padded to 256 otherwise
+    auto dstride = [](size_t bytes) { return (bytes & 15) == 0 ? bytes : align256(bytes); };
+    const size_t fsrc = dstride((size_t)sw * sh * 4);
+    const size_t fres = resize_out ? dstride(pl->info.resize_bytes) : 0;
+    const size_t fth = thumb_out ? dstride(pl->info.thumb_bytes) : 0;
+    const size_t fwm = wm_out ? dstride(pl->info.wm_bytes) : 0;
     const size_t per_frame = fsrc + fres + fth + fwm;
-    // chunk the batch so that copies of one chunk overlap kernels of another on a different lane
-    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ctx->lane_bytes / per_frame));
-    chunk = std::min(chunk, std::max(1, (n + (int)ctx->lanes.size() - 1) / (int)ctx->lanes.size()));
+    // chunk the batch so that H2D of one chunk, the kernel of another and D2H of a third overlap on
+    // different lanes (one stream each); several chunks per lane keep all three engines busy
+    const int nl = (int)ctx->lanes.size();
+    int chunk = std::max(1, (n + 4 * nl - 1) / (4 * nl));
+    chunk = (int)std::min<size_t>((size_t)chunk, std::max<size_t>(1, ctx->lane_bytes / per_frame));
+    chunk = std::max(1, std::min(chunk, env_int("IPX_HOST_CHUNK", 16)));
 
     // take every lane: this call is the pipeline
     std::vector<Lane *> lanes;
@@ -868,34 +874,41 @@ int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *sr
     int rc = IPX_OK;
     hipError_t e = hipSuccess;
     for (auto *l : lanes) {
-        rc = lane_reserve(*l, per_frame * chunk);
+        rc = lane_reserve(*l, per_frame * chunk + 256);
         if (rc) break;
     }
+    const bool src_tight = sstride == sw * 4 && src_frame_stride == fsrc;
+    auto d2h = [&](uint8_t *host, size_t host_stride, const uint8_t *dev, size_t dev_stride, size_t bytes, int i0, int m,
+                   hipStream_t st) {
+        if (!dev || !bytes) return hipSuccess;
+        if (host_stride == dev_stride)  // tight on both sides: one copy for the chunk
+            return hipMemcpyAsync(host + (size_t)i0 * host_stride, dev, dev_stride * (m - 1) + bytes, hipMemcpyDeviceToHost, st);
+        hipError_t r = hipSuccess;
+        for (int i = 0; i < m && r == hipSuccess; i++)
+            r = hipMemcpyAsync(host + (size_t)(i0 + i) * host_stride, dev + dev_stride * i, bytes, hipMemcpyDeviceToHost, st);
+        return r;
+    };
     for (int i0 = 0, c = 0; !rc && e == hipSuccess && i0 < n; i0 += chunk, c++) {
         Lane &l = *lanes[c % lanes.size()];
         const int m = std::min(chunk, n - i0);
-        uint8_t *dsrc = l.dev;
+        uint8_t *dsrc = (uint8_t *)(((uintptr_t)l.dev + 255) & ~(uintptr_t)255);
         uint8_t *dres = fres ? dsrc + fsrc * chunk : nullptr;
-        uint8_t *dth = fth ? l.dev + (fsrc + fres) * chunk : nullptr;
-        uint8_t *dwm = fwm ? l.dev + (fsrc + fres + fth) * chunk : nullptr;
+        uint8_t *dth = fth ? dsrc + (fsrc + fres) * chunk : nullptr;
+        uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * chunk : nullptr;
         // the lane's stream serialises reuse of its scratch: chunk c waits for chunk c - lanes
-        for (int i = 0; i < m && e == hipSuccess; i++)
-            e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * 4, src + (size_t)(i0 + i) * src_frame_stride, sstride,
-                                 (size_t)sw * 4, sh, hipMemcpyHostToDevice, l.stream);
+        if (src_tight) {
+            e = hipMemcpyAsync(dsrc, src + (size_t)i0 * src_frame_stride, fsrc * m, hipMemcpyHostToDevice, l.stream);
+        } else {
+            for (int i = 0; i < m && e == hipSuccess; i++)
+                e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * 4, src + (size_t)(i0 + i) * src_frame_stride, sstride,
+                                     (size_t)sw * 4, sh, hipMemcpyHostToDevice, l.stream);
+        }
         if (e != hipSuccess) break;
         rc = ipx_plan_run_dev(ctx, l.stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm);
         if (rc) break;
-        for (int i = 0; i < m && e == hipSuccess; i++) {
-            if (dres && pl->info.resize_bytes)
-                e = hipMemcpyAsync(resize_out + (size_t)(i0 + i) * resize_frame_stride, dres + fres * i,
-                                   pl->info.resize_bytes, hipMemcpyDeviceToHost, l.stream);
-            if (e == hipSuccess && dth && pl->info.thumb_bytes)
-                e = hipMemcpyAsync(thumb_out + (size_t)(i0 + i) * thumb_frame_stride, dth + fth * i,
-                                   pl->info.thumb_bytes, hipMemcpyDeviceToHost, l.stream);
-            if (e == hipSuccess && dwm && pl->info.wm_bytes)
-                e = hipMemcpyAsync(wm_out + (size_t)(i0 + i) * wm_frame_stride, dwm + fwm * i, pl->info.wm_bytes,
-                                   hipMemcpyDeviceToHost, l.stream);
-        }
+        e = d2h(resize_out, resize_frame_stride, dres, fres, pl->info.resize_bytes, i0, m, l.stream);
+        if (e == hipSuccess) e = d2h(thumb_out, thumb_frame_stride, dth, fth, pl->info.thumb_bytes, i0, m, l.stream);
+        if (e == hipSuccess) e = d2h(wm_out, wm_frame_stride, dwm, fwm, pl->info.wm_bytes, i0, m, l.stream);
     }
     for (auto *l : lanes) {
         hipError_t e2 = hipStreamSynchronize(l->stream);

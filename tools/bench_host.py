@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the host boundary: frames in pinned host memory -> H2D -> fused kernel -> D2H
+-> pinned host memory, pipelined over the context's lanes (ipx_plan_run_host).  This is the
+PCIe-inclusive figure quoted in DESIGN.md; it is never bench.py's `value`."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import imageprocessor_amd as ipx  # noqa: E402
+from helpers import DEFAULT_COL, rgba_frames, text_glyphs  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+sw, sh = 1920, 1080
+ctx = ipx.Context(lanes=lanes, lane_bytes=1 << 30)
+gs = ctx.glyphset(text_glyphs(sw, sh), DEFAULT_COL)
+plan = ctx.plan(sw, sh, resize=(1024, 768, False), thumbnail=(200, True), watermark=gs)
+i = plan.info
+for pinned in (True, False):
+    alloc = ctx.host_alloc if pinned else (lambda shape: np.empty(shape, np.uint8))
+    src = alloc((n, sh, sw, 4))
+    src[:] = np.resize(rgba_frames(8, sw, sh, seed=3), src.shape)
+    out = {"resize": alloc((n, i.resize_h, i.resize_w, 4)), "thumbnail": alloc((n, i.thumb_h, i.thumb_w, 4)),
+           "watermark": alloc((n, i.wm_h, i.wm_w, 4))}
+    plan.run_host(src, out=out)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        plan.run_host(src, out=out)
+        best = min(best, time.perf_counter() - t0)
+    gb = n * (sw * sh * 4 + i.resize_bytes + i.thumb_bytes + i.wm_bytes) / 1e9
+    print("host->host %s memory, %d lanes: %d frames in %.1f ms = %.0f images/s, %.1f GB/s over PCIe (both directions summed)"
+          % ("pinned" if pinned else "pageable", lanes, n, best * 1e3, n / best, gb / best))
