@@ -112,6 +112,7 @@ struct BandArgs {
     int nx;                    // destination columns per thread: 1, 2 or kBandNX
     int pipe_wgs;              // > 0: persistent pipelined kernel, this many workgroups per CU wanted
     int cus;                   // compute units of the device
+    int dbg;                   // IPX_DBG timing experiments: 1 = skip scaling, 2 = skip tile loads
     uint8_t *wm; size_t wm_frame_stride; int wm_stride;   // NULL = no watermark copy
     int nscale;
     ScaleOut sc[2];
@@ -120,6 +121,8 @@ struct BandArgs {
     uint32_t cr, cg, cb, ca;
 };
 hipError_t launch_band(const BandArgs &a, hipStream_t s);
+hipError_t launch_ring(const BandArgs &a, hipStream_t s);   // loader-wave variant (ipx_ring.hip)
+size_t ring_lds_bytes(int band_rows, int blk_cols);
 size_t band_lds_bytes(int band_rows, int blk_cols);
 int band_tile_slots(int band_rows, int blk_cols);
 

@@ -74,6 +74,7 @@ struct ipx_plan {
     ipx_plan_info info{};
     bool fused = false;
     int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0, nx = kBandNX;
+    int most_rows = 0;    // most destination rows any band owns, over the scaled outputs
     PlanScale sc[2];      // 0 = resize, 1 = thumbnail
     uint8_t *blob = nullptr;
     ClippedGlyphs glyphs;
@@ -697,6 +698,7 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
                 cbv[k][c] = c == pl->ncolblk ? s.dw : d;
             }
             for (int c = 0; c < pl->ncolblk; c++) widest = std::max(widest, cbv[k][c + 1] - cbv[k][c]);
+            for (int b = 0; b < pl->nbands; b++) pl->most_rows = std::max(pl->most_rows, rb[k][b + 1] - rb[k][b]);
         }
         pl->nx = widest <= 256 ? 1 : widest <= 512 ? 2 : kBandNX;
         if (widest <= 256 * kBandNX) break;
@@ -789,6 +791,7 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         // most kPipeMaxSlots chunks per thread; otherwise one workgroup per item
         a.pipe_wgs = 0;
         a.cus = ctx->cus;
+        a.dbg = env_int("IPX_DBG", 0);
         const bool aligned = (sw & 3) == 0 && ((((uintptr_t)src) | (uintptr_t)sstride | src_frame_stride) & 15) == 0 &&
                              (!wm || ((((uintptr_t)wm) | wm_frame_stride) & 15) == 0);
         if (aligned && env_int("IPX_PIPE", 1) && band_tile_slots(pl->band_rows, pl->blk_cols) <= kPipeMaxSlots) {
@@ -809,7 +812,9 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
         a.cr = col[0]; a.cg = col[1]; a.cb = col[2]; a.ca = col[3];
         if (!wm && a.nscale == 0) return IPX_OK;
-        IPX_HIP(launch_band(a, s));
+        const bool ring = aligned && env_int("IPX_RING", 0) && pl->most_rows <= 64 &&
+                          ring_lds_bytes(pl->band_rows, pl->blk_cols) <= (160u << 10);
+        IPX_HIP(ring ? launch_ring(a, s) : launch_band(a, s));
         return IPX_OK;
     }
 
