@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step")
-    ap.add_argument("--workload", choices=["full", "resize", "full-keepaspect", "wm"], default="full")
+    ap.add_argument("--workload", choices=["full", "resize", "full-keepaspect", "wm", "thumb", "resize-wm"], default="full")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pool", type=int, default=32, help="distinct seeded frames tiled over the batch")
@@ -94,9 +94,9 @@ def main():
 
     sw, sh, F = args.width, args.height, args.frames
     resize = {"full": (1024, 768, False), "resize": (1024, 768, False), "full-keepaspect": (1024, 768, True),
-              "wm": None}[args.workload]
-    thumb = None if args.workload in ("resize", "wm") else (200, True)
-    do_wm = args.workload != "resize"
+              "wm": None, "thumb": None, "resize-wm": (1024, 768, False)}[args.workload]
+    thumb = None if args.workload in ("resize", "wm", "resize-wm") else (200, True)
+    do_wm = args.workload not in ("resize", "thumb")
 
     ctx = ipx.Context(device=local_rank % max(1, ipx.device_count()))
     glyphs = text_glyphs(sw, sh) if do_wm else []
@@ -192,7 +192,8 @@ def main():
                 "full": "full pipeline: resize 1024x768 (keep_aspect=false) + thumbnail 200 crop + watermark 16 glyphs",
                 "resize": "resize to 1024x768 only",
                 "full-keepaspect": "full pipeline, product-default keep_aspect=true (1024x576)",
-                "wm": "watermark only (copy + 16 glyphs)"}[args.workload]),
+                "wm": "watermark only (copy + 16 glyphs)", "thumb": "thumbnail 200 crop only",
+                "resize-wm": "resize 1024x768 + watermark"}[args.workload]),
                 "frames_per_gpu": F, "sharding": "independent frames, round-robin by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

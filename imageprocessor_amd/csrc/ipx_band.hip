@@ -19,8 +19,8 @@
 // Two kernels share these steps:
 //   band_pipe_kernel  persistent: a workgroup walks a contiguous run of items and keeps the NEXT
 //                     item's tile in flight (global -> registers) while it computes the current one
-//                     from LDS, so HBM never idles behind the float64 lerp.  Needs 16-byte aligned
-//                     rows.  This is the throughput path.
+//                     from LDS, so HBM never idles behind the lerp.  Needs 16-byte aligned rows.
+//                     This is the throughput path.
 //   band_kernel       one workgroup per item, any alignment or width; the fallback.
 //
 // Bound: HBM.  Per 1080p frame 8.29 MB in, 11.6 MB out; the lerp is ~0.1 flop/B.
@@ -131,11 +131,12 @@ __global__ __launch_bounds__(256) void band_kernel(BandArgs a)
 
     // taps first: the oldest loads of the wave, so nothing later waits behind a store
     AxisTap *ytap = (AxisTap *)(lds + (a.band_rows + 1) * t.pitch);  // [2][kYChunk]
-    int dyA[2] = {0, 0}, dyB[2] = {0, 0}, dxA[2] = {0, 0}, dxB[2] = {0, 0};
-    XTap tx[2][NX];
+    int dyA[2] = {0, 0}, dyB[2] = {0, 0};
+    OutCols<NX, true> o0, o1;
     v4u ty_stage[2][2];  // an AxisTap as two 16-byte words
     if (a.nscale > 0) {
-        load_xtaps<NX>(a, cb, tid, tx, dxA, dxB);
+        load_xtaps<NX, true>(a, 0, cb, tid, o0);
+        load_xtaps<NX, true>(a, 1, cb, tid, o1);
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const ScaleOut &S = a.sc[k];
@@ -168,7 +169,10 @@ __global__ __launch_bounds__(256) void band_kernel(BandArgs a)
     __syncthreads();
     // the composite goes first so that its few loads are not queued behind the pixel stores
     if (glyph_tile) glyph_phase(a, t, wframe, lds, tid);
-    if (a.nscale > 0) scale_phase<NX>(a, t, f, lds, ytap, tid, tx, dxA, dxB, dyA, dyB);
+    if (a.nscale > 0) {
+        scale_out<NX, true, true>(a, 0, t, f, lds, ytap, tid, o0, dyA[0], dyB[0]);
+        scale_out<NX, true, true>(a, 1, t, f, lds, ytap + kYChunk, tid, o1, dyA[1], dyB[1]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -178,24 +182,24 @@ __global__ __launch_bounds__(256) void band_kernel(BandArgs a)
 // change.  Per item:
 //     A  the staged tile (registers, loaded during the previous item's compute) -> LDS, and the
 //        owned chunks -> watermark frame;                                   barrier
-//     B  issue the NEXT item's tile loads into the same registers (S x 16 B per thread in flight)
+//     B  issue the NEXT item's tile loads into the same registers (ROWS*CH x 16 B per thread)
 //     C  composite + scale the current item from LDS, pixel stores;         barrier
-// The tile is spread over the workgroup as a flat list of 16-byte chunks: thread t holds chunks
-// t, t+256, ... (S of them), each mapped to (row, chunk-in-row) with a multiply-high division.
+// The tile is laid over the workgroup as ROWS x CH slots per thread: slot (r, h) is tile row r,
+// chunk tid + 256*h, so every address is base + r*stride + constant: no per-slot division.
+// Template parameters: NXk = destination columns per thread of output k (256*NXk per column block),
+// FPk = output k may be non-dyadic (float64 lerp, float64 x weights in registers).
 // ---------------------------------------------------------------------------------------------
 struct Item {
     int f, b, cb;
+    bool valid;
     Tile t;
-    int nq;            // chunks of the tile (0 = no item: every offset out of range)
-    uint32_t magic;    // ceil(2^32 / nchunk): q / nchunk == umulhi(q, magic) for q < 2^16
     int dyA[2], dyB[2];
 };
 
 __device__ __forceinline__ void item_setup(const BandArgs &a, Item &it, bool valid)
 {
+    it.valid = valid;
     it.t = make_tile(a, it.b, it.cb);
-    it.nq = valid ? it.t.rows_ld * it.t.nchunk : 0;
-    it.magic = 0xffffffffu / (uint32_t)it.t.nchunk + 1u;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         it.dyA[k] = a.nscale > 0 ? a.sc[k].row_begin[it.b] : 0;
@@ -203,20 +207,27 @@ __device__ __forceinline__ void item_setup(const BandArgs &a, Item &it, bool val
     }
 }
 
-template <int S>
-__device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, int tid, v4u (&stage)[S],
+template <int ROWS, int CH>
+__device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, int tid, v4u (&stage)[ROWS * CH],
                                            v4u (&ty_stage)[2][2])
 {
     const int frame_bytes = (a.sh - 1) * a.sstride + a.sw * 4;
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.src + (size_t)it.f * a.src_frame_stride), 0, frame_bytes, 0x00020000);
-    const int base = it.t.r0 * a.sstride + it.t.c0 * 4;
+    const int rows = it.valid && !(a.dbg & 2) ? it.t.rows_ld : 0;   // no item: every offset out of range
+    int voff[CH];
+    bool in_tile[CH];
 #pragma unroll
-    for (int s = 0; s < S; s++) {
-        const int q = tid + 256 * s;
-        const int row = (int)__umulhi((uint32_t)q, it.magic);
-        const int ch = q - row * it.t.nchunk;
-        stage[s] = __builtin_amdgcn_raw_buffer_load_b128(srs, q < it.nq && !(a.dbg & 2) ? base + row * a.sstride + ch * 16 : kOOB, 0, IPX_AUX_LOAD);
+    for (int h = 0; h < CH; h++) {
+        const int ch = tid + 256 * h;
+        in_tile[h] = ch < it.t.nchunk;
+        voff[h] = it.t.r0 * a.sstride + it.t.c0 * 4 + ch * 16;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+        for (int h = 0; h < CH; h++)   // r < rows is wave-uniform
+            stage[r * CH + h] = __builtin_amdgcn_raw_buffer_load_b128(srs, in_tile[h] && r < rows ? voff[h] + r * a.sstride : kOOB, 0, 0);
     }
     if (a.nscale > 0) {
 #pragma unroll
@@ -227,29 +238,35 @@ __device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, in
     }
 }
 
-template <int S>
-__device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, int tid, const v4u (&stage)[S],
-                                           const v4u (&ty_stage)[2][2], uint8_t *lds, AxisTap *ytap,
-                                           bool any_glyph)
+template <int ROWS, int CH>
+__device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, int tid, const v4u (&stage)[ROWS * CH],
+                                           const v4u (&ty_stage)[2][2], uint8_t *lds, AxisTap *ytap, bool any_glyph)
 {
     uint8_t *wframe = a.wm ? a.wm + (size_t)it.f * a.wm_frame_stride : nullptr;
     const int wm_bytes = wframe ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wframe, 0, wm_bytes, 0x00020000);
-    const int wbase = it.t.r0 * a.wm_stride + it.t.c0 * 4;
+    const bool gl_rows = any_glyph && it.t.r0 < a.gbox.y1 && it.t.r1 > a.gbox.y0;   // wave-uniform
+    int woff[CH], loff[CH];
+    bool in_tile[CH], owned[CH];
 #pragma unroll
-    for (int s = 0; s < S; s++) {
-        const int q = tid + 256 * s;
-        const int row = (int)__umulhi((uint32_t)q, it.magic);
-        const int ch = q - row * it.t.nchunk;
-        const bool ok = q < it.nq;
-        if (ok) *(v4u *)(lds + row * it.t.pitch + ch * 16) = stage[s];
-#if !IPX_WM_FROM_LDS
-        bool w = ok && wframe && row < it.t.own_rows && ch * 4 < it.t.own_cols;
-        if (any_glyph && chunk_in_textbox(a, it.t.c0 + ch * 4, it.t.r0 + row)) w = false;
-        __builtin_amdgcn_raw_buffer_store_b128(stage[s], wrs, w ? wbase + row * a.wm_stride + ch * 16 : kOOB, 0, IPX_AUX_WM);
-#endif
+    for (int h = 0; h < CH; h++) {
+        const int ch = tid + 256 * h;
+        in_tile[h] = ch < it.t.nchunk;
+        loff[h] = ch * 16;
+        owned[h] = wframe && ch * 4 < it.t.own_cols;
+        woff[h] = it.t.r0 * a.wm_stride + it.t.c0 * 4 + ch * 16;
     }
-    (void)wrs; (void)wbase;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+        for (int h = 0; h < CH; h++) {
+            if (r < it.t.rows_ld && in_tile[h]) *(v4u *)(lds + r * it.t.pitch + loff[h]) = stage[r * CH + h];
+            int off = r < it.t.own_rows && owned[h] ? woff[h] + r * a.wm_stride : kOOB;
+            // chunks that meet the text box are written by the composite step
+            if (gl_rows && chunk_in_textbox(a, it.t.c0 + (tid + 256 * h) * 4, it.t.r0 + r)) off = kOOB;
+            __builtin_amdgcn_raw_buffer_store_b128(stage[r * CH + h], wrs, off, 0, 0);
+        }
+    }
     if (a.nscale > 0) {
 #pragma unroll
         for (int k = 0; k < 2; k++)
@@ -260,30 +277,7 @@ __device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, in
     }
 }
 
-// Variant (IPX_WM_FROM_LDS): the watermark copy of the current item is stored from LDS AFTER the next
-// item's loads have been issued, so that the loads are in flight during the store burst as well.
-template <int S>
-__device__ __forceinline__ void wm_from_lds(const BandArgs &a, const Item &it, int tid, const uint8_t *lds,
-                                            bool any_glyph)
-{
-    uint8_t *wframe = a.wm ? a.wm + (size_t)it.f * a.wm_frame_stride : nullptr;
-    const int wm_bytes = wframe ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wframe, 0, wm_bytes, 0x00020000);
-    const int wbase = it.t.r0 * a.wm_stride + it.t.c0 * 4;
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        const int q = tid + 256 * s;
-        const int qc = min(q, it.nq - 1);
-        const int row = (int)__umulhi((uint32_t)qc, it.magic);
-        const int ch = qc - row * it.t.nchunk;
-        const v4u v = *(const v4u *)(lds + row * it.t.pitch + ch * 16);
-        bool w = q < it.nq && wframe && row < it.t.own_rows && ch * 4 < it.t.own_cols;
-        if (any_glyph && chunk_in_textbox(a, it.t.c0 + ch * 4, it.t.r0 + row)) w = false;
-        __builtin_amdgcn_raw_buffer_store_b128(v, wrs, w ? wbase + row * a.wm_stride + ch * 16 : kOOB, 0, IPX_AUX_WM);
-    }
-}
-
-template <int NX, int S>
+template <int NX0, bool FP0, int NX1, bool FP1, int ROWS, int CH>
 __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
 {
     extern __shared__ uint4 lds_raw[];
@@ -306,44 +300,58 @@ __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
     cur.b = idx - cur.cb * per_cb - cur.f * a.nbands;
     item_setup(a, cur, true);
 
-    XTap tx[2][NX];
-    int dxA[2] = {0, 0}, dxB[2] = {0, 0};
-    if (a.nscale > 0) load_xtaps<NX>(a, cur.cb, tid, tx, dxA, dxB);
+    OutCols<NX0, FP0> o0;
+    OutCols<NX1, FP1> o1;
+    if (a.nscale > 0) { load_xtaps<NX0, FP0>(a, 0, cur.cb, tid, o0); load_xtaps<NX1, FP1>(a, 1, cur.cb, tid, o1); }
 
-    v4u stage[S];
+    v4u stage[ROWS * CH];
     v4u ty_stage[2][2];
-    issue_tile<S>(a, cur, tid, stage, ty_stage);
+    issue_tile<ROWS, CH>(a, cur, tid, stage, ty_stage);
 
+    unsigned long long acc[5] = {0, 0, 0, 0, 0};
+#define IPX_STAMP(i) do { if (a.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc[i] += now_ - tprev; tprev = now_; } } while (0)
+    unsigned long long tprev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
     for (;;) {
         // A: staged tile -> LDS (+ watermark copy)
-        drain_tile<S>(a, cur, tid, stage, ty_stage, lds, ytap, any_glyph);
+        drain_tile<ROWS, CH>(a, cur, tid, stage, ty_stage, lds, ytap, any_glyph);
+        IPX_STAMP(0);
         __syncthreads();
+        IPX_STAMP(1);
 
         // B: the next item's loads go out now and land while C computes.  Past the end of the run
-        // the "item" has no chunks: the same loads are issued with out-of-range offsets, which
-        // keeps this block free of branches around memory operations.
+        // the "item" is not valid: the same loads are issued with out-of-range offsets, which keeps
+        // this block free of branches around memory operations.
         Item nxt;
         nxt.b = cur.b + 1; nxt.f = cur.f; nxt.cb = cur.cb;
         if (nxt.b == a.nbands) { nxt.b = 0; if (++nxt.f == a.nframes) { nxt.f = 0; ++nxt.cb; } }
         const bool has_next = idx + 1 < idx_end;
         if (!has_next) { nxt.b = cur.b; nxt.f = cur.f; nxt.cb = cur.cb; }
         item_setup(a, nxt, has_next);
-        issue_tile<S>(a, nxt, tid, stage, ty_stage);
-#if IPX_WM_FROM_LDS
-        if (a.wm) wm_from_lds<S>(a, cur, tid, lds, any_glyph);
-#endif
+        issue_tile<ROWS, CH>(a, nxt, tid, stage, ty_stage);
+        IPX_STAMP(2);
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, cur.t))
             glyph_phase(a, cur.t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
-        if (a.nscale > 0 && !(a.dbg & 1)) scale_phase<NX>(a, cur.t, cur.f, lds, ytap, tid, tx, dxA, dxB, cur.dyA, cur.dyB);
+        if (a.nscale > 0 && !(a.dbg & 1)) {
+            scale_out<NX0, FP0, false>(a, 0, cur.t, cur.f, lds, ytap, tid, o0, cur.dyA[0], cur.dyB[0]);
+            scale_out<NX1, FP1, false>(a, 1, cur.t, cur.f, lds, ytap + kYChunk, tid, o1, cur.dyA[1], cur.dyB[1]);
+        }
+        IPX_STAMP(3);
         __syncthreads();
+        IPX_STAMP(4);
 
         if (!has_next) break;
-        if (nxt.cb != cur.cb && a.nscale > 0) load_xtaps<NX>(a, nxt.cb, tid, tx, dxA, dxB);
+        if (nxt.cb != cur.cb && a.nscale > 0) {
+            load_xtaps<NX0, FP0>(a, 0, nxt.cb, tid, o0);
+            load_xtaps<NX1, FP1>(a, 1, nxt.cb, tid, o1);
+        }
         cur = nxt;
         ++idx;
     }
+    if (a.stamps && (tid & 63) == 0)
+        for (int i = 0; i < 5; i++) atomicAdd(&a.stamps[i], acc[i]);
+#undef IPX_STAMP
 }
 
 template <int NX>
@@ -360,19 +368,19 @@ hipError_t launch_nx(const BandArgs &a, unsigned total, size_t lds, hipStream_t 
     return hipGetLastError();
 }
 
-template <int NX, int S>
+template <int NX0, bool FP0, int NX1, bool FP1, int ROWS, int CH>
 hipError_t launch_pipe(const BandArgs &a, long long items, size_t lds, hipStream_t s)
 {
     // a persistent grid must be fully resident: size it from the occupancy the runtime reports for
     // this instantiation and LDS size, not from the LDS arithmetic alone (VGPRs may bind first)
     static thread_local size_t lds_set = 0;
     static thread_local int resident = 0;
+    auto kern = band_pipe_kernel<NX0, FP0, NX1, FP1, ROWS, CH>;
     if (lds != lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)band_pipe_kernel<NX, S>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         int n = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)band_pipe_kernel<NX, S>, 256, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, 256, lds);
         if (e != hipSuccess) return e;
         resident = std::max(1, n);
         lds_set = lds;
@@ -381,20 +389,26 @@ hipError_t launch_pipe(const BandArgs &a, long long items, size_t lds, hipStream
     static thread_local bool said = false;
     if (!said && getenv("IPX_DEBUG")) {
         said = true;
-        fprintf(stderr, "[ipx] band_pipe_kernel<%d,%d>: tile %d rows x %d cols, lds %zu B, resident %d/CU, grid %lld, items %lld\n",
-                NX, S, a.band_rows, a.blk_cols, lds, resident, grid, items);
+        fprintf(stderr, "[ipx] band_pipe_kernel<%d,%d,%d,%d,%d,%d>: tile %d rows x %d cols, lds %zu B, resident %d/CU, grid %lld, items %lld\n",
+                NX0, (int)FP0, NX1, (int)FP1, ROWS, CH, a.band_rows, a.blk_cols, lds, resident, grid, items);
     }
-    hipLaunchKernelGGL((band_pipe_kernel<NX, S>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
-template <int NX>
-hipError_t launch_pipe_s(const BandArgs &a, int slots, long long items, size_t lds, hipStream_t s)
+// column / lerp configurations built for the pipelined kernel, cheapest first
+template <int ROWS, int CH>
+hipError_t launch_pipe_cfg(const BandArgs &a, long long items, size_t lds, hipStream_t s, bool *matched)
 {
-    if (slots <= 5) return launch_pipe<NX, 5>(a, items, lds, s);
-    if (slots <= 9) return launch_pipe<NX, 9>(a, items, lds, s);
-    if (slots <= 13) return launch_pipe<NX, 13>(a, items, lds, s);
-    return launch_pipe<NX, kPipeMaxSlots>(a, items, lds, s);
+    const int need0 = a.nscale > 0 ? a.nx_out[0] : 0, need1 = a.nscale > 1 ? a.nx_out[1] : 0;
+    const bool fp0 = a.nscale > 0 && a.sc[0].dyadic_shift < 0, fp1 = a.nscale > 1 && a.sc[1].dyadic_shift < 0;
+    *matched = true;
+    if (need0 <= 1 && need1 <= 1) return launch_pipe<1, true, 1, true, ROWS, CH>(a, items, lds, s);
+    if (need0 <= 4 && !fp0 && need1 <= 1) return launch_pipe<4, false, 1, true, ROWS, CH>(a, items, lds, s);
+    if (need0 <= 4 && need1 <= 1) return launch_pipe<4, true, 1, true, ROWS, CH>(a, items, lds, s);
+    if (need0 <= 4 && need1 <= 4 && !fp0 && !fp1) return launch_pipe<4, false, 4, false, ROWS, CH>(a, items, lds, s);
+    *matched = false;
+    return hipSuccess;
 }
 
 }  // namespace
@@ -404,9 +418,14 @@ size_t band_lds_bytes(int band_rows, int blk_cols)
     return (size_t)(band_rows + 1) * (size_t)(blk_cols + 4) * 4 + 2 * kYChunk * sizeof(AxisTap);
 }
 
-int band_tile_slots(int band_rows, int blk_cols)
+// tile shapes (rows incl. halo, 256-chunk column groups) the pipelined kernel is built for
+bool band_pipe_shape(int band_rows, int blk_cols, int *rows, int *ch)
 {
-    return ((band_rows + 1) * (blk_cols / 4 + 1) + 255) / 256;
+    const int r = band_rows + 1, c = blk_cols / 4 + 1;
+    if (c <= 256 && r <= 9) { *rows = 9; *ch = 1; return true; }
+    if (c <= 256 && r <= 17) { *rows = 17; *ch = 1; return true; }
+    if (c <= 512 && r <= 9) { *rows = 9; *ch = 2; return true; }
+    return false;
 }
 
 hipError_t launch_band(const BandArgs &a, hipStream_t s)
@@ -415,14 +434,18 @@ hipError_t launch_band(const BandArgs &a, hipStream_t s)
     if (total <= 0) return hipSuccess;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds = band_lds_bytes(a.band_rows, a.blk_cols);
-    if (a.pipe_wgs > 0) {
-        const int slots = band_tile_slots(a.band_rows, a.blk_cols);
-        if (a.nx <= 1) return launch_pipe_s<1>(a, slots, total, lds, s);
-        if (a.nx <= 2) return launch_pipe_s<2>(a, slots, total, lds, s);
-        return launch_pipe_s<kBandNX>(a, slots, total, lds, s);
+    int rows = 0, ch = 0;
+    if (a.pipe_wgs > 0 && band_pipe_shape(a.band_rows, a.blk_cols, &rows, &ch)) {
+        bool matched = false;
+        hipError_t e = hipSuccess;
+        if (rows == 9 && ch == 1) e = launch_pipe_cfg<9, 1>(a, total, lds, s, &matched);
+        else if (rows == 17 && ch == 1) e = launch_pipe_cfg<17, 1>(a, total, lds, s, &matched);
+        else e = launch_pipe_cfg<9, 2>(a, total, lds, s, &matched);
+        if (matched) return e;
     }
-    if (a.nx <= 1) return launch_nx<1>(a, (unsigned)total, lds, s);
-    if (a.nx <= 2) return launch_nx<2>(a, (unsigned)total, lds, s);
+    const int nx = std::max(a.nx_out[0], a.nx_out[1]);
+    if (nx <= 1) return launch_nx<1>(a, (unsigned)total, lds, s);
+    if (nx <= 2) return launch_nx<2>(a, (unsigned)total, lds, s);
     return launch_nx<kBandNX>(a, (unsigned)total, lds, s);
 }
 

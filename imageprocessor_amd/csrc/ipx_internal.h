@@ -90,7 +90,6 @@ hipError_t launch_composite(uint8_t *dst, int dstride, size_t frame_stride, int 
                             uint32_t sb, uint32_t sa, hipStream_t s);
 
 // fused band kernel (resize + thumbnail + watermark copy in one pass over the source)
-constexpr int kPipeMaxSlots = 17;  // 16-byte chunks a thread stages per tile in the pipelined kernel
 constexpr int kBandNX = 4;  // a column block holds at most 256 * kBandNX destination columns per output
 struct ScaleOut {
     uint8_t *out;              // frame 0
@@ -99,7 +98,7 @@ struct ScaleOut {
     int dw, dh;
     int sr_x0, sr_y0;          // source rectangle origin
     const AxisTap *xt, *yt;    // dw / dh entries, device
-    int dyadic_shift;          // kx + ky when both axes are dyadic (exact fp32 path), else -1
+    int dyadic_shift;          // kx + ky when both axes are dyadic, else -1 (float64 lerp)
     const int *row_begin;      // nbands+1 entries: first output row owned by each band
     const int *col_begin;      // ncolblk+1 entries
 };
@@ -109,10 +108,11 @@ struct BandArgs {
     int band_rows, nbands;     // owned source rows per workgroup
     int blk_cols, ncolblk;     // owned source columns per workgroup (multiple of 4)
     int nframes;
-    int nx;                    // destination columns per thread: 1, 2 or kBandNX
+    int nx_out[2];             // per scaled output: destination columns per thread and column block (of 256)
     int pipe_wgs;              // > 0: persistent pipelined kernel, this many workgroups per CU wanted
     int cus;                   // compute units of the device
     int dbg;                   // IPX_DBG timing experiments: 1 = skip scaling, 2 = skip tile loads
+    unsigned long long *stamps; // IPX_STAMPS diagnostic build: per-phase cycle sums (8 counters), else NULL
     uint8_t *wm; size_t wm_frame_stride; int wm_stride;   // NULL = no watermark copy
     int nscale;
     ScaleOut sc[2];
@@ -121,9 +121,7 @@ struct BandArgs {
     uint32_t cr, cg, cb, ca;
 };
 hipError_t launch_band(const BandArgs &a, hipStream_t s);
-hipError_t launch_ring(const BandArgs &a, hipStream_t s);   // loader-wave variant (ipx_ring.hip)
-size_t ring_lds_bytes(int band_rows, int blk_cols);
 size_t band_lds_bytes(int band_rows, int blk_cols);
-int band_tile_slots(int band_rows, int blk_cols);
+bool band_pipe_shape(int band_rows, int blk_cols, int *rows, int *ch);  // tile shapes the pipelined kernel is built for
 
 }  // namespace ipx

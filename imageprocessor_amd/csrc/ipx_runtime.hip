@@ -73,7 +73,8 @@ struct ipx_plan {
     ipx_plan_params p{};
     ipx_plan_info info{};
     bool fused = false;
-    int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0, nx = kBandNX;
+    int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0;
+    int nx_out[2] = {0, 0}; // per output: ceil(widest column block / 256)
     int most_rows = 0;    // most destination rows any band owns, over the scaled outputs
     PlanScale sc[2];      // 0 = resize, 1 = thumbnail
     uint8_t *blob = nullptr;
@@ -668,7 +669,7 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
 
     // block shape: owned columns per workgroup (multiple of 4 pixels = 16 B) and owned rows; a
     // column block may hold at most 256 * kBandNX destination columns of any scaled output
-    int max_cols = std::max(4, env_int("IPX_BLK_COLS", 2048)) & ~3;
+    int max_cols = std::max(4, env_int("IPX_BLK_COLS", 2044)) & ~3;
     const size_t lds_budget = ((size_t)std::max(8, env_int("IPX_LDS_KB", 72)) << 10) - band_lds_bytes(-1, -4);
     int bc = 0, br = 0;
     std::vector<int> rb[2], cbv[2];
@@ -676,13 +677,15 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
         const int ncb = (sw + max_cols - 1) / max_cols;
         bc = std::max(4, ((sw + ncb - 1) / ncb + 3) & ~3);
         br = (int)(lds_budget / ((size_t)(bc + 4) * 4)) - 1;
-        br = std::max(1, std::min(br, env_int("IPX_BAND_ROWS_MAX", 16)));
+        br = std::max(1, std::min(br, env_int("IPX_BAND_ROWS_MAX", bc / 4 + 1 > 256 ? 8 : 16)));  // shapes of band_pipe_shape
         if (env_int("IPX_BAND_ROWS", 0) > 0) br = env_int("IPX_BAND_ROWS", 0);
         br = std::min(br, sh);
         pl->blk_cols = bc; pl->band_rows = br;
         pl->ncolblk = (sw + bc - 1) / bc;
         pl->nbands = (sh + br - 1) / br;
         int widest = 0;
+        pl->most_rows = 0;
+        pl->nx_out[0] = pl->nx_out[1] = 0;
         for (int k = 0; k < 2; k++) {
             PlanScale &s = pl->sc[k];
             if (xt[k].empty()) continue;
@@ -697,10 +700,12 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
                 while (d < s.dw && s.sr.x0 + xt[k][d].base < c * bc) d++;
                 cbv[k][c] = c == pl->ncolblk ? s.dw : d;
             }
-            for (int c = 0; c < pl->ncolblk; c++) widest = std::max(widest, cbv[k][c + 1] - cbv[k][c]);
+            int wk = 0;
+            for (int c = 0; c < pl->ncolblk; c++) wk = std::max(wk, cbv[k][c + 1] - cbv[k][c]);
+            widest = std::max(widest, wk);
+            pl->nx_out[k] = (wk + 255) / 256;
             for (int b = 0; b < pl->nbands; b++) pl->most_rows = std::max(pl->most_rows, rb[k][b + 1] - rb[k][b]);
         }
-        pl->nx = widest <= 256 ? 1 : widest <= 512 ? 2 : kBandNX;
         if (widest <= 256 * kBandNX) break;
         if (bc <= 4) { pl->fused = false; *out = pl; return IPX_OK; }  // enormous upscale: per-operation kernels
         max_cols = std::max(4, (int)((long long)bc * 256 * kBandNX / widest) & ~3);
@@ -786,19 +791,27 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         a.band_rows = pl->band_rows; a.nbands = pl->nbands;
         a.blk_cols = pl->blk_cols; a.ncolblk = pl->ncolblk;
         a.nframes = n;
-        a.nx = pl->nx;
         // the persistent pipelined kernel needs 16-byte aligned rows on both frames and a tile of at
         // most kPipeMaxSlots chunks per thread; otherwise one workgroup per item
         a.pipe_wgs = 0;
         a.cus = ctx->cus;
         a.dbg = env_int("IPX_DBG", 0);
+        a.stamps = nullptr;
+        static unsigned long long *stamp_buf = nullptr;   // diagnostic only (IPX_STAMPS=1), never in a timed run
+        if (env_int("IPX_STAMPS", 0)) {
+            if (!stamp_buf) IPX_HIP(hipMalloc((void **)&stamp_buf, 8 * sizeof(unsigned long long)));
+            IPX_HIP(hipMemsetAsync(stamp_buf, 0, 8 * sizeof(unsigned long long), s));
+            a.stamps = stamp_buf;
+        }
         const bool aligned = (sw & 3) == 0 && ((((uintptr_t)src) | (uintptr_t)sstride | src_frame_stride) & 15) == 0 &&
                              (!wm || ((((uintptr_t)wm) | wm_frame_stride) & 15) == 0);
-        if (aligned && env_int("IPX_PIPE", 1) && band_tile_slots(pl->band_rows, pl->blk_cols) <= kPipeMaxSlots) {
+        int pr = 0, pc = 0;
+        if (aligned && env_int("IPX_PIPE", 1) && pl->most_rows <= 64 && band_pipe_shape(pl->band_rows, pl->blk_cols, &pr, &pc)) {
             a.pipe_wgs = std::max(1, env_int("IPX_PIPE_WGS", 8));  // clamped to what is resident at launch
         }
         a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
         a.nscale = 0;
+        a.nx_out[0] = a.nx_out[1] = 0;
         for (int k = 0; k < 2; k++) {
             const PlanScale &ps = pl->sc[k];
             if (!outs[k] || ps.dw <= 0 || ps.dh <= 0) continue;
@@ -807,14 +820,21 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
             o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
             o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
             o.dyadic_shift = ps.dyadic_shift;
+            a.nx_out[a.nscale - 1] = pl->nx_out[k];
         }
         if (a.nscale == 1) a.sc[1] = a.sc[0];  // keeps the kernel's unconditional tap loads legal
         a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
         a.cr = col[0]; a.cg = col[1]; a.cb = col[2]; a.ca = col[3];
         if (!wm && a.nscale == 0) return IPX_OK;
-        const bool ring = aligned && env_int("IPX_RING", 0) && pl->most_rows <= 64 &&
-                          ring_lds_bytes(pl->band_rows, pl->blk_cols) <= (160u << 10);
-        IPX_HIP(ring ? launch_ring(a, s) : launch_band(a, s));
+        IPX_HIP(launch_band(a, s));
+        if (a.stamps) {
+            unsigned long long h[8];
+            IPX_HIP(hipMemcpyAsync(h, a.stamps, sizeof h, hipMemcpyDeviceToHost, s));
+            IPX_HIP(hipStreamSynchronize(s));
+            const double items = (double)pl->nbands * pl->ncolblk * n, waves = 4.0;
+            fprintf(stderr, "[ipx stamps] cycles per item per wave: drain %.0f  barrier1 %.0f  issue %.0f  compute %.0f  barrier2 %.0f\n",
+                    h[0] / items / waves, h[1] / items / waves, h[2] / items / waves, h[3] / items / waves, h[4] / items / waves);
+        }
         return IPX_OK;
     }
 
