@@ -35,6 +35,10 @@
 
 #include "ipx_internal.h"
 
+#ifndef IPX_DIAG
+#define IPX_DIAG 0
+#endif
+
 #pragma clang fp contract(off)
 
 #include "ipx_device.h"
@@ -214,7 +218,11 @@ __device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, in
     const int frame_bytes = (a.sh - 1) * a.sstride + a.sw * 4;
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.src + (size_t)it.f * a.src_frame_stride), 0, frame_bytes, 0x00020000);
-    const int rows = it.valid && !(a.dbg & 2) ? it.t.rows_ld : 0;   // no item: every offset out of range
+#if IPX_DIAG
+    const int rows = it.valid && !(a.dbg & 2) ? it.t.rows_ld : 0;
+#else
+    const int rows = it.valid ? it.t.rows_ld : 0;   // no item: every offset out of range
+#endif
     int voff[CH];
     bool in_tile[CH];
 #pragma unroll
@@ -308,9 +316,15 @@ __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
     v4u ty_stage[2][2];
     issue_tile<ROWS, CH>(a, cur, tid, stage, ty_stage);
 
+    // In-kernel phase stamps exist only in the diagnostic build (-DIPX_DIAG=1, tools/build_diag.sh);
+    // the shipped kernel executes none.
+#if IPX_DIAG
     unsigned long long acc[5] = {0, 0, 0, 0, 0};
 #define IPX_STAMP(i) do { if (a.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc[i] += now_ - tprev; tprev = now_; } } while (0)
     unsigned long long tprev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+#else
+#define IPX_STAMP(i) do { } while (0)
+#endif
     for (;;) {
         // A: staged tile -> LDS (+ watermark copy)
         drain_tile<ROWS, CH>(a, cur, tid, stage, ty_stage, lds, ytap, any_glyph);
@@ -333,7 +347,11 @@ __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, cur.t))
             glyph_phase(a, cur.t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
+#if IPX_DIAG
         if (a.nscale > 0 && !(a.dbg & 1)) {
+#else
+        if (a.nscale > 0) {
+#endif
             scale_out<NX0, FP0, false>(a, 0, cur.t, cur.f, lds, ytap, tid, o0, cur.dyA[0], cur.dyB[0]);
             scale_out<NX1, FP1, false>(a, 1, cur.t, cur.f, lds, ytap + kYChunk, tid, o1, cur.dyA[1], cur.dyB[1]);
         }
@@ -349,8 +367,10 @@ __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
         cur = nxt;
         ++idx;
     }
+#if IPX_DIAG
     if (a.stamps && (tid & 63) == 0)
         for (int i = 0; i < 5; i++) atomicAdd(&a.stamps[i], acc[i]);
+#endif
 #undef IPX_STAMP
 }
 

@@ -111,8 +111,8 @@ struct BandArgs {
     int nx_out[2];             // per scaled output: destination columns per thread and column block (of 256)
     int pipe_wgs;              // > 0: persistent pipelined kernel, this many workgroups per CU wanted
     int cus;                   // compute units of the device
-    int dbg;                   // IPX_DBG timing experiments: 1 = skip scaling, 2 = skip tile loads
-    unsigned long long *stamps; // IPX_STAMPS diagnostic build: per-phase cycle sums (8 counters), else NULL
+    int dbg;                   // diagnostic build only (-DIPX_DIAG=1): 1 = skip scaling, 2 = skip tile loads
+    unsigned long long *stamps; // diagnostic build only: per-phase cycle sums, else NULL
     uint8_t *wm; size_t wm_frame_stride; int wm_stride;   // NULL = no watermark copy
     int nscale;
     ScaleOut sc[2];

@@ -16,6 +16,10 @@
 
 #include "ipx_internal.h"
 
+#ifndef IPX_DIAG
+#define IPX_DIAG 0
+#endif
+
 using namespace ipx;
 
 // ---------------------------------------------------------------------------------------------
@@ -795,14 +799,17 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         // most kPipeMaxSlots chunks per thread; otherwise one workgroup per item
         a.pipe_wgs = 0;
         a.cus = ctx->cus;
-        a.dbg = env_int("IPX_DBG", 0);
+        a.dbg = 0;
         a.stamps = nullptr;
-        static unsigned long long *stamp_buf = nullptr;   // diagnostic only (IPX_STAMPS=1), never in a timed run
+#if IPX_DIAG
+        a.dbg = env_int("IPX_DBG", 0);
+        static unsigned long long *stamp_buf = nullptr;   // IPX_STAMPS=1: phase stamps, never in a timed run
         if (env_int("IPX_STAMPS", 0)) {
             if (!stamp_buf) IPX_HIP(hipMalloc((void **)&stamp_buf, 8 * sizeof(unsigned long long)));
             IPX_HIP(hipMemsetAsync(stamp_buf, 0, 8 * sizeof(unsigned long long), s));
             a.stamps = stamp_buf;
         }
+#endif
         const bool aligned = (sw & 3) == 0 && ((((uintptr_t)src) | (uintptr_t)sstride | src_frame_stride) & 15) == 0 &&
                              (!wm || ((((uintptr_t)wm) | wm_frame_stride) & 15) == 0);
         int pr = 0, pc = 0;

@@ -183,6 +183,48 @@ def test_plan_subsets_and_unfused(ctx, monkeypatch):
     gs.close()
 
 
+PATH_ENVS = [{"IPX_PIPE": "0"},                                  # one workgroup per item (band_kernel)
+             {"IPX_NO_DYADIC": "1"},                             # float64 lerp everywhere
+             {"IPX_NO_DYADIC": "1", "IPX_PIPE": "0"},
+             {"IPX_PIPE_WGS": "1"},                              # one persistent workgroup per CU
+             {"IPX_BLK_COLS": "256"},                            # many column blocks (x taps change)
+             {"IPX_BLK_COLS": "1000", "IPX_BAND_ROWS": "16"}]    # the 17-row single-column-group tile shape
+
+
+@pytest.mark.parametrize("env", PATH_ENVS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_every_kernel_path_is_bit_exact(ctx, env, monkeypatch):
+    """The shipped default is the persistent pipelined kernel with the exact fp32 lerp on dyadic
+    axes; the fallbacks (one workgroup per item, float64 lerp, other tile shapes) must give the same
+    bytes."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for sw, sh, n, resize in ((1920, 1080, 3, (1024, 768, False)), (1280, 720, 2, (1024, 768, True)),
+                              (854, 480, 2, (1024, 768, True))):
+        frames = rgba_frames(n, sw, sh, seed=sw)
+        glyphs = text_glyphs(sw, sh)
+        gs = ctx.glyphset(glyphs, DEFAULT_COL)
+        plan = ctx.plan(sw, sh, resize=resize, thumbnail=(200, True), watermark=gs)
+        got = plan.run_host(frames)
+        for i in range(n):
+            want = oracle.process(frames[i], resize=resize, thumb=(200, True), glyphs=glyphs, col=DEFAULT_COL)
+            for k in ("resize", "thumbnail", "watermark"):
+                np.testing.assert_array_equal(got[k][i], want[k], err_msg="%s frame %d %s" % (k, i, env))
+        plan.close()
+        gs.close()
+
+
+def test_config1_plumbing_640x480_thumbnail(ctx):
+    """BASELINE config 1: one 640x480 frame -> 200x200 thumbnail (crop 480^2 at x=80), GPU vs oracle."""
+    frame = rgba_frames(1, 640, 480, seed=1)
+    plan = ctx.plan(640, 480, resize=None, thumbnail=(200, True), watermark=None)
+    assert (plan.info.thumb_w, plan.info.thumb_h) == (200, 200)
+    c = plan.info.thumb_crop
+    assert (c.x0, c.y0, c.x1, c.y1) == (80, 0, 560, 480)
+    got = plan.run_host(frame)["thumbnail"][0]
+    np.testing.assert_array_equal(got, oracle.process(frame[0], thumb=(200, True), want=("thumbnail",))["thumbnail"])
+    plan.close()
+
+
 def test_one_pixel_wide_source_takes_unfused_path(ctx):
     frames = rgba_frames(2, 1, 40, seed=11, opaque=False)
     plan = ctx.plan(1, 40, resize=(8, 8, False), thumbnail=(4, True), watermark=True)
