@@ -311,6 +311,51 @@ class Context:
                                     src.ctypes.data, sw, sh, sw * 4, int(sp[0]), int(sp[1]), op))
         return dst
 
+    # ---- source-type variants: *image.NRGBA and *image.YCbCr sources -------------
+    def scale_bilinear_nrgba(self, src, dw, dh, sr=None, dr=None, op=OP_OVER, dst=None):
+        src = _frame(src)
+        sh, sw = src.shape[:2]
+        if dst is None:
+            dst = np.zeros((dh, dw, 4), np.uint8)
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous and dst.shape == (dh, dw, 4)
+        _check(lib().ipx_scale_bilinear_nrgba8(
+            self.handle, dst.ctypes.data, dw, dh, dw * 4, _rect(dr if dr is not None else (0, 0, dw, dh)),
+            src.ctypes.data, sw, sh, sw * 4, _rect(sr if sr is not None else (0, 0, sw, sh)), op))
+        return dst
+
+    def draw_nrgba(self, dst, r, src, sp=(0, 0), op=OP_SRC):
+        src = _frame(src)
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous
+        dh, dw = dst.shape[:2]
+        sh, sw = src.shape[:2]
+        _check(lib().ipx_draw_nrgba8(self.handle, dst.ctypes.data, dw, dh, dw * 4, _rect(r), src.ctypes.data, sw, sh,
+                                     sw * 4, int(sp[0]), int(sp[1]), op))
+        return dst
+
+    @staticmethod
+    def _ycbcr(y, cb, cr, ratio):
+        y, cb, cr = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, cb, cr))
+        h, w = y.shape
+        return _lib.YCbCr(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, w, cb.shape[1], w, h, int(ratio)), (y, cb, cr)
+
+    def scale_bilinear_ycbcr(self, y, cb, cr, ratio, dw, dh, sr=None, dr=None, dst=None):
+        st, keep = self._ycbcr(y, cb, cr, ratio)
+        if dst is None:
+            dst = np.zeros((dh, dw, 4), np.uint8)
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous and dst.shape == (dh, dw, 4)
+        _check(lib().ipx_scale_bilinear_ycbcr(self.handle, dst.ctypes.data, dw, dh, dw * 4,
+                                              _rect(dr if dr is not None else (0, 0, dw, dh)), C.byref(st),
+                                              _rect(sr if sr is not None else (0, 0, st.w, st.h))))
+        return dst
+
+    def draw_ycbcr(self, dst, r, y, cb, cr, ratio, sp=(0, 0)):
+        st, keep = self._ycbcr(y, cb, cr, ratio)
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous
+        dh, dw = dst.shape[:2]
+        _check(lib().ipx_draw_ycbcr(self.handle, dst.ctypes.data, dw, dh, dw * 4, _rect(r), C.byref(st), int(sp[0]),
+                                    int(sp[1])))
+        return dst
+
     def composite_glyphs(self, dst, glyphs, col):
         assert dst.dtype == np.uint8 and dst.flags.c_contiguous
         dh, dw = dst.shape[:2]

@@ -37,6 +37,11 @@ class PlanInfo(C.Structure):
                 ("algorithmic_bytes", C.c_size_t)]
 
 
+class YCbCr(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p), ("ystride", C.c_int32),
+                ("cstride", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("ratio", C.c_int32)]
+
+
 class Param(C.Structure):
     _fields_ = [("key", C.c_char_p), ("type", C.c_int32), ("f64", C.c_double), ("i64", C.c_int64),
                 ("str", C.c_char_p)]
@@ -98,6 +103,10 @@ SIGNATURES = {
     "ipx_scale_bilinear_rgba8": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, Rect, _I]),
     "ipx_draw_rgba8": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, _I, _I, _I]),
     "ipx_composite_glyphs_rgba8": (_I, [_P, _P, _I, _I, _I, C.POINTER(Glyph), _I, _P]),
+    "ipx_scale_bilinear_nrgba8": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, Rect, _I]),
+    "ipx_draw_nrgba8": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, _I, _I, _I]),
+    "ipx_scale_bilinear_ycbcr": (_I, [_P, _P, _I, _I, _I, Rect, C.POINTER(YCbCr), Rect]),
+    "ipx_draw_ycbcr": (_I, [_P, _P, _I, _I, _I, Rect, C.POINTER(YCbCr), _I, _I]),
     "ipx_dev_scale_bilinear_rgba8": (_I, [_P, _P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, Rect, _I]),
     "ipx_dev_draw_rgba8": (_I, [_P, _P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, _I, _I, _I]),
     "ipx_glyphset_create": (_I, [_P, C.POINTER(Glyph), _I, _P, C.POINTER(_P)]),

@@ -72,12 +72,20 @@ struct ScaleArgs {
     double xscale, yscale;
     int op;                         // IPX_OP_*
     const int *opaque_flag;         // device int: nonzero when the whole source is opaque (Over only)
+    int kind;                       // IPX_SRC_*: src is RGBA / NRGBA pixels, or the Y plane of a YCbCr image
+    const uint8_t *cb, *cr;         // YCbCr only
+    int cstride, ratio;
 };
+enum { IPX_SRC_RGBA = 0, IPX_SRC_NRGBA = 1, IPX_SRC_YCBCR = 2 };
 hipError_t launch_scale_generic(const ScaleArgs &a, hipStream_t s);
 hipError_t launch_opaque_scan(const uint8_t *src, int sw, int sh, int sstride, int *flag,
                               hipStream_t s);
 hipError_t launch_draw(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h,
                        int op, hipStream_t s);
+hipError_t launch_draw_nrgba(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h, int op,
+                             hipStream_t s);
+hipError_t launch_draw_ycbcr(uint8_t *dst, int dstride, const uint8_t *y, int ystride, const uint8_t *cb,
+                             const uint8_t *cr, int cstride, int ratio, int spx, int spy, int w, int h, hipStream_t s);
 
 struct DevGlyph {           // one clipped DrawMask call, masks resident in HBM
     const uint8_t *mask;    // points at mask(mpx, mpy) after clipping

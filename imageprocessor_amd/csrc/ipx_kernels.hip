@@ -23,6 +23,50 @@ namespace {
 // Generic scale: any rectangles, Src or Over, one thread per destination pixel, taps straight
 // from global memory.  This is the per-operation seam; the batched path uses band_kernel.
 // ---------------------------------------------------------------------------------------------
+// 16-bit premultiplied RGBA of one source pixel, per source type:
+//   RGBA   scale_RGBA_RGBA_*      c * 0x101
+//   NRGBA  scale_RGBA_NRGBA_*     a16 = a * 0x101; c * a16 / 0xff          (PNG with alpha)
+//   YCbCr  scale_RGBA_YCbCr4xx_Src: color.YCbCr.RGBA inlined, clamped to 16 bit, alpha 0xffff (JPEG)
+struct Tap16 { uint32_t r, g, b, a; };
+
+template <int KIND>
+__device__ __forceinline__ Tap16 tap16(const ScaleArgs &a, int x, int y)
+{
+    Tap16 t;
+    if (KIND == IPX_SRC_YCBCR) {
+        const int cx = (a.ratio == IPX_YCBCR_422 || a.ratio == IPX_YCBCR_420) ? x / 2 : x;
+        const int cy = (a.ratio == IPX_YCBCR_420 || a.ratio == IPX_YCBCR_440) ? y / 2 : y;
+        const size_t ci = (size_t)cy * a.cstride + cx;
+        const int yy1 = (int)a.src[(size_t)y * a.sstride + x] * 0x10101;
+        const int cb1 = (int)a.cb[ci] - 128, cr1 = (int)a.cr[ci] - 128;
+        t.r = (uint32_t)min(max((yy1 + 91881 * cr1) >> 8, 0), 0xffff);
+        t.g = (uint32_t)min(max((yy1 - 22554 * cb1 - 46802 * cr1) >> 8, 0), 0xffff);
+        t.b = (uint32_t)min(max((yy1 + 116130 * cb1) >> 8, 0), 0xffff);
+        t.a = 0xffffu;
+    } else {
+        const uint32_t p = *(const uint32_t *)(a.src + (size_t)y * a.sstride + (size_t)x * 4);
+        if (KIND == IPX_SRC_NRGBA) {
+            t.a = (p >> 24) * 0x101u;
+            t.r = (p & 0xffu) * t.a / 0xffu;
+            t.g = ((p >> 8) & 0xffu) * t.a / 0xffu;
+            t.b = ((p >> 16) & 0xffu) * t.a / 0xffu;
+        } else {
+            t.r = (p & 0xffu) * 0x101u; t.g = ((p >> 8) & 0xffu) * 0x101u;
+            t.b = ((p >> 16) & 0xffu) * 0x101u; t.a = (p >> 24) * 0x101u;
+        }
+    }
+    return t;
+}
+
+__device__ __forceinline__ uint32_t lerp16(uint32_t s00, uint32_t s10, uint32_t s01, uint32_t s11, double xw0,
+                                           double xw1, double yw0, double yw1)
+{
+    const double top = xw0 * (double)s00 + xw1 * (double)s10;
+    const double bot = xw0 * (double)s01 + xw1 * (double)s11;
+    return (uint32_t)(yw0 * top + yw1 * bot);
+}
+
+template <int KIND>
 __global__ __launch_bounds__(256) void scale_generic_kernel(ScaleArgs a)
 {
     const int dx = a.adr_x0 + (int)(blockIdx.x * 64 + threadIdx.x);
@@ -45,17 +89,12 @@ __global__ __launch_bounds__(256) void scale_generic_kernel(ScaleArgs a)
     if (sx < 0) { sx0 = 0; sx1 = 0; xf0 = 0; xf1 = 1; }
     else if (sx1 > a.ssw - 1) { sx0 = a.ssw - 1; sx1 = a.ssw - 1; xf0 = 1; xf1 = 0; }
 
-    const uint8_t *row0 = a.src + (size_t)(a.sr_y0 + sy0) * a.sstride;
-    const uint8_t *row1 = a.src + (size_t)(a.sr_y0 + sy1) * a.sstride;
-    const uint32_t p00 = *(const uint32_t *)(row0 + (size_t)(a.sr_x0 + sx0) * 4);
-    const uint32_t p10 = *(const uint32_t *)(row0 + (size_t)(a.sr_x0 + sx1) * 4);
-    const uint32_t p01 = *(const uint32_t *)(row1 + (size_t)(a.sr_x0 + sx0) * 4);
-    const uint32_t p11 = *(const uint32_t *)(row1 + (size_t)(a.sr_x0 + sx1) * 4);
-
-    const uint32_t pr = lerp_channel<0>(p00, p10, p01, p11, xf1, xf0, yf1, yf0);
-    const uint32_t pg = lerp_channel<1>(p00, p10, p01, p11, xf1, xf0, yf1, yf0);
-    const uint32_t pb = lerp_channel<2>(p00, p10, p01, p11, xf1, xf0, yf1, yf0);
-    const uint32_t pa = lerp_channel<3>(p00, p10, p01, p11, xf1, xf0, yf1, yf0);
+    const Tap16 t00 = tap16<KIND>(a, a.sr_x0 + sx0, a.sr_y0 + sy0), t10 = tap16<KIND>(a, a.sr_x0 + sx1, a.sr_y0 + sy0);
+    const Tap16 t01 = tap16<KIND>(a, a.sr_x0 + sx0, a.sr_y0 + sy1), t11 = tap16<KIND>(a, a.sr_x0 + sx1, a.sr_y0 + sy1);
+    const uint32_t pr = lerp16(t00.r, t10.r, t01.r, t11.r, xf1, xf0, yf1, yf0);
+    const uint32_t pg = lerp16(t00.g, t10.g, t01.g, t11.g, xf1, xf0, yf1, yf0);
+    const uint32_t pb = lerp16(t00.b, t10.b, t01.b, t11.b, xf1, xf0, yf1, yf0);
+    const uint32_t pa = lerp16(t00.a, t10.a, t01.a, t11.a, xf1, xf0, yf1, yf0);
 
     uint32_t *d = (uint32_t *)(a.dst + (size_t)(a.dr_y0 + dy) * a.dstride + (size_t)(a.dr_x0 + dx) * 4);
     int op = a.op;
@@ -109,6 +148,51 @@ __global__ __launch_bounds__(256) void draw_px_kernel(uint8_t *dst, int dstride,
     }
 }
 
+// drawNRGBASrc / drawNRGBAOver: premultiply each source pixel, then as drawCopySrc / drawCopyOver
+__global__ __launch_bounds__(256) void draw_nrgba_kernel(uint8_t *dst, int dstride, const uint8_t *src,
+                                                         int sstride, int w, int h, int op)
+{
+    const int y = blockIdx.y;
+    if (y >= h) return;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256) {
+        const uint32_t s = *(const uint32_t *)(src + (size_t)y * sstride + (size_t)x * 4);
+        uint32_t *dp = (uint32_t *)(dst + (size_t)y * dstride + (size_t)x * 4);
+        const uint32_t sa = (s >> 24) * 0x101u;
+        const uint32_t sr = (s & 0xffu) * sa / 0xffu, sg = ((s >> 8) & 0xffu) * sa / 0xffu, sb = ((s >> 16) & 0xffu) * sa / 0xffu;
+        if (op == IPX_OP_SRC) { *dp = (sr >> 8) | (sg & 0xff00u) | ((sb & 0xff00u) << 8) | ((sa & 0xff00u) << 16); continue; }
+        const uint32_t d = *dp;
+        const uint32_t al = (kM - sa) * 0x101u;
+        const uint32_t r = (((d & 0xffu) * al / kM + sr) >> 8) & 0xffu;
+        const uint32_t g = ((((d >> 8) & 0xffu) * al / kM + sg) >> 8) & 0xffu;
+        const uint32_t b = ((((d >> 16) & 0xffu) * al / kM + sb) >> 8) & 0xffu;
+        const uint32_t a = (((d >> 24) * al / kM + sa) >> 8) & 0xffu;
+        *dp = r | (g << 8) | (b << 16) | (a << 24);
+    }
+}
+
+// imageutil.DrawYCbCr: color.YCbCrToRGB per pixel (8 bit, the uint32 overflow test of the Go code), A = 255
+__global__ __launch_bounds__(256) void draw_ycbcr_kernel(uint8_t *dst, int dstride, const uint8_t *yp, int ystride,
+                                                         const uint8_t *cb, const uint8_t *cr, int cstride, int ratio,
+                                                         int spx, int spy, int w, int h)
+{
+    const int y = blockIdx.y;
+    if (y >= h) return;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256) {
+        const int sx = spx + x, sy = spy + y;
+        const int cx = (ratio == IPX_YCBCR_422 || ratio == IPX_YCBCR_420) ? sx / 2 : sx;
+        const int cy = (ratio == IPX_YCBCR_420 || ratio == IPX_YCBCR_440) ? sy / 2 : sy;
+        const size_t ci = (size_t)cy * cstride + cx;
+        const int32_t yy1 = (int32_t)yp[(size_t)sy * ystride + sx] * 0x10101;
+        const int32_t cb1 = (int32_t)cb[ci] - 128, cr1 = (int32_t)cr[ci] - 128;
+        int32_t r = yy1 + 91881 * cr1, g = yy1 - 22554 * cb1 - 46802 * cr1, b = yy1 + 116130 * cb1;
+        r = ((uint32_t)r & 0xff000000u) == 0 ? r >> 16 : ~(r >> 31);
+        g = ((uint32_t)g & 0xff000000u) == 0 ? g >> 16 : ~(g >> 31);
+        b = ((uint32_t)b & 0xff000000u) == 0 ? b >> 16 : ~(b >> 31);
+        *(uint32_t *)(dst + (size_t)y * dstride + (size_t)x * 4) =
+            ((uint32_t)r & 0xffu) | (((uint32_t)g & 0xffu) << 8) | (((uint32_t)b & 0xffu) << 16) | 0xff000000u;
+    }
+}
+
 // Stand-alone composite over the bounding box of the clipped glyph rectangles.  One wave covers
 // a 64-pixel row segment: the glyph table is wave-uniform (scalar loads), a ballot skips glyphs
 // no lane of the segment touches, and the untouched pixels are never written.
@@ -145,7 +229,28 @@ hipError_t launch_scale_generic(const ScaleArgs &a, hipStream_t s)
     const int w = a.adr_x1 - a.adr_x0, h = a.adr_y1 - a.adr_y0;
     if (w <= 0 || h <= 0) return hipSuccess;
     dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(scale_generic_kernel, grid, block, 0, s, a);
+    if (a.kind == IPX_SRC_NRGBA) hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_NRGBA>, grid, block, 0, s, a);
+    else if (a.kind == IPX_SRC_YCBCR) hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_YCBCR>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_RGBA>, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_draw_nrgba(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h, int op,
+                             hipStream_t s)
+{
+    if (w <= 0 || h <= 0) return hipSuccess;
+    dim3 grid(min(8, (w + 255) / 256), h);
+    hipLaunchKernelGGL(draw_nrgba_kernel, grid, dim3(256), 0, s, dst, dstride, src, sstride, w, h, op);
+    return hipGetLastError();
+}
+
+hipError_t launch_draw_ycbcr(uint8_t *dst, int dstride, const uint8_t *y, int ystride, const uint8_t *cb,
+                             const uint8_t *cr, int cstride, int ratio, int spx, int spy, int w, int h, hipStream_t s)
+{
+    if (w <= 0 || h <= 0) return hipSuccess;
+    dim3 grid(min(8, (w + 255) / 256), h);
+    hipLaunchKernelGGL(draw_ycbcr_kernel, grid, dim3(256), 0, s, dst, dstride, y, ystride, cb, cr, cstride, ratio, spx,
+                       spy, w, h);
     return hipGetLastError();
 }
 

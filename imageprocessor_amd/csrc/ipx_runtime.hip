@@ -180,35 +180,75 @@ int scale_prepare(int dw, int dh, const Rect &dr, int sw, int sh, const Rect &sr
 }
 
 // dst / src are device pointers at pixel (0,0)
-int dev_draw(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect r, const uint8_t *src,
-             int sw, int sh, int sstride, int spx, int spy, int op)
+// a source image resident in HBM: RGBA / NRGBA pixels, or the three planes of a YCbCr image
+struct DevSrc {
+    int kind = IPX_SRC_RGBA;
+    const uint8_t *pix = nullptr;   // pixels, or the Y plane
+    int stride = 0;                 // bytes per row of pix
+    const uint8_t *cb = nullptr, *cr = nullptr;
+    int cstride = 0, ratio = 0;
+    int w = 0, h = 0;
+};
+
+int dev_draw_src(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect r, const DevSrc &src, int spx,
+                 int spy, int op)
 {
     if (op != IPX_OP_OVER && op != IPX_OP_SRC) { set_error("draw: unknown op %d", op); return IPX_ERR_INVALID; }
     int mx = 0, my = 0;
-    if (!draw_clip(r, dw, dh, true, sw, sh, spx, spy, false, 0, 0, mx, my)) return IPX_OK;
-    IPX_HIP(launch_draw(dst + (size_t)r.y0 * dstride + (size_t)r.x0 * 4, dstride,
-                        src + (size_t)spy * sstride + (size_t)spx * 4, sstride, r.dx(), r.dy(), op, s));
+    if (!draw_clip(r, dw, dh, true, src.w, src.h, spx, spy, false, 0, 0, mx, my)) return IPX_OK;
+    uint8_t *d = dst + (size_t)r.y0 * dstride + (size_t)r.x0 * 4;
+    if (src.kind == IPX_SRC_YCBCR)   // opaque source: Over == Src (image/draw.DrawMask's YCbCr arm)
+        IPX_HIP(launch_draw_ycbcr(d, dstride, src.pix, src.stride, src.cb, src.cr, src.cstride, src.ratio, spx, spy,
+                                  r.dx(), r.dy(), s));
+    else if (src.kind == IPX_SRC_NRGBA)
+        IPX_HIP(launch_draw_nrgba(d, dstride, src.pix + (size_t)spy * src.stride + (size_t)spx * 4, src.stride, r.dx(),
+                                  r.dy(), op, s));
+    else
+        IPX_HIP(launch_draw(d, dstride, src.pix + (size_t)spy * src.stride + (size_t)spx * 4, src.stride, r.dx(), r.dy(),
+                            op, s));
     return IPX_OK;
 }
 
-int dev_scale(hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int dstride, const Rect &dr,
-              const uint8_t *src, int sw, int sh, int sstride, const Rect &sr, int op)
+int dev_scale_src(hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int dstride, const Rect &dr,
+                  const DevSrc &src, const Rect &sr, int op)
 {
     ScalePrep pr;
-    int rc = scale_prepare(dw, dh, dr, sw, sh, sr, op, &pr);
+    int rc = scale_prepare(dw, dh, dr, src.w, src.h, sr, op, &pr);
     if (rc) return rc;
-    if (pr.copy) return dev_draw(s, dst, dw, dh, dstride, dr, src, sw, sh, sstride, sr.x0, sr.y0, op);
+    if (pr.copy) return dev_draw_src(s, dst, dw, dh, dstride, dr, src, sr.x0, sr.y0, op);
     if (pr.empty) return IPX_OK;
-    if (op == IPX_OP_OVER) IPX_HIP(launch_opaque_scan(src, sw, sh, sstride, flag, s));
+    if (src.kind == IPX_SRC_YCBCR) op = IPX_OP_SRC;   // (*image.YCbCr).Opaque() is always true
+    if (op == IPX_OP_OVER) IPX_HIP(launch_opaque_scan(src.pix, src.w, src.h, src.stride, flag, s));  // RGBA and NRGBA: alpha scan
     ScaleArgs a;
-    a.dst = dst; a.dstride = dstride; a.src = src; a.sstride = sstride;
+    a.dst = dst; a.dstride = dstride; a.src = src.pix; a.sstride = src.stride;
     a.dr_x0 = dr.x0; a.dr_y0 = dr.y0;
     a.adr_x0 = pr.adr.x0; a.adr_y0 = pr.adr.y0; a.adr_x1 = pr.adr.x1; a.adr_y1 = pr.adr.y1;
     a.sr_x0 = sr.x0; a.sr_y0 = sr.y0; a.ssw = sr.dx(); a.ssh = sr.dy();
     a.xscale = pr.xscale; a.yscale = pr.yscale;
     a.op = op; a.opaque_flag = op == IPX_OP_OVER ? flag : nullptr;
+    a.kind = src.kind; a.cb = src.cb; a.cr = src.cr; a.cstride = src.cstride; a.ratio = src.ratio;
     IPX_HIP(launch_scale_generic(a, s));
     return IPX_OK;
+}
+
+DevSrc rgba_src(const uint8_t *p, int w, int h, int stride, int kind = IPX_SRC_RGBA)
+{
+    DevSrc d;
+    d.kind = kind; d.pix = p; d.stride = stride; d.w = w; d.h = h;
+    return d;
+}
+
+// dst / src are device pointers at pixel (0,0)
+int dev_draw(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect r, const uint8_t *src,
+             int sw, int sh, int sstride, int spx, int spy, int op)
+{
+    return dev_draw_src(s, dst, dw, dh, dstride, r, rgba_src(src, sw, sh, sstride), spx, spy, op);
+}
+
+int dev_scale(hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int dstride, const Rect &dr,
+              const uint8_t *src, int sw, int sh, int sstride, const Rect &sr, int op)
+{
+    return dev_scale_src(s, flag, dst, dw, dh, dstride, dr, rgba_src(src, sw, sh, sstride), sr, op);
 }
 
 // clip every glyph against a dw x dh frame (image/draw.clip) and cache the device table
@@ -607,6 +647,125 @@ int ipx_composite_glyphs_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int d
     ipx_glyphset_destroy(ctx, gs);
     return rc;
 }
+
+}  // extern "C"
+
+// ---- source-type variants: host pointers, staged through a lane ----------------------------------------
+namespace {
+
+// dst goes up and down; the source planes go up; `run` launches on the lane's stream
+template <typename F>
+int stage_and_run(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, size_t src_bytes, F &&upload_and_run)
+{
+    LaneLease lane(ctx);
+    const size_t dbytes = align256((size_t)dw * dh * 4);
+    int rc = lane_reserve(lane.get(), dbytes + src_bytes + 1024);
+    if (rc) return rc;
+    uint8_t *ddst = lane->dev, *dsrc = lane->dev + dbytes;
+    hipStream_t s = lane->stream;
+    IPX_HIP(hipMemcpy2DAsync(ddst, (size_t)dw * 4, dst, dstride, (size_t)dw * 4, dh, hipMemcpyHostToDevice, s));
+    rc = upload_and_run(s, lane->flag, ddst, dsrc);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    IPX_HIP(hipMemcpy2DAsync(dst, dstride, ddst, (size_t)dw * 4, (size_t)dw * 4, dh, hipMemcpyDeviceToHost, s));
+    IPX_HIP(hipStreamSynchronize(s));
+    return IPX_OK;
+}
+
+bool ycbcr_ok(const ipx_ycbcr *y, int *cw, int *ch)
+{
+    if (!y || !y->y || !y->cb || !y->cr || y->w <= 0 || y->h <= 0 || y->ratio < 0 || y->ratio > IPX_YCBCR_440) return false;
+    *cw = (y->ratio == IPX_YCBCR_422 || y->ratio == IPX_YCBCR_420) ? (y->w + 1) / 2 : y->w;   // image.NewYCbCr
+    *ch = (y->ratio == IPX_YCBCR_420 || y->ratio == IPX_YCBCR_440) ? (y->h + 1) / 2 : y->h;
+    return y->ystride >= y->w && y->cstride >= *cw;
+}
+
+int upload_ycbcr(hipStream_t s, const ipx_ycbcr *y, int cw, int ch, uint8_t *dsrc, DevSrc *out)
+{
+    const size_t yb = align256((size_t)y->w * y->h), cbytes = align256((size_t)cw * ch);
+    IPX_HIP(hipMemcpy2DAsync(dsrc, y->w, y->y, y->ystride, y->w, y->h, hipMemcpyHostToDevice, s));
+    IPX_HIP(hipMemcpy2DAsync(dsrc + yb, cw, y->cb, y->cstride, cw, ch, hipMemcpyHostToDevice, s));
+    IPX_HIP(hipMemcpy2DAsync(dsrc + yb + cbytes, cw, y->cr, y->cstride, cw, ch, hipMemcpyHostToDevice, s));
+    out->kind = IPX_SRC_YCBCR; out->pix = dsrc; out->stride = y->w;
+    out->cb = dsrc + yb; out->cr = dsrc + yb + cbytes; out->cstride = cw; out->ratio = y->ratio;
+    out->w = y->w; out->h = y->h;
+    return IPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ipx_scale_bilinear_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
+                              const uint8_t *src, int sw, int sh, int sstride, ipx_rect sr, int op)
+{
+    IPX_ENTER(ctx);
+    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
+        set_error("ipx_scale_bilinear_nrgba8: bad frame arguments");
+        return IPX_ERR_INVALID;
+    }
+    if (!dw || !dh || !sw || !sh) return IPX_OK;
+    return stage_and_run(ctx, dst, dw, dh, dstride, align256((size_t)sw * sh * 4), [&](hipStream_t s, int *flag, uint8_t *ddst, uint8_t *dsrc) -> int {
+        IPX_HIP(hipMemcpy2DAsync(dsrc, (size_t)sw * 4, src, sstride, (size_t)sw * 4, sh, hipMemcpyHostToDevice, s));
+        return dev_scale_src(s, flag, ddst, dw, dh, dw * 4, to_rect(dr), rgba_src(dsrc, sw, sh, sw * 4, IPX_SRC_NRGBA), to_rect(sr), op);
+    });
+}
+
+int ipx_draw_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r, const uint8_t *src,
+                    int sw, int sh, int sstride, int spx, int spy, int op)
+{
+    IPX_ENTER(ctx);
+    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
+        set_error("ipx_draw_nrgba8: bad frame arguments");
+        return IPX_ERR_INVALID;
+    }
+    if (!dw || !dh || !sw || !sh) return IPX_OK;
+    return stage_and_run(ctx, dst, dw, dh, dstride, align256((size_t)sw * sh * 4), [&](hipStream_t s, int *, uint8_t *ddst, uint8_t *dsrc) -> int {
+        IPX_HIP(hipMemcpy2DAsync(dsrc, (size_t)sw * 4, src, sstride, (size_t)sw * 4, sh, hipMemcpyHostToDevice, s));
+        return dev_draw_src(s, ddst, dw, dh, dw * 4, to_rect(r), rgba_src(dsrc, sw, sh, sw * 4, IPX_SRC_NRGBA), spx, spy, op);
+    });
+}
+
+int ipx_scale_bilinear_ycbcr(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
+                             const ipx_ycbcr *src, ipx_rect sr)
+{
+    IPX_ENTER(ctx);
+    int cw = 0, ch = 0;
+    if (!frame_args_ok(dst, dw, dh, dstride) || !ycbcr_ok(src, &cw, &ch)) {
+        set_error("ipx_scale_bilinear_ycbcr: bad arguments");
+        return IPX_ERR_INVALID;
+    }
+    if (!dw || !dh) return IPX_OK;
+    const size_t bytes = align256((size_t)src->w * src->h) + 2 * align256((size_t)cw * ch);
+    return stage_and_run(ctx, dst, dw, dh, dstride, bytes, [&](hipStream_t s, int *flag, uint8_t *ddst, uint8_t *dsrc) -> int {
+        DevSrc d;
+        int rc = upload_ycbcr(s, src, cw, ch, dsrc, &d);
+        if (rc) return rc;
+        return dev_scale_src(s, flag, ddst, dw, dh, dw * 4, to_rect(dr), d, to_rect(sr), IPX_OP_SRC);
+    });
+}
+
+int ipx_draw_ycbcr(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r, const ipx_ycbcr *src,
+                   int spx, int spy)
+{
+    IPX_ENTER(ctx);
+    int cw = 0, ch = 0;
+    if (!frame_args_ok(dst, dw, dh, dstride) || !ycbcr_ok(src, &cw, &ch)) {
+        set_error("ipx_draw_ycbcr: bad arguments");
+        return IPX_ERR_INVALID;
+    }
+    if (!dw || !dh) return IPX_OK;
+    const size_t bytes = align256((size_t)src->w * src->h) + 2 * align256((size_t)cw * ch);
+    return stage_and_run(ctx, dst, dw, dh, dstride, bytes, [&](hipStream_t s, int *, uint8_t *ddst, uint8_t *dsrc) -> int {
+        DevSrc d;
+        int rc = upload_ycbcr(s, src, cw, ch, dsrc, &d);
+        if (rc) return rc;
+        return dev_draw_src(s, ddst, dw, dh, dw * 4, to_rect(r), d, spx, spy, IPX_OP_SRC);
+    });
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- plans -------------------------------------------------------------------------------------------
 int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)

@@ -123,6 +123,29 @@ int ipx_draw_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_
 int ipx_composite_glyphs_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride,
                                const ipx_glyph *glyphs, int n, const uint8_t col[4]);
 
+/* ---- source-type variants of the same helpers ---------------------------------
+ * image.Decode hands the reference *image.NRGBA for PNGs with alpha and *image.YCbCr for JPEGs
+ * (image_processor.go:47); resizeImage / cropAndResize / draw.Draw take them as they are.  These
+ * entries do the same on the GPU: per-tap conversion inside the interpolator exactly as x/image/draw
+ * does it (scale_RGBA_NRGBA_*, scale_RGBA_YCbCr4xx_Src), and image/draw's drawNRGBA{Src,Over} /
+ * imageutil.DrawYCbCr for copies (the watermark's draw.Draw and the thumbnail's crop copy). */
+int ipx_scale_bilinear_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
+                              const uint8_t *src, int sw, int sh, int sstride, ipx_rect sr, int op);
+int ipx_draw_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r,
+                    const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op);
+
+/* *image.YCbCr with Rect.Min = (0,0); ratio numbered as image.YCbCrSubsampleRatio */
+enum { IPX_YCBCR_444 = 0, IPX_YCBCR_422 = 1, IPX_YCBCR_420 = 2, IPX_YCBCR_440 = 3 };
+typedef struct {
+    const uint8_t *y, *cb, *cr;
+    int32_t ystride, cstride, w, h, ratio;
+} ipx_ycbcr;
+/* A YCbCr image is opaque, so the reference's Over becomes Src: there is no op argument. */
+int ipx_scale_bilinear_ycbcr(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
+                             const ipx_ycbcr *src, ipx_rect sr);
+int ipx_draw_ycbcr(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r,
+                   const ipx_ycbcr *src, int spx, int spy);
+
 /* ---- same operations on frames already resident in HBM, asynchronous on `stream` -------------
  * `stream` is a hipStream_t (NULL = the context's own stream).  Pointers are device pointers. */
 

@@ -189,3 +189,88 @@ def process(src, resize=(1024, 768, True), thumb=(200, True), glyphs=(), col=(25
     if rc:
         raise RuntimeError("oracle pipeline failed: %d" % rc)
     return out
+
+
+# ---- source-type variants ------------------------------------------------------
+
+class YCbCrStruct(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p), ("ystride", C.c_int32),
+                ("cstride", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("ratio", C.c_int32)]
+
+
+RATIO_444, RATIO_422, RATIO_420, RATIO_440 = 0, 1, 2, 3
+
+
+def chroma_shape(w, h, ratio):
+    """Plane size of Cb / Cr for an image.YCbCr with Rect.Min = (0,0) (image.NewYCbCr)."""
+    cw = (w + 1) // 2 if ratio in (RATIO_422, RATIO_420) else w
+    chh = (h + 1) // 2 if ratio in (RATIO_420, RATIO_440) else h
+    return chh, cw
+
+
+def _ycbcr(y, cb, cr, ratio):
+    y = np.ascontiguousarray(y, np.uint8)
+    cb = np.ascontiguousarray(cb, np.uint8)
+    cr = np.ascontiguousarray(cr, np.uint8)
+    h, w = y.shape
+    assert cb.shape == cr.shape == chroma_shape(w, h, ratio), (cb.shape, chroma_shape(w, h, ratio))
+    return YCbCrStruct(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, w, cb.shape[1], w, h, ratio), (y, cb, cr)
+
+
+def _decl_variants():
+    L = lib()
+    if getattr(L, "_variants", False):
+        return L
+    L.ipxo_scale_bilinear_nrgba8.restype = C.c_int
+    L.ipxo_scale_bilinear_nrgba8.argtypes = L.ipxo_scale_bilinear_rgba8.argtypes
+    L.ipxo_draw_nrgba8.restype = None
+    L.ipxo_draw_nrgba8.argtypes = L.ipxo_draw_rgba8.argtypes
+    L.ipxo_scale_bilinear_ycbcr.restype = C.c_int
+    L.ipxo_scale_bilinear_ycbcr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect, C.POINTER(YCbCrStruct), Rect]
+    L.ipxo_draw_ycbcr.restype = None
+    L.ipxo_draw_ycbcr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect, C.POINTER(YCbCrStruct), C.c_int, C.c_int]
+    L._variants = True
+    return L
+
+
+def scale_bilinear_nrgba(src, dw, dh, sr=None, dr=None, op=OP_OVER, dst=None):
+    src = _u8(src)
+    sh, sw = src.shape[:2]
+    if dst is None:
+        dst = np.zeros((dh, dw, 4), np.uint8)
+    dst = _u8(dst)
+    rc = _decl_variants().ipxo_scale_bilinear_nrgba8(dst.ctypes.data, dw, dh, dw * 4,
+                                                     _rect(dr if dr is not None else (0, 0, dw, dh)), src.ctypes.data,
+                                                     sw, sh, sw * 4, _rect(sr if sr is not None else (0, 0, sw, sh)), op)
+    if rc:
+        raise ValueError("source rectangle leaves the source image")
+    return dst
+
+
+def draw_nrgba(dst, r, src, sp=(0, 0), op=OP_SRC):
+    src = _u8(src)
+    dh, dw = dst.shape[:2]
+    sh, sw = src.shape[:2]
+    _decl_variants().ipxo_draw_nrgba8(dst.ctypes.data, dw, dh, dw * 4, _rect(r), src.ctypes.data, sw, sh, sw * 4,
+                                      int(sp[0]), int(sp[1]), op)
+    return dst
+
+
+def scale_bilinear_ycbcr(y, cb, cr, ratio, dw, dh, sr=None, dr=None, dst=None):
+    st, keep = _ycbcr(y, cb, cr, ratio)
+    if dst is None:
+        dst = np.zeros((dh, dw, 4), np.uint8)
+    dst = _u8(dst)
+    rc = _decl_variants().ipxo_scale_bilinear_ycbcr(dst.ctypes.data, dw, dh, dw * 4,
+                                                    _rect(dr if dr is not None else (0, 0, dw, dh)), C.byref(st),
+                                                    _rect(sr if sr is not None else (0, 0, st.w, st.h)))
+    if rc:
+        raise ValueError("source rectangle leaves the source image")
+    return dst
+
+
+def draw_ycbcr(dst, r, y, cb, cr, ratio, sp=(0, 0)):
+    st, keep = _ycbcr(y, cb, cr, ratio)
+    dh, dw = dst.shape[:2]
+    _decl_variants().ipxo_draw_ycbcr(dst.ctypes.data, dw, dh, dw * 4, _rect(r), C.byref(st), int(sp[0]), int(sp[1]))
+    return dst

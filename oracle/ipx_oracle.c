@@ -370,3 +370,194 @@ int ipxo_process_rgba8(const ipxo_pipeline *p, const uint8_t *src, int sw, int s
     }
     return 0;
 }
+
+/* ======================================================================================================
+ * Source-type variants.  Same interpolator, different tap fetch.
+ * Upstream routines restated: x/image@v0.33.0 draw/impl.go scale_RGBA_NRGBA_{Src,Over},
+ * scale_RGBA_YCbCr{444,422,420,440}_Src; Go 1.24 image/draw drawNRGBAOver / drawNRGBASrc;
+ * image/internal/imageutil DrawYCbCr; image/color YCbCr.RGBA / YCbCrToRGB.
+ * ====================================================================================================== */
+
+typedef void (*tap_fn)(const void *src, int x, int y, uint32_t out[4]); /* 16-bit premultiplied RGBA */
+
+static void scale_core(uint8_t *dst, int dstride, ipxo_rect dr, ipxo_rect adr, const void *src, tap_fn tap,
+                       ipxo_rect sr, int op)
+{
+    const int32_t ssw = sr.x1 - sr.x0, ssh = sr.y1 - sr.y0;
+    const double yscale = (double)ssh / (double)(dr.y1 - dr.y0);
+    const double xscale = (double)ssw / (double)(dr.x1 - dr.x0);
+    int32_t dx, dy;
+    for (dy = adr.y0; dy < adr.y1; dy++) {
+        double sy = ((double)dy + 0.5) * yscale - 0.5;
+        int32_t sy0 = (int32_t)sy;
+        double yf0 = sy - (double)sy0, yf1 = 1 - yf0;
+        int32_t sy1 = sy0 + 1;
+        uint8_t *d;
+        if (sy < 0) { sy0 = 0; sy1 = 0; yf0 = 0; yf1 = 1; }
+        else if (sy1 > ssh - 1) { sy0 = ssh - 1; sy1 = ssh - 1; yf0 = 1; yf1 = 0; }
+        d = dst + (size_t)(dr.y0 + dy) * dstride + (size_t)(dr.x0 + adr.x0) * 4;
+        for (dx = adr.x0; dx < adr.x1; dx++, d += 4) {
+            double sx = ((double)dx + 0.5) * xscale - 0.5;
+            int32_t sx0 = (int32_t)sx;
+            double xf0 = sx - (double)sx0, xf1 = 1 - xf0;
+            int32_t sx1 = sx0 + 1;
+            uint32_t t00[4], t10[4], t01[4], t11[4], p[4];
+            int c;
+            if (sx < 0) { sx0 = 0; sx1 = 0; xf0 = 0; xf1 = 1; }
+            else if (sx1 > ssw - 1) { sx0 = ssw - 1; sx1 = ssw - 1; xf0 = 1; xf1 = 0; }
+            tap(src, sr.x0 + sx0, sr.y0 + sy0, t00);
+            tap(src, sr.x0 + sx1, sr.y0 + sy0, t10);
+            tap(src, sr.x0 + sx0, sr.y0 + sy1, t01);
+            tap(src, sr.x0 + sx1, sr.y0 + sy1, t11);
+            for (c = 0; c < 4; c++) {
+                double s00 = (double)t00[c], s10 = (double)t10[c], s01 = (double)t01[c], s11 = (double)t11[c];
+                s10 = xf1 * s00 + xf0 * s10;
+                s11 = xf1 * s01 + xf0 * s11;
+                s11 = yf1 * s10 + yf0 * s11;
+                p[c] = (uint32_t)s11;
+            }
+            if (op == IPXO_OP_SRC) {
+                d[0] = (uint8_t)(p[0] >> 8); d[1] = (uint8_t)(p[1] >> 8);
+                d[2] = (uint8_t)(p[2] >> 8); d[3] = (uint8_t)(p[3] >> 8);
+            } else {
+                uint32_t pa1 = (0xffff - p[3]) * 0x101;
+                d[0] = (uint8_t)(((uint32_t)d[0] * pa1 / 0xffff + p[0]) >> 8);
+                d[1] = (uint8_t)(((uint32_t)d[1] * pa1 / 0xffff + p[1]) >> 8);
+                d[2] = (uint8_t)(((uint32_t)d[2] * pa1 / 0xffff + p[2]) >> 8);
+                d[3] = (uint8_t)(((uint32_t)d[3] * pa1 / 0xffff + p[3]) >> 8);
+            }
+        }
+    }
+}
+
+/* ---- *image.NRGBA ---------------------------------------------------------------------------------- */
+
+typedef struct { const uint8_t *pix; int stride; } nrgba_src;
+
+static void tap_nrgba(const void *s, int x, int y, uint32_t out[4])
+{
+    const nrgba_src *n = (const nrgba_src *)s;
+    const uint8_t *p = n->pix + (size_t)y * n->stride + (size_t)x * 4;
+    uint32_t a = (uint32_t)p[3] * 0x101;
+    out[0] = (uint32_t)p[0] * a / 0xff;
+    out[1] = (uint32_t)p[1] * a / 0xff;
+    out[2] = (uint32_t)p[2] * a / 0xff;
+    out[3] = a;
+}
+
+void ipxo_draw_nrgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r,
+                      const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op)
+{
+    const uint32_t m = 0xffff;
+    ipxo_rect db = {0, 0, dw, dh}, sb = {0, 0, sw, sh};
+    int ox = r.x0, oy = r.y0, x, y;
+    r = rect_intersect(r, db);
+    r = rect_intersect(r, rect_add(sb, ox - spx, oy - spy));
+    if (rect_empty(r)) return;
+    spx += r.x0 - ox;
+    spy += r.y0 - oy;
+    for (y = 0; y < r.y1 - r.y0; y++) {
+        uint8_t *d = dst + (size_t)(r.y0 + y) * dstride + (size_t)r.x0 * 4;
+        const uint8_t *s = src + (size_t)(spy + y) * sstride + (size_t)spx * 4;
+        for (x = 0; x < r.x1 - r.x0; x++, d += 4, s += 4) {
+            uint32_t sa = (uint32_t)s[3] * 0x101;
+            uint32_t sr_ = (uint32_t)s[0] * sa / 0xff, sg_ = (uint32_t)s[1] * sa / 0xff, sb_ = (uint32_t)s[2] * sa / 0xff;
+            if (op == IPXO_OP_SRC) { /* drawNRGBASrc */
+                d[0] = (uint8_t)(sr_ >> 8); d[1] = (uint8_t)(sg_ >> 8); d[2] = (uint8_t)(sb_ >> 8); d[3] = (uint8_t)(sa >> 8);
+            } else {                 /* drawNRGBAOver */
+                uint32_t a = (m - sa) * 0x101;
+                d[0] = (uint8_t)(((uint32_t)d[0] * a / m + sr_) >> 8);
+                d[1] = (uint8_t)(((uint32_t)d[1] * a / m + sg_) >> 8);
+                d[2] = (uint8_t)(((uint32_t)d[2] * a / m + sb_) >> 8);
+                d[3] = (uint8_t)(((uint32_t)d[3] * a / m + sa) >> 8);
+            }
+        }
+    }
+}
+
+int ipxo_scale_bilinear_nrgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr,
+                               const uint8_t *src, int sw, int sh, int sstride, ipxo_rect sr, int op)
+{
+    ipxo_rect db = {0, 0, dw, dh}, adr;
+    nrgba_src n;
+    if (dr.x1 - dr.x0 == sr.x1 - sr.x0 && dr.y1 - dr.y0 == sr.y1 - sr.y0) {
+        ipxo_draw_nrgba8(dst, dw, dh, dstride, dr, src, sw, sh, sstride, sr.x0, sr.y0, op);
+        return 0;
+    }
+    adr = rect_intersect(db, dr);
+    if (rect_empty(adr) || rect_empty(sr)) return 0;
+    adr = rect_add(adr, -dr.x0, -dr.y0);
+    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) return -1;
+    if (op == IPXO_OP_OVER && rgba_opaque(src, sw, sh, sstride)) op = IPXO_OP_SRC; /* (*NRGBA).Opaque: same scan */
+    n.pix = src; n.stride = sstride;
+    scale_core(dst, dstride, dr, adr, &n, tap_nrgba, sr, op);
+    return 0;
+}
+
+/* ---- *image.YCbCr ---------------------------------------------------------------------------------- */
+
+static size_t ycbcr_coff(const ipxo_ycbcr *s, int x, int y) /* image.(*YCbCr).COffset with Rect.Min = 0 */
+{
+    switch (s->ratio) {
+    case 1: return (size_t)y * s->cstride + (size_t)(x / 2);          /* 4:2:2 */
+    case 2: return (size_t)(y / 2) * s->cstride + (size_t)(x / 2);    /* 4:2:0 */
+    case 3: return (size_t)(y / 2) * s->cstride + (size_t)x;          /* 4:4:0 */
+    default: return (size_t)y * s->cstride + (size_t)x;               /* 4:4:4 */
+    }
+}
+
+static void tap_ycbcr(const void *sv, int x, int y, uint32_t out[4]) /* color.YCbCr.RGBA, inlined upstream */
+{
+    const ipxo_ycbcr *s = (const ipxo_ycbcr *)sv;
+    size_t ci = ycbcr_coff(s, x, y);
+    int yy1 = (int)s->y[(size_t)y * s->ystride + x] * 0x10101;
+    int cb1 = (int)s->cb[ci] - 128, cr1 = (int)s->cr[ci] - 128;
+    int r = (yy1 + 91881 * cr1) >> 8;
+    int g = (yy1 - 22554 * cb1 - 46802 * cr1) >> 8;
+    int b = (yy1 + 116130 * cb1) >> 8;
+    out[0] = (uint32_t)(r < 0 ? 0 : r > 0xffff ? 0xffff : r);
+    out[1] = (uint32_t)(g < 0 ? 0 : g > 0xffff ? 0xffff : g);
+    out[2] = (uint32_t)(b < 0 ? 0 : b > 0xffff ? 0xffff : b);
+    out[3] = 0xffff;
+}
+
+void ipxo_draw_ycbcr(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r, const ipxo_ycbcr *src,
+                     int spx, int spy)
+{
+    ipxo_rect db = {0, 0, dw, dh}, sb = {0, 0, src->w, src->h};
+    int ox = r.x0, oy = r.y0, x, y;
+    r = rect_intersect(r, db);
+    r = rect_intersect(r, rect_add(sb, ox - spx, oy - spy));
+    if (rect_empty(r)) return;
+    spx += r.x0 - ox;
+    spy += r.y0 - oy;
+    for (y = 0; y < r.y1 - r.y0; y++) {
+        uint8_t *d = dst + (size_t)(r.y0 + y) * dstride + (size_t)r.x0 * 4;
+        for (x = 0; x < r.x1 - r.x0; x++, d += 4) { /* color.YCbCrToRGB */
+            size_t ci = ycbcr_coff(src, spx + x, spy + y);
+            int32_t yy1 = (int32_t)src->y[(size_t)(spy + y) * src->ystride + spx + x] * 0x10101;
+            int32_t cb1 = (int32_t)src->cb[ci] - 128, cr1 = (int32_t)src->cr[ci] - 128;
+            int32_t rr = yy1 + 91881 * cr1, gg = yy1 - 22554 * cb1 - 46802 * cr1, bb = yy1 + 116130 * cb1;
+            rr = ((uint32_t)rr & 0xff000000u) == 0 ? rr >> 16 : ~(rr >> 31);
+            gg = ((uint32_t)gg & 0xff000000u) == 0 ? gg >> 16 : ~(gg >> 31);
+            bb = ((uint32_t)bb & 0xff000000u) == 0 ? bb >> 16 : ~(bb >> 31);
+            d[0] = (uint8_t)rr; d[1] = (uint8_t)gg; d[2] = (uint8_t)bb; d[3] = 255;
+        }
+    }
+}
+
+int ipxo_scale_bilinear_ycbcr(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr,
+                              const ipxo_ycbcr *src, ipxo_rect sr)
+{
+    ipxo_rect db = {0, 0, dw, dh}, adr;
+    if (dr.x1 - dr.x0 == sr.x1 - sr.x0 && dr.y1 - dr.y0 == sr.y1 - sr.y0) {
+        ipxo_draw_ycbcr(dst, dw, dh, dstride, dr, src, sr.x0, sr.y0);
+        return 0;
+    }
+    adr = rect_intersect(db, dr);
+    if (rect_empty(adr) || rect_empty(sr)) return 0;
+    adr = rect_add(adr, -dr.x0, -dr.y0);
+    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > src->w || sr.y1 > src->h) return -1;
+    scale_core(dst, dstride, dr, adr, src, tap_ycbcr, sr, IPXO_OP_SRC); /* a YCbCr image is opaque */
+    return 0;
+}

@@ -82,4 +82,34 @@ int ipxo_process_rgba8(const ipxo_pipeline *p, const uint8_t *src, int sw, int s
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- source-type variants: PNG with alpha decodes to *image.NRGBA, JPEG to
+ * *image.YCbCr; the reference hands those straight to the same three helpers. ------------------ */
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* x/image/draw scale_RGBA_NRGBA_{Src,Over}: each tap premultiplied (c * a16 / 0xff) before the lerp.
+ * Equal sizes go to image/draw drawNRGBAOver / drawNRGBASrc like Copy does. */
+int ipxo_scale_bilinear_nrgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr,
+                               const uint8_t *src, int sw, int sh, int sstride, ipxo_rect sr, int op);
+void ipxo_draw_nrgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r,
+                      const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op);
+
+/* *image.YCbCr with Rect.Min = (0,0); ratio = image.YCbCrSubsampleRatio (444=0, 422=1, 420=2, 440=3) */
+typedef struct {
+    const uint8_t *y, *cb, *cr;
+    int32_t ystride, cstride, w, h, ratio;
+} ipxo_ycbcr;
+/* x/image/draw scale_RGBA_YCbCr{444,422,420,440}_Src (YCbCr is opaque, so Over becomes Src): each tap
+ * converted with color.YCbCr.RGBA's 16-bit integer formula, alpha 0xffff.  Equal sizes: DrawYCbCr. */
+int ipxo_scale_bilinear_ycbcr(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr,
+                              const ipxo_ycbcr *src, ipxo_rect sr);
+/* image/internal/imageutil.DrawYCbCr (draw.Draw / Copy from a YCbCr source): 8-bit conversion, A = 255 */
+void ipxo_draw_ycbcr(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r, const ipxo_ycbcr *src,
+                     int spx, int spy);
+
+#ifdef __cplusplus
+}
+#endif
 #endif

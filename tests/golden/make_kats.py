@@ -146,6 +146,121 @@ def model_glyphs(dst, dw, dh, glyphs, col):
                     dst[di + c] = ((((dst[di + c] * a + s * ma) & U32) // M) >> 8) & 0xFF
 
 
+# ---- source-type variants: *image.NRGBA and *image.YCbCr sources ------------------------
+
+def tap_nrgba(src, sw, x, y):
+    i = (y * sw + x) * 4
+    a = src[i + 3] * 0x101
+    return [src[i] * a // 0xFF, src[i + 1] * a // 0xFF, src[i + 2] * a // 0xFF, a]
+
+
+def chroma_shape(w, h, ratio):
+    cw = (w + 1) // 2 if ratio in (1, 2) else w
+    ch = (h + 1) // 2 if ratio in (2, 3) else h
+    return cw, ch
+
+
+def coff(ratio, cw, x, y):
+    return {0: y * cw + x, 1: y * cw + x // 2, 2: (y // 2) * cw + x // 2, 3: (y // 2) * cw + x}[ratio]
+
+
+def tap_ycbcr(img, x, y):
+    """color.YCbCr.RGBA as x/image/draw inlines it: 16-bit, clamped, alpha 0xffff."""
+    w, cw = img["w"], chroma_shape(img["w"], img["h"], img["ratio"])[0]
+    ci = coff(img["ratio"], cw, x, y)
+    yy1 = img["y"][y * w + x] * 0x10101
+    cb1, cr1 = img["cb"][ci] - 128, img["cr"][ci] - 128
+    out = [(yy1 + 91881 * cr1) >> 8, (yy1 - 22554 * cb1 - 46802 * cr1) >> 8, (yy1 + 116130 * cb1) >> 8]
+    return [min(max(v, 0), 0xFFFF) for v in out] + [0xFFFF]
+
+
+def ycbcr_to_rgb8(img, x, y):
+    """color.YCbCrToRGB (imageutil.DrawYCbCr): 8-bit with the overflow trick."""
+    w, cw = img["w"], chroma_shape(img["w"], img["h"], img["ratio"])[0]
+    ci = coff(img["ratio"], cw, x, y)
+    yy1 = img["y"][y * w + x] * 0x10101
+    cb1, cr1 = img["cb"][ci] - 128, img["cr"][ci] - 128
+    out = []
+    for v in (yy1 + 91881 * cr1, yy1 - 22554 * cb1 - 46802 * cr1, yy1 + 116130 * cb1):
+        out.append(v >> 16 if 0 <= v < (1 << 24) else (0 if v < 0 else 255))
+    return out + [255]
+
+
+def model_scale_taps(dst, dw, dh, dr, tap, sw, sh, sr, op):
+    """ablInterpolator.Scale's loop with a tap function returning 16-bit premultiplied RGBA."""
+    ax0, ay0, ax1, ay1 = max(dr[0], 0), max(dr[1], 0), min(dr[2], dw), min(dr[3], dh)
+    if ax0 >= ax1 or ay0 >= ay1 or sr[0] >= sr[2] or sr[1] >= sr[3]:
+        return
+    ax0, ax1, ay0, ay1 = ax0 - dr[0], ax1 - dr[0], ay0 - dr[1], ay1 - dr[1]
+    ssw, ssh = sr[2] - sr[0], sr[3] - sr[1]
+    yscale = float(ssh) / float(dr[3] - dr[1])
+    xscale = float(ssw) / float(dr[2] - dr[0])
+    for dy in range(ay0, ay1):
+        sy = (float(dy) + 0.5) * yscale - 0.5
+        sy0 = trunc_i32(sy)
+        yf0 = sy - float(sy0)
+        yf1 = 1 - yf0
+        sy1 = sy0 + 1
+        if sy < 0:
+            sy0, sy1, yf0, yf1 = 0, 0, 0.0, 1.0
+        elif sy1 > ssh - 1:
+            sy0, sy1, yf0, yf1 = ssh - 1, ssh - 1, 1.0, 0.0
+        for dx in range(ax0, ax1):
+            sx = (float(dx) + 0.5) * xscale - 0.5
+            sx0 = trunc_i32(sx)
+            xf0 = sx - float(sx0)
+            xf1 = 1 - xf0
+            sx1 = sx0 + 1
+            if sx < 0:
+                sx0, sx1, xf0, xf1 = 0, 0, 0.0, 1.0
+            elif sx1 > ssw - 1:
+                sx0, sx1, xf0, xf1 = ssw - 1, ssw - 1, 1.0, 0.0
+            t00, t10 = tap(sr[0] + sx0, sr[1] + sy0), tap(sr[0] + sx1, sr[1] + sy0)
+            t01, t11 = tap(sr[0] + sx0, sr[1] + sy1), tap(sr[0] + sx1, sr[1] + sy1)
+            p = []
+            for c in range(4):
+                s10 = xf1 * float(t00[c]) + xf0 * float(t10[c])
+                s11 = xf1 * float(t01[c]) + xf0 * float(t11[c])
+                p.append(int(yf1 * s10 + yf0 * s11))
+            di = ((dr[1] + dy) * dw + dr[0] + dx) * 4
+            if op == SRC:
+                for c in range(4):
+                    dst[di + c] = (p[c] >> 8) & 0xFF
+            else:
+                pa1 = ((0xFFFF - p[3]) * 0x101) & U32
+                for c in range(4):
+                    dst[di + c] = ((((dst[di + c] * pa1) & U32) // 0xFFFF + p[c]) >> 8) & 0xFF
+
+
+def model_draw_nrgba(dst, dw, dh, r, src, sw, sh, sp, op):
+    x0, y0, x1, y1 = r
+    ox, oy = x0, y0
+    spx, spy = sp
+    x0, y0, x1, y1 = max(x0, 0), max(y0, 0), min(x1, dw), min(y1, dh)
+    x0, y0, x1, y1 = max(x0, ox - spx), max(y0, oy - spy), min(x1, sw + ox - spx), min(y1, sh + oy - spy)
+    if x0 >= x1 or y0 >= y1:
+        return
+    spx += x0 - ox
+    spy += y0 - oy
+    for y in range(y1 - y0):
+        for x in range(x1 - x0):
+            di = ((y0 + y) * dw + x0 + x) * 4
+            t = tap_nrgba(src, sw, spx + x, spy + y)
+            if op == SRC:
+                for c in range(4):
+                    dst[di + c] = (t[c] >> 8) & 0xFF
+            else:
+                a = ((M - t[3]) * 0x101) & U32
+                for c in range(4):
+                    dst[di + c] = ((((dst[di + c] * a) & U32) // M + t[c]) >> 8) & 0xFF
+
+
+def rnd_ycbcr(rng, w, h, ratio):
+    cw, ch = chroma_shape(w, h, ratio)
+    return {"w": w, "h": h, "ratio": ratio, "y": [rng.randrange(256) for _ in range(w * h)],
+            "cb": [rng.randrange(256) for _ in range(cw * ch)], "cr": [rng.randrange(256) for _ in range(cw * ch)]}
+
+
 # ---- cases ------------------------------------------------------------------------------------
 
 def rnd_frame(rng, w, h, opaque=False, premul=True):
@@ -343,6 +458,58 @@ def main():
         model_glyphs(exp, dw, dh, glyphs, col_)
         cases.append({"kind": "glyphs", "name": "clip+overlap col=%s" % col_, "origin": "model",
                       "dw": dw, "dh": dh, "dst": dst0, "glyphs": glyphs, "col": col_, "expect": exp})
+
+    # ---- NRGBA and YCbCr sources ---------------------------------------------------------------------
+    # hand: NRGBA (255,128,0,128) under Src: a16 = 32896; r = 255*32896/255 = 32896 -> 128;
+    # g = 128*32896/255 = 16512 -> 64; b = 0; a -> 128.
+    cases.append({"kind": "draw_nrgba", "name": "hand premultiply", "origin": "hand", "sw": 1, "sh": 1,
+                  "src": [255, 128, 0, 128], "dw": 1, "dh": 1, "r": [0, 0, 1, 1], "sp": [0, 0], "op": SRC,
+                  "dst": [9, 9, 9, 9], "expect": [128, 64, 0, 128]})
+    for name, op in (("nrgba draw src", SRC), ("nrgba draw over", OVER)):
+        src = rnd_frame(rng, 7, 5, premul=False)
+        dst0 = rnd_frame(rng, 9, 6)
+        exp = list(dst0)
+        model_draw_nrgba(exp, 9, 6, (1, 1, 10, 8), src, 7, 5, (0, 1), op)
+        cases.append({"kind": "draw_nrgba", "name": name, "origin": "model", "sw": 7, "sh": 5, "src": src, "dw": 9,
+                      "dh": 6, "r": [1, 1, 10, 8], "sp": [0, 1], "op": op, "dst": dst0, "expect": exp})
+    for name, sw, sh, dw, dh, op, opaque, used, sr in (("nrgba down over zero dst", 13, 9, 5, 4, OVER, False, False, None),
+                                                         ("nrgba up src", 5, 4, 11, 9, SRC, False, True, None),
+                                                         ("nrgba over used dst", 12, 8, 7, 5, OVER, False, True, (1, 1, 11, 7)),
+                                                         ("nrgba opaque over used dst -> Src", 12, 8, 7, 5, OVER, True, True, None)):
+        src = rnd_frame(rng, sw, sh, opaque=opaque, premul=False)
+        dst0 = rnd_frame(rng, dw, dh) if used else [0] * (dw * dh * 4)
+        sr_ = list(sr or (0, 0, sw, sh))
+        exp = list(dst0)
+        op_eff = SRC if (op == OVER and opaque) else op
+        model_scale_taps(exp, dw, dh, (0, 0, dw, dh), lambda x, y: tap_nrgba(src, sw, x, y), sw, sh, sr_, op_eff)
+        cases.append({"kind": "scale_nrgba", "name": name, "origin": "model", "sw": sw, "sh": sh, "src": src, "dw": dw,
+                      "dh": dh, "sr": sr_, "dr": [0, 0, dw, dh], "op": op, "dst": dst0, "expect": exp})
+    # hand: grey (Cb = Cr = 128) converts to R = G = B = Y in both the 8-bit and the 16-bit formula;
+    # and Y=76, Cb=85, Cr=255: r = 5000268 + 91881*127 = 16669155 -> 254; g = 26236 -> 0; b = 6678 -> 0.
+    grey = {"w": 4, "h": 4, "ratio": 2, "y": [(i * 17) & 255 for i in range(16)], "cb": [128] * 4, "cr": [128] * 4}
+    cases.append({"kind": "draw_ycbcr", "name": "hand grey 4:2:0", "origin": "hand", "img": grey, "dw": 4, "dh": 4,
+                  "r": [0, 0, 4, 4], "sp": [0, 0], "dst": [0] * 64,
+                  "expect": sum([[v, v, v, 255] for v in grey["y"]], [])})
+    red = {"w": 1, "h": 1, "ratio": 0, "y": [76], "cb": [85], "cr": [255]}
+    cases.append({"kind": "draw_ycbcr", "name": "hand red", "origin": "hand", "img": red, "dw": 1, "dh": 1,
+                  "r": [0, 0, 1, 1], "sp": [0, 0], "dst": [0] * 4, "expect": [254, 0, 0, 255]})
+    for ratio in (0, 1, 2, 3):
+        img = rnd_ycbcr(rng, 11, 9, ratio)
+        dst0 = rnd_frame(rng, 11, 9)
+        exp = list(dst0)
+        r, sp = (2, 1, 10, 8), (1, 1)          # odd source origin: exercises the x/2, y/2 chroma indexing
+        for y in range(r[3] - r[1]):
+            for x in range(r[2] - r[0]):
+                di = ((r[1] + y) * 11 + r[0] + x) * 4
+                exp[di:di + 4] = ycbcr_to_rgb8(img, sp[0] + x, sp[1] + y)
+        cases.append({"kind": "draw_ycbcr", "name": "draw ratio %d" % ratio, "origin": "model", "img": img, "dw": 11,
+                      "dh": 9, "r": list(r), "sp": list(sp), "dst": dst0, "expect": exp})
+        for dw, dh, sr in ((5, 4, (0, 0, 11, 9)), (13, 14, (0, 0, 11, 9)), (4, 3, (1, 1, 10, 8))):
+            exp = [0] * (dw * dh * 4)
+            model_scale_taps(exp, dw, dh, (0, 0, dw, dh), lambda x, y: tap_ycbcr(img, x, y), 11, 9, list(sr), SRC)
+            cases.append({"kind": "scale_ycbcr", "name": "scale ratio %d -> %dx%d" % (ratio, dw, dh), "origin": "model",
+                          "img": img, "dw": dw, "dh": dh, "sr": list(sr), "dr": [0, 0, dw, dh], "dst": [0] * (dw * dh * 4),
+                          "expect": exp})
 
     with open(os.path.join(HERE, "kats.json"), "w") as f:
         json.dump({"note": "hand/model-derived known answers; NOT reference output (parity unpinned)",

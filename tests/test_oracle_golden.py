@@ -49,6 +49,35 @@ def test_glyphs(c):
     np.testing.assert_array_equal(dst, _frame(c["expect"], c["dw"], c["dh"]))
 
 
+def _planes(img):
+    w, h, ratio = img["w"], img["h"], img["ratio"]
+    chh, cw = oracle.chroma_shape(w, h, ratio)
+    return (np.array(img["y"], np.uint8).reshape(h, w), np.array(img["cb"], np.uint8).reshape(chh, cw),
+            np.array(img["cr"], np.uint8).reshape(chh, cw), ratio)
+
+
+@pytest.mark.parametrize("c", _by("draw_nrgba") + _by("scale_nrgba"), ids=lambda c: c["name"])
+def test_nrgba_sources(c):
+    src = _frame(c["src"], c["sw"], c["sh"])
+    dst = _frame(c["dst"], c["dw"], c["dh"]).copy()
+    if c["kind"] == "draw_nrgba":
+        oracle.draw_nrgba(dst, c["r"], src, c["sp"], c["op"])
+    else:
+        oracle.scale_bilinear_nrgba(src, c["dw"], c["dh"], sr=c["sr"], dr=c["dr"], op=c["op"], dst=dst)
+    np.testing.assert_array_equal(dst, _frame(c["expect"], c["dw"], c["dh"]))
+
+
+@pytest.mark.parametrize("c", _by("draw_ycbcr") + _by("scale_ycbcr"), ids=lambda c: c["name"])
+def test_ycbcr_sources(c):
+    y, cb, cr, ratio = _planes(c["img"])
+    dst = _frame(c["dst"], c["dw"], c["dh"]).copy()
+    if c["kind"] == "draw_ycbcr":
+        oracle.draw_ycbcr(dst, c["r"], y, cb, cr, ratio, c["sp"])
+    else:
+        oracle.scale_bilinear_ycbcr(y, cb, cr, ratio, c["dw"], c["dh"], sr=c["sr"], dr=c["dr"], dst=dst)
+    np.testing.assert_array_equal(dst, _frame(c["expect"], c["dw"], c["dh"]))
+
+
 def test_geometry():
     for c in _by("resize_dims"):
         assert list(oracle.resize_dims(c["ow"], c["oh"], c["w"], c["h"], c["keep_aspect"])) == c["expect"]
