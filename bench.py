@@ -117,7 +117,7 @@ def run_mixed(args, ipx, shard, rank, local_rank, world):
             "metric": "images/sec (resize+thumb+watermark) on mixed-size batch (480p-8K), work stealing",
             "value": round(frames_done / elapsed, 1), "unit": "images/sec", "n_gpus": world, "steps": 1, "warmup": 1,
             "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8 (taps interpolated in f64, composite in u32)",
+            "dtype": "u8",
             "data": "synthetic: one seeded frame per size tiled per chunk, resident in HBM",
             "config": {"workload": "%d frames of sizes %s drawn uniformly (seed 0x51), full pipeline keep_aspect=true"
                                    % (int(frames_done), MIXED_SIZES), "items": len(items),
@@ -278,7 +278,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 (taps interpolated in f64, composite in u32)",
+            "dtype": "u8",
             "data": "synthetic: %d seeded opaque RGBA8 frames per GPU tiled over %d slots resident in HBM" % (P, F),
             "config": {"workload": "%d x %dx%d RGBA8, %s" % (F, sw, sh, {
                 "full": "full pipeline: resize 1024x768 (keep_aspect=false) + thumbnail 200 crop + watermark 16 glyphs",
@@ -286,7 +286,8 @@ def main():
                 "full-keepaspect": "full pipeline, product-default keep_aspect=true (1024x576)",
                 "wm": "watermark only (copy + 16 glyphs)", "thumb": "thumbnail 200 crop only",
                 "resize-wm": "resize 1024x768 + watermark"}[args.workload]),
-                "frames_per_gpu": F, "sharding": "independent frames, round-robin by rank, no collective"},
+                "frames_per_gpu": F, "sharding": "independent frames, round-robin by rank, no collective",
+                "arithmetic": "u8 pixels; taps interpolated in f64 (exact fp32 on dyadic axes), composite in u32"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "band_pipe_kernel", "algorithmic_bytes_per_launch": alg,

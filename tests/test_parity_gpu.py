@@ -213,6 +213,40 @@ def test_every_kernel_path_is_bit_exact(ctx, env, monkeypatch):
         gs.close()
 
 
+def test_random_geometries_vs_oracle(ctx, monkeypatch):
+    """Seeded sweep over frame sizes (odd widths included), operator parameters and tile shapes: the
+    ownership tables (which block produces which destination row / column) and both lerps must agree
+    with the oracle on every byte."""
+    rng = np.random.default_rng(20261004)
+    for trial in range(36):
+        sw = int(rng.choice([rng.integers(2, 90), rng.integers(90, 700), 4 * rng.integers(60, 500)]))
+        sh = int(rng.choice([rng.integers(2, 60), rng.integers(60, 500)]))
+        resize = (int(rng.integers(1, 1300)), int(rng.integers(1, 900)), bool(rng.integers(0, 2)))
+        thumb = (int(rng.integers(1, 300)), bool(rng.integers(0, 2)))
+        for k in ("IPX_BLK_COLS", "IPX_BAND_ROWS", "IPX_PIPE"):
+            monkeypatch.delenv(k, raising=False)
+        if rng.random() < 0.5:
+            monkeypatch.setenv("IPX_BLK_COLS", str(int(rng.choice([8, 64, 252, 1000, 2044]))))
+        if rng.random() < 0.5:
+            monkeypatch.setenv("IPX_BAND_ROWS", str(int(rng.choice([1, 2, 5, 8, 16]))))
+        if rng.random() < 0.25:
+            monkeypatch.setenv("IPX_PIPE", "0")
+        n = int(rng.integers(1, 4))
+        frames = rgba_frames(n, sw, sh, seed=trial, opaque=bool(rng.integers(0, 2)))
+        glyphs = text_glyphs(sw, sh, n=5, width_px=min(60, sw), height_px=min(20, sh))
+        gs = ctx.glyphset(glyphs, DEFAULT_COL)
+        plan = ctx.plan(sw, sh, resize=resize, thumbnail=thumb, watermark=gs)
+        got = plan.run_host(frames)
+        for i in range(n):
+            want = oracle.process(frames[i], resize=resize, thumb=thumb, glyphs=glyphs, col=DEFAULT_COL)
+            for k in ("resize", "thumbnail", "watermark"):
+                if k in got:
+                    np.testing.assert_array_equal(got[k][i], want[k], err_msg="trial %d %s %dx%d resize=%s thumb=%s env=%s" % (
+                        trial, k, sw, sh, resize, thumb, {e: os.environ.get(e) for e in ("IPX_BLK_COLS", "IPX_BAND_ROWS", "IPX_PIPE")}))
+        plan.close()
+        gs.close()
+
+
 def test_config1_plumbing_640x480_thumbnail(ctx):
     """BASELINE config 1: one 640x480 frame -> 200x200 thumbnail (crop 480^2 at x=80), GPU vs oracle."""
     frame = rgba_frames(1, 640, 480, seed=1)
