@@ -208,6 +208,28 @@ class Plan:
                                        p("watermark"), i.wm_bytes))
         return out
 
+    def run_host_ycbcr(self, y, cb, cr, ratio, want=("resize", "thumbnail", "watermark")):
+        """A batch of decoded JPEG frames: y n x H x W, cb / cr n x CH x CW uint8 (image.YCbCr planes)."""
+        y, cb, cr = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, cb, cr))
+        n, h, w = y.shape
+        assert (w, h) == (self._sw, self._sh) and cb.shape == cr.shape and cb.shape[0] == n
+        b = _lib.YCbCrBatch(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, w, cb.shape[2], h * w,
+                            cb.shape[1] * cb.shape[2], int(ratio))
+        i = self.info
+        out = {}
+        if "resize" in want and i.resize_bytes:
+            out["resize"] = np.empty((n, i.resize_h, i.resize_w, 4), np.uint8)
+        if "thumbnail" in want and i.thumb_bytes:
+            out["thumbnail"] = np.empty((n, i.thumb_h, i.thumb_w, 4), np.uint8)
+        if "watermark" in want and i.wm_bytes:
+            out["watermark"] = np.empty((n, i.wm_h, i.wm_w, 4), np.uint8)
+
+        def p(k):
+            return out[k].ctypes.data if k in out else None
+        _check(lib().ipx_plan_run_host_ycbcr(self.ctx.handle, self.handle, n, C.byref(b), p("resize"), i.resize_bytes,
+                                             p("thumbnail"), i.thumb_bytes, p("watermark"), i.wm_bytes))
+        return out
+
     def close(self):
         if self.handle:
             lib().ipx_plan_destroy(self.ctx.handle, self.handle)

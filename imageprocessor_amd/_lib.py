@@ -42,6 +42,12 @@ class YCbCr(C.Structure):
                 ("cstride", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("ratio", C.c_int32)]
 
 
+class YCbCrBatch(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p), ("ystride", C.c_int32),
+                ("cstride", C.c_int32), ("y_frame_stride", C.c_size_t), ("c_frame_stride", C.c_size_t),
+                ("ratio", C.c_int32)]
+
+
 class Param(C.Structure):
     _fields_ = [("key", C.c_char_p), ("type", C.c_int32), ("f64", C.c_double), ("i64", C.c_int64),
                 ("str", C.c_char_p)]
@@ -117,6 +123,8 @@ SIGNATURES = {
     "ipx_plan_query": (_I, [_P, C.POINTER(PlanInfo)]),
     "ipx_plan_run_dev": (_I, [_P, _P, _P, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
     "ipx_plan_run_host": (_I, [_P, _P, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
+    "ipx_plan_run_dev_ycbcr": (_I, [_P, _P, _P, _I, C.POINTER(YCbCrBatch), _P, _Z, _P, _Z, _P, _Z]),
+    "ipx_plan_run_host_ycbcr": (_I, [_P, _P, _I, C.POINTER(YCbCrBatch), _P, _Z, _P, _Z, _P, _Z]),
     "ipx_event_create": (_P, [_P]),
     "ipx_event_record": (_I, [_P, _P, _P]),
     "ipx_event_elapsed_ms": (_I, [_P, _P, _P, C.POINTER(C.c_float)]),

@@ -75,6 +75,8 @@ struct ScaleArgs {
     int kind;                       // IPX_SRC_*: src is RGBA / NRGBA pixels, or the Y plane of a YCbCr image
     const uint8_t *cb, *cr;         // YCbCr only
     int cstride, ratio;
+    size_t dst_fs, src_fs, c_fs;    // bytes between frames of a batch (grid z = frame); 0 for one frame
+    int nframes;
 };
 enum { IPX_SRC_RGBA = 0, IPX_SRC_NRGBA = 1, IPX_SRC_YCBCR = 2 };
 hipError_t launch_scale_generic(const ScaleArgs &a, hipStream_t s);
@@ -85,7 +87,8 @@ hipError_t launch_draw(uint8_t *dst, int dstride, const uint8_t *src, int sstrid
 hipError_t launch_draw_nrgba(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h, int op,
                              hipStream_t s);
 hipError_t launch_draw_ycbcr(uint8_t *dst, int dstride, const uint8_t *y, int ystride, const uint8_t *cb,
-                             const uint8_t *cr, int cstride, int ratio, int spx, int spy, int w, int h, hipStream_t s);
+                             const uint8_t *cr, int cstride, int ratio, int spx, int spy, int w, int h, hipStream_t s,
+                             int nframes = 1, size_t dst_fs = 0, size_t y_fs = 0, size_t c_fs = 0);
 
 struct DevGlyph {           // one clipped DrawMask call, masks resident in HBM
     const uint8_t *mask;    // points at mask(mpx, mpy) after clipping

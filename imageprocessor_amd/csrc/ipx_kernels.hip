@@ -69,6 +69,9 @@ __device__ __forceinline__ uint32_t lerp16(uint32_t s00, uint32_t s10, uint32_t 
 template <int KIND>
 __global__ __launch_bounds__(256) void scale_generic_kernel(ScaleArgs a)
 {
+    a.dst += blockIdx.z * a.dst_fs;      // frame of a batch (all zero for a single frame)
+    a.src += blockIdx.z * a.src_fs;
+    if (KIND == IPX_SRC_YCBCR) { a.cb += blockIdx.z * a.c_fs; a.cr += blockIdx.z * a.c_fs; }
     const int dx = a.adr_x0 + (int)(blockIdx.x * 64 + threadIdx.x);
     const int dy = a.adr_y0 + (int)(blockIdx.y * 4 + threadIdx.y);
     if (dx >= a.adr_x1 || dy >= a.adr_y1) return;
@@ -173,10 +176,12 @@ __global__ __launch_bounds__(256) void draw_nrgba_kernel(uint8_t *dst, int dstri
 // imageutil.DrawYCbCr: color.YCbCrToRGB per pixel (8 bit, the uint32 overflow test of the Go code), A = 255
 __global__ __launch_bounds__(256) void draw_ycbcr_kernel(uint8_t *dst, int dstride, const uint8_t *yp, int ystride,
                                                          const uint8_t *cb, const uint8_t *cr, int cstride, int ratio,
-                                                         int spx, int spy, int w, int h)
+                                                         int spx, int spy, int w, int h, size_t dst_fs, size_t y_fs,
+                                                         size_t c_fs)
 {
     const int y = blockIdx.y;
     if (y >= h) return;
+    dst += blockIdx.z * dst_fs; yp += blockIdx.z * y_fs; cb += blockIdx.z * c_fs; cr += blockIdx.z * c_fs;
     for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256) {
         const int sx = spx + x, sy = spy + y;
         const int cx = (ratio == IPX_YCBCR_422 || ratio == IPX_YCBCR_420) ? sx / 2 : sx;
@@ -228,7 +233,7 @@ hipError_t launch_scale_generic(const ScaleArgs &a, hipStream_t s)
 {
     const int w = a.adr_x1 - a.adr_x0, h = a.adr_y1 - a.adr_y0;
     if (w <= 0 || h <= 0) return hipSuccess;
-    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4);
+    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4, a.nframes > 0 ? a.nframes : 1);
     if (a.kind == IPX_SRC_NRGBA) hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_NRGBA>, grid, block, 0, s, a);
     else if (a.kind == IPX_SRC_YCBCR) hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_YCBCR>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_RGBA>, grid, block, 0, s, a);
@@ -245,12 +250,13 @@ hipError_t launch_draw_nrgba(uint8_t *dst, int dstride, const uint8_t *src, int 
 }
 
 hipError_t launch_draw_ycbcr(uint8_t *dst, int dstride, const uint8_t *y, int ystride, const uint8_t *cb,
-                             const uint8_t *cr, int cstride, int ratio, int spx, int spy, int w, int h, hipStream_t s)
+                             const uint8_t *cr, int cstride, int ratio, int spx, int spy, int w, int h, hipStream_t s,
+                             int nframes, size_t dst_fs, size_t y_fs, size_t c_fs)
 {
-    if (w <= 0 || h <= 0) return hipSuccess;
-    dim3 grid(min(8, (w + 255) / 256), h);
+    if (w <= 0 || h <= 0 || nframes <= 0) return hipSuccess;
+    dim3 grid(min(8, (w + 255) / 256), h, nframes);
     hipLaunchKernelGGL(draw_ycbcr_kernel, grid, dim3(256), 0, s, dst, dstride, y, ystride, cb, cr, cstride, ratio, spx,
-                       spy, w, h);
+                       spy, w, h, dst_fs, y_fs, c_fs);
     return hipGetLastError();
 }
 

@@ -83,6 +83,8 @@ struct ipx_plan {
     PlanScale sc[2];      // 0 = resize, 1 = thumbnail
     uint8_t *blob = nullptr;
     ClippedGlyphs glyphs;
+    mutable std::mutex mu;
+    mutable ipx_plan *thumb_only = nullptr;   // RGBA sub-plan for YCbCr batches (thumbnail of the converted frame)
 };
 
 namespace {
@@ -188,10 +190,12 @@ struct DevSrc {
     const uint8_t *cb = nullptr, *cr = nullptr;
     int cstride = 0, ratio = 0;
     int w = 0, h = 0;
+    int nframes = 1;                // a batch: frames frame_stride / c_frame_stride bytes apart
+    size_t frame_stride = 0, c_frame_stride = 0;
 };
 
 int dev_draw_src(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect r, const DevSrc &src, int spx,
-                 int spy, int op)
+                 int spy, int op, size_t dst_fs = 0)
 {
     if (op != IPX_OP_OVER && op != IPX_OP_SRC) { set_error("draw: unknown op %d", op); return IPX_ERR_INVALID; }
     int mx = 0, my = 0;
@@ -199,7 +203,7 @@ int dev_draw_src(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect 
     uint8_t *d = dst + (size_t)r.y0 * dstride + (size_t)r.x0 * 4;
     if (src.kind == IPX_SRC_YCBCR)   // opaque source: Over == Src (image/draw.DrawMask's YCbCr arm)
         IPX_HIP(launch_draw_ycbcr(d, dstride, src.pix, src.stride, src.cb, src.cr, src.cstride, src.ratio, spx, spy,
-                                  r.dx(), r.dy(), s));
+                                  r.dx(), r.dy(), s, src.nframes, dst_fs, src.frame_stride, src.c_frame_stride));
     else if (src.kind == IPX_SRC_NRGBA)
         IPX_HIP(launch_draw_nrgba(d, dstride, src.pix + (size_t)spy * src.stride + (size_t)spx * 4, src.stride, r.dx(),
                                   r.dy(), op, s));
@@ -210,12 +214,12 @@ int dev_draw_src(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect 
 }
 
 int dev_scale_src(hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int dstride, const Rect &dr,
-                  const DevSrc &src, const Rect &sr, int op)
+                  const DevSrc &src, const Rect &sr, int op, size_t dst_fs = 0)
 {
     ScalePrep pr;
     int rc = scale_prepare(dw, dh, dr, src.w, src.h, sr, op, &pr);
     if (rc) return rc;
-    if (pr.copy) return dev_draw_src(s, dst, dw, dh, dstride, dr, src, sr.x0, sr.y0, op);
+    if (pr.copy) return dev_draw_src(s, dst, dw, dh, dstride, dr, src, sr.x0, sr.y0, op, dst_fs);
     if (pr.empty) return IPX_OK;
     if (src.kind == IPX_SRC_YCBCR) op = IPX_OP_SRC;   // (*image.YCbCr).Opaque() is always true
     if (op == IPX_OP_OVER) IPX_HIP(launch_opaque_scan(src.pix, src.w, src.h, src.stride, flag, s));  // RGBA and NRGBA: alpha scan
@@ -227,6 +231,7 @@ int dev_scale_src(hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int ds
     a.xscale = pr.xscale; a.yscale = pr.yscale;
     a.op = op; a.opaque_flag = op == IPX_OP_OVER ? flag : nullptr;
     a.kind = src.kind; a.cb = src.cb; a.cr = src.cr; a.cstride = src.cstride; a.ratio = src.ratio;
+    a.nframes = src.nframes; a.src_fs = src.frame_stride; a.c_fs = src.c_frame_stride; a.dst_fs = dst_fs;
     IPX_HIP(launch_scale_generic(a, s));
     return IPX_OK;
 }
@@ -917,6 +922,7 @@ void ipx_plan_destroy(ipx_ctx *ctx, ipx_plan *plan)
     if (!plan) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     if (plan->blob) (void)hipFree(plan->blob);
+    if (plan->thumb_only) ipx_plan_destroy(ctx, plan->thumb_only);
     delete plan;
 }
 
@@ -1112,6 +1118,127 @@ int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *sr
     ctx->cv.notify_all();
     if (!rc && e != hipSuccess) { set_error("ipx_plan_run_host: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
     return rc;
+}
+
+
+// ---- decoded JPEG batches ---------------------------------------------------------------------------
+// The reference treats a *image.YCbCr source differently per operator:
+//   resize, non-crop thumbnail: scale_RGBA_YCbCr4xx_Src -- every TAP converted to 16 bit, then the lerp;
+//   crop thumbnail: the crop copy converts to RGBA8 first (imageutil.DrawYCbCr), the scale then reads RGBA8;
+//   watermark: draw.Draw converts to RGBA8 (DrawYCbCr), the glyphs go over that.
+// So: one conversion pass into the watermark frame (or scratch), the RGBA band kernel for the crop
+// thumbnail on the converted frames, the glyph composite in place, and a batched YCbCr scale.
+int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src,
+                           uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
+                           size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !src || !src->y || !src->cb || !src->cr || src->ratio < 0 || src->ratio > IPX_YCBCR_440 ||
+        src->ystride < pl->p.sw) {
+        set_error("ipx_plan_run_dev_ycbcr: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    if (n == 0) return IPX_OK;
+    if (n > 65535) { set_error("ipx_plan_run_dev_ycbcr: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    uint8_t *res = pl->sc[0].on ? resize_out : nullptr;
+    uint8_t *th = pl->sc[1].on ? thumb_out : nullptr;
+    uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
+    const bool crop_thumb = th && pl->p.crop_to_fit;
+
+    DevSrc ysrc;
+    ysrc.kind = IPX_SRC_YCBCR; ysrc.pix = src->y; ysrc.stride = src->ystride; ysrc.cb = src->cb; ysrc.cr = src->cr;
+    ysrc.cstride = src->cstride; ysrc.ratio = src->ratio; ysrc.w = sw; ysrc.h = sh;
+    ysrc.nframes = n; ysrc.frame_stride = src->y_frame_stride; ysrc.c_frame_stride = src->c_frame_stride;
+
+    // RGBA8 conversion of the whole batch, straight into the watermark frames when they are wanted
+    uint8_t *conv = wm;
+    size_t conv_fs = wm_frame_stride;
+    uint8_t *scratch = nullptr;
+    if (!conv && crop_thumb) {
+        conv_fs = (size_t)sw * sh * 4;
+        IPX_HIP(hipMallocAsync((void **)&scratch, conv_fs * n, s));
+        conv = scratch;
+    }
+    int rc = IPX_OK;
+    if (conv)
+        IPX_HIP(launch_draw_ycbcr(conv, sw * 4, src->y, src->ystride, src->cb, src->cr, src->cstride, src->ratio, 0, 0, sw,
+                                  sh, s, n, conv_fs, src->y_frame_stride, src->c_frame_stride));
+    if (crop_thumb) {
+        ipx_plan *sub = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(pl->mu);
+            if (!pl->thumb_only) {
+                ipx_plan_params tp;
+                memset(&tp, 0, sizeof tp);
+                tp.sw = sw; tp.sh = sh; tp.do_thumbnail = 1; tp.thumb_size = pl->p.thumb_size; tp.crop_to_fit = 1;
+                rc = ipx_plan_create(ctx, &tp, &pl->thumb_only);
+            }
+            sub = pl->thumb_only;
+        }
+        if (!rc) rc = ipx_plan_run_dev(ctx, s, sub, n, conv, sw * 4, conv_fs, nullptr, 0, th, thumb_frame_stride, nullptr, 0);
+    }
+    if (!rc && wm && pl->glyphs.n && pl->p.glyphs) {
+        const uint8_t *c = pl->p.glyphs->col;
+        hipError_t e = launch_composite(wm, sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox,
+                                        c[0] * 0x101u, c[1] * 0x101u, c[2] * 0x101u, c[3] * 0x101u, s);
+        if (e != hipSuccess) { set_error("composite launch failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
+    }
+    for (int k = 0; k < 2 && !rc; k++) {   // 16-bit-tap scales straight from the planes
+        const PlanScale &ps = pl->sc[k];
+        uint8_t *o = k == 0 ? res : (crop_thumb ? nullptr : th);
+        const size_t ofs = k == 0 ? resize_frame_stride : thumb_frame_stride;
+        if (!o || ps.dw <= 0 || ps.dh <= 0) continue;
+        rc = dev_scale_src(s, nullptr, o, ps.dw, ps.dh, ps.dw * 4, Rect{0, 0, ps.dw, ps.dh}, ysrc, ps.sr, IPX_OP_SRC, ofs);
+    }
+    if (scratch) (void)hipFreeAsync(scratch, s);
+    return rc;
+}
+
+int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, uint8_t *resize_out,
+                            size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride,
+                            uint8_t *wm_out, size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !src || !src->y || !src->cb || !src->cr || src->ratio < 0 || src->ratio > IPX_YCBCR_440) {
+        set_error("ipx_plan_run_host_ycbcr: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    if (n == 0) return IPX_OK;
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    const int cw = (src->ratio == IPX_YCBCR_422 || src->ratio == IPX_YCBCR_420) ? (sw + 1) / 2 : sw;
+    const int ch = (src->ratio == IPX_YCBCR_420 || src->ratio == IPX_YCBCR_440) ? (sh + 1) / 2 : sh;
+    const size_t yb = align256((size_t)sw * sh), cbb = align256((size_t)cw * ch);
+    const size_t fres = resize_out ? align256(pl->info.resize_bytes) : 0, fth = thumb_out ? align256(pl->info.thumb_bytes) : 0;
+    const size_t fwm = wm_out ? align256(pl->info.wm_bytes) : 0;
+    LaneLease lane(ctx);
+    int rc = lane_reserve(lane.get(), (yb + 2 * cbb + fres + fth + fwm) * n + 1024);
+    if (rc) return rc;
+    hipStream_t s = lane->stream;
+    uint8_t *dy = lane->dev, *dcb = dy + yb * n, *dcr = dcb + cbb * n;
+    uint8_t *dres = fres ? dcr + cbb * n : nullptr, *dth = fth ? dcr + cbb * n + fres * n : nullptr;
+    uint8_t *dwm = fwm ? dcr + cbb * n + (fres + fth) * n : nullptr;
+    for (int i = 0; i < n; i++) {
+        IPX_HIP(hipMemcpy2DAsync(dy + yb * i, sw, src->y + src->y_frame_stride * i, src->ystride, sw, sh, hipMemcpyHostToDevice, s));
+        IPX_HIP(hipMemcpy2DAsync(dcb + cbb * i, cw, src->cb + src->c_frame_stride * i, src->cstride, cw, ch, hipMemcpyHostToDevice, s));
+        IPX_HIP(hipMemcpy2DAsync(dcr + cbb * i, cw, src->cr + src->c_frame_stride * i, src->cstride, cw, ch, hipMemcpyHostToDevice, s));
+    }
+    ipx_ycbcr_batch d;
+    d.y = dy; d.cb = dcb; d.cr = dcr; d.ystride = sw; d.cstride = cw; d.y_frame_stride = yb; d.c_frame_stride = cbb;
+    d.ratio = src->ratio;
+    rc = ipx_plan_run_dev_ycbcr(ctx, s, pl, n, &d, dres, fres, dth, fth, dwm, fwm);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    for (int i = 0; i < n; i++) {
+        if (dres && pl->info.resize_bytes)
+            IPX_HIP(hipMemcpyAsync(resize_out + resize_frame_stride * i, dres + fres * i, pl->info.resize_bytes, hipMemcpyDeviceToHost, s));
+        if (dth && pl->info.thumb_bytes)
+            IPX_HIP(hipMemcpyAsync(thumb_out + thumb_frame_stride * i, dth + fth * i, pl->info.thumb_bytes, hipMemcpyDeviceToHost, s));
+        if (dwm && pl->info.wm_bytes)
+            IPX_HIP(hipMemcpyAsync(wm_out + wm_frame_stride * i, dwm + fwm * i, pl->info.wm_bytes, hipMemcpyDeviceToHost, s));
+    }
+    IPX_HIP(hipStreamSynchronize(s));
+    return IPX_OK;
 }
 
 }  // extern "C"

@@ -207,6 +207,24 @@ int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *plan, int n, const uint8_t *
                       uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
                       size_t wm_frame_stride);
 
+/* A batch of decoded JPEG frames (what image.Decode returns, image_processor.go:47) for the same plan:
+ * planes of frame i at y + i*y_frame_stride and cb / cr + i*c_frame_stride.  Per operator the reference
+ * converts differently (16-bit per tap inside resize; RGBA8 first for the crop thumbnail and the
+ * watermark); the results are those of the reference's helpers on the *image.YCbCr itself.  The host
+ * variant uploads 1.5 bytes per pixel for 4:2:0 instead of 4. */
+typedef struct {
+    const uint8_t *y, *cb, *cr;
+    int32_t ystride, cstride;
+    size_t y_frame_stride, c_frame_stride;
+    int32_t ratio;                  /* IPX_YCBCR_* */
+} ipx_ycbcr_batch;
+int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const ipx_ycbcr_batch *src,
+                           uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
+                           size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
+int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *plan, int n, const ipx_ycbcr_batch *src,
+                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
+                            size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
+
 /* Average duration in milliseconds of the last `ipx_plan_run_dev` launches on `stream` is a
  * measurement concern of the caller: bracket calls with ipx_event_* below (HIP events on the
  * stream the kernels run on). */

@@ -101,3 +101,52 @@ def test_nrgba_vs_oracle(ctx):
         d0 = rgba_frames(1, 640, 360, seed=4, opaque=False)[0]
         np.testing.assert_array_equal(ctx.draw_nrgba(d0.copy(), (5, 5, 700, 400), src, (2, 3), op),
                                       oracle.draw_nrgba(d0.copy(), (5, 5, 700, 400), src, (2, 3), op))
+
+
+def _expect_ycbcr_ops(y, cb, cr, ratio, resize, thumb, glyphs, col):
+    """What the reference's three helpers give on one *image.YCbCr, via the oracle."""
+    h, w = y.shape
+    nw, nh = oracle.resize_dims(w, h, *resize)
+    out = {"resize": oracle.scale_bilinear_ycbcr(y, cb, cr, ratio, nw, nh)}
+    crop, tw, th = oracle.thumb_geometry(w, h, *thumb)
+    if thumb[1]:   # cropAndResize: Scale of equal size = DrawYCbCr copy, then the RGBA scale
+        cs = crop[2] - crop[0]
+        cropped = oracle.scale_bilinear_ycbcr(y, cb, cr, ratio, cs, cs, sr=crop)
+        out["thumbnail"] = oracle.scale_bilinear(cropped, tw, th)
+    else:          # resizeImage straight from the YCbCr source
+        out["thumbnail"] = oracle.scale_bilinear_ycbcr(y, cb, cr, ratio, tw, th)
+    wm = oracle.draw_ycbcr(np.zeros((h, w, 4), np.uint8), (0, 0, w, h), y, cb, cr, ratio)
+    out["watermark"] = oracle.composite_glyphs(wm, glyphs, col)
+    return out
+
+
+@pytest.mark.parametrize("case", [(1920, 1080, 2, 2, (1024, 768, True), (200, True)),
+                                  (640, 480, 3, 2, (1024, 768, True), (200, True)),
+                                  (854, 480, 2, 1, (1024, 768, False), (120, False)),
+                                  (333, 251, 2, 0, (200, 100, True), (64, True)),
+                                  (200, 200, 1, 3, (200, 200, False), (200, True))],
+                         ids=lambda c: "%dx%d r%d" % (c[0], c[1], c[3]))
+def test_ycbcr_batch_plan(ctx, case):
+    from helpers import DEFAULT_COL, text_glyphs
+    w, h, n, ratio, resize, thumb = case
+    planes = [_rand_ycbcr(w, h, ratio, 50 + i) for i in range(n)]
+    y = np.stack([p[0] for p in planes]); cb = np.stack([p[1] for p in planes]); cr = np.stack([p[2] for p in planes])
+    glyphs = text_glyphs(w, h, n=6, width_px=min(150, w), height_px=min(30, h))
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(w, h, resize=resize, thumbnail=thumb, watermark=gs)
+    got = plan.run_host_ycbcr(y, cb, cr, ratio)
+    for i in range(n):
+        want = _expect_ycbcr_ops(y[i], cb[i], cr[i], ratio, resize, thumb, glyphs, DEFAULT_COL)
+        for k in ("resize", "thumbnail", "watermark"):
+            np.testing.assert_array_equal(got[k][i], want[k], err_msg="%s frame %d" % (k, i))
+    # subsets: thumbnail only (conversion goes to scratch), resize only (no conversion at all)
+    for kw, keys in ((dict(resize=None, thumbnail=thumb, watermark=None), ("thumbnail",)),
+                     (dict(resize=resize, thumbnail=None, watermark=None), ("resize",))):
+        p2 = ctx.plan(w, h, **kw)
+        g2 = p2.run_host_ycbcr(y, cb, cr, ratio)
+        want = _expect_ycbcr_ops(y[0], cb[0], cr[0], ratio, resize, thumb, glyphs, DEFAULT_COL)
+        for k in keys:
+            np.testing.assert_array_equal(g2[k][0], want[k])
+        p2.close()
+    plan.close()
+    gs.close()
