@@ -208,6 +208,13 @@ class Plan:
                                        p("watermark"), i.wm_bytes))
         return out
 
+    def run_dev_ycbcr(self, n, y_ptr, cb_ptr, cr_ptr, ratio, ystride, cstride, y_frame_stride, c_frame_stride,
+                      resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
+        i = self.info
+        b = _lib.YCbCrBatch(y_ptr, cb_ptr, cr_ptr, ystride, cstride, y_frame_stride, c_frame_stride, int(ratio))
+        _check(lib().ipx_plan_run_dev_ycbcr(self.ctx.handle, stream, self.handle, n, C.byref(b), resize_ptr,
+                                            i.resize_bytes, thumb_ptr, i.thumb_bytes, wm_ptr, i.wm_bytes))
+
     def run_host_ycbcr(self, y, cb, cr, ratio, want=("resize", "thumbnail", "watermark")):
         """A batch of decoded JPEG frames: y n x H x W, cb / cr n x CH x CW uint8 (image.YCbCr planes)."""
         y, cb, cr = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, cb, cr))

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Throughput of the decoded-JPEG batch path (ipx_plan_run_dev_ycbcr): n x 1920x1080 4:2:0 frames
+resident in HBM -> resize 1024x576 + thumbnail 200 + watermark.  Three kernels per batch (RGBA8
+conversion into the watermark frames, the RGBA band kernel for the crop thumbnail, the batched
+16-bit-tap scale) plus the glyph composite: not fused yet."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import imageprocessor_amd as ipx  # noqa: E402
+from helpers import DEFAULT_COL, text_glyphs  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+w, h, ratio = 1920, 1080, 2
+cw, ch = (w + 1) // 2, (h + 1) // 2
+ctx = ipx.Context()
+gs = ctx.glyphset(text_glyphs(w, h), DEFAULT_COL)
+plan = ctx.plan(w, h, resize=(1024, 768, True), thumbnail=(200, True), watermark=gs)
+i = plan.info
+rng = np.random.default_rng(3)
+pool = 8
+y = ctx.alloc(n * w * h).upload(np.resize(rng.integers(0, 256, (pool, h, w), dtype=np.uint8), (n, h, w)))
+cb = ctx.alloc(n * cw * ch).upload(np.resize(rng.integers(0, 256, (pool, ch, cw), dtype=np.uint8), (n, ch, cw)))
+cr = ctx.alloc(n * cw * ch).upload(np.resize(rng.integers(0, 256, (pool, ch, cw), dtype=np.uint8), (n, ch, cw)))
+res, th, wm = ctx.alloc(n * i.resize_bytes), ctx.alloc(n * i.thumb_bytes), ctx.alloc(n * i.wm_bytes)
+
+
+def step():
+    plan.run_dev_ycbcr(n, y.ptr, cb.ptr, cr.ptr, ratio, w, cw, w * h, cw * ch, res.ptr, th.ptr, wm.ptr)
+
+
+for _ in range(3):
+    step()
+ctx.device_sync()
+ms = min(ctx.timed(step) for _ in range(10))
+alg = n * (w * h * 1.5 + i.resize_bytes + i.thumb_bytes + i.wm_bytes)
+print("ycbcr 4:2:0 batch: %d frames in %.3f ms = %.0f images/s; algorithmic %.1f GB/s (1.5 B/px in + outputs = %.2f MB per frame)"
+      % (n, ms, n / ms * 1e3, alg / ms / 1e6, alg / n / 1e6))
