@@ -205,12 +205,15 @@ def main():
     for i in range(P, F, P):
         m = min(P, F - i)
         ctx.copy_d2d(src.ptr + i * fbytes, src.ptr, m * fbytes)
-    res = ctx.alloc(F * info.resize_bytes) if info.resize_bytes else None
-    th = ctx.alloc(F * info.thumb_bytes) if info.thumb_bytes else None
+    # experiment switch: IPX_BENCH_PAD=bytes widens the OUTPUT frame strides (a 1024x768 frame is exactly 3 MiB)
+    pad = int(os.environ.get("IPX_BENCH_PAD", "0"))
+    res = ctx.alloc(F * (info.resize_bytes + pad)) if info.resize_bytes else None
+    th = ctx.alloc(F * (info.thumb_bytes + pad)) if info.thumb_bytes else None
     wm = ctx.alloc(F * info.wm_bytes) if info.wm_bytes else None
 
     def step():
-        plan.run_dev(F, src.ptr, res.ptr if res else None, th.ptr if th else None, wm.ptr if wm else None)
+        plan.run_dev(F, src.ptr, res.ptr if res else None, th.ptr if th else None, wm.ptr if wm else None,
+                     resize_frame_stride=info.resize_bytes + pad, thumb_frame_stride=info.thumb_bytes + pad)
 
     L = ipx.lib()
     for _ in range(args.warmup):

@@ -211,7 +211,7 @@ __device__ __forceinline__ void item_setup(const BandArgs &a, Item &it, bool val
     }
 }
 
-template <int ROWS, int CH>
+template <int ROWS, int CH, int NT>
 __device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, int tid, v4u (&stage)[ROWS * CH],
                                            v4u (&ty_stage)[2][2])
 {
@@ -227,7 +227,7 @@ __device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, in
     bool in_tile[CH];
 #pragma unroll
     for (int h = 0; h < CH; h++) {
-        const int ch = tid + 256 * h;
+        const int ch = tid + NT * h;
         in_tile[h] = ch < it.t.nchunk;
         voff[h] = it.t.r0 * a.sstride + it.t.c0 * 4 + ch * 16;
     }
@@ -246,7 +246,7 @@ __device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, in
     }
 }
 
-template <int ROWS, int CH>
+template <int ROWS, int CH, int NT>
 __device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, int tid, const v4u (&stage)[ROWS * CH],
                                            const v4u (&ty_stage)[2][2], uint8_t *lds, AxisTap *ytap, bool any_glyph)
 {
@@ -258,7 +258,7 @@ __device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, in
     bool in_tile[CH], owned[CH];
 #pragma unroll
     for (int h = 0; h < CH; h++) {
-        const int ch = tid + 256 * h;
+        const int ch = tid + NT * h;
         in_tile[h] = ch < it.t.nchunk;
         loff[h] = ch * 16;
         owned[h] = wframe && ch * 4 < it.t.own_cols;
@@ -271,7 +271,7 @@ __device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, in
             if (r < it.t.rows_ld && in_tile[h]) *(v4u *)(lds + r * it.t.pitch + loff[h]) = stage[r * CH + h];
             int off = r < it.t.own_rows && owned[h] ? woff[h] + r * a.wm_stride : kOOB;
             // chunks that meet the text box are written by the composite step
-            if (gl_rows && chunk_in_textbox(a, it.t.c0 + (tid + 256 * h) * 4, it.t.r0 + r)) off = kOOB;
+            if (gl_rows && chunk_in_textbox(a, it.t.c0 + (tid + NT * h) * 4, it.t.r0 + r)) off = kOOB;
             __builtin_amdgcn_raw_buffer_store_b128(stage[r * CH + h], wrs, off, 0, 0);
         }
     }
@@ -285,8 +285,8 @@ __device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, in
     }
 }
 
-template <int NX0, bool FP0, int NX1, bool FP1, int ROWS, int CH>
-__global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
+template <int NX0, bool FP0, int NX1, bool FP1, int ROWS, int CH, int NT>
+__global__ __launch_bounds__(NT) void band_pipe_kernel(BandArgs a)
 {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = (uint8_t *)lds_raw;
@@ -294,9 +294,23 @@ __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
 
     const int per_cb = a.nframes * a.nbands;
     const int items = per_cb * a.ncolblk;
-    const int per = (items + (int)gridDim.x - 1) / (int)gridDim.x;
-    int idx = blockIdx.x * per;
-    const int idx_end = min(items, idx + per);
+    // pipe_order 0: a workgroup walks a contiguous run of items (its own stream through HBM);
+    // pipe_order 1: the grid sweeps the items together, workgroup `slot` takes items slot, slot + G, ...;
+    //   slots are XCD-contiguous (blockIdx % 8 = XCD), so neighbouring bands (shared halo row) meet in one L2
+    //   and the whole chip reads / writes one moving window of ~G tiles.
+    const int G = (int)gridDim.x;
+    int idx, idx_end, step;
+    if (a.pipe_order == 0) {
+        const int per = (items + G - 1) / G;
+        idx = blockIdx.x * per;
+        idx_end = min(items, idx + per);
+        step = 1;
+    } else {
+        const int bid = blockIdx.x;
+        idx = (G & 7) == 0 ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
+        idx_end = items;
+        step = G;
+    }
     if (idx >= idx_end) return;
 
     AxisTap *ytap = (AxisTap *)(lds + (a.band_rows + 1) * ((a.blk_cols + 4) * 4));  // [2][kYChunk]
@@ -310,11 +324,11 @@ __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
 
     OutCols<NX0, FP0> o0;
     OutCols<NX1, FP1> o1;
-    if (a.nscale > 0) { load_xtaps<NX0, FP0>(a, 0, cur.cb, tid, o0); load_xtaps<NX1, FP1>(a, 1, cur.cb, tid, o1); }
+    if (a.nscale > 0) { load_xtaps<NX0, FP0, NT>(a, 0, cur.cb, tid, o0); load_xtaps<NX1, FP1, NT>(a, 1, cur.cb, tid, o1); }
 
     v4u stage[ROWS * CH];
     v4u ty_stage[2][2];
-    issue_tile<ROWS, CH>(a, cur, tid, stage, ty_stage);
+    issue_tile<ROWS, CH, NT>(a, cur, tid, stage, ty_stage);
 
     // In-kernel phase stamps exist only in the diagnostic build (-DIPX_DIAG=1, tools/build_diag.sh);
     // the shipped kernel executes none.
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
 #endif
     for (;;) {
         // A: staged tile -> LDS (+ watermark copy)
-        drain_tile<ROWS, CH>(a, cur, tid, stage, ty_stage, lds, ytap, any_glyph);
+        drain_tile<ROWS, CH, NT>(a, cur, tid, stage, ty_stage, lds, ytap, any_glyph);
         IPX_STAMP(0);
         __syncthreads();
         IPX_STAMP(1);
@@ -336,24 +350,31 @@ __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
         // the "item" is not valid: the same loads are issued with out-of-range offsets, which keeps
         // this block free of branches around memory operations.
         Item nxt;
-        nxt.b = cur.b + 1; nxt.f = cur.f; nxt.cb = cur.cb;
-        if (nxt.b == a.nbands) { nxt.b = 0; if (++nxt.f == a.nframes) { nxt.f = 0; ++nxt.cb; } }
-        const bool has_next = idx + 1 < idx_end;
+        const bool has_next = idx + step < idx_end;
         if (!has_next) { nxt.b = cur.b; nxt.f = cur.f; nxt.cb = cur.cb; }
+        else if (step == 1) {
+            nxt.b = cur.b + 1; nxt.f = cur.f; nxt.cb = cur.cb;
+            if (nxt.b == a.nbands) { nxt.b = 0; if (++nxt.f == a.nframes) { nxt.f = 0; ++nxt.cb; } }
+        } else {
+            const int ni = idx + step;
+            nxt.cb = ni / per_cb;
+            nxt.f = (ni - nxt.cb * per_cb) / a.nbands;
+            nxt.b = ni - nxt.cb * per_cb - nxt.f * a.nbands;
+        }
         item_setup(a, nxt, has_next);
-        issue_tile<ROWS, CH>(a, nxt, tid, stage, ty_stage);
+        issue_tile<ROWS, CH, NT>(a, nxt, tid, stage, ty_stage);
         IPX_STAMP(2);
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, cur.t))
-            glyph_phase(a, cur.t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
+            glyph_phase<NT>(a, cur.t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
 #if IPX_DIAG
         if (a.nscale > 0 && !(a.dbg & 1)) {
 #else
         if (a.nscale > 0) {
 #endif
-            scale_out<NX0, FP0, false>(a, 0, cur.t, cur.f, lds, ytap, tid, o0, cur.dyA[0], cur.dyB[0]);
-            scale_out<NX1, FP1, false>(a, 1, cur.t, cur.f, lds, ytap + kYChunk, tid, o1, cur.dyA[1], cur.dyB[1]);
+            scale_out<NX0, FP0, false, NT>(a, 0, cur.t, cur.f, lds, ytap, tid, o0, cur.dyA[0], cur.dyB[0]);
+            scale_out<NX1, FP1, false, NT>(a, 1, cur.t, cur.f, lds, ytap + kYChunk, tid, o1, cur.dyA[1], cur.dyB[1]);
         }
         IPX_STAMP(3);
         __syncthreads();
@@ -361,14 +382,14 @@ __global__ __launch_bounds__(256) void band_pipe_kernel(BandArgs a)
 
         if (!has_next) break;
         if (nxt.cb != cur.cb && a.nscale > 0) {
-            load_xtaps<NX0, FP0>(a, 0, nxt.cb, tid, o0);
-            load_xtaps<NX1, FP1>(a, 1, nxt.cb, tid, o1);
+            load_xtaps<NX0, FP0, NT>(a, 0, nxt.cb, tid, o0);
+            load_xtaps<NX1, FP1, NT>(a, 1, nxt.cb, tid, o1);
         }
         cur = nxt;
-        ++idx;
+        idx += step;
     }
 #if IPX_DIAG
-    if (a.stamps && (tid & 63) == 0)
+    if (a.stamps && (tid & 63) == 0 && tid < 256)
         for (int i = 0; i < 5; i++) atomicAdd(&a.stamps[i], acc[i]);
 #endif
 #undef IPX_STAMP
@@ -388,19 +409,19 @@ hipError_t launch_nx(const BandArgs &a, unsigned total, size_t lds, hipStream_t 
     return hipGetLastError();
 }
 
-template <int NX0, bool FP0, int NX1, bool FP1, int ROWS, int CH>
+template <int NX0, bool FP0, int NX1, bool FP1, int ROWS, int CH, int NT>
 hipError_t launch_pipe(const BandArgs &a, long long items, size_t lds, hipStream_t s)
 {
     // a persistent grid must be fully resident: size it from the occupancy the runtime reports for
     // this instantiation and LDS size, not from the LDS arithmetic alone (VGPRs may bind first)
     static thread_local size_t lds_set = 0;
     static thread_local int resident = 0;
-    auto kern = band_pipe_kernel<NX0, FP0, NX1, FP1, ROWS, CH>;
+    auto kern = band_pipe_kernel<NX0, FP0, NX1, FP1, ROWS, CH, NT>;
     if (lds != lds_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         int n = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, 256, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, NT, lds);
         if (e != hipSuccess) return e;
         resident = std::max(1, n);
         lds_set = lds;
@@ -409,24 +430,26 @@ hipError_t launch_pipe(const BandArgs &a, long long items, size_t lds, hipStream
     static thread_local bool said = false;
     if (!said && getenv("IPX_DEBUG")) {
         said = true;
-        fprintf(stderr, "[ipx] band_pipe_kernel<%d,%d,%d,%d,%d,%d>: tile %d rows x %d cols, lds %zu B, resident %d/CU, grid %lld, items %lld\n",
-                NX0, (int)FP0, NX1, (int)FP1, ROWS, CH, a.band_rows, a.blk_cols, lds, resident, grid, items);
+        fprintf(stderr, "[ipx] band_pipe_kernel<%d,%d,%d,%d,%d,%d,%d>: tile %d rows x %d cols, lds %zu B, resident %d/CU, grid %lld, items %lld\n",
+                NX0, (int)FP0, NX1, (int)FP1, ROWS, CH, NT, a.band_rows, a.blk_cols, lds, resident, grid, items);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, s, a);
     return hipGetLastError();
 }
 
 // column / lerp configurations built for the pipelined kernel, cheapest first
-template <int ROWS, int CH>
+template <int ROWS, int CH, int NT>
 hipError_t launch_pipe_cfg(const BandArgs &a, long long items, size_t lds, hipStream_t s, bool *matched)
 {
-    const int need0 = a.nscale > 0 ? a.nx_out[0] : 0, need1 = a.nscale > 1 ? a.nx_out[1] : 0;
+    // a.nx_out counts blocks of 256 destination columns; a thread of an NT-wide workgroup serves NT-strided ones
+    constexpr int W = NT / 256, N4 = 4 / W;   // N4 x NT = 1024 columns per block
+    const int need0 = a.nscale > 0 ? (a.nx_out[0] + W - 1) / W : 0, need1 = a.nscale > 1 ? (a.nx_out[1] + W - 1) / W : 0;
     const bool fp0 = a.nscale > 0 && a.sc[0].dyadic_shift < 0, fp1 = a.nscale > 1 && a.sc[1].dyadic_shift < 0;
     *matched = true;
-    if (need0 <= 1 && need1 <= 1) return launch_pipe<1, true, 1, true, ROWS, CH>(a, items, lds, s);
-    if (need0 <= 4 && !fp0 && need1 <= 1) return launch_pipe<4, false, 1, true, ROWS, CH>(a, items, lds, s);
-    if (need0 <= 4 && need1 <= 1) return launch_pipe<4, true, 1, true, ROWS, CH>(a, items, lds, s);
-    if (need0 <= 4 && need1 <= 4 && !fp0 && !fp1) return launch_pipe<4, false, 4, false, ROWS, CH>(a, items, lds, s);
+    if (need0 <= 1 && need1 <= 1) return launch_pipe<1, true, 1, true, ROWS, CH, NT>(a, items, lds, s);
+    if (need0 <= N4 && !fp0 && need1 <= 1) return launch_pipe<N4, false, 1, true, ROWS, CH, NT>(a, items, lds, s);
+    if (need0 <= N4 && need1 <= 1) return launch_pipe<N4, true, 1, true, ROWS, CH, NT>(a, items, lds, s);
+    if (need0 <= N4 && need1 <= N4 && !fp0 && !fp1) return launch_pipe<N4, false, N4, false, ROWS, CH, NT>(a, items, lds, s);
     *matched = false;
     return hipSuccess;
 }
@@ -458,9 +481,13 @@ hipError_t launch_band(const BandArgs &a, hipStream_t s)
     if (a.pipe_wgs > 0 && band_pipe_shape(a.band_rows, a.blk_cols, &rows, &ch)) {
         bool matched = false;
         hipError_t e = hipSuccess;
-        if (rows == 9 && ch == 1) e = launch_pipe_cfg<9, 1>(a, total, lds, s, &matched);
-        else if (rows == 17 && ch == 1) e = launch_pipe_cfg<17, 1>(a, total, lds, s, &matched);
-        else e = launch_pipe_cfg<9, 2>(a, total, lds, s, &matched);
+        // wide 9-row tiles: 512 threads per workgroup (one 16-byte chunk per thread and row) put twice the
+        // waves on a CU for the same LDS, which is what the latency-bound lerp phase wants
+        const bool wide = a.pipe_nt == 512;
+        if (rows == 9 && ch == 1) e = launch_pipe_cfg<9, 1, 256>(a, total, lds, s, &matched);
+        else if (rows == 17 && ch == 1) e = launch_pipe_cfg<17, 1, 256>(a, total, lds, s, &matched);
+        else if (wide) e = launch_pipe_cfg<9, 1, 512>(a, total, lds, s, &matched);
+        else e = launch_pipe_cfg<9, 2, 256>(a, total, lds, s, &matched);
         if (matched) return e;
     }
     const int nx = std::max(a.nx_out[0], a.nx_out[1]);

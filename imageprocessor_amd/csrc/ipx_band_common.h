@@ -73,13 +73,14 @@ __device__ __forceinline__ bool tile_meets_textbox(const BandArgs &a, const Tile
 }
 
 // Step 3: glyph composite over the block's share of the text box, source pixels from LDS.
+template <int NT = 256>
 __device__ __forceinline__ void glyph_phase(const BandArgs &a, const Tile &t, uint8_t *wframe,
                                             const uint8_t *lds, int tid)
 {
     const int gy0 = max(a.gbox.y0, t.r0), gy1 = min(a.gbox.y1, t.r1);
     const int gx0 = max(a.gbox.x0 & ~3, t.c0), gx1 = min((a.gbox.x1 + 3) & ~3, t.c1);  // whole skipped chunks
     const int gw = gx1 - gx0, gn = gw * (gy1 - gy0);
-    for (int i = tid; i < gn; i += 256) {
+    for (int i = tid; i < gn; i += NT) {
         const int yy = i / gw, x = gx0 + (i - yy * gw), y = gy0 + yy;
         uint32_t d = lds_u32(lds, (y - t.r0) * t.pitch + (x - t.c0) * 4);
         d = glyph_run(d, x, y, a.glyphs, a.nglyphs, a.cr, a.cg, a.cb, a.ca);
@@ -88,7 +89,8 @@ __device__ __forceinline__ void glyph_phase(const BandArgs &a, const Tile &t, ui
 }
 
 // ---- per-output state a thread keeps in registers -------------------------------------------------
-// A thread serves destination columns dxA + tid + 256*i, i < NX, of one scaled output.  FP = the
+// A thread serves destination columns dxA + tid + NT*i, i < NX, of one scaled output (NT = threads of
+// the workgroup).  FP = the
 // output may need the float64 lerp (non-dyadic axis), so the float64 x weights are kept as well; an
 // output known to be dyadic keeps two floats and an index per column.
 template <bool FP>
@@ -113,7 +115,7 @@ struct OutCols {
 
 // x taps of column block cb.  Loads are unconditional (index clamped into the table).
 // (a.sc[1] mirrors a.sc[0] when only one output is scaled, so the loads are always legal.)
-template <int NX, bool FP>
+template <int NX, bool FP, int NT = 256>
 __device__ __forceinline__ void load_xtaps(const BandArgs &a, int k, int cb, int tid, OutCols<NX, FP> &o)
 {
     const ScaleOut &S = a.sc[k];
@@ -121,7 +123,7 @@ __device__ __forceinline__ void load_xtaps(const BandArgs &a, int k, int cb, int
     o.dxB = k < a.nscale ? S.col_begin[cb + 1] : o.dxA;
 #pragma unroll
     for (int i = 0; i < NX; i++) {
-        const AxisTap *p = &S.xt[min(o.dxA + tid + 256 * i, S.dw - 1)];
+        const AxisTap *p = &S.xt[min(o.dxA + tid + NT * i, S.dw - 1)];
         if constexpr (FP) { o.tx[i].w0 = p->w0; o.tx[i].w1 = p->w1; }
         o.tx[i].f0 = p->f0; o.tx[i].f1 = p->f1; o.tx[i].base = p->base;
     }
@@ -134,7 +136,7 @@ __device__ __forceinline__ void load_xtaps(const BandArgs &a, int k, int cb, int
 // is fetched once for NX pixels and the NX x 4 tap reads are issued together, so their LDS latency
 // overlaps.  All reads are unconditional (clamped taps keep the addresses inside the tile); only the
 // store is predicated.
-template <int NX, bool FP, bool REFILL>
+template <int NX, bool FP, bool REFILL, int NT = 256>
 __device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &t, int f, const uint8_t *lds,
                                           AxisTap *ytap_k, int tid, const OutCols<NX, FP> &o, int dyA, int dyB)
 {
@@ -154,7 +156,7 @@ __device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &
         uint32_t *op[NX];
 #pragma unroll
         for (int i = 0; i < NX; i++) {
-            const int dx = o.dxA + tid + 256 * i;
+            const int dx = o.dxA + tid + NT * i;
             live[i] = dx < o.dxB;
             lx[i] = (xbias + o.tx[i].base) * 4;
             op[i] = (uint32_t *)(oframe + (size_t)chunk * S.ostride + (size_t)dx * 4);

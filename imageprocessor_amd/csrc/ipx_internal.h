@@ -121,6 +121,8 @@ struct BandArgs {
     int nframes;
     int nx_out[2];             // per scaled output: destination columns per thread and column block (of 256)
     int pipe_wgs;              // > 0: persistent pipelined kernel, this many workgroups per CU wanted
+    int pipe_nt;               // threads per workgroup of the pipelined kernel for wide tiles: 256 or 512
+    int pipe_order;            // 0: contiguous run of items per workgroup; 1: grid-interleaved, XCD-contiguous slots
     int cus;                   // compute units of the device
     int dbg;                   // diagnostic build only (-DIPX_DIAG=1): 1 = skip scaling, 2 = skip tile loads
     unsigned long long *stamps; // diagnostic build only: per-phase cycle sums, else NULL

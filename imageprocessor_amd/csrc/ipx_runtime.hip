@@ -963,6 +963,8 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         // the persistent pipelined kernel needs 16-byte aligned rows on both frames and a tile of at
         // most kPipeMaxSlots chunks per thread; otherwise one workgroup per item
         a.pipe_wgs = 0;
+        a.pipe_nt = 256;
+        a.pipe_order = 0;
         a.cus = ctx->cus;
         a.dbg = 0;
         a.stamps = nullptr;
@@ -980,6 +982,8 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         int pr = 0, pc = 0;
         if (aligned && env_int("IPX_PIPE", 1) && pl->most_rows <= 64 && band_pipe_shape(pl->band_rows, pl->blk_cols, &pr, &pc)) {
             a.pipe_wgs = std::max(1, env_int("IPX_PIPE_WGS", 8));  // clamped to what is resident at launch
+            a.pipe_nt = env_int("IPX_PIPE_NT", 512) == 512 ? 512 : 256;
+            a.pipe_order = -1;   // chosen below, once the operators are known
         }
         a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
         a.nscale = 0;
@@ -998,6 +1002,10 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
         a.cr = col[0]; a.cg = col[1]; a.cb = col[2]; a.ca = col[3];
         if (!wm && a.nscale == 0) return IPX_OK;
+        // item order of the persistent kernel: the grid-interleaved sweep is steadier when outputs are scaled
+        // (run-to-run 3.63-3.74 ms against 3.65-4.13 ms on one box, profiles/r01_item_order.txt); a plain
+        // watermark copy is ~2 % faster with one contiguous run per workgroup
+        if (a.pipe_order < 0) a.pipe_order = env_int("IPX_PIPE_ORDER", a.nscale > 0 ? 1 : 0) ? 1 : 0;
         IPX_HIP(launch_band(a, s));
         if (a.stamps) {
             unsigned long long h[8];

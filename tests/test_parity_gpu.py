@@ -188,7 +188,12 @@ PATH_ENVS = [{"IPX_PIPE": "0"},                                  # one workgroup
              {"IPX_NO_DYADIC": "1", "IPX_PIPE": "0"},
              {"IPX_PIPE_WGS": "1"},                              # one persistent workgroup per CU
              {"IPX_BLK_COLS": "256"},                            # many column blocks (x taps change)
-             {"IPX_BLK_COLS": "1000", "IPX_BAND_ROWS": "16"}]    # the 17-row single-column-group tile shape
+             {"IPX_BLK_COLS": "1000", "IPX_BAND_ROWS": "16"},    # the 17-row single-column-group tile shape
+             {"IPX_PIPE_NT": "256"},                             # 256-thread workgroups on wide tiles (two chunks per thread)
+             {"IPX_PIPE_NT": "256", "IPX_NO_DYADIC": "1"},
+             {"IPX_PIPE_ORDER": "0"},                            # one contiguous run of items per workgroup
+             {"IPX_PIPE_ORDER": "0", "IPX_BLK_COLS": "256"},
+             {"IPX_PIPE_ORDER": "1", "IPX_BLK_COLS": "256"}]     # grid-interleaved order over several column blocks
 
 
 @pytest.mark.parametrize("env", PATH_ENVS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
