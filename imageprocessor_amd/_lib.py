@@ -58,7 +58,7 @@ class Image(C.Structure):
 
 
 MEASURE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_double, C.POINTER(C.c_int))
-GLYPHS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_double, C.c_int, C.c_int,
+GLYPHS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                         C.POINTER(C.POINTER(Glyph)), C.POINTER(C.c_int))
 RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p)
 
@@ -136,6 +136,16 @@ SIGNATURES = {
                                      C.POINTER(TextRasterizer), C.POINTER(Image), _P]),
     "ipx_processor_process": (_I, [_P, C.POINTER(Task), C.POINTER(Image), C.c_char_p, C.POINTER(TextRasterizer),
                                    C.POINTER(Processed), C.POINTER(_I)]),
+    "ipx_font_create": (_I, [_P, _Z, C.POINTER(_P)]),
+    "ipx_font_destroy": (None, [_P]),
+    "ipx_font_glyph_index": (_I, [_P, C.c_uint32]),
+    "ipx_font_glyph_advance": (_I, [_P, C.c_uint32, C.c_double, C.POINTER(C.c_int32)]),
+    "ipx_font_kern": (_I, [_P, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.c_int32)]),
+    "ipx_font_text_width": (_I, [_P, C.c_char_p, C.c_double, C.POINTER(C.c_int32), C.POINTER(_I)]),
+    "ipx_font_draw_string": (_I, [_P, C.c_char_p, C.c_double, _I, _I, _I, _I, C.POINTER(C.POINTER(Glyph)),
+                                  C.POINTER(_I), C.POINTER(C.c_int32)]),
+    "ipx_font_release_thread": (None, []),
+    "ipx_font_rasterizer": (_I, [_P, C.POINTER(TextRasterizer)]),
 }
 
 _lib = None

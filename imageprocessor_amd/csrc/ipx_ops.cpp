@@ -135,7 +135,7 @@ int run_ops(ipx_ctx *ctx, const ipx_image *img, const ResizeReq *rz, const Thumb
         ipx_watermark_anchor(wm->position.c_str(), img->w, img->h, width_px, height_px, &px, &py);
         const ipx_glyph *gl = nullptr;
         int ng = 0;
-        if (font->glyphs(font->user, wm->text.c_str(), wm->font_size, px, py, &gl, &ng)) {
+        if (font->glyphs(font->user, wm->text.c_str(), wm->font_size, px, py, img->w, img->h, &gl, &ng)) {
             *err = "failed to draw watermark text: rasteriser failed";
             return IPX_ERR_INVALID;
         }

@@ -67,7 +67,7 @@ def _take(img):
 
 class Font:
     """Host-side text rasteriser handed across the boundary (ipx_text_rasterizer).  `measure(text,
-    font_size) -> width_px` and `glyphs(text, font_size, px, py) -> [{"mask", "dr", "mp"}]` are the
+    font_size) -> width_px` and `glyphs(text, font_size, px, py, w, h) -> [{"mask", "dr", "mp"}]` are the
     two things the reference asks of golang/freetype (watermark.go:105-117 and :151)."""
 
     def __init__(self, measure, glyphs):
@@ -81,9 +81,9 @@ class Font:
             except Exception:
                 return 1
 
-        def c_glyphs(user, text, size, px, py, out, n):
+        def c_glyphs(user, text, size, px, py, w, h, out, n):
             try:
-                gl = list(self._glyphs(text.decode(), size, px, py))
+                gl = list(self._glyphs(text.decode(), size, px, py, w, h))
                 arr = (Glyph * max(1, len(gl)))()
                 masks = []
                 for i, g in enumerate(gl):
@@ -104,6 +104,70 @@ class Font:
 
         self._cb = (MEASURE_FN(c_measure), GLYPHS_FN(c_glyphs), RELEASE_FN(c_release))
         self.struct = TextRasterizer(None, *self._cb)
+
+
+class TrueTypeFont:
+    """truetype.Parse + freetype.Context.DrawString of the library itself (ipx_font_*, csrc/ipx_font.cpp):
+    what NewWatermarker holds (watermark.go:25-38).  Usable wherever a `Font` is."""
+
+    def __init__(self, ttf_bytes):
+        self.handle = C.c_void_p()
+        self._bytes = bytes(ttf_bytes)
+        rc = lib().ipx_font_create(self._bytes, len(self._bytes), C.byref(self.handle))
+        if rc:
+            raise IpxError(rc, lib().ipx_last_error().decode(errors="replace"))
+        self.struct = TextRasterizer()
+        lib().ipx_font_rasterizer(self.handle, C.byref(self.struct))
+
+    @classmethod
+    def from_file(cls, path):
+        with open(path, "rb") as f:
+            return cls(f.read())
+
+    def index(self, rune):
+        return lib().ipx_font_glyph_index(self.handle, ord(rune) if isinstance(rune, str) else int(rune))
+
+    def glyph_advance(self, rune, size):
+        v = C.c_int32()
+        rc = lib().ipx_font_glyph_advance(self.handle, ord(rune) if isinstance(rune, str) else int(rune), size, C.byref(v))
+        if rc:
+            raise IpxError(rc, lib().ipx_last_error().decode(errors="replace"))
+        return v.value
+
+    def kern(self, r0, r1, size):
+        v = C.c_int32()
+        rc = lib().ipx_font_kern(self.handle, ord(r0), ord(r1), size, C.byref(v))
+        if rc:
+            raise IpxError(rc, lib().ipx_last_error().decode(errors="replace"))
+        return v.value
+
+    def text_width(self, text, size):
+        """-> (textWidth as 26.6 fixed, int(textWidth.Ceil())) of watermark.go:108-117"""
+        w, px = C.c_int32(), C.c_int()
+        rc = lib().ipx_font_text_width(self.handle, text.encode(), size, C.byref(w), C.byref(px))
+        if rc:
+            raise IpxError(rc, lib().ipx_last_error().decode(errors="replace"))
+        return w.value, px.value
+
+    def draw_string(self, text, size, px, py, clip_w, clip_h):
+        """-> ([{"mask", "dr", "mp"}] in DrawMask order, X of the returned point as 26.6 fixed)"""
+        out, n, endx = C.POINTER(Glyph)(), C.c_int(), C.c_int32()
+        rc = lib().ipx_font_draw_string(self.handle, text.encode() if isinstance(text, str) else text, size, px, py,
+                                        clip_w, clip_h, C.byref(out), C.byref(n), C.byref(endx))
+        if rc:
+            raise IpxError(rc, lib().ipx_last_error().decode(errors="replace"))
+        gl = []
+        for i in range(n.value):
+            g = out[i]
+            m = np.frombuffer((C.c_uint8 * (g.mh * g.mstride)).from_address(g.mask), np.uint8).reshape(g.mh, g.mstride)
+            gl.append({"mask": m[:, :g.mw].copy(), "dr": (g.dr.x0, g.dr.y0, g.dr.x1, g.dr.y1), "mp": (g.mpx, g.mpy)})
+        lib().ipx_font_release_thread()
+        return gl, endx.value
+
+    def close(self):
+        if self.handle:
+            lib().ipx_font_destroy(self.handle)
+            self.handle = C.c_void_p()
 
 
 def _font_ptr(font):

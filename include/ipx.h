@@ -257,18 +257,47 @@ typedef struct {
 typedef struct { uint8_t *pix; int32_t w, h, stride; } ipx_image;
 void ipx_image_free(ipx_image *img);
 
-/* The text rasteriser stays on the host side of the boundary (the reference uses golang/freetype
- * with the Go Regular face, watermark.go:29-38,98-118,151; SURVEY.md 8(f) N1).  measure() returns
- * int(textWidth.Ceil()) of watermark.go:109-117; glyphs() returns, for the baseline point (px, py),
- * the DrawMask calls DrawString would make (valid until release()).  A NULL rasteriser makes
- * Watermarker.Process fail with "font not loaded" like a nil font (watermark.go:87-89). */
+/* The text rasteriser sits on the host side of the boundary (the reference uses golang/freetype
+ * with the Go Regular face, watermark.go:29-38,98-118,151).  measure() returns
+ * int(textWidth.Ceil()) of watermark.go:109-117; glyphs() returns, for the baseline point (px, py)
+ * and a frame of w x h (c.SetClip(result.Bounds()), watermark.go:101), the DrawMask calls
+ * DrawString would make (valid until release()).  A NULL rasteriser makes Watermarker.Process fail
+ * with "font not loaded" like a nil font (watermark.go:87-89).  ipx_font_rasterizer() below fills
+ * one in from a parsed TrueType font; a caller may also supply its own. */
 typedef struct {
     void *user;
     int (*measure)(void *user, const char *text, double font_size, int *width_px);
-    int (*glyphs)(void *user, const char *text, double font_size, int px, int py,
+    int (*glyphs)(void *user, const char *text, double font_size, int px, int py, int w, int h,
                   const ipx_glyph **out, int *n);
     void (*release)(void *user);
 } ipx_text_rasterizer;
+
+/* ---- glyph mask producer: truetype.Parse + freetype.Context.DrawString ------
+ * A restatement of github.com/golang/freetype @ e2365dfdc4a0 (go.mod:42) without hinting, which is
+ * all the reference uses: cmap formats 4 / 12, simple and compound glyphs, kern format 0, the
+ * quadratic-spline cell rasteriser (even-odd), 4 horizontal sub-pixel positions.  Host code: the
+ * masks are a few hundred bytes each and cached; the composite is the GPU's part. */
+typedef struct ipx_font ipx_font;
+/* truetype.Parse (watermark.go:31).  Failure = the reference's nil font; text in ipx_last_error(). */
+int ipx_font_create(const uint8_t *ttf, size_t len, ipx_font **out);
+void ipx_font_destroy(ipx_font *font);
+/* (f *Font).Index */
+int ipx_font_glyph_index(const ipx_font *font, uint32_t rune);
+/* face.GlyphAdvance of truetype.NewFace(font, {Size, DPI: 72}) (watermark.go:105-111), 26.6 fixed */
+int ipx_font_glyph_advance(const ipx_font *font, uint32_t rune, double font_size, int32_t *advance26_6);
+/* (f *Font).Kern at the freetype.Context's scale (what DrawString adds between runes), 26.6 fixed */
+int ipx_font_kern(const ipx_font *font, uint32_t rune0, uint32_t rune1, double font_size, int32_t *kern26_6);
+/* watermark.go:108-117: textWidth = sum of advances (no kerning) and int(textWidth.Ceil()) */
+int ipx_font_text_width(const ipx_font *font, const char *text, double font_size, int32_t *width26_6,
+                        int *width_px);
+/* c.DrawString(text, freetype.Pt(px, py)) with c.SetClip((0,0)-(clip_w,clip_h)) (watermark.go:98-104,151):
+ * the DrawMask calls in rune order.  *out stays valid until the next call on the calling thread or
+ * ipx_font_release_thread().  end_x26_6 (may be NULL) receives the returned point's X. */
+int ipx_font_draw_string(ipx_font *font, const char *text, double font_size, int px, int py, int clip_w,
+                         int clip_h, const ipx_glyph **out, int *n, int32_t *end_x26_6);
+void ipx_font_release_thread(void);
+/* Fills an ipx_text_rasterizer whose callbacks are the three entries above. */
+int ipx_font_rasterizer(ipx_font *font, ipx_text_rasterizer *out);
 
 /* out_format receives "jpeg" / "png" / "gif" as the reference's encoder switch would name it
  * (resize.go:78-91, thumbnail.go:68-81, watermark.go:66-79: a GIF watermark becomes JPEG). */

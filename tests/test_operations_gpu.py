@@ -34,7 +34,7 @@ def fake_measure(text, size):
     return int(len(text) * size * 0.52) + 1
 
 
-def fake_glyphs(text, size, px, py):
+def fake_glyphs(text, size, px, py, w=None, h=None):
     out = []
     x = px
     for i, ch in enumerate(text):
@@ -139,6 +139,49 @@ def test_watermarker(ctx, ops, ipx, font):
     with pytest.raises(ipx.IpxError) as e:
         ops.Watermarker(None).Process(ctx, SRC, "png", {})
     assert e.value.text == "failed to add watermark: font not loaded"           # watermark.go:87-89,61-64
+
+
+def test_watermarker_with_the_library_font(ctx, ops, ipx):
+    """NewWatermarker's font slot filled by the library's own truetype / freetype restatement (ipx_font_*):
+    text -> glyph masks on the host -> composite on the GPU, against the Python model of the glyph producer
+    plus the oracle's composite."""
+    import os
+    from oracle import ft_model
+    path = "/usr/share/fonts/truetype/dejavu/DejaVuSans.ttf"
+    if not os.path.exists(path):
+        pytest.skip("DejaVuSans.ttf not in this image")
+    f = ops.TrueTypeFont.from_file(path)
+    model = ft_model.Font(path)
+    w = ops.Watermarker(f)
+    h_, w_ = SRC.shape[:2]
+    for params, (text, pos, opacity, size, color) in (
+            ({}, ("© ImageProcessor", "bottom-right", 0.5, 36, "255,255,255")),
+            ({"text": "Grüße, Welt!", "position": "top-left", "font_size": 23.5, "font_color": "250,10,10", "opacity": 0.9},
+             ("Grüße, Welt!", "top-left", 0.9, 23.5, "250,10,10")),
+            ({"text": "a very long line of text that runs out of the frame on the right hand side", "position": "center",
+              "font_size": 48.0}, ("a very long line of text that runs out of the frame on the right hand side", "center", 0.5, 48.0,
+                                   "255,255,255"))):
+        got, _ = w.Process(ctx, SRC, "png", params)
+        col, _ = oracle.parse_color(color, opacity)
+        _, width_px = ft_model.text_width(model, text, size)
+        px, py = oracle.watermark_anchor(pos, w_, h_, width_px, oracle.text_height_px(size))
+        glyphs, _ = ft_model.draw_string(model, text, size, px, py, w_, h_)
+        want = SRC.copy()
+        oracle.composite_glyphs(want, glyphs, col)
+        np.testing.assert_array_equal(got, want, err_msg=str(params))
+        assert (got != SRC).any()
+    # the same font feeding a batch plan
+    gl, _ = f.draw_string("© ImageProcessor", 36, 100, 300, w_, h_)
+    gs = ctx.glyphset(gl, (255, 255, 255, 127))
+    plan = ctx.plan(w_, h_, watermark=gs)
+    out = plan.run_host(np.stack([SRC, SRC[::-1].copy()]))
+    for i, src in enumerate((SRC, SRC[::-1])):
+        want = src.copy()
+        oracle.composite_glyphs(want, gl, (255, 255, 255, 127))
+        np.testing.assert_array_equal(out["watermark"][i], want)
+    plan.close()
+    gs.close()
+    f.close()
 
 
 def _task(ops_list, fmt=""):
