@@ -134,6 +134,20 @@ struct BandArgs {
     uint32_t cr, cg, cb, ca;
 };
 hipError_t launch_band(const BandArgs &a, hipStream_t s);
+
+// the fused band kernel on *image.YCbCr planes (ipx_band_ycc.hip): BandArgs without `src`, plus the planes
+struct YccArgs {
+    BandArgs b;
+    const uint8_t *y, *cb, *cr;
+    int ystride, cstride;
+    size_t y_fs, c_fs;         // frame strides of the luma / chroma planes
+    int cw, ch;                // chroma plane size
+    int ratio;                 // IPX_YCBCR_*
+    int mode[2];               // per b.sc entry: 0 = taps converted to 16-bit RGB (scale_RGBA_YCbCr4xx_Src),
+                               //                 1 = RGBA8 first (the crop copy), then scale_RGBA_RGBA_Src
+};
+// *matched = false: shape / alignment the kernel is not built for, nothing was launched
+hipError_t launch_band_ycc(const YccArgs &a, hipStream_t s, bool *matched);
 size_t band_lds_bytes(int band_rows, int blk_cols);
 bool band_pipe_shape(int band_rows, int blk_cols, int *rows, int *ch);  // tile shapes the pipelined kernel is built for
 

@@ -71,6 +71,7 @@ struct PlanScale {
     AxisTap *xt = nullptr, *yt = nullptr;
     int *row_begin = nullptr, *col_begin = nullptr;
     int dyadic_shift = -1;
+    int kx = -1, ky = -1;   // dyadic bits per axis (dyadic_shift = kx + ky), -1 = not dyadic
 };
 
 struct ipx_plan {
@@ -831,7 +832,7 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
         if (!env_int("IPX_NO_DYADIC", 0)) {
             const int kx = axis_dyadic_bits(xt[k].data(), s.dw, 12);
             const int ky = axis_dyadic_bits(yt[k].data(), s.dh, 12);
-            if (kx >= 0 && ky >= 0 && kx + ky <= 16) s.dyadic_shift = kx + ky;  // 8 + kx + ky <= 24 bits
+            if (kx >= 0 && ky >= 0 && kx + ky <= 16) { s.dyadic_shift = kx + ky; s.kx = kx; s.ky = ky; }  // 8 + kx + ky <= 24 bits
         }
     }
 
@@ -1154,6 +1155,47 @@ int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     uint8_t *th = pl->sc[1].on ? thumb_out : nullptr;
     uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
     const bool crop_thumb = th && pl->p.crop_to_fit;
+
+    // one fused pass over the planes when the tile shape and alignments allow it (ipx_band_ycc.hip)
+    if (pl->fused && env_int("IPX_YCC_FUSED", 1) && pl->band_rows <= 8 && pl->most_rows <= 64) {
+        YccArgs A{};
+        BandArgs &a = A.b;
+        a.sw = sw; a.sh = sh;
+        a.band_rows = pl->band_rows; a.nbands = pl->nbands;
+        a.blk_cols = pl->blk_cols; a.ncolblk = pl->ncolblk;
+        a.nframes = n;
+        a.pipe_wgs = std::max(1, env_int("IPX_PIPE_WGS", 8));
+        a.pipe_nt = 512; a.pipe_order = 1;
+        a.cus = ctx->cus;
+        a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
+        uint8_t *outs[2] = {res, th};
+        const size_t ostr[2] = {resize_frame_stride, thumb_frame_stride};
+        for (int k = 0; k < 2; k++) {
+            const PlanScale &ps = pl->sc[k];
+            if (!outs[k] || ps.dw <= 0 || ps.dh <= 0) continue;
+            A.mode[a.nscale] = k == 1 && pl->p.crop_to_fit ? 1 : 0;
+            ScaleOut &o = a.sc[a.nscale++];
+            o.out = outs[k]; o.frame_stride = ostr[k]; o.ostride = ps.dw * 4;
+            o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
+            o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
+            o.dyadic_shift = ps.dyadic_shift;
+            // 16-bit taps in u32: x0*tap + x1*tap < 2^24 and the weights below 2^9 keep every product in 24 x 24 bits
+            if (A.mode[a.nscale - 1] == 0 && (ps.kx > 8 || ps.ky > 8)) o.dyadic_shift = -1;
+            a.nx_out[a.nscale - 1] = pl->nx_out[k];
+        }
+        if (a.nscale == 1) { a.sc[1] = a.sc[0]; A.mode[1] = A.mode[0]; }
+        const uint8_t *c = pl->p.glyphs ? pl->p.glyphs->col : nullptr;
+        a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
+        a.cr = c ? c[0] * 0x101u : 0; a.cg = c ? c[1] * 0x101u : 0; a.cb = c ? c[2] * 0x101u : 0; a.ca = c ? c[3] * 0x101u : 0;
+        if (!wm && a.nscale == 0) return IPX_OK;
+        A.y = src->y; A.cb = src->cb; A.cr = src->cr; A.ystride = src->ystride; A.cstride = src->cstride;
+        A.y_fs = src->y_frame_stride; A.c_fs = src->c_frame_stride; A.ratio = src->ratio;
+        A.cw = (src->ratio == IPX_YCBCR_422 || src->ratio == IPX_YCBCR_420) ? (sw + 1) / 2 : sw;
+        A.ch = (src->ratio == IPX_YCBCR_420 || src->ratio == IPX_YCBCR_440) ? (sh + 1) / 2 : sh;
+        bool matched = false;
+        if (src->cstride >= A.cw) IPX_HIP(launch_band_ycc(A, s, &matched));
+        if (matched) return IPX_OK;
+    }
 
     DevSrc ysrc;
     ysrc.kind = IPX_SRC_YCBCR; ysrc.pix = src->y; ysrc.stride = src->ystride; ysrc.cb = src->cb; ysrc.cr = src->cr;

@@ -124,9 +124,18 @@ def _expect_ycbcr_ops(y, cb, cr, ratio, resize, thumb, glyphs, col):
                                   (640, 480, 3, 2, (1024, 768, True), (200, True)),
                                   (854, 480, 2, 1, (1024, 768, False), (120, False)),
                                   (333, 251, 2, 0, (200, 100, True), (64, True)),
-                                  (200, 200, 1, 3, (200, 200, False), (200, True))],
+                                  (200, 200, 1, 3, (200, 200, False), (200, True)),
+                                  # shapes the fused planar kernel takes (width % 4 == 0), every subsampling ratio
+                                  (1280, 720, 2, 0, (1024, 768, True), (200, True)),
+                                  (1280, 720, 2, 1, (1024, 768, False), (200, False)),     # non-crop thumbnail: 16-bit taps
+                                  (640, 361, 2, 2, (1000, 700, False), (64, True)),        # odd height, non-dyadic resize
+                                  (640, 360, 2, 3, (320, 180, True), (200, True)),
+                                  (2560, 1440, 1, 2, (1024, 768, True), (200, True)),      # two column blocks
+                                  (1920, 1080, 1, 2, (3840, 2160, False), (200, True))],   # upscale: falls back (too many columns)
                          ids=lambda c: "%dx%d r%d" % (c[0], c[1], c[3]))
-def test_ycbcr_batch_plan(ctx, case):
+@pytest.mark.parametrize("fused", ["1", "0"], ids=["fused", "three-kernel"])
+def test_ycbcr_batch_plan(ctx, case, fused, monkeypatch):
+    monkeypatch.setenv("IPX_YCC_FUSED", fused)
     from helpers import DEFAULT_COL, text_glyphs
     w, h, n, ratio, resize, thumb = case
     planes = [_rand_ycbcr(w, h, ratio, 50 + i) for i in range(n)]
