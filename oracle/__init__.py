@@ -36,7 +36,7 @@ class Pipeline(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ipx_oracle.c", "ipx_oracle.h"))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ipx_oracle.c", "ipx_jpeg_oracle.c", "ipx_oracle.h"))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
         subprocess.check_call(["make", "-s", "-C", _HERE, "libipx_oracle.so"])
     return _SO
@@ -274,3 +274,52 @@ def draw_ycbcr(dst, r, y, cb, cr, ratio, sp=(0, 0)):
     dh, dw = dst.shape[:2]
     _decl_variants().ipxo_draw_ycbcr(dst.ctypes.data, dw, dh, dw * 4, _rect(r), C.byref(st), int(sp[0]), int(sp[1]))
     return dst
+
+
+# ---- image/jpeg encoder (oracle/ipx_jpeg_oracle.c) ----------------------------------------------------
+def jpeg_quant(quality):
+    """The two quantisation tables of jpeg.Encode at `quality`, zig-zag order as DQT carries them."""
+    out = (C.c_uint8 * 128)()
+    lib().ipxo_jpeg_quant(int(quality), out)
+    return np.frombuffer(out, np.uint8).reshape(2, 64).copy()
+
+
+def _take_bytes(p, n):
+    data = C.string_at(p, n.value)
+    lib().ipxo_free(p)
+    return data
+
+
+def jpeg_encode_rgba(frame, quality=85, want_coefs=False):
+    """jpeg.Encode(w, *image.RGBA, &jpeg.Options{Quality}) -> bytes (and the quantised blocks in scan order)."""
+    L = lib()
+    L.ipxo_jpeg_encode_rgba8.restype = C.c_int
+    L.ipxo_jpeg_encode_rgba8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_size_t), C.c_void_p]
+    L.ipxo_free.argtypes = [C.c_void_p]
+    f = _u8(frame)
+    h, w = f.shape[:2]
+    coefs = np.zeros((((h + 15) // 16) * ((w + 15) // 16), 6, 64), np.int16) if want_coefs else None
+    p, n = C.c_void_p(), C.c_size_t()
+    rc = L.ipxo_jpeg_encode_rgba8(f.ctypes.data, w, h, f.strides[0], int(quality), C.byref(p), C.byref(n),
+                                  coefs.ctypes.data if want_coefs else None)
+    if rc:
+        raise ValueError("jpeg: image is too large to encode" if rc == -1 else "out of memory")
+    data = _take_bytes(p, n)
+    return (data, coefs) if want_coefs else data
+
+
+def jpeg_encode_gray(plane, quality=85):
+    L = lib()
+    L.ipxo_jpeg_encode_gray8.restype = C.c_int
+    L.ipxo_jpeg_encode_gray8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_size_t)]
+    L.ipxo_free.argtypes = [C.c_void_p]
+    g = np.ascontiguousarray(plane, dtype=np.uint8)
+    assert g.ndim == 2
+    h, w = g.shape
+    p, n = C.c_void_p(), C.c_size_t()
+    rc = L.ipxo_jpeg_encode_gray8(g.ctypes.data, w, h, g.strides[0], int(quality), C.byref(p), C.byref(n))
+    if rc:
+        raise ValueError("jpeg: image is too large to encode" if rc == -1 else "out of memory")
+    return _take_bytes(p, n)
