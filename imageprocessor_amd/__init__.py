@@ -385,6 +385,32 @@ class Context:
                                     int(sp[1])))
         return dst
 
+    # ---- jpeg.Encode (include/ipx.h, "jpeg.Encode") -------------------------------------------------------
+    def jpeg_encode(self, frame, quality=85):
+        """jpeg.Encode(w, *image.RGBA, &jpeg.Options{Quality}) of one host frame -> bytes"""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w = frame.shape[:2]
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().ipx_jpeg_encode_rgba8(self.handle, frame.ctypes.data, w, h, w * 4, int(quality), C.byref(out), C.byref(n)))
+        data = C.string_at(out, n.value)
+        lib().ipx_buffer_free(out)
+        return data
+
+    def jpeg_fdct_dev(self, src_ptr, w, h, n, coefs_ptr, quality=85, stride=None, frame_stride=None, stream=None):
+        _check(lib().ipx_dev_jpeg_fdct_rgba8(self.handle, stream, src_ptr, w, h, stride or w * 4,
+                                             frame_stride if frame_stride is not None else w * h * 4, n, int(quality), coefs_ptr))
+
+    def jpeg_encode_batch_dev(self, src_ptr, w, h, n, quality=85, threads=0, stride=None, frame_stride=None):
+        outs, lens = (C.c_void_p * n)(), (C.c_size_t * n)()
+        _check(lib().ipx_jpeg_encode_batch_dev(self.handle, src_ptr, w, h, stride or w * 4,
+                                               frame_stride if frame_stride is not None else w * h * 4, n, int(quality),
+                                               int(threads), outs, lens))
+        res = []
+        for i in range(n):
+            res.append(C.string_at(outs[i], lens[i]))
+            lib().ipx_buffer_free(outs[i])
+        return res
+
     def composite_glyphs(self, dst, glyphs, col):
         assert dst.dtype == np.uint8 and dst.flags.c_contiguous
         dh, dw = dst.shape[:2]
@@ -393,3 +419,20 @@ class Context:
         _check(lib().ipx_composite_glyphs_rgba8(self.handle, dst.ctypes.data, dw, dh, dw * 4, arr,
                                                 len(glyphs), c))
         return dst
+
+
+def jpeg_entropy_encode(coefs, w, h, quality=85):
+    """Host half of jpeg.Encode: quantised coefficients (int16, 6 x 64 per MCU, zig-zag) -> the byte stream."""
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+    assert coefs.size == lib().ipx_jpeg_coef_count(w, h)
+    out, n = C.c_void_p(), C.c_size_t()
+    _check(lib().ipx_jpeg_entropy_encode(coefs.ctypes.data, w, h, int(quality), C.byref(out), C.byref(n)))
+    data = C.string_at(out, n.value)
+    lib().ipx_buffer_free(out)
+    return data
+
+
+def jpeg_quant_tables(quality):
+    out = (C.c_uint8 * 128)()
+    _check(lib().ipx_jpeg_quant_tables(int(quality), out))
+    return np.frombuffer(out, np.uint8).reshape(2, 64).copy()

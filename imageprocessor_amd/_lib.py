@@ -136,6 +136,13 @@ SIGNATURES = {
                                      C.POINTER(TextRasterizer), C.POINTER(Image), _P]),
     "ipx_processor_process": (_I, [_P, C.POINTER(Task), C.POINTER(Image), C.c_char_p, C.POINTER(TextRasterizer),
                                    C.POINTER(Processed), C.POINTER(_I)]),
+    "ipx_jpeg_coef_count": (_Z, [_I, _I]),
+    "ipx_jpeg_quant_tables": (_I, [_I, _P]),
+    "ipx_dev_jpeg_fdct_rgba8": (_I, [_P, _P, _P, _I, _I, _I, _Z, _I, _I, _P]),
+    "ipx_jpeg_entropy_encode": (_I, [_P, _I, _I, _I, C.POINTER(_P), C.POINTER(_Z)]),
+    "ipx_jpeg_encode_rgba8": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_Z)]),
+    "ipx_jpeg_encode_batch_dev": (_I, [_P, _P, _I, _I, _I, _Z, _I, _I, _I, C.POINTER(_P), C.POINTER(_Z)]),
+    "ipx_buffer_free": (None, [_P]),
     "ipx_font_create": (_I, [_P, _Z, C.POINTER(_P)]),
     "ipx_font_destroy": (None, [_P]),
     "ipx_font_glyph_index": (_I, [_P, C.c_uint32]),

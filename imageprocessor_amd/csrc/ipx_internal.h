@@ -151,4 +151,26 @@ hipError_t launch_band_ycc(const YccArgs &a, hipStream_t s, bool *matched);
 size_t band_lds_bytes(int band_rows, int blk_cols);
 bool band_pipe_shape(int band_rows, int blk_cols, int *rows, int *ch);  // tile shapes the pipelined kernel is built for
 
+
+// ---- jpeg.Encode: transform on the GPU (ipx_jpeg.hip), tables / headers / entropy coder on the host ----
+struct JpegTables {
+    uint8_t quant[2][64];     // zig-zag order, as DQT carries them (e.quant of writer.go)
+    uint16_t div8[2][64];     // 8 * quant, natural order: the divisor of writeBlock's div()
+    uint32_t recip[2][64];    // ceil(2^32 / div8): floor(n / div8) == mulhi(n, recip) for n < 2^20
+};
+void jpeg_tables(int quality, JpegTables *t);
+struct JpegArgs {
+    const uint8_t *src; size_t frame_stride; int stride, w, h;
+    int aligned16;            // base, row stride and frame stride are multiples of 16
+    int16_t *coefs; int mcus_per_frame;
+    uint32_t recip[2][64];
+    uint16_t div8[2][64];
+};
+hipError_t launch_jpeg_fdct(const JpegArgs &a, int n, hipStream_t s);
+
+}  // namespace ipx
+
+#include <vector>
+namespace ipx {
+void jpeg_write_stream(const int16_t *coefs, int w, int h, const JpegTables &t, std::vector<uint8_t> *out);
 }  // namespace ipx

@@ -1292,3 +1292,105 @@ int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_y
 }
 
 }  // extern "C"
+
+
+// ---- jpeg.Encode: the entries that touch the device (tables / entropy coder: ipx_jpeg_host.cpp) ----------
+#include <atomic>
+#include <thread>
+
+extern "C" {
+
+int ipx_dev_jpeg_fdct_rgba8(ipx_ctx *ctx, void *stream, const uint8_t *src, int w, int h, int stride, size_t frame_stride,
+                            int n, int quality, int16_t *coefs)
+{
+    IPX_ENTER(ctx);
+    if (!src || !coefs || n < 0 || w <= 0 || h <= 0 || (long long)stride < (long long)w * 4) {
+        set_error("ipx_dev_jpeg_fdct_rgba8: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    if (w >= 1 << 16 || h >= 1 << 16) { set_error("jpeg: image is too large to encode"); return IPX_ERR_INVALID; }
+    if (n == 0) return IPX_OK;
+    if (n > 65535) { set_error("ipx_dev_jpeg_fdct_rgba8: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
+    JpegTables t;
+    jpeg_tables(quality, &t);
+    JpegArgs a;
+    a.src = src; a.frame_stride = frame_stride; a.stride = stride; a.w = w; a.h = h;
+    a.aligned16 = ((((uintptr_t)src) | (uintptr_t)stride | frame_stride) & 15) == 0;
+    a.coefs = coefs; a.mcus_per_frame = ((w + 15) / 16) * ((h + 15) / 16);
+    memcpy(a.recip, t.recip, sizeof a.recip);
+    memcpy(a.div8, t.div8, sizeof a.div8);
+    IPX_HIP(launch_jpeg_fdct(a, n, stream ? (hipStream_t)stream : ctx->stream));
+    return IPX_OK;
+}
+
+int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, int stride, size_t frame_stride, int n,
+                              int quality, int threads, uint8_t **outs, size_t *lens)
+{
+    IPX_ENTER(ctx);
+    if (!outs || !lens || n < 0) { set_error("ipx_jpeg_encode_batch_dev: bad argument"); return IPX_ERR_INVALID; }
+    if (n == 0) return IPX_OK;
+    const size_t per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
+    LaneLease lane(ctx);
+    int rc = lane_reserve(lane.get(), per * n);
+    if (rc) return rc;
+    hipStream_t s = lane->stream;
+    rc = ipx_dev_jpeg_fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, (int16_t *)lane->dev);
+    if (rc) return rc;
+    int16_t *host = nullptr;
+    IPX_HIP(hipHostMalloc((void **)&host, per * n, hipHostMallocDefault));
+    hipError_t e = hipMemcpyAsync(host, lane->dev, per * n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipHostFree(host); set_error("coefficient download failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
+    JpegTables t;
+    jpeg_tables(quality, &t);
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, n));
+    std::atomic<int> next{0}, failed{0};
+    auto work = [&] {
+        std::vector<uint8_t> v;
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            jpeg_write_stream(host + (per / sizeof(int16_t)) * (size_t)i, w, h, t, &v);
+            uint8_t *p = (uint8_t *)malloc(v.size() ? v.size() : 1);
+            if (!p) { failed = 1; outs[i] = nullptr; lens[i] = 0; continue; }
+            memcpy(p, v.data(), v.size());
+            outs[i] = p; lens[i] = v.size();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nt; i++) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    (void)hipHostFree(host);
+    if (failed) {
+        for (int i = 0; i < n; i++) { free(outs[i]); outs[i] = nullptr; }
+        set_error("out of memory");
+        return IPX_ERR_NOMEM;
+    }
+    return IPX_OK;
+}
+
+int ipx_jpeg_encode_rgba8(ipx_ctx *ctx, const uint8_t *pix, int w, int h, int stride, int quality, uint8_t **out, size_t *len)
+{
+    IPX_ENTER(ctx);
+    if (!pix || !out || !len || w <= 0 || h <= 0 || (long long)stride < (long long)w * 4) {
+        set_error("ipx_jpeg_encode_rgba8: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    if (w >= 1 << 16 || h >= 1 << 16) { set_error("jpeg: image is too large to encode"); return IPX_ERR_INVALID; }
+    const size_t fbytes = align256((size_t)w * h * 4), per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
+    std::vector<int16_t> host(per / sizeof(int16_t));
+    {
+        LaneLease lane(ctx);
+        int rc = lane_reserve(lane.get(), fbytes + per);
+        if (rc) return rc;
+        hipStream_t s = lane->stream;
+        IPX_HIP(hipMemcpy2DAsync(lane->dev, (size_t)w * 4, pix, stride, (size_t)w * 4, h, hipMemcpyHostToDevice, s));
+        rc = ipx_dev_jpeg_fdct_rgba8(ctx, s, lane->dev, w, h, w * 4, fbytes, 1, quality, (int16_t *)(lane->dev + fbytes));
+        if (rc) { (void)hipStreamSynchronize(s); return rc; }
+        IPX_HIP(hipMemcpyAsync(host.data(), lane->dev + fbytes, per, hipMemcpyDeviceToHost, s));
+        IPX_HIP(hipStreamSynchronize(s));
+    }
+    return ipx_jpeg_entropy_encode(host.data(), w, h, quality, out, len);
+}
+
+}  // extern "C"

@@ -332,6 +332,30 @@ int ipx_processor_process(ipx_ctx *ctx, const ipx_task *task, const ipx_image *d
                           const char *decoded_format, const ipx_text_rasterizer *font,
                           ipx_processed *out, int *n_out);
 
+/* ---- jpeg.Encode (encoder side) ------------------------------------------------
+ * Every operator of the reference ends in jpeg.Encode(buf, img, &jpeg.Options{Quality: 85}) on its
+ * *image.RGBA (resize.go:80, thumbnail.go:70, watermark.go:68,73,76).  Go's writer is restated in two
+ * halves: colour conversion, 2x2 chroma box, jfdctint and the quantiser run on the GPU and leave int16
+ * coefficients (zig-zag order, 6 x 64 per 16x16 MCU in scan order Y0 Y1 Y2 Y3 Cb Cr); SOI / DQT / SOF0 /
+ * DHT / SOS, the Huffman coder with 0xff stuffing and EOI run on the host.  The byte stream is the one
+ * Go's encoder writes (no JFIF segment, both DQT tables, 4:2:0, Annex K Huffman tables). */
+size_t ipx_jpeg_coef_count(int w, int h);                 /* int16 elements per frame                 */
+int ipx_jpeg_quant_tables(int quality, uint8_t out[128]); /* the two DQT tables, zig-zag order         */
+/* n frames resident in HBM -> coefficients in HBM (n * ipx_jpeg_coef_count int16).  Asynchronous. */
+int ipx_dev_jpeg_fdct_rgba8(ipx_ctx *ctx, void *stream, const uint8_t *src, int w, int h, int stride,
+                            size_t frame_stride, int n, int quality, int16_t *coefs);
+/* Host half: coefficients (host memory) -> the complete stream.  *out is malloc'd: ipx_buffer_free. */
+int ipx_jpeg_entropy_encode(const int16_t *coefs, int w, int h, int quality, uint8_t **out, size_t *len);
+/* jpeg.Encode for one frame in host memory (upload, transform, download, entropy coding). */
+int ipx_jpeg_encode_rgba8(ipx_ctx *ctx, const uint8_t *pix, int w, int h, int stride, int quality,
+                          uint8_t **out, size_t *len);
+/* n frames resident in HBM -> n streams: one transform launch, one download, entropy coding on
+ * `threads` host threads (0 = all cores).  outs[i] are malloc'd. */
+int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, int stride,
+                              size_t frame_stride, int n, int quality, int threads, uint8_t **outs,
+                              size_t *lens);
+void ipx_buffer_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif
