@@ -400,15 +400,19 @@ class Context:
         _check(lib().ipx_dev_jpeg_fdct_rgba8(self.handle, stream, src_ptr, w, h, stride or w * 4,
                                              frame_stride if frame_stride is not None else w * h * 4, n, int(quality), coefs_ptr))
 
-    def jpeg_encode_batch_dev(self, src_ptr, w, h, n, quality=85, threads=0, stride=None, frame_stride=None):
-        outs, lens = (C.c_void_p * n)(), (C.c_size_t * n)()
+    def jpeg_encode_batch_dev(self, src_ptr, w, h, n, quality=85, stride=None, frame_stride=None, copy=True):
+        """n frames in HBM -> n streams.  copy=False returns (memoryviews into the pinned block, release()) instead of bytes."""
+        blob, offs, lens = C.c_void_p(), (C.c_size_t * n)(), (C.c_size_t * n)()
         _check(lib().ipx_jpeg_encode_batch_dev(self.handle, src_ptr, w, h, stride or w * 4,
                                                frame_stride if frame_stride is not None else w * h * 4, n, int(quality),
-                                               int(threads), outs, lens))
-        res = []
-        for i in range(n):
-            res.append(C.string_at(outs[i], lens[i]))
-            lib().ipx_buffer_free(outs[i])
+                                               C.byref(blob), offs, lens))
+        if not copy:
+            total = offs[n - 1] + lens[n - 1]
+            buf = (C.c_uint8 * total).from_address(blob.value)
+            mv = memoryview(buf)
+            return [mv[offs[i]:offs[i] + lens[i]] for i in range(n)], (lambda: lib().ipx_host_free(self.handle, blob))
+        res = [C.string_at(blob.value + offs[i], lens[i]) for i in range(n)]
+        lib().ipx_host_free(self.handle, blob)
         return res
 
     def composite_glyphs(self, dst, glyphs, col):

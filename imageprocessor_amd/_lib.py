@@ -141,7 +141,7 @@ SIGNATURES = {
     "ipx_dev_jpeg_fdct_rgba8": (_I, [_P, _P, _P, _I, _I, _I, _Z, _I, _I, _P]),
     "ipx_jpeg_entropy_encode": (_I, [_P, _I, _I, _I, C.POINTER(_P), C.POINTER(_Z)]),
     "ipx_jpeg_encode_rgba8": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_Z)]),
-    "ipx_jpeg_encode_batch_dev": (_I, [_P, _P, _I, _I, _I, _Z, _I, _I, _I, C.POINTER(_P), C.POINTER(_Z)]),
+    "ipx_jpeg_encode_batch_dev": (_I, [_P, _P, _I, _I, _I, _Z, _I, _I, C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z)]),
     "ipx_buffer_free": (None, [_P]),
     "ipx_font_create": (_I, [_P, _Z, C.POINTER(_P)]),
     "ipx_font_destroy": (None, [_P]),

@@ -173,4 +173,17 @@ hipError_t launch_jpeg_fdct(const JpegArgs &a, int n, hipStream_t s);
 #include <vector>
 namespace ipx {
 void jpeg_write_stream(const int16_t *coefs, int w, int h, const JpegTables &t, std::vector<uint8_t> *out);
+void jpeg_write_header(int w, int h, const JpegTables &t, std::vector<uint8_t> *out);
+void jpeg_huff_packed(uint32_t out[1024]);
+// the entropy coder on the GPU (ipx_jpeg_entropy.hip)
+hipError_t launch_jpeg_len(const int16_t *coefs, int nblk, int n, const uint32_t *tables, uint32_t *len, hipStream_t s);
+hipError_t launch_jpeg_bits(const int16_t *coefs, int nblk, int n, const uint32_t *tables, const uint32_t *off, const uint32_t *total_bits,
+                            const unsigned long long *ubase, uint8_t *ustream, hipStream_t s);
+hipError_t launch_scan(uint32_t *v, int per_frame, int n, uint32_t *total, hipStream_t s);
+int jpeg_chunk_bytes();
+hipError_t launch_jpeg_ffcount(const uint8_t *ustream, const unsigned long long *ubase, const uint32_t *ubytes, int max_chunks, int n,
+                               uint32_t *ffcount, hipStream_t s);
+hipError_t launch_jpeg_stuff(const uint8_t *ustream, const unsigned long long *ubase, const uint32_t *ubytes, int max_chunks, int n,
+                             const uint32_t *ffoff, const uint8_t *header, int hdr_len, const unsigned long long *obase, uint8_t *ostream,
+                             hipStream_t s);
 }  // namespace ipx

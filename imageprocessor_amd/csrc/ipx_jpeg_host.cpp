@@ -153,14 +153,11 @@ void jpeg_tables(int quality, JpegTables *t)
         }
 }
 
-// The whole stream of jpeg.Encode for a w x h *image.RGBA whose quantised coefficients are `coefs`
-// (6 x 64 int16 per 16x16 MCU, scan order Y0 Y1 Y2 Y3 Cb Cr, zig-zag inside a block).
-void jpeg_write_stream(const int16_t *coefs, int w, int h, const JpegTables &t, std::vector<uint8_t> *out)
+// SOI, DQT, SOF0, DHT and the SOS header of jpeg.Encode for a w x h *image.RGBA (623 bytes)
+void jpeg_write_header(int w, int h, const JpegTables &t, std::vector<uint8_t> *out)
 {
     std::vector<uint8_t> &o = *out;
     o.clear();
-    const size_t mcus = (size_t)((w + 15) / 16) * (size_t)((h + 15) / 16);
-    o.reserve(1024 + mcus * 96);
     o.push_back(0xff); o.push_back(0xd8);                                   // SOI
     o.push_back(0xff); o.push_back(0xdb); put16(o, 2 + 2 * 65);              // writeDQT
     for (int i = 0; i < 2; i++) { o.push_back((uint8_t)i); o.insert(o.end(), t.quant[i], t.quant[i] + 64); }
@@ -173,6 +170,24 @@ void jpeg_write_stream(const int16_t *coefs, int w, int h, const JpegTables &t, 
     { const uint8_t tc_th[4] = {0x00, 0x10, 0x01, 0x11};
       for (int i = 0; i < 4; i++) { o.push_back(tc_th[i]); o.insert(o.end(), kBits[i], kBits[i] + 16); o.insert(o.end(), kVals[i], kVals[i] + kNVals[i]); } }
     { const uint8_t sos[14] = {0xff, 0xda, 0x00, 0x0c, 0x03, 0x01, 0x00, 0x02, 0x11, 0x03, 0x11, 0x00, 0x3f, 0x00}; o.insert(o.end(), sos, sos + 14); }
+}
+
+// the four Huffman tables as the GPU coder reads them: [table][symbol] = length << 16 | code
+void jpeg_huff_packed(uint32_t out[1024])
+{
+    const HuffTables &h = huff();
+    for (int t = 0; t < 4; t++)
+        for (int i = 0; i < 256; i++) out[t * 256 + i] = h.sym[t][i].len << 16 | h.sym[t][i].code;
+}
+
+// The whole stream of jpeg.Encode for a w x h *image.RGBA whose quantised coefficients are `coefs`
+// (6 x 64 int16 per 16x16 MCU, scan order Y0 Y1 Y2 Y3 Cb Cr, zig-zag inside a block).
+void jpeg_write_stream(const int16_t *coefs, int w, int h, const JpegTables &t, std::vector<uint8_t> *out)
+{
+    std::vector<uint8_t> &o = *out;
+    const size_t mcus = (size_t)((w + 15) / 16) * (size_t)((h + 15) / 16);
+    jpeg_write_header(w, h, t, out);
+    o.reserve(1024 + mcus * 96);
     BitWriter bw(&o);
     int32_t dc_y = 0, dc_cb = 0, dc_cr = 0;
     for (size_t m = 0; m < mcus; m++, coefs += 384) {

@@ -1323,49 +1323,141 @@ int ipx_dev_jpeg_fdct_rgba8(ipx_ctx *ctx, void *stream, const uint8_t *src, int 
     return IPX_OK;
 }
 
-int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, int stride, size_t frame_stride, int n,
-                              int quality, int threads, uint8_t **outs, size_t *lens)
+}  // extern "C"
+
+// host entropy coding of a downloaded coefficient batch (IPX_JPEG_HOST_ENTROPY=1, and the reference point of tools/bench_jpeg.py)
+static int jpeg_batch_host_entropy(ipx_ctx *ctx, Lane &lane, const int16_t *dcoefs, int w, int h, int n, int quality,
+                                   uint8_t **blob, size_t *offs, size_t *lens)
 {
-    IPX_ENTER(ctx);
-    if (!outs || !lens || n < 0) { set_error("ipx_jpeg_encode_batch_dev: bad argument"); return IPX_ERR_INVALID; }
-    if (n == 0) return IPX_OK;
     const size_t per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
-    LaneLease lane(ctx);
-    int rc = lane_reserve(lane.get(), per * n);
-    if (rc) return rc;
-    hipStream_t s = lane->stream;
-    rc = ipx_dev_jpeg_fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, (int16_t *)lane->dev);
-    if (rc) return rc;
+    hipStream_t s = lane.stream;
     int16_t *host = nullptr;
     IPX_HIP(hipHostMalloc((void **)&host, per * n, hipHostMallocDefault));
-    hipError_t e = hipMemcpyAsync(host, lane->dev, per * n, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipMemcpyAsync(host, dcoefs, per * n, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { (void)hipHostFree(host); set_error("coefficient download failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
     JpegTables t;
     jpeg_tables(quality, &t);
-    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
-    nt = std::max(1, std::min(nt, n));
-    std::atomic<int> next{0}, failed{0};
+    const int nt = std::max(1, std::min((int)std::thread::hardware_concurrency(), n));
+    std::vector<std::vector<uint8_t>> streams(n);
+    std::atomic<int> next{0};
     auto work = [&] {
-        std::vector<uint8_t> v;
-        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-            jpeg_write_stream(host + (per / sizeof(int16_t)) * (size_t)i, w, h, t, &v);
-            uint8_t *p = (uint8_t *)malloc(v.size() ? v.size() : 1);
-            if (!p) { failed = 1; outs[i] = nullptr; lens[i] = 0; continue; }
-            memcpy(p, v.data(), v.size());
-            outs[i] = p; lens[i] = v.size();
-        }
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1))
+            jpeg_write_stream(host + (per / sizeof(int16_t)) * (size_t)i, w, h, t, &streams[i]);
     };
     std::vector<std::thread> pool;
     for (int i = 1; i < nt; i++) pool.emplace_back(work);
     work();
     for (auto &th : pool) th.join();
     (void)hipHostFree(host);
-    if (failed) {
-        for (int i = 0; i < n; i++) { free(outs[i]); outs[i] = nullptr; }
-        set_error("out of memory");
-        return IPX_ERR_NOMEM;
+    size_t total = 0;
+    for (int i = 0; i < n; i++) { offs[i] = total; lens[i] = streams[i].size(); total += (lens[i] + 15) & ~(size_t)15; }
+    uint8_t *b = (uint8_t *)ipx_host_alloc(ctx, total ? total : 1);
+    if (!b) return IPX_ERR_NOMEM;
+    for (int i = 0; i < n; i++) memcpy(b + offs[i], streams[i].data(), lens[i]);
+    *blob = b;
+    return IPX_OK;
+}
+
+namespace {
+struct AsyncFree {   // stream-ordered scratch of one call
+    hipStream_t s;
+    std::vector<void *> p;
+    ~AsyncFree() { for (void *q : p) (void)hipFreeAsync(q, s); }
+    template <class T> hipError_t get(T **out, size_t bytes)
+    {
+        void *q = nullptr;
+        hipError_t e = hipMallocAsync(&q, bytes ? bytes : 1, s);
+        if (e == hipSuccess) p.push_back(q);
+        *out = (T *)q;
+        return e;
     }
+};
+}  // namespace
+
+extern "C" {
+
+int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, int stride, size_t frame_stride, int n,
+                              int quality, uint8_t **blob, size_t *offs, size_t *lens)
+{
+    IPX_ENTER(ctx);
+    if (!blob || !offs || !lens || n < 0) { set_error("ipx_jpeg_encode_batch_dev: bad argument"); return IPX_ERR_INVALID; }
+    *blob = nullptr;
+    if (n == 0) return IPX_OK;
+    const size_t per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
+    LaneLease lane(ctx);
+    int rc = lane_reserve(lane.get(), per * n);
+    if (rc) return rc;
+    hipStream_t s = lane->stream;
+    int16_t *dcoefs = (int16_t *)lane->dev;
+    rc = ipx_dev_jpeg_fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, dcoefs);
+    if (rc) return rc;
+    if (env_int("IPX_JPEG_HOST_ENTROPY", 0)) return jpeg_batch_host_entropy(ctx, lane.get(), dcoefs, w, h, n, quality, blob, offs, lens);
+
+    // ---- entropy coding on the GPU: size, scan, place, stuff (ipx_jpeg_entropy.hip); two small read-backs ----
+    const int nblk = (int)(per / 128);
+    JpegTables t;
+    jpeg_tables(quality, &t);
+    std::vector<uint8_t> hdr;
+    jpeg_write_header(w, h, t, &hdr);
+    uint32_t packed[1024];
+    jpeg_huff_packed(packed);
+    AsyncFree mem{s, {}};
+    uint32_t *d_tab, *d_len, *d_tot, *d_ubytes, *d_ff, *d_fftot;
+    unsigned long long *d_ubase, *d_obase;
+    uint8_t *d_hdr, *d_ustream = nullptr, *d_ostream = nullptr;
+    IPX_HIP(mem.get(&d_tab, sizeof packed));
+    IPX_HIP(mem.get(&d_len, (size_t)n * nblk * 4));
+    IPX_HIP(mem.get(&d_tot, (size_t)n * 4));
+    IPX_HIP(mem.get(&d_ubytes, (size_t)n * 4));
+    IPX_HIP(mem.get(&d_fftot, (size_t)n * 4));
+    IPX_HIP(mem.get(&d_ubase, (size_t)n * 8));
+    IPX_HIP(mem.get(&d_obase, (size_t)n * 8));
+    IPX_HIP(mem.get(&d_hdr, hdr.size()));
+    IPX_HIP(hipMemcpyAsync(d_tab, packed, sizeof packed, hipMemcpyHostToDevice, s));
+    IPX_HIP(hipMemcpyAsync(d_hdr, hdr.data(), hdr.size(), hipMemcpyHostToDevice, s));
+    IPX_HIP(launch_jpeg_len(dcoefs, nblk, n, d_tab, d_len, s));
+    IPX_HIP(launch_scan(d_len, nblk, n, d_tot, s));
+    std::vector<uint32_t> tot(n), ubytes(n), ff(n);
+    IPX_HIP(hipMemcpyAsync(tot.data(), d_tot, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    IPX_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> ubase(n), obase(n);
+    unsigned long long utotal = 0;
+    uint32_t umax = 0;
+    for (int i = 0; i < n; i++) {
+        ubytes[i] = (tot[i] + 7) / 8;
+        ubase[i] = utotal;
+        utotal += align256((size_t)ubytes[i] + 8);
+        umax = std::max(umax, ubytes[i]);
+    }
+    const int chunk = jpeg_chunk_bytes();
+    const int max_chunks = (int)((umax + chunk - 1) / chunk);
+    IPX_HIP(mem.get(&d_ustream, (size_t)utotal));
+    IPX_HIP(mem.get(&d_ff, (size_t)n * max_chunks * 4));
+    IPX_HIP(hipMemsetAsync(d_ustream, 0, (size_t)utotal, s));
+    IPX_HIP(hipMemcpyAsync(d_ubase, ubase.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    IPX_HIP(hipMemcpyAsync(d_ubytes, ubytes.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    IPX_HIP(launch_jpeg_bits(dcoefs, nblk, n, d_tab, d_len, d_tot, d_ubase, d_ustream, s));
+    IPX_HIP(launch_jpeg_ffcount(d_ustream, d_ubase, d_ubytes, max_chunks, n, d_ff, s));
+    IPX_HIP(launch_scan(d_ff, max_chunks, n, d_fftot, s));
+    IPX_HIP(hipMemcpyAsync(ff.data(), d_fftot, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    IPX_HIP(hipStreamSynchronize(s));
+    unsigned long long ototal = 0;
+    for (int i = 0; i < n; i++) {
+        lens[i] = hdr.size() + ubytes[i] + ff[i] + 2;
+        obase[i] = ototal;
+        offs[i] = (size_t)ototal;
+        ototal += (lens[i] + 15) & ~(size_t)15;
+    }
+    IPX_HIP(mem.get(&d_ostream, (size_t)ototal));
+    IPX_HIP(hipMemcpyAsync(d_obase, obase.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    IPX_HIP(launch_jpeg_stuff(d_ustream, d_ubase, d_ubytes, max_chunks, n, d_ff, d_hdr, (int)hdr.size(), d_obase, d_ostream, s));
+    uint8_t *host = (uint8_t *)ipx_host_alloc(ctx, (size_t)ototal ? (size_t)ototal : 1);   // pinned: the download runs at link speed
+    if (!host) return IPX_ERR_NOMEM;
+    hipError_t e = hipMemcpyAsync(host, d_ostream, (size_t)ototal, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)ipx_host_free(ctx, host); set_error("stream download failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
+    *blob = host;
     return IPX_OK;
 }
 

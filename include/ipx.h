@@ -349,10 +349,12 @@ int ipx_jpeg_entropy_encode(const int16_t *coefs, int w, int h, int quality, uin
 /* jpeg.Encode for one frame in host memory (upload, transform, download, entropy coding). */
 int ipx_jpeg_encode_rgba8(ipx_ctx *ctx, const uint8_t *pix, int w, int h, int stride, int quality,
                           uint8_t **out, size_t *len);
-/* n frames resident in HBM -> n streams: one transform launch, one download, entropy coding on
- * `threads` host threads (0 = all cores).  outs[i] are malloc'd. */
+/* n frames resident in HBM -> n streams in ONE block of host memory: transform, entropy coding (sizing,
+ * placement and 0xff stuffing) and headers all happen on the GPU and only the finished streams cross the
+ * link.  *blob is pinned memory owned by the library (ipx_host_free); stream i is blob[offs[i] ..
+ * offs[i] + lens[i]).  cgo: wrap each with unsafe.Slice, write it out, then free the block. */
 int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, int stride,
-                              size_t frame_stride, int n, int quality, int threads, uint8_t **outs,
+                              size_t frame_stride, int n, int quality, uint8_t **blob, size_t *offs,
                               size_t *lens);
 void ipx_buffer_free(void *p);
 

@@ -185,10 +185,35 @@ def test_gpu_batch_encode_from_hbm(ctx):
     plan.run_dev(n, src.ptr, res.ptr, th.ptr, wm.ptr)
     ctx.sync()
     for buf, (ow, oh), key in ((res, (i.resize_w, i.resize_h), "resize"), (th, (i.thumb_w, i.thumb_h), "thumbnail"), (wm, (w, h), "watermark")):
-        got = ctx.jpeg_encode_batch_dev(buf.ptr, ow, oh, n, 85, threads=4)
+        got = ctx.jpeg_encode_batch_dev(buf.ptr, ow, oh, n, 85)
         for k in range(n):
             want = oracle.process(frames[k], resize=(1024, 768, True), thumb=(200, True), glyphs=glyphs, col=DEFAULT_COL)[key]
             assert got[k] == oracle.jpeg_encode_rgba(want, 85), (key, k)
         assert Image.open(io.BytesIO(got[0])).size == (ow, oh)
     plan.close()
     gs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host_entropy", ["0", "1"], ids=["gpu-entropy", "host-entropy"])
+def test_gpu_batch_entropy_paths(ctx, host_entropy, monkeypatch):
+    """Both entropy coders behind ipx_jpeg_encode_batch_dev: sizing + scan + placement + stuffing on the GPU (default) and the
+    host loop over downloaded coefficients.  Frames of one batch differ wildly in stream length; q=100 on black / white
+    noise gives the longest codes and the most 0xff bytes; 1x1 and 17x9 frames are a single (partial) MCU."""
+    from helpers import rgba_frames
+    monkeypatch.setenv("IPX_JPEG_HOST_ENTROPY", host_entropy)
+    rng = np.random.default_rng(21)
+    for (w, h), q in (((320, 200), 85), ((64, 64), 100), ((17, 9), 85), ((1, 1), 50), ((640, 360), 20), ((1024, 64), 95)):
+        frames = rgba_frames(4, w, h, seed=w + q)
+        frames[1][...] = 128                                                     # flat: EOB only
+        frames[2][..., :3] = rng.integers(0, 2, (h, w, 3), dtype=np.uint8) * 255   # binary noise
+        yy, xx = np.mgrid[0:h, 0:w]
+        frames[3][..., 0] = (xx * 3) % 256
+        frames[3][..., 1] = (yy * 5) % 256
+        frames[3][..., 2] = ((xx + yy) // 2) % 256
+        src = ctx.alloc(frames.nbytes).upload(frames)
+        got = ctx.jpeg_encode_batch_dev(src.ptr, w, h, 4, q)
+        for k in range(4):
+            want = oracle.jpeg_encode_rgba(frames[k], q)
+            assert got[k] == want, ((w, h), q, k, len(got[k]), len(want))
+        src.free()
