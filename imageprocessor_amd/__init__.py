@@ -208,6 +208,25 @@ class Plan:
                                        p("watermark"), i.wm_bytes))
         return out
 
+    def run_host_jpeg(self, frames, quality=85, want=("resize", "thumbnail", "watermark"), copy=True):
+        """frames: n x H x W x 4 uint8 (host, ideally pinned) -> {operator: [jpeg bytes] * n}: operators and jpeg.Encode on
+        the GPU, only the streams come back.  copy=False: lengths only (the streams are released unread; for timing)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n = frames.shape[0]
+        i = self.info
+        arrs = {}
+        for k, present in (("resize", i.resize_bytes), ("thumbnail", i.thumb_bytes), ("watermark", i.wm_bytes)):
+            if k in want and present:
+                arrs[k] = (_lib.Bytes * n)()
+        res = C.c_void_p()
+        _check(lib().ipx_plan_run_host_jpeg(self.ctx.handle, self.handle, n, frames.ctypes.data, self._sw * 4, self._sw * self._sh * 4,
+                                            int(quality), arrs.get("resize"), arrs.get("thumbnail"), arrs.get("watermark"), C.byref(res)))
+        out = {}
+        for k, a in arrs.items():
+            out[k] = [C.string_at(a[j].data, a[j].len) if copy else a[j].len for j in range(n)]
+        lib().ipx_jpeg_result_free(self.ctx.handle, res)
+        return out
+
     def run_dev_ycbcr(self, n, y_ptr, cb_ptr, cr_ptr, ratio, ystride, cstride, y_frame_stride, c_frame_stride,
                       resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
         i = self.info

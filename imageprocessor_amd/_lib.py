@@ -63,6 +63,10 @@ GLYPHS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_double, C.c_int, C.
 RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p)
 
 
+class Bytes(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_size_t)]
+
+
 class TextRasterizer(C.Structure):
     _fields_ = [("user", C.c_void_p), ("measure", MEASURE_FN), ("glyphs", GLYPHS_FN), ("release", RELEASE_FN)]
 
@@ -143,6 +147,8 @@ SIGNATURES = {
     "ipx_jpeg_encode_rgba8": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_Z)]),
     "ipx_jpeg_encode_batch_dev": (_I, [_P, _P, _I, _I, _I, _Z, _I, _I, C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z)]),
     "ipx_buffer_free": (None, [_P]),
+    "ipx_plan_run_host_jpeg": (_I, [_P, _P, _I, _P, _I, _Z, _I, C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(_P)]),
+    "ipx_jpeg_result_free": (None, [_P, _P]),
     "ipx_font_create": (_I, [_P, _Z, C.POINTER(_P)]),
     "ipx_font_destroy": (None, [_P]),
     "ipx_font_glyph_index": (_I, [_P, C.c_uint32]),

@@ -1296,6 +1296,8 @@ int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_y
 
 // ---- jpeg.Encode: the entries that touch the device (tables / entropy coder: ipx_jpeg_host.cpp) ----------
 #include <atomic>
+#include <memory>
+#include <string>
 #include <thread>
 
 extern "C" {
@@ -1377,6 +1379,14 @@ struct AsyncFree {   // stream-ordered scratch of one call
 
 extern "C" {
 
+}  // extern "C"
+
+// n frames in HBM -> streams in one pinned block, everything on stream s; dcoefs = n * ipx_jpeg_coef_count int16 of scratch
+static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const uint8_t *src, int w, int h, int stride, size_t frame_stride,
+                            int n, int quality, uint8_t **blob, size_t *offs, size_t *lens);
+
+extern "C" {
+
 int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, int stride, size_t frame_stride, int n,
                               int quality, uint8_t **blob, size_t *offs, size_t *lens)
 {
@@ -1388,11 +1398,23 @@ int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, in
     LaneLease lane(ctx);
     int rc = lane_reserve(lane.get(), per * n);
     if (rc) return rc;
-    hipStream_t s = lane->stream;
     int16_t *dcoefs = (int16_t *)lane->dev;
-    rc = ipx_dev_jpeg_fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, dcoefs);
+    if (env_int("IPX_JPEG_HOST_ENTROPY", 0)) {
+        rc = ipx_dev_jpeg_fdct_rgba8(ctx, lane->stream, src, w, h, stride, frame_stride, n, quality, dcoefs);
+        if (rc) return rc;
+        return jpeg_batch_host_entropy(ctx, lane.get(), dcoefs, w, h, n, quality, blob, offs, lens);
+    }
+    return jpeg_encode_core(ctx, lane->stream, dcoefs, src, w, h, stride, frame_stride, n, quality, blob, offs, lens);
+}
+
+}  // extern "C"
+
+static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const uint8_t *src, int w, int h, int stride, size_t frame_stride,
+                            int n, int quality, uint8_t **blob, size_t *offs, size_t *lens)
+{
+    const size_t per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
+    int rc = ipx_dev_jpeg_fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, dcoefs);
     if (rc) return rc;
-    if (env_int("IPX_JPEG_HOST_ENTROPY", 0)) return jpeg_batch_host_entropy(ctx, lane.get(), dcoefs, w, h, n, quality, blob, offs, lens);
 
     // ---- entropy coding on the GPU: size, scan, place, stuff (ipx_jpeg_entropy.hip); two small read-backs ----
     const int nblk = (int)(per / 128);
@@ -1458,6 +1480,114 @@ int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, in
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { (void)ipx_host_free(ctx, host); set_error("stream download failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
     *blob = host;
+    return IPX_OK;
+}
+
+// ---- host frames in, JPEG streams out: the worker's whole GPU leg ----------------------------------------
+struct ipx_jpeg_result { std::vector<uint8_t *> blobs; };
+
+extern "C" {
+
+void ipx_jpeg_result_free(ipx_ctx *ctx, ipx_jpeg_result *r)
+{
+    if (!r) return;
+    for (uint8_t *b : r->blobs) (void)ipx_host_free(ctx, b);
+    delete r;
+}
+
+int ipx_plan_run_host_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
+                           int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, ipx_jpeg_result **result)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !src || !result || (long long)sstride < (long long)pl->p.sw * 4) {
+        set_error("ipx_plan_run_host_jpeg: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    *result = nullptr;
+    if (n == 0) return IPX_OK;
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    const size_t fsrc = align256((size_t)sw * sh * 4);
+    const size_t fres = resize_out ? align256(pl->info.resize_bytes) : 0, fth = thumb_out ? align256(pl->info.thumb_bytes) : 0;
+    const size_t fwm = wm_out ? align256(pl->info.wm_bytes) : 0;
+    const size_t cres = fres ? ipx_jpeg_coef_count(pl->info.resize_w, pl->info.resize_h) * 2 : 0;
+    const size_t cth = fth ? ipx_jpeg_coef_count(pl->info.thumb_w, pl->info.thumb_h) * 2 : 0;
+    const size_t cwm = fwm ? ipx_jpeg_coef_count(sw, sh) * 2 : 0;
+    const size_t ccoef = align256(std::max(cres, std::max(cth, cwm)));
+    const size_t per_frame = fsrc + fres + fth + fwm + ccoef;
+    // every lane runs its own host thread: upload, operators, three encodes (each with two small read-backs) --
+    // the threads block independently, so copies and kernels of different chunks overlap
+    std::vector<Lane *> lanes;
+    {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        ctx->cv.wait(lk, [&] { for (auto &l : ctx->lanes) if (l.busy) return false; return true; });
+        for (auto &l : ctx->lanes) { l.busy = true; lanes.push_back(&l); }
+    }
+    const int nl = (int)lanes.size();
+    int chunk = std::max(1, (n + 2 * nl - 1) / (2 * nl));
+    chunk = (int)std::min<size_t>((size_t)chunk, std::max<size_t>(1, ctx->lane_bytes / per_frame));
+    chunk = std::max(1, std::min(chunk, env_int("IPX_HOST_CHUNK_JPEG", 32)));
+    std::unique_ptr<ipx_jpeg_result> res(new ipx_jpeg_result);
+    std::mutex res_mu;
+    std::atomic<int> next{0};
+    std::atomic<int> status{IPX_OK};
+    std::string err_text;
+    const int nchunks = (n + chunk - 1) / chunk;
+    auto worker = [&](Lane *l) {
+        if (hipSetDevice(ctx->device) != hipSuccess) { status = IPX_ERR_HIP; return; }
+        int rc = lane_reserve(*l, per_frame * chunk + 256);
+        std::vector<size_t> offs(chunk), lens(chunk);
+        for (int c = next.fetch_add(1); !rc && c < nchunks && status == IPX_OK; c = next.fetch_add(1)) {
+            const int i0 = c * chunk, m = std::min(chunk, n - i0);
+            uint8_t *dsrc = (uint8_t *)(((uintptr_t)l->dev + 255) & ~(uintptr_t)255);
+            uint8_t *dres = fres ? dsrc + fsrc * chunk : nullptr;
+            uint8_t *dth = fth ? dsrc + (fsrc + fres) * chunk : nullptr;
+            uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * chunk : nullptr;
+            int16_t *dcoef = (int16_t *)(dsrc + (fsrc + fres + fth + fwm) * chunk);
+            hipError_t e = hipSuccess;
+            if (sstride == sw * 4 && src_frame_stride == fsrc)
+                e = hipMemcpyAsync(dsrc, src + (size_t)i0 * src_frame_stride, fsrc * m, hipMemcpyHostToDevice, l->stream);
+            else
+                for (int i = 0; i < m && e == hipSuccess; i++)
+                    e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * 4, src + (size_t)(i0 + i) * src_frame_stride, sstride,
+                                         (size_t)sw * 4, sh, hipMemcpyHostToDevice, l->stream);
+            if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; break; }
+            rc = ipx_plan_run_dev(ctx, l->stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm);
+            struct Out { uint8_t *dev; size_t fs; int w, h; ipx_bytes *dst; };
+            const Out outs[3] = {{dres, fres, pl->info.resize_w, pl->info.resize_h, resize_out},
+                                 {dth, fth, pl->info.thumb_w, pl->info.thumb_h, thumb_out},
+                                 {dwm, fwm, sw, sh, wm_out}};
+            for (int k = 0; k < 3 && !rc; k++) {
+                const Out &o = outs[k];
+                if (!o.dev || o.w <= 0 || o.h <= 0) continue;
+                uint8_t *blob = nullptr;
+                rc = jpeg_encode_core(ctx, l->stream, dcoef, o.dev, o.w, o.h, o.w * 4, o.fs, m, quality, &blob, offs.data(), lens.data());
+                if (rc) break;
+                for (int i = 0; i < m; i++) { o.dst[i0 + i].data = blob + offs[i]; o.dst[i0 + i].len = lens[i]; }
+                std::lock_guard<std::mutex> lk(res_mu);
+                res->blobs.push_back(blob);
+            }
+        }
+        if (rc) {
+            std::lock_guard<std::mutex> lk(res_mu);
+            if (status == IPX_OK) { status = rc; err_text = ipx_last_error(); }
+        }
+        (void)hipStreamSynchronize(l->stream);
+    };
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nl; i++) pool.emplace_back(worker, lanes[i]);
+    worker(lanes[0]);
+    for (auto &t : pool) t.join();
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (auto *l : lanes) l->busy = false;
+    }
+    ctx->cv.notify_all();
+    if (status != IPX_OK) {
+        ipx_jpeg_result_free(ctx, res.release());
+        set_error("%s", err_text.c_str());
+        return status;
+    }
+    *result = res.release();
     return IPX_OK;
 }
 

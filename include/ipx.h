@@ -358,6 +358,19 @@ int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, in
                               size_t *lens);
 void ipx_buffer_free(void *p);
 
+/* The worker's whole GPU leg for a batch of decoded frames in host memory (image_processor.go:64-77 without
+ * image.Decode): upload, every requested operator in one pass, jpeg.Encode of each output on the GPU, and
+ * only the finished streams come back.  resize_out / thumb_out / wm_out (n entries each, or NULL to skip)
+ * receive pointers into pinned blocks owned by *result; release them with ipx_jpeg_result_free once the
+ * streams are written out (fileRepo.SaveProcessed, image_processor.go:76).  Chunks run on the context's
+ * lanes, one host thread per lane, so uploads, kernels and downloads of different chunks overlap. */
+typedef struct { const uint8_t *data; size_t len; } ipx_bytes;
+typedef struct ipx_jpeg_result ipx_jpeg_result;
+int ipx_plan_run_host_jpeg(ipx_ctx *ctx, const ipx_plan *plan, int n, const uint8_t *src, int sstride,
+                           size_t src_frame_stride, int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out,
+                           ipx_bytes *wm_out, ipx_jpeg_result **result);
+void ipx_jpeg_result_free(ipx_ctx *ctx, ipx_jpeg_result *result);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,3 +217,28 @@ def test_gpu_batch_entropy_paths(ctx, host_entropy, monkeypatch):
             want = oracle.jpeg_encode_rgba(frames[k], q)
             assert got[k] == want, ((w, h), q, k, len(got[k]), len(want))
         src.free()
+
+
+@pytest.mark.gpu
+def test_host_frames_to_jpeg_streams(ctx):
+    """ipx_plan_run_host_jpeg: decoded frames in host memory -> the three encoded objects the worker stores
+    (image_processor.go:64-77), chunked over the lanes; byte-exact against oracle operators + oracle encoder."""
+    from helpers import DEFAULT_COL, rgba_frames, text_glyphs
+    w, h, n = 640, 360, 11
+    frames = rgba_frames(n, w, h, seed=9)
+    glyphs = text_glyphs(w, h)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    for kw, chunk in ((dict(resize=(1024, 768, True), thumbnail=(200, True), watermark=gs), "4"), (dict(resize=None, thumbnail=(64, False)), "32")):
+        import os
+        os.environ["IPX_HOST_CHUNK_JPEG"] = chunk
+        plan = ctx.plan(w, h, **kw)
+        got = plan.run_host_jpeg(frames, 85)
+        for k in range(n):
+            want = oracle.process(frames[k], resize=kw.get("resize") or (1, 1, False), thumb=kw.get("thumbnail") or (1, False),
+                                  glyphs=glyphs if "watermark" in kw else [], col=DEFAULT_COL)
+            for key in got:
+                assert got[key][k] == oracle.jpeg_encode_rgba(want[key], 85), (key, k)
+        assert set(got) == {x for x in kw if kw[x] is not None}
+        plan.close()
+    os.environ.pop("IPX_HOST_CHUNK_JPEG", None)
+    gs.close()
