@@ -227,6 +227,24 @@ class Plan:
         lib().ipx_jpeg_result_free(self.ctx.handle, res)
         return out
 
+    def run_host_ycbcr_jpeg(self, y, cb, cr, ratio, quality=85, want=("resize", "thumbnail", "watermark"), copy=True):
+        """Decoded JPEG planes (host) -> {operator: [jpeg bytes] * n}; see run_host_jpeg."""
+        y, cb, cr = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, cb, cr))
+        n, h, w = y.shape
+        assert (w, h) == (self._sw, self._sh) and cb.shape == cr.shape and cb.shape[0] == n
+        b = _lib.YCbCrBatch(y.ctypes.data, cb.ctypes.data, cr.ctypes.data, w, cb.shape[2], h * w, cb.shape[1] * cb.shape[2], int(ratio))
+        i = self.info
+        arrs = {}
+        for k, present in (("resize", i.resize_bytes), ("thumbnail", i.thumb_bytes), ("watermark", i.wm_bytes)):
+            if k in want and present:
+                arrs[k] = (_lib.Bytes * n)()
+        res = C.c_void_p()
+        _check(lib().ipx_plan_run_host_ycbcr_jpeg(self.ctx.handle, self.handle, n, C.byref(b), int(quality), arrs.get("resize"),
+                                                  arrs.get("thumbnail"), arrs.get("watermark"), C.byref(res)))
+        out = {k: [C.string_at(a[j].data, a[j].len) if copy else a[j].len for j in range(n)] for k, a in arrs.items()}
+        lib().ipx_jpeg_result_free(self.ctx.handle, res)
+        return out
+
     def run_dev_ycbcr(self, n, y_ptr, cb_ptr, cr_ptr, ratio, ystride, cstride, y_frame_stride, c_frame_stride,
                       resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
         i = self.info

@@ -149,6 +149,8 @@ SIGNATURES = {
     "ipx_buffer_free": (None, [_P]),
     "ipx_plan_run_host_jpeg": (_I, [_P, _P, _I, _P, _I, _Z, _I, C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(_P)]),
     "ipx_jpeg_result_free": (None, [_P, _P]),
+    "ipx_plan_run_host_ycbcr_jpeg": (_I, [_P, _P, _I, C.POINTER(YCbCrBatch), _I, C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(Bytes),
+                                          C.POINTER(_P)]),
     "ipx_font_create": (_I, [_P, _Z, C.POINTER(_P)]),
     "ipx_font_destroy": (None, [_P]),
     "ipx_font_glyph_index": (_I, [_P, C.c_uint32]),

@@ -39,6 +39,12 @@ struct ipx_ctx {
     size_t lane_bytes = 0;
     std::mutex mu;
     std::condition_variable cv;
+    // pinned host blocks: hipHostMalloc / hipHostFree cost milliseconds each, and the encoder hands out one block per
+    // batch and output, so freed blocks are kept (up to host_cache_limit bytes) and reused for requests they fit
+    std::mutex host_mu;
+    std::map<void *, size_t> host_size;            // every live block handed out by ipx_host_alloc
+    std::multimap<size_t, void *> host_free_blocks;
+    size_t host_cached = 0, host_cache_limit = (size_t)2 << 30;
 };
 
 struct GlyphHost {
@@ -370,6 +376,7 @@ void ipx_destroy(ipx_ctx *c)
         if (l.flag) (void)hipFree(l.flag);
     }
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (auto &b : c->host_free_blocks) (void)hipHostFree(b.second);
     delete c;
 }
 
@@ -378,17 +385,45 @@ void *ipx_host_alloc(ipx_ctx *ctx, size_t bytes)
 {
     clear_error();
     if (!ctx || !bytes) { set_error("ipx_host_alloc: bad argument"); return nullptr; }
+    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);   // 1 MiB classes
+    {
+        std::lock_guard<std::mutex> lk(ctx->host_mu);
+        auto it = ctx->host_free_blocks.lower_bound(want);
+        if (it != ctx->host_free_blocks.end() && it->first <= 2 * want + ((size_t)4 << 20)) {
+            void *p = it->second;
+            ctx->host_cached -= it->first;
+            ctx->host_size[p] = it->first;
+            ctx->host_free_blocks.erase(it);
+            return p;
+        }
+    }
     (void)hipSetDevice(ctx->device);
     void *p = nullptr;
-    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
-    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); return nullptr; }
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); return nullptr; }
+    std::lock_guard<std::mutex> lk(ctx->host_mu);
+    ctx->host_size[p] = want;
     return p;
 }
 
 int ipx_host_free(ipx_ctx *ctx, void *p)
 {
     IPX_ENTER(ctx);
-    if (p) IPX_HIP(hipHostFree(p));
+    if (!p) return IPX_OK;
+    {
+        std::lock_guard<std::mutex> lk(ctx->host_mu);
+        auto it = ctx->host_size.find(p);
+        if (it != ctx->host_size.end()) {
+            const size_t sz = it->second;
+            ctx->host_size.erase(it);
+            if (ctx->host_cached + sz <= ctx->host_cache_limit) {
+                ctx->host_free_blocks.emplace(sz, p);
+                ctx->host_cached += sz;
+                return IPX_OK;
+            }
+        }
+    }
+    IPX_HIP(hipHostFree(p));
     return IPX_OK;
 }
 
@@ -1495,18 +1530,20 @@ void ipx_jpeg_result_free(ipx_ctx *ctx, ipx_jpeg_result *r)
     delete r;
 }
 
-int ipx_plan_run_host_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
-                           int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, ipx_jpeg_result **result)
+}  // extern "C"
+
+// one implementation for both source kinds: ysrc == nullptr -> RGBA frames at src
+static int run_host_jpeg_impl(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
+                              const ipx_ycbcr_batch *ysrc, int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out,
+                              ipx_jpeg_result **result)
 {
-    IPX_ENTER(ctx);
-    if (!pl || n < 0 || !src || !result || (long long)sstride < (long long)pl->p.sw * 4) {
-        set_error("ipx_plan_run_host_jpeg: bad argument");
-        return IPX_ERR_INVALID;
-    }
     *result = nullptr;
     if (n == 0) return IPX_OK;
     const int sw = pl->p.sw, sh = pl->p.sh;
-    const size_t fsrc = align256((size_t)sw * sh * 4);
+    const int cw = ysrc ? ((ysrc->ratio == IPX_YCBCR_422 || ysrc->ratio == IPX_YCBCR_420) ? (sw + 1) / 2 : sw) : 0;
+    const int ch = ysrc ? ((ysrc->ratio == IPX_YCBCR_420 || ysrc->ratio == IPX_YCBCR_440) ? (sh + 1) / 2 : sh) : 0;
+    const size_t yb = ysrc ? align256((size_t)sw * sh) : 0, cbb = ysrc ? align256((size_t)cw * ch) : 0;
+    const size_t fsrc = ysrc ? yb + 2 * cbb : align256((size_t)sw * sh * 4);
     const size_t fres = resize_out ? align256(pl->info.resize_bytes) : 0, fth = thumb_out ? align256(pl->info.thumb_bytes) : 0;
     const size_t fwm = wm_out ? align256(pl->info.wm_bytes) : 0;
     const size_t cres = fres ? ipx_jpeg_coef_count(pl->info.resize_w, pl->info.resize_h) * 2 : 0;
@@ -1544,14 +1581,34 @@ int ipx_plan_run_host_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_
             uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * chunk : nullptr;
             int16_t *dcoef = (int16_t *)(dsrc + (fsrc + fres + fth + fwm) * chunk);
             hipError_t e = hipSuccess;
-            if (sstride == sw * 4 && src_frame_stride == fsrc)
-                e = hipMemcpyAsync(dsrc, src + (size_t)i0 * src_frame_stride, fsrc * m, hipMemcpyHostToDevice, l->stream);
-            else
-                for (int i = 0; i < m && e == hipSuccess; i++)
-                    e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * 4, src + (size_t)(i0 + i) * src_frame_stride, sstride,
-                                         (size_t)sw * 4, sh, hipMemcpyHostToDevice, l->stream);
-            if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; break; }
-            rc = ipx_plan_run_dev(ctx, l->stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm);
+            if (ysrc) {
+                // planes of the chunk: [m x Y][m x Cb][m x Cr]
+                uint8_t *dy = dsrc, *dcb = dy + yb * chunk, *dcr = dcb + cbb * chunk;
+                auto up = [&](uint8_t *d, size_t dfs, int w, int h, const uint8_t *hsrc, int hstride, size_t hfs) {
+                    if (hstride == w && hfs == dfs) return hipMemcpyAsync(d, hsrc + hfs * i0, dfs * m, hipMemcpyHostToDevice, l->stream);
+                    hipError_t r = hipSuccess;
+                    for (int i = 0; i < m && r == hipSuccess; i++)
+                        r = hipMemcpy2DAsync(d + dfs * i, w, hsrc + hfs * (size_t)(i0 + i), hstride, w, h, hipMemcpyHostToDevice, l->stream);
+                    return r;
+                };
+                e = up(dy, yb, sw, sh, ysrc->y, ysrc->ystride, ysrc->y_frame_stride);
+                if (e == hipSuccess) e = up(dcb, cbb, cw, ch, ysrc->cb, ysrc->cstride, ysrc->c_frame_stride);
+                if (e == hipSuccess) e = up(dcr, cbb, cw, ch, ysrc->cr, ysrc->cstride, ysrc->c_frame_stride);
+                if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; break; }
+                ipx_ycbcr_batch d;
+                d.y = dy; d.cb = dcb; d.cr = dcr; d.ystride = sw; d.cstride = cw; d.y_frame_stride = yb; d.c_frame_stride = cbb;
+                d.ratio = ysrc->ratio;
+                rc = ipx_plan_run_dev_ycbcr(ctx, l->stream, pl, m, &d, dres, fres, dth, fth, dwm, fwm);
+            } else {
+                if (sstride == sw * 4 && src_frame_stride == fsrc)
+                    e = hipMemcpyAsync(dsrc, src + (size_t)i0 * src_frame_stride, fsrc * m, hipMemcpyHostToDevice, l->stream);
+                else
+                    for (int i = 0; i < m && e == hipSuccess; i++)
+                        e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * 4, src + (size_t)(i0 + i) * src_frame_stride, sstride,
+                                             (size_t)sw * 4, sh, hipMemcpyHostToDevice, l->stream);
+                if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; break; }
+                rc = ipx_plan_run_dev(ctx, l->stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm);
+            }
             struct Out { uint8_t *dev; size_t fs; int w, h; ipx_bytes *dst; };
             const Out outs[3] = {{dres, fres, pl->info.resize_w, pl->info.resize_h, resize_out},
                                  {dth, fth, pl->info.thumb_w, pl->info.thumb_h, thumb_out},
@@ -1589,6 +1646,31 @@ int ipx_plan_run_host_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_
     }
     *result = res.release();
     return IPX_OK;
+}
+
+extern "C" {
+
+int ipx_plan_run_host_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
+                           int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, ipx_jpeg_result **result)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !src || !result || (long long)sstride < (long long)pl->p.sw * 4) {
+        set_error("ipx_plan_run_host_jpeg: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    return run_host_jpeg_impl(ctx, pl, n, src, sstride, src_frame_stride, nullptr, quality, resize_out, thumb_out, wm_out, result);
+}
+
+int ipx_plan_run_host_ycbcr_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, int quality,
+                                 ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, ipx_jpeg_result **result)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !result || !src || !src->y || !src->cb || !src->cr || src->ratio < 0 || src->ratio > IPX_YCBCR_440 ||
+        src->ystride < pl->p.sw) {
+        set_error("ipx_plan_run_host_ycbcr_jpeg: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    return run_host_jpeg_impl(ctx, pl, n, nullptr, 0, 0, src, quality, resize_out, thumb_out, wm_out, result);
 }
 
 int ipx_jpeg_encode_rgba8(ipx_ctx *ctx, const uint8_t *pix, int w, int h, int stride, int quality, uint8_t **out, size_t *len)

@@ -369,6 +369,10 @@ typedef struct ipx_jpeg_result ipx_jpeg_result;
 int ipx_plan_run_host_jpeg(ipx_ctx *ctx, const ipx_plan *plan, int n, const uint8_t *src, int sstride,
                            size_t src_frame_stride, int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out,
                            ipx_bytes *wm_out, ipx_jpeg_result **result);
+/* The same for a batch of decoded JPEGs (*image.YCbCr planes): 1.5 bytes per pixel go up for 4:2:0 instead of 4. */
+int ipx_plan_run_host_ycbcr_jpeg(ipx_ctx *ctx, const ipx_plan *plan, int n, const ipx_ycbcr_batch *src,
+                                 int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out,
+                                 ipx_jpeg_result **result);
 void ipx_jpeg_result_free(ipx_ctx *ctx, ipx_jpeg_result *result);
 
 #ifdef __cplusplus

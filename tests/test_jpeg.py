@@ -242,3 +242,25 @@ def test_host_frames_to_jpeg_streams(ctx):
         plan.close()
     os.environ.pop("IPX_HOST_CHUNK_JPEG", None)
     gs.close()
+
+
+@pytest.mark.gpu
+def test_decoded_jpeg_planes_to_jpeg_streams(ctx):
+    """ipx_plan_run_host_ycbcr_jpeg: *image.YCbCr planes in, encoded objects out -- the reference's per-operator conversion rules
+     followed by jpeg.Encode, against the oracle's composition of the same helpers."""
+    from helpers import DEFAULT_COL, text_glyphs
+    from test_sources_gpu import _expect_ycbcr_ops, _rand_ycbcr
+    for (w, h, ratio) in ((640, 360, 2), (320, 240, 0), (333, 251, 1)):   # the last one takes the three-kernel operator path
+        n = 5
+        planes = [_rand_ycbcr(w, h, ratio, 70 + i) for i in range(n)]
+        y = np.stack([p[0] for p in planes]); cb = np.stack([p[1] for p in planes]); cr = np.stack([p[2] for p in planes])
+        glyphs = text_glyphs(w, h, n=6, width_px=min(150, w), height_px=min(30, h))
+        gs = ctx.glyphset(glyphs, DEFAULT_COL)
+        plan = ctx.plan(w, h, resize=(512, 384, True), thumbnail=(100, True), watermark=gs)
+        got = plan.run_host_ycbcr_jpeg(y, cb, cr, ratio, 85)
+        for k in range(n):
+            want = _expect_ycbcr_ops(y[k], cb[k], cr[k], ratio, (512, 384, True), (100, True), glyphs, DEFAULT_COL)
+            for key in ("resize", "thumbnail", "watermark"):
+                assert got[key][k] == oracle.jpeg_encode_rgba(want[key], 85), (w, h, ratio, key, k)
+        plan.close()
+        gs.close()
