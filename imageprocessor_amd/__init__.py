@@ -452,6 +452,40 @@ class Context:
         lib().ipx_host_free(self.handle, blob)
         return res
 
+    def jpeg_decode_batch(self, files, w=0, h=0, download=True):
+        """image.Decode of a batch of JPEG byte strings on the GPU.  -> (info, status list); info = dict(w, h, ratio, ystride,
+        cstride, y, cb, cr) with the planes as n x rows x stride arrays (download=True) or device pointers + `free()`."""
+        n = len(files)
+        keep = [bytes(f) for f in files]
+        arr = (_lib.Bytes * n)()
+        for i, f in enumerate(keep):
+            arr[i].data = C.cast(C.c_char_p(f), C.c_void_p)
+            arr[i].len = len(f)
+        cw, chh = C.c_int(w), C.c_int(h)
+        b = _lib.YCbCrBatch()
+        status = (C.c_int * n)()
+        owner = C.c_void_p()
+        _check(lib().ipx_jpeg_decode_batch(self.handle, None, arr, n, C.byref(cw), C.byref(chh), C.byref(b), status, C.byref(owner)))
+        st = list(status)
+        if not b.y:
+            return None, st
+        info = {"w": cw.value, "h": chh.value, "ratio": b.ratio, "ystride": b.ystride, "cstride": b.cstride}
+        v0 = 2 if b.ratio in (2, 3) else 1          # 4:2:0 and 4:4:0 halve the chroma rows
+        myy = (chh.value + 8 * v0 - 1) // (8 * v0)
+        yrows, crows = 8 * v0 * myy, 8 * myy            # image.NewYCbCr(Rect(0, 0, 8*h0*mxx, 8*v0*myy), ratio)
+        if download:
+            def grab(ptr, fs, rows, stride):
+                out = np.empty((n, fs), np.uint8)
+                _check(lib().ipx_memcpy_d2h(self.handle, out.ctypes.data, ptr, out.nbytes))
+                return out[:, :rows * stride].reshape(n, rows, stride)
+            info["y"] = grab(b.y, b.y_frame_stride, yrows, b.ystride)
+            info["cb"] = grab(b.cb, b.c_frame_stride, crows, b.cstride)
+            info["cr"] = grab(b.cr, b.c_frame_stride, crows, b.cstride)
+            lib().ipx_jpeg_planes_free(self.handle, owner)
+        else:
+            info.update(batch=b, free=lambda: lib().ipx_jpeg_planes_free(self.handle, owner))
+        return info, st
+
     def composite_glyphs(self, dst, glyphs, col):
         assert dst.dtype == np.uint8 and dst.flags.c_contiguous
         dh, dw = dst.shape[:2]

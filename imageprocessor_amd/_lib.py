@@ -147,6 +147,9 @@ SIGNATURES = {
     "ipx_jpeg_encode_rgba8": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(_P), C.POINTER(_Z)]),
     "ipx_jpeg_encode_batch_dev": (_I, [_P, _P, _I, _I, _I, _Z, _I, _I, C.POINTER(_P), C.POINTER(_Z), C.POINTER(_Z)]),
     "ipx_buffer_free": (None, [_P]),
+    "ipx_jpeg_decode_batch": (_I, [_P, _P, C.POINTER(Bytes), _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(YCbCrBatch), C.POINTER(_I),
+                                   C.POINTER(_P)]),
+    "ipx_jpeg_planes_free": (None, [_P, _P]),
     "ipx_plan_run_host_jpeg": (_I, [_P, _P, _I, _P, _I, _Z, _I, C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(_P)]),
     "ipx_jpeg_result_free": (None, [_P, _P]),
     "ipx_plan_run_host_ycbcr_jpeg": (_I, [_P, _P, _I, C.POINTER(YCbCrBatch), _I, C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(Bytes),

@@ -168,6 +168,31 @@ struct JpegArgs {
 };
 hipError_t launch_jpeg_fdct(const JpegArgs &a, int n, hipStream_t s);
 
+
+// ---- image.Decode for baseline JPEGs (ipx_jpeg_dec_host.cpp parses, ipx_jpeg_dec.hip decodes) ------------
+struct JpegDecInfo {
+    int w, h, h0, v0, ratio, ri;
+    uint8_t td[3], ta[3];      // kernel table slots of the three components: 0,1 = DC tables, 2,3 = AC tables
+    size_t scan_off, scan_len; // entropy-coded data within the file
+};
+struct JpegDecTables {         // per image, as the kernels read them
+    uint16_t lut[4][256];      // first level: length << 8 | symbol for codes of at most 8 bits, else 0
+    int32_t maxcode[4][18];    // by code length; -1 = no code of that length
+    int32_t valoff[4][18];     // symbol index = valoff[len] + code
+    uint8_t vals[4][256];
+    uint16_t qnat[3][64];      // quantiser per component, natural order
+};
+struct JpegDecImage { unsigned long long scan_off; uint32_t scan_len, ri; uint8_t td[3], ta[3], valid, pad; };
+struct JpegDecArgs {
+    const uint8_t *blob; const JpegDecImage *img; const JpegDecTables *tab;
+    int16_t *coefs; int *status;
+    int n, mxx, myy, h0, v0, nblk;
+};
+struct JpegPlanes { uint8_t *y, *cb, *cr; int ystride, cstride; size_t y_fs, c_fs; };
+int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *tab);
+hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s);
+hipError_t launch_jpeg_idct(const JpegDecArgs &a, const JpegPlanes &pl, hipStream_t s);
+
 }  // namespace ipx
 
 #include <vector>

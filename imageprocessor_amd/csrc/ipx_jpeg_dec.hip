@@ -1,0 +1,278 @@
+// ipx_jpeg_dec.hip -- image.Decode for baseline JPEGs on the GPU: entropy decoding and reconstruction.
+//
+// Go's decoder (image/jpeg scan.go processSOS / decodeHuffman / receiveExtend, reader.go reconstructBlock, idct.go)
+// walks the scan serially: Huffman symbols have no length prefix, so a block's position in the byte stream is only
+// known once everything before it has been decoded.  Two kernels:
+//
+//   jpeg_huff_kernel   one LANE per image: 64 images advance through their scans in lock step (the instruction stream
+//                      -- fetch bits, table look-up, extend, store -- is the same for every lane; only rare branches
+//                      diverge).  Each lane keeps its four 8-bit first-level Huffman tables in LDS (2 KiB per image,
+//                      128 KiB per wave), falls back to the canonical mincode / maxcode search for longer codes, and
+//                      writes the non-zero quantised coefficients, de-zig-zagged, into a zeroed int16 array.  0xff00
+//                      unstuffing and RSTn handling follow F.1.2.3 / Go's processSOS (DC predictions and the bit reader
+//                      reset at every restart interval).  A single image gains nothing here; a batch of a few thousand
+//                      fills the chip, which is how the worker is fed anyway.
+//   jpeg_idct_kernel   parallel over blocks: b[unzig[zig]] *= qt[zig]; idct (the Chen-Wang integer transform of
+//                      idct.go, row pass in registers, column pass through LDS); level shift, clip, 8-byte row stores
+//                      into the MCU-padded planes of image.NewYCbCr.
+// The planes feed band_ycc_kernel directly (ipx_plan_run_dev_ycbcr): decoded pixels never leave HBM.
+#include "ipx_internal.h"
+
+namespace ipx {
+
+namespace {
+
+constexpr int kLutStride = 2048 + 8;   // bytes of LDS per lane: 4 x 256 x uint16, padded off the bank period
+
+__constant__ uint8_t c_unzig[64] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct BitReader {
+    const uint8_t *p, *end;
+    unsigned long long acc = 0;
+    int cnt = 0;
+    bool stop = false;     // a marker or the end of the data was reached: no more bytes
+    bool err = false;
+
+    __device__ __forceinline__ void refill()
+    {
+        while (cnt <= 56 && !stop) {
+            if (p >= end) { stop = true; break; }
+            uint32_t c = *p;
+            if (c == 0xff) {
+                if (p + 1 >= end || p[1] != 0x00) { stop = true; break; }   // marker: left unread
+                p += 2;
+            } else {
+                p += 1;
+            }
+            acc = (acc << 8) | c;
+            cnt += 8;
+        }
+    }
+    // next 16 bits, zero padded past the end of the data
+    __device__ __forceinline__ uint32_t peek16()
+    {
+        if (cnt < 16) refill();
+        return cnt >= 16 ? (uint32_t)(acc >> (cnt - 16)) & 0xffffu : (uint32_t)(acc << (16 - cnt)) & 0xffffu;
+    }
+    __device__ __forceinline__ void skip(int n)
+    {
+        if (n > cnt) { err = true; cnt = 0; return; }
+        cnt -= n;
+    }
+    __device__ __forceinline__ int receive_extend(int t)   // huffman.go receiveExtend
+    {
+        if (t == 0) return 0;
+        const uint32_t v = peek16() >> (16 - t);
+        skip(t);
+        return (int)v < (1 << (t - 1)) ? (int)v + (int)(0xffffffffu << t) + 1 : (int)v;
+    }
+};
+
+__device__ __forceinline__ int decode_symbol(BitReader &br, const uint16_t *lut, const JpegDecTables *tab, int slot)
+{
+    const uint32_t bits = br.peek16();
+    const uint32_t e = lut[bits >> 8];
+    if (e) { br.skip((int)(e >> 8)); return (int)(e & 0xffu); }
+    for (int len = 9; len <= 16; len++) {     // canonical search for the long codes
+        const int code = (int)(bits >> (16 - len));
+        if (code <= tab->maxcode[slot][len]) {
+            br.skip(len);
+            return tab->vals[slot][(tab->valoff[slot][len] + code) & 255];
+        }
+    }
+    br.err = true;    // "bad Huffman code"
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
+{
+    extern __shared__ uint4 lds_raw[];
+    uint8_t *lds = (uint8_t *)lds_raw;
+    const int lane = threadIdx.x;
+    const int img = blockIdx.x * 64 + lane;
+    const bool live = img < a.n && a.img[img].valid;
+    uint16_t *lut = (uint16_t *)(lds + lane * kLutStride);
+    const JpegDecTables *tab = a.tab + (live ? img : 0);
+    if (live) {
+        const uint4 *src = (const uint4 *)&tab->lut[0][0];
+        uint2 *dst = (uint2 *)lut;                       // kLutStride keeps 8-byte alignment
+        for (int i = 0; i < 128; i++) { const uint4 v = src[i]; dst[2 * i] = make_uint2(v.x, v.y); dst[2 * i + 1] = make_uint2(v.z, v.w); }
+    }
+    uint8_t *unz = lds + 64 * kLutStride;                // the zig-zag -> natural map, shared (lanes index it divergently)
+    unz[lane] = c_unzig[lane];
+    __syncthreads();
+    if (!live) return;                                   // no barrier below: each lane works on its own LDS region
+    const JpegDecImage im = a.img[img];
+    BitReader br;
+    br.p = a.blob + im.scan_off;
+    br.end = br.p + im.scan_len;
+    int16_t *coefs = a.coefs + (size_t)img * a.nblk * 64;
+    const int ybl = a.h0 * a.v0, bpm = ybl + 2, nmcu = a.mxx * a.myy;
+    int dc[3] = {0, 0, 0};
+    int status = 0;
+    uint32_t expected_rst = 0xd0;
+    for (int m = 0; m < nmcu && !status; m++) {
+        for (int bi = 0; bi < bpm; bi++) {
+            const int c = bi < ybl ? 0 : bi - ybl + 1;
+            int16_t *b = coefs + ((size_t)m * bpm + bi) * 64;
+            const int t = decode_symbol(br, lut + im.td[c] * 256, tab, im.td[c]);
+            if (t > 16) { br.err = true; break; }        // "excessive DC component"
+            dc[c] += br.receive_extend(t);
+            if (dc[c] < -32768 || dc[c] > 32767) { br.err = true; break; }   // Go keeps int32; out of int16 = not a sane file
+            if (dc[c]) b[0] = (int16_t)dc[c];
+            const uint16_t *aclut = lut + im.ta[c] * 256;
+            for (int zig = 1; zig < 64; zig++) {
+                const int v = decode_symbol(br, aclut, tab, im.ta[c]);
+                const int r = v >> 4, sz = v & 15;
+                if (sz) {
+                    zig += r;
+                    if (zig > 63) break;
+                    const int ac = br.receive_extend(sz);
+                    b[unz[zig]] = (int16_t)ac;
+                } else {
+                    if (r != 15) break;
+                    zig += 15;
+                }
+                if (br.err) break;
+            }
+            if (br.err) break;
+        }
+        if (br.err) { status = IPX_ERR_INVALID; break; }
+        if (im.ri > 0 && (m + 1) % (int)im.ri == 0 && m + 1 < nmcu) {
+            // the RSTn marker sits on the next byte boundary: what is left in the accumulator must be padding only
+            if (br.cnt >= 8) { status = IPX_ERR_UNSUPPORTED; break; }
+            if (br.p + 2 > br.end || br.p[0] != 0xff || br.p[1] != expected_rst) { status = IPX_ERR_UNSUPPORTED; break; }
+            br.p += 2;
+            expected_rst = expected_rst == 0xd7 ? 0xd0 : expected_rst + 1;
+            br.acc = 0; br.cnt = 0; br.stop = false;
+            dc[0] = dc[1] = dc[2] = 0;
+        }
+    }
+    a.status[img] = status;
+}
+
+// ---- reconstruction -----------------------------------------------------------------------------------------
+constexpr int W1 = 2841, W2 = 2676, W3 = 2408, W5 = 1609, W6 = 1108, W7 = 565, R2 = 181;
+
+__device__ __forceinline__ void idct_row(int (&s)[8])   // idct.go, horizontal pass (the all-zero-AC shortcut gives the same values)
+{
+    int x0 = (int)((uint32_t)s[0] << 11) + 128, x1 = (int)((uint32_t)s[4] << 11), x2 = s[6], x3 = s[2], x4 = s[1], x5 = s[7], x6 = s[5], x7 = s[3];
+    int x8 = W7 * (x4 + x5);
+    x4 = x8 + (W1 - W7) * x4;
+    x5 = x8 - (W1 + W7) * x5;
+    x8 = W3 * (x6 + x7);
+    x6 = x8 - (W3 - W5) * x6;
+    x7 = x8 - (W3 + W5) * x7;
+    x8 = x0 + x1;
+    x0 -= x1;
+    x1 = W6 * (x3 + x2);
+    x2 = x1 - (W2 + W6) * x2;
+    x3 = x1 + (W2 - W6) * x3;
+    x1 = x4 + x6;
+    x4 -= x6;
+    x6 = x5 + x7;
+    x5 -= x7;
+    x7 = x8 + x3;
+    x8 -= x3;
+    x3 = x0 + x2;
+    x0 -= x2;
+    x2 = (R2 * (x4 + x5) + 128) >> 8;
+    x4 = (R2 * (x4 - x5) + 128) >> 8;
+    s[0] = (x7 + x1) >> 8; s[1] = (x3 + x2) >> 8; s[2] = (x0 + x4) >> 8; s[3] = (x8 + x6) >> 8;
+    s[4] = (x8 - x6) >> 8; s[5] = (x0 - x4) >> 8; s[6] = (x3 - x2) >> 8; s[7] = (x7 - x1) >> 8;
+}
+__device__ __forceinline__ void idct_col(int (&s)[8])   // vertical pass
+{
+    int y0 = (int)((uint32_t)s[0] << 8) + 8192, y1 = (int)((uint32_t)s[4] << 8), y2 = s[6], y3 = s[2], y4 = s[1], y5 = s[7], y6 = s[5], y7 = s[3];
+    int y8 = W7 * (y4 + y5) + 4;
+    y4 = (y8 + (W1 - W7) * y4) >> 3;
+    y5 = (y8 - (W1 + W7) * y5) >> 3;
+    y8 = W3 * (y6 + y7) + 4;
+    y6 = (y8 - (W3 - W5) * y6) >> 3;
+    y7 = (y8 - (W3 + W5) * y7) >> 3;
+    y8 = y0 + y1;
+    y0 -= y1;
+    y1 = W6 * (y3 + y2) + 4;
+    y2 = (y1 - (W2 + W6) * y2) >> 3;
+    y3 = (y1 + (W2 - W6) * y3) >> 3;
+    y1 = y4 + y6;
+    y4 -= y6;
+    y6 = y5 + y7;
+    y5 -= y7;
+    y7 = y8 + y3;
+    y8 -= y3;
+    y3 = y0 + y2;
+    y0 -= y2;
+    y2 = (R2 * (y4 + y5) + 128) >> 8;
+    y4 = (R2 * (y4 - y5) + 128) >> 8;
+    s[0] = (y7 + y1) >> 14; s[1] = (y3 + y2) >> 14; s[2] = (y0 + y4) >> 14; s[3] = (y8 + y6) >> 14;
+    s[4] = (y8 - y6) >> 14; s[5] = (y0 - y4) >> 14; s[6] = (y3 - y2) >> 14; s[7] = (y7 - y1) >> 14;
+}
+
+__global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegDecArgs a, JpegPlanes pl)
+{
+    __shared__ int ws[32 * 72];
+    __shared__ __attribute__((aligned(8))) uint8_t ob[32 * 64];
+    const int t = threadIdx.x, blk = t >> 3, r = t & 7;
+    const int img = blockIdx.y;
+    if (!a.img[img].valid) return;                        // uniform over the workgroup
+    const int gb = blockIdx.x * 32 + blk;
+    const bool live = gb < a.nblk;
+    const int ybl = a.h0 * a.v0, bpm = ybl + 2;
+    const int m = live ? gb / bpm : 0, bi = live ? gb - m * bpm : 0;
+    const int c = bi < ybl ? 0 : bi - ybl + 1;
+    int s[8];
+    if (live) {
+        const uint4 v = *(const uint4 *)(a.coefs + ((size_t)img * a.nblk + gb) * 64 + r * 8);
+        const uint16_t *q = &a.tab[img].qnat[c][r * 8];
+        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = (int)(int16_t)(wv[i >> 1] >> (16 * (i & 1))) * (int)q[i];   // b[unzig[zig]] *= qt[zig]
+        idct_row(s);
+#pragma unroll
+        for (int i = 0; i < 8; i++) ws[blk * 72 + r * 8 + i] = s[i];
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = ws[blk * 72 + i * 8 + r];   // column r
+        idct_col(s);
+#pragma unroll
+        for (int i = 0; i < 8; i++) ob[blk * 64 + i * 8 + r] = (uint8_t)(min(max(s[i], -128), 127) + 128);   // level shift, clip
+    }
+    __syncthreads();
+    if (live) {
+        const int mx = m % a.mxx, my = m / a.mxx;
+        int bx, by, stride;
+        uint8_t *plane;
+        if (c == 0) { bx = a.h0 * mx + bi % a.h0; by = a.v0 * my + bi / a.h0; stride = pl.ystride; plane = pl.y + (size_t)img * pl.y_fs; }
+        else { bx = mx; by = my; stride = pl.cstride; plane = (c == 1 ? pl.cb : pl.cr) + (size_t)img * pl.c_fs; }
+        *(uint2 *)(plane + (size_t)(by * 8 + r) * stride + bx * 8) = *(const uint2 *)(ob + blk * 64 + r * 8);
+    }
+}
+
+}  // namespace
+
+size_t jpeg_huff_lds_bytes() { return (size_t)64 * kLutStride + 64; }
+
+hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s)
+{
+    static thread_local bool set = false;
+    if (!set) {
+        hipError_t e = hipFuncSetAttribute((const void *)jpeg_huff_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jpeg_huff_lds_bytes());
+        if (e != hipSuccess) return e;
+        set = true;
+    }
+    hipLaunchKernelGGL(jpeg_huff_kernel, dim3((a.n + 63) / 64), dim3(64), jpeg_huff_lds_bytes(), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_jpeg_idct(const JpegDecArgs &a, const JpegPlanes &pl, hipStream_t s)
+{
+    hipLaunchKernelGGL(jpeg_idct_kernel, dim3((a.nblk + 31) / 32, a.n), dim3(256), 0, s, a, pl);
+    return hipGetLastError();
+}
+
+}  // namespace ipx

@@ -1698,3 +1698,110 @@ int ipx_jpeg_encode_rgba8(ipx_ctx *ctx, const uint8_t *pix, int w, int h, int st
 }
 
 }  // extern "C"
+
+
+// ---- image.Decode for JPEG batches -----------------------------------------------------------------------
+struct ipx_jpeg_planes { std::vector<void *> dev; };
+
+extern "C" {
+
+void ipx_jpeg_planes_free(ipx_ctx *ctx, ipx_jpeg_planes *o)
+{
+    if (!o) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    for (void *p : o->dev) (void)hipFree(p);
+    delete o;
+}
+
+int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, int n, int *w, int *h, ipx_ycbcr_batch *planes,
+                          int *status, ipx_jpeg_planes **owner)
+{
+    IPX_ENTER(ctx);
+    if (!jpegs || n < 0 || !w || !h || !planes || !status || !owner) { set_error("ipx_jpeg_decode_batch: bad argument"); return IPX_ERR_INVALID; }
+    *owner = nullptr;
+    memset(planes, 0, sizeof *planes);
+    if (n == 0) return IPX_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    std::vector<JpegDecInfo> info(n);
+    std::vector<JpegDecTables> tabs(n);
+    std::vector<JpegDecImage> imgs(n);
+    int ref = -1;
+    size_t blob_bytes = 0;
+    for (int i = 0; i < n; i++) {
+        status[i] = jpegs[i].data ? jpeg_parse(jpegs[i].data, jpegs[i].len, &info[i], &tabs[i]) : IPX_ERR_INVALID;
+        if (status[i] == IPX_OK) {
+            if (ref < 0 && (*w <= 0 || (info[i].w == *w && info[i].h == *h))) ref = i;
+            if (ref >= 0 && (info[i].w != info[ref].w || info[i].h != info[ref].h || info[i].h0 != info[ref].h0 || info[i].v0 != info[ref].v0))
+                status[i] = IPX_ERR_UNSUPPORTED;
+            else if (ref < 0) status[i] = IPX_ERR_UNSUPPORTED;   // a size other than the one asked for
+        }
+        memset(&imgs[i], 0, sizeof imgs[i]);
+        if (status[i] == IPX_OK) {
+            imgs[i].scan_off = blob_bytes; imgs[i].scan_len = (uint32_t)info[i].scan_len; imgs[i].ri = (uint32_t)info[i].ri;
+            memcpy(imgs[i].td, info[i].td, 3); memcpy(imgs[i].ta, info[i].ta, 3);
+            imgs[i].valid = 1;
+            blob_bytes += (info[i].scan_len + 15) & ~(size_t)15;
+        }
+    }
+    if (ref < 0) return IPX_OK;
+    const JpegDecInfo &R = info[ref];
+    *w = R.w; *h = R.h;
+    JpegDecArgs a{};
+    a.n = n; a.h0 = R.h0; a.v0 = R.v0;
+    a.mxx = (R.w + 8 * R.h0 - 1) / (8 * R.h0); a.myy = (R.h + 8 * R.v0 - 1) / (8 * R.v0);
+    a.nblk = a.mxx * a.myy * (R.h0 * R.v0 + 2);
+    JpegPlanes pl{};
+    pl.ystride = 8 * R.h0 * a.mxx; pl.cstride = 8 * a.mxx;
+    pl.y_fs = align256((size_t)pl.ystride * 8 * R.v0 * a.myy); pl.c_fs = align256((size_t)pl.cstride * 8 * a.myy);
+
+    std::unique_ptr<ipx_jpeg_planes> own(new ipx_jpeg_planes);
+    auto dalloc = [&](void **p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+        if (e == hipSuccess) own->dev.push_back(*p);
+        return e;
+    };
+    auto fail = [&](hipError_t e, const char *what) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        ipx_jpeg_planes_free(ctx, own.release());
+        return IPX_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = dalloc((void **)&pl.y, pl.y_fs * n)) != hipSuccess) return fail(e, "plane allocation");
+    if ((e = dalloc((void **)&pl.cb, pl.c_fs * n)) != hipSuccess) return fail(e, "plane allocation");
+    if ((e = dalloc((void **)&pl.cr, pl.c_fs * n)) != hipSuccess) return fail(e, "plane allocation");
+    // scratch of this call, stream-ordered
+    AsyncFree mem{s, {}};
+    uint8_t *d_blob; JpegDecImage *d_img; JpegDecTables *d_tab; int16_t *d_coefs; int *d_status;
+    if ((e = mem.get(&d_blob, blob_bytes + 16)) != hipSuccess) return fail(e, "scratch allocation");
+    if ((e = mem.get(&d_img, sizeof(JpegDecImage) * n)) != hipSuccess) return fail(e, "scratch allocation");
+    if ((e = mem.get(&d_tab, sizeof(JpegDecTables) * n)) != hipSuccess) return fail(e, "scratch allocation");
+    if ((e = mem.get(&d_coefs, (size_t)n * a.nblk * 128)) != hipSuccess) return fail(e, "scratch allocation");
+    if ((e = mem.get(&d_status, sizeof(int) * n)) != hipSuccess) return fail(e, "scratch allocation");
+    uint8_t *hblob = (uint8_t *)ipx_host_alloc(ctx, blob_bytes + 16);
+    if (!hblob) { ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
+    for (int i = 0; i < n; i++)
+        if (imgs[i].valid) memcpy(hblob + imgs[i].scan_off, jpegs[i].data + info[i].scan_off, info[i].scan_len);
+    e = hipMemcpyAsync(d_blob, hblob, blob_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_img, imgs.data(), sizeof(JpegDecImage) * n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tabs.data(), sizeof(JpegDecTables) * n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_coefs, 0, (size_t)n * a.nblk * 128, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int) * n, s);
+    a.blob = d_blob; a.img = d_img; a.tab = d_tab; a.coefs = d_coefs; a.status = d_status;
+    if (e == hipSuccess) e = launch_jpeg_huff(a, s);
+    if (e == hipSuccess) e = launch_jpeg_idct(a, pl, s);
+    std::vector<int> dev_status(n, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(dev_status.data(), d_status, sizeof(int) * n, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);   // the host tables and the blob may go now
+    (void)ipx_host_free(ctx, hblob);
+    if (e != hipSuccess) return fail(e, "jpeg decode");
+    for (int i = 0; i < n; i++)
+        if (status[i] == IPX_OK && dev_status[i]) status[i] = dev_status[i];
+    planes->y = pl.y; planes->cb = pl.cb; planes->cr = pl.cr;
+    planes->ystride = pl.ystride; planes->cstride = pl.cstride;
+    planes->y_frame_stride = pl.y_fs; planes->c_frame_stride = pl.c_fs;
+    planes->ratio = R.ratio;
+    *owner = own.release();
+    return IPX_OK;
+}
+
+}  // extern "C"

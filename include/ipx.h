@@ -375,6 +375,20 @@ int ipx_plan_run_host_ycbcr_jpeg(ipx_ctx *ctx, const ipx_plan *plan, int n, cons
                                  ipx_jpeg_result **result);
 void ipx_jpeg_result_free(ipx_ctx *ctx, ipx_jpeg_result *result);
 
+/* ---- image.Decode for JPEGs (decoder side) -------------------------------------------
+ * image_processor.go:47 decodes every upload; for JPEG files that is Go's image/jpeg.  A batch of baseline,
+ * three-component files of one size and one sampling (4:4:4 / 4:2:2 / 4:2:0 / 4:4:0) is decoded on the GPU:
+ * the compressed bytes go up, Huffman decoding runs one lane per image, the integer IDCT of idct.go runs
+ * block-parallel, and the *image.YCbCr planes (MCU-padded strides, as image.NewYCbCr lays them out) stay in
+ * HBM, ready for ipx_plan_run_dev_ycbcr.  status[i]: IPX_OK, IPX_ERR_INVALID (malformed) or
+ * IPX_ERR_UNSUPPORTED (progressive, Gray, CMYK / RGB, other samplings, several scans, a size or sampling
+ * different from the batch's): the worker decodes those with Go as before.  planes->y == NULL when no
+ * image was decodable.  Free the planes with ipx_jpeg_planes_free. */
+typedef struct ipx_jpeg_planes ipx_jpeg_planes;
+int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, int n, int *w, int *h,
+                          ipx_ycbcr_batch *planes, int *status, ipx_jpeg_planes **owner);
+void ipx_jpeg_planes_free(ipx_ctx *ctx, ipx_jpeg_planes *owner);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,7 @@ class Pipeline(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ipx_oracle.c", "ipx_jpeg_oracle.c", "ipx_oracle.h"))
+    src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ipx_oracle.c", "ipx_jpeg_oracle.c", "ipx_jpeg_dec_oracle.c", "ipx_oracle.h"))
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < src_m:
         subprocess.check_call(["make", "-s", "-C", _HERE, "libipx_oracle.so"])
     return _SO
@@ -323,3 +323,32 @@ def jpeg_encode_gray(plane, quality=85):
     if rc:
         raise ValueError("jpeg: image is too large to encode" if rc == -1 else "out of memory")
     return _take_bytes(p, n)
+
+
+# ---- image/jpeg decoder, baseline (oracle/ipx_jpeg_dec_oracle.c) --------------------------------------------
+class Decoded(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("ratio", C.c_int), ("ystride", C.c_int), ("cstride", C.c_int),
+                ("yrows", C.c_int), ("crows", C.c_int), ("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p)]
+
+
+def jpeg_decode(data, want_coefs=False):
+    """image.Decode of a baseline 3-component JPEG -> dict(w, h, ratio, y, cb, cr) with the MCU-padded planes of
+    image.NewYCbCr (y: yrows x ystride, cb / cr: crows x cstride).  Raises ValueError("malformed" | "unsupported")."""
+    L = lib()
+    L.ipxo_jpeg_decode.restype = C.c_int
+    L.ipxo_jpeg_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Decoded), C.c_void_p, C.c_size_t]
+    L.ipxo_decoded_free.argtypes = [C.POINTER(Decoded)]
+    d = Decoded()
+    coefs = np.zeros(max(64, len(data) * 64), np.int16) if want_coefs else None
+    rc = L.ipxo_jpeg_decode(bytes(data), len(data), C.byref(d), coefs.ctypes.data if want_coefs else None,
+                            coefs.size if want_coefs else 0)
+    if rc:
+        raise ValueError({-1: "malformed", -2: "unsupported"}.get(rc, "out of memory"))
+    def plane(p, rows, stride):
+        return np.frombuffer(C.string_at(p, rows * stride), np.uint8).reshape(rows, stride).copy()
+    out = {"w": d.w, "h": d.h, "ratio": d.ratio, "y": plane(d.y, d.yrows, d.ystride), "cb": plane(d.cb, d.crows, d.cstride),
+           "cr": plane(d.cr, d.crows, d.cstride)}
+    L.ipxo_decoded_free(C.byref(d))
+    if want_coefs:
+        out["coefs"] = coefs
+    return out

@@ -1,0 +1,192 @@
+"""image.Decode for JPEGs (image_processor.go:47 -> Go's image/jpeg): baseline decoder.
+
+oracle/ipx_jpeg_dec_oracle.c restates reader.go / scan.go / huffman.go / idct.go; the product parses on the host and
+decodes on the GPU (csrc/ipx_jpeg_dec_host.cpp, csrc/ipx_jpeg_dec.hip).  PARITY UNPINNED against Go itself.  Pins of
+the oracle: decode(encode(x)) returns the pinned encoder's coefficients exactly (Huffman decoding, de-zig-zag, DC
+prediction), and libjpeg (Pillow) decodes the same files to within +-1..2 of its different IDCT.
+"""
+import io
+
+import numpy as np
+import pytest
+
+import oracle
+
+ZIG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+       35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def picture(w, h, seed=0, noise=8.0):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([np.sin(xx / 9.0 + seed) * 100 + 128, np.cos(yy / 7.0) * 100 + 128, (xx * 2 + yy + 31 * seed) % 256], -1)
+    return (img + rng.normal(0, noise, img.shape)).clip(0, 255).astype(np.uint8)
+
+
+def pil_jpeg(img, **kw):
+    from PIL import Image, ImageFile
+    ImageFile.MAXBLOCK = 1 << 25    # libjpeg's optimize pass needs the whole file in one buffer ("Suspension not allowed here")
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def test_decode_of_our_encoder_returns_its_coefficients():
+    for (w, h), q in (((150, 97), 85), ((16, 16), 50), ((33, 70), 100), ((1, 1), 85)):
+        rgb = picture(w, h, seed=w)
+        rgba = np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], -1)
+        data, coefs = oracle.jpeg_encode_rgba(rgba, q, want_coefs=True)
+        d = oracle.jpeg_decode(data, want_coefs=True)
+        enc = coefs.reshape(-1, 64)
+        nat = np.zeros_like(enc)
+        nat[:, ZIG] = enc
+        np.testing.assert_array_equal(d["coefs"][:enc.size].reshape(-1, 64), nat)
+        assert (d["w"], d["h"], d["ratio"]) == (w, h, 2)
+        assert d["y"].shape == (16 * ((h + 15) // 16), 16 * ((w + 15) // 16)) and d["cb"].shape == (8 * ((h + 15) // 16), 8 * ((w + 15) // 16))
+
+
+@pytest.mark.parametrize("sub", [0, 1, 2], ids=["444", "422", "420"])
+def test_close_to_libjpeg(sub):
+    """Same file through libjpeg (Pillow, luma of the YCbCr draft mode): the two integer IDCTs differ by at most 2."""
+    from PIL import Image
+    img = picture(150, 97, seed=4)
+    for kw in ({}, {"restart_marker_blocks": 3}, {"optimize": True}, {"quality": 30}):
+        b = pil_jpeg(img, subsampling=sub, **{"quality": 85, **kw})
+        d = oracle.jpeg_decode(b)
+        p = Image.open(io.BytesIO(b))
+        p.draft("YCbCr", (150, 97))
+        p.load()
+        assert p.mode == "YCbCr" and d["ratio"] == sub
+        ref = np.asarray(p).astype(int)
+        diff = np.abs(d["y"][:97, :150].astype(int) - ref[..., 0])
+        assert diff.max() <= 2 and diff.mean() < 0.1, (sub, kw, diff.max(), diff.mean())
+
+
+def test_unsupported_and_malformed():
+    from PIL import Image
+    img = picture(64, 48)
+    for blob, what in ((pil_jpeg(img, progressive=True), "unsupported"),
+                       (pil_jpeg(img[..., 0]), "unsupported"),                      # Gray
+                       (pil_jpeg(img)[:200], "malformed"),
+                       (b"not a jpeg at all", "malformed")):
+        with pytest.raises(ValueError, match=what):
+            oracle.jpeg_decode(blob)
+    buf = io.BytesIO()
+    Image.fromarray(np.dstack([img, img[..., :1]]), "CMYK").save(buf, "JPEG")
+    with pytest.raises(ValueError, match="unsupported"):
+        oracle.jpeg_decode(buf.getvalue())
+    ok = pil_jpeg(img)
+    with pytest.raises(ValueError, match="malformed"):
+        oracle.jpeg_decode(ok[:len(ok) // 2])                                       # scan data runs out
+
+
+# ---- GPU --------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ctx():
+    import imageprocessor_amd as ipx
+    c = ipx.Context()
+    yield c
+    c.close()
+
+
+def _check_batch(ctx, files, expect_status=None):
+    info, st = ctx.jpeg_decode_batch(files)
+    for i, f in enumerate(files):
+        try:
+            want = oracle.jpeg_decode(f)
+        except ValueError as e:
+            assert st[i] == (-1 if "malformed" in str(e) else -4), (i, st[i], str(e))
+            continue
+        if expect_status and expect_status[i]:
+            assert st[i] == expect_status[i]
+            continue
+        assert st[i] == 0, (i, st[i])
+        assert (info["w"], info["h"], info["ratio"]) == (want["w"], want["h"], want["ratio"])
+        for k in ("y", "cb", "cr"):
+            np.testing.assert_array_equal(info[k][i], want[k], err_msg="%s of file %d" % (k, i))
+    return info, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sub", [0, 1, 2], ids=["444", "422", "420"])
+def test_gpu_decode_matches_oracle(ctx, sub):
+    for (w, h) in ((150, 97), (640, 360), (16, 8), (1920, 1080)):
+        n = 3 if w * h > 500000 else 70   # more than one wave of images
+        files = []
+        for i in range(n):
+            kw = [{}, {"restart_marker_blocks": 5}, {"optimize": True}, {"quality": 100}, {"quality": 25, "restart_marker_rows": 1}][i % 5]
+            files.append(pil_jpeg(picture(w, h, seed=i, noise=4.0 + 10 * (i % 4)), subsampling=sub, **{"quality": 85, **kw}))
+        _check_batch(ctx, files)
+
+
+@pytest.mark.gpu
+def test_gpu_decode_of_go_style_streams_and_440(ctx):
+    """Streams as Go's own encoder writes them (no JFIF, both tables, 4:2:0), and 4:4:0 built by transposing a 4:2:2 file's role:
+    Pillow cannot write 4:4:0, so the sampling bytes of a 4:2:2 file are swapped -- a valid 4:4:0 stream of other content."""
+    files = []
+    for i in range(5):
+        rgb = picture(200, 120, seed=10 + i)
+        files.append(oracle.jpeg_encode_rgba(np.concatenate([rgb, np.full((120, 200, 1), 255, np.uint8)], -1), 85))
+    _check_batch(ctx, files)
+    b = bytearray(pil_jpeg(picture(64, 64, seed=1), subsampling=1, quality=90))
+    i = b.index(b"\xff\xc0")
+    assert b[i + 11] == 0x21
+    b[i + 11] = 0x12                      # Y sampling 1 x 2: 4:4:0.  64x64: 4 x 8 MCUs of 16x8 become 8 x 4 MCUs of 8x16, same block count
+    _check_batch(ctx, [bytes(b)] * 2)
+
+
+@pytest.mark.gpu
+def test_gpu_decode_statuses(ctx):
+    """A batch is one size and one sampling; the odd ones out, progressive / Gray files and broken files get a status and
+    the rest still decode."""
+    good = [pil_jpeg(picture(96, 64, seed=i), quality=85) for i in range(4)]
+    other_size = pil_jpeg(picture(64, 64), quality=85)
+    other_sampling = pil_jpeg(picture(96, 64), quality=85, subsampling=0)
+    progressive = pil_jpeg(picture(96, 64), progressive=True)
+    gray = pil_jpeg(picture(96, 64)[..., 0])
+    truncated = good[0][:len(good[0]) // 2]
+    garbage = b"\xff\xd8" + bytes(100)
+    files = [good[0], other_size, good[1], other_sampling, progressive, gray, truncated, garbage, good[2], good[3]]
+    info, st = ctx.jpeg_decode_batch(files)
+    assert st == [0, -4, 0, -4, -4, -4, -1, -1, 0, 0]
+    for i in (0, 2, 8, 9):
+        want = oracle.jpeg_decode(files[i])
+        np.testing.assert_array_equal(info["y"][i], want["y"])
+    info, st = ctx.jpeg_decode_batch([progressive, gray])
+    assert info is None and st == [-4, -4]
+    # asking for a size: everything else is refused
+    info, st = ctx.jpeg_decode_batch([other_size, good[0]], w=96, h=64)
+    assert st == [-4, 0]
+
+
+@pytest.mark.gpu
+def test_decode_operators_encode_entirely_on_the_gpu(ctx):
+    """Compressed bytes up, planes stay in HBM, ipx_plan_run_dev_ycbcr on them, streams down: against the oracle's decoder +
+    operators (per-operator YCbCr rules) + encoder."""
+    from helpers import DEFAULT_COL, text_glyphs
+    from test_sources_gpu import _expect_ycbcr_ops
+    w, h, n = 640, 360, 6
+    files = [pil_jpeg(picture(w, h, seed=20 + i), quality=90) for i in range(n)]
+    info, st = ctx.jpeg_decode_batch(files, download=False)
+    assert st == [0] * n
+    b = info["batch"]
+    glyphs = text_glyphs(w, h, n=6, width_px=150, height_px=30)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(w, h, resize=(512, 384, True), thumbnail=(100, True), watermark=gs)
+    i_ = plan.info
+    res, th, wm = ctx.alloc(n * i_.resize_bytes), ctx.alloc(n * i_.thumb_bytes), ctx.alloc(n * i_.wm_bytes)
+    plan.run_dev_ycbcr(n, b.y, b.cb, b.cr, b.ratio, b.ystride, b.cstride, b.y_frame_stride, b.c_frame_stride, res.ptr, th.ptr, wm.ptr)
+    ctx.sync()
+    streams = {"resize": ctx.jpeg_encode_batch_dev(res.ptr, i_.resize_w, i_.resize_h, n), "thumbnail": ctx.jpeg_encode_batch_dev(th.ptr, i_.thumb_w, i_.thumb_h, n),
+               "watermark": ctx.jpeg_encode_batch_dev(wm.ptr, w, h, n)}
+    info["free"]()
+    for k in range(n):
+        d = oracle.jpeg_decode(files[k])
+        # the operators see the *image.YCbCr with its MCU-padded strides; the oracle helpers take tight planes
+        ch, cw = (h + 1) // 2, (w + 1) // 2
+        want = _expect_ycbcr_ops(np.ascontiguousarray(d["y"][:h, :w]), np.ascontiguousarray(d["cb"][:ch, :cw]), np.ascontiguousarray(d["cr"][:ch, :cw]),
+                                 2, (512, 384, True), (100, True), glyphs, DEFAULT_COL)
+        for key in streams:
+            assert streams[key][k] == oracle.jpeg_encode_rgba(want[key], 85), (key, k)
+    plan.close()
+    gs.close()
