@@ -245,6 +245,28 @@ class Plan:
         lib().ipx_jpeg_result_free(self.ctx.handle, res)
         return out
 
+    def run_jpeg_jpeg(self, files, quality=85, want=("resize", "thumbnail", "watermark"), copy=True):
+        """JPEG byte strings in -> ({operator: [jpeg bytes | None] * n}, status list): decode, operators, encode on the GPU."""
+        n = len(files)
+        keep = [bytes(f) for f in files]
+        arr = (_lib.Bytes * n)()
+        for j, f in enumerate(keep):
+            arr[j].data = C.cast(C.c_char_p(f), C.c_void_p)
+            arr[j].len = len(f)
+        i = self.info
+        outs = {}
+        for k, present in (("resize", i.resize_bytes), ("thumbnail", i.thumb_bytes), ("watermark", i.wm_bytes)):
+            if k in want and present:
+                outs[k] = (_lib.Bytes * n)()
+        status = (C.c_int * n)()
+        res = C.c_void_p()
+        _check(lib().ipx_plan_run_jpeg_jpeg(self.ctx.handle, self.handle, n, arr, int(quality), outs.get("resize"), outs.get("thumbnail"),
+                                            outs.get("watermark"), status, C.byref(res)))
+        out = {k: [(C.string_at(a[j].data, a[j].len) if copy else a[j].len) if a[j].data else None for j in range(n)] for k, a in outs.items()}
+        if res:
+            lib().ipx_jpeg_result_free(self.ctx.handle, res)
+        return out, list(status)
+
     def run_dev_ycbcr(self, n, y_ptr, cb_ptr, cr_ptr, ratio, ystride, cstride, y_frame_stride, c_frame_stride,
                       resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
         i = self.info

@@ -150,6 +150,8 @@ SIGNATURES = {
     "ipx_jpeg_decode_batch": (_I, [_P, _P, C.POINTER(Bytes), _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(YCbCrBatch), C.POINTER(_I),
                                    C.POINTER(_P)]),
     "ipx_jpeg_planes_free": (None, [_P, _P]),
+    "ipx_plan_run_jpeg_jpeg": (_I, [_P, _P, _I, C.POINTER(Bytes), _I, C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(_I),
+                                    C.POINTER(_P)]),
     "ipx_plan_run_host_jpeg": (_I, [_P, _P, _I, _P, _I, _Z, _I, C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(_P)]),
     "ipx_jpeg_result_free": (None, [_P, _P]),
     "ipx_plan_run_host_ycbcr_jpeg": (_I, [_P, _P, _I, C.POINTER(YCbCrBatch), _I, C.POINTER(Bytes), C.POINTER(Bytes), C.POINTER(Bytes),

@@ -187,6 +187,7 @@ struct JpegDecArgs {
     const uint8_t *blob; const JpegDecImage *img; const JpegDecTables *tab;
     int16_t *coefs; int *status;
     int n, mxx, myy, h0, v0, nblk;
+    int shared_tables, first_valid;   // every valid image carries the Huffman tables of image first_valid
 };
 struct JpegPlanes { uint8_t *y, *cb, *cr; int ystride, cstride; size_t y_fs, c_fs; };
 int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *tab);

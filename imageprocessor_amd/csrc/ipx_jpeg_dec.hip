@@ -28,24 +28,53 @@ __constant__ uint8_t c_unzig[64] = {
     0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+// The scan bytes of one image, read 16 at a time: a lane's loads are the latency that nothing else on its SIMD hides, so
+// they are made rare.  scan data starts 16-byte aligned in the blob and the blob is padded by 16 bytes.
 struct BitReader {
-    const uint8_t *p, *end;
+    const uint4 *base;
+    uint32_t pos = 0, len = 0;        // bytes consumed / available
+    unsigned long long lo = 0, hi = 0;
+    int have = 0;                     // bytes left in lo / hi
     unsigned long long acc = 0;
     int cnt = 0;
     bool stop = false;     // a marker or the end of the data was reached: no more bytes
     bool err = false;
 
+    __device__ __forceinline__ void load_chunk()
+    {
+        const uint4 v = base[pos >> 4];   // have == 0 only at multiples of 16
+        lo = (unsigned long long)v.y << 32 | v.x;
+        hi = (unsigned long long)v.w << 32 | v.z;
+        have = 16;
+    }
+    __device__ __forceinline__ uint32_t peek_byte()
+    {
+        if (have == 0) load_chunk();
+        return (uint32_t)lo & 0xffu;
+    }
+    __device__ __forceinline__ uint32_t peek_second()   // the byte after the next one
+    {
+        if (have >= 2) return (uint32_t)(lo >> 8) & 0xffu;
+        return ((const uint8_t *)base)[pos + 1];         // straddles a chunk: rare
+    }
+    __device__ __forceinline__ void advance()
+    {
+        if (have == 0) load_chunk();
+        lo = (lo >> 8) | (hi << 56);
+        hi >>= 8;
+        have--;
+        pos++;
+    }
     __device__ __forceinline__ void refill()
     {
         while (cnt <= 56 && !stop) {
-            if (p >= end) { stop = true; break; }
-            uint32_t c = *p;
+            if (pos >= len) { stop = true; break; }
+            const uint32_t c = peek_byte();
             if (c == 0xff) {
-                if (p + 1 >= end || p[1] != 0x00) { stop = true; break; }   // marker: left unread
-                p += 2;
-            } else {
-                p += 1;
+                if (pos + 1 >= len || peek_second() != 0x00) { stop = true; break; }   // marker: left unread
+                advance();
             }
+            advance();
             acc = (acc << 8) | c;
             cnt += 8;
         }
@@ -86,28 +115,39 @@ __device__ __forceinline__ int decode_symbol(BitReader &br, const uint16_t *lut,
     return 0;
 }
 
-__global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
+// SHARED: every image of the batch carries the same Huffman tables (the usual case: Annex K tables, or one encoder's
+// output), so one 2 KiB copy per workgroup serves all lanes and many waves fit on a CU; otherwise each lane keeps its own.
+template <bool SHARED>
+__global__ __launch_bounds__(SHARED ? 256 : 64) void jpeg_huff_kernel(JpegDecArgs a)
 {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = (uint8_t *)lds_raw;
     const int lane = threadIdx.x;
-    const int img = blockIdx.x * 64 + lane;
+    const int img = blockIdx.x * (SHARED ? 256 : 64) + lane;
     const bool live = img < a.n && a.img[img].valid;
-    uint16_t *lut = (uint16_t *)(lds + lane * kLutStride);
-    const JpegDecTables *tab = a.tab + (live ? img : 0);
-    if (live) {
-        const uint4 *src = (const uint4 *)&tab->lut[0][0];
-        uint2 *dst = (uint2 *)lut;                       // kLutStride keeps 8-byte alignment
-        for (int i = 0; i < 128; i++) { const uint4 v = src[i]; dst[2 * i] = make_uint2(v.x, v.y); dst[2 * i + 1] = make_uint2(v.z, v.w); }
+    uint16_t *lut = (uint16_t *)(SHARED ? lds : lds + lane * kLutStride);
+    const JpegDecTables *tab = a.tab + (SHARED ? a.first_valid : (live ? img : 0));
+    uint8_t *unz;
+    if (SHARED) {
+        const uint2 *src = (const uint2 *)&tab->lut[0][0];
+        ((uint2 *)lds)[lane] = src[lane];                // 256 threads x 8 bytes = the four tables
+        unz = lds + 2048;
+        if (lane < 64) unz[lane] = c_unzig[lane];
+    } else {
+        if (live) {
+            const uint4 *src = (const uint4 *)&tab->lut[0][0];
+            uint2 *dst = (uint2 *)lut;                   // kLutStride keeps 8-byte alignment
+            for (int i = 0; i < 128; i++) { const uint4 v = src[i]; dst[2 * i] = make_uint2(v.x, v.y); dst[2 * i + 1] = make_uint2(v.z, v.w); }
+        }
+        unz = lds + 64 * kLutStride;                     // the zig-zag -> natural map, shared (lanes index it divergently)
+        unz[lane] = c_unzig[lane];
     }
-    uint8_t *unz = lds + 64 * kLutStride;                // the zig-zag -> natural map, shared (lanes index it divergently)
-    unz[lane] = c_unzig[lane];
     __syncthreads();
-    if (!live) return;                                   // no barrier below: each lane works on its own LDS region
+    if (!live) return;                                   // no barrier below
     const JpegDecImage im = a.img[img];
     BitReader br;
-    br.p = a.blob + im.scan_off;
-    br.end = br.p + im.scan_len;
+    br.base = (const uint4 *)(a.blob + im.scan_off);
+    br.len = im.scan_len;
     int16_t *coefs = a.coefs + (size_t)img * a.nblk * 64;
     const int ybl = a.h0 * a.v0, bpm = ybl + 2, nmcu = a.mxx * a.myy;
     int dc[3] = {0, 0, 0};
@@ -143,8 +183,8 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
         if (im.ri > 0 && (m + 1) % (int)im.ri == 0 && m + 1 < nmcu) {
             // the RSTn marker sits on the next byte boundary: what is left in the accumulator must be padding only
             if (br.cnt >= 8) { status = IPX_ERR_UNSUPPORTED; break; }
-            if (br.p + 2 > br.end || br.p[0] != 0xff || br.p[1] != expected_rst) { status = IPX_ERR_UNSUPPORTED; break; }
-            br.p += 2;
+            if (br.pos + 2 > br.len || br.peek_byte() != 0xff || br.peek_second() != expected_rst) { status = IPX_ERR_UNSUPPORTED; break; }
+            br.advance(); br.advance();
             expected_rst = expected_rst == 0xd7 ? 0xd0 : expected_rst + 1;
             br.acc = 0; br.cnt = 0; br.stop = false;
             dc[0] = dc[1] = dc[2] = 0;
@@ -255,17 +295,20 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegDecArgs a, JpegPlane
 
 }  // namespace
 
-size_t jpeg_huff_lds_bytes() { return (size_t)64 * kLutStride + 64; }
-
 hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s)
 {
+    if (a.shared_tables) {
+        hipLaunchKernelGGL(jpeg_huff_kernel<true>, dim3((a.n + 255) / 256), dim3(256), 2048 + 64, s, a);
+        return hipGetLastError();
+    }
+    const size_t lds = (size_t)64 * kLutStride + 64;
     static thread_local bool set = false;
     if (!set) {
-        hipError_t e = hipFuncSetAttribute((const void *)jpeg_huff_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jpeg_huff_lds_bytes());
+        hipError_t e = hipFuncSetAttribute((const void *)jpeg_huff_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         set = true;
     }
-    hipLaunchKernelGGL(jpeg_huff_kernel, dim3((a.n + 63) / 64), dim3(64), jpeg_huff_lds_bytes(), s, a);
+    hipLaunchKernelGGL(jpeg_huff_kernel<false>, dim3((a.n + 63) / 64), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 

@@ -1787,6 +1787,12 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     if (e == hipSuccess) e = hipMemsetAsync(d_coefs, 0, (size_t)n * a.nblk * 128, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int) * n, s);
     a.blob = d_blob; a.img = d_img; a.tab = d_tab; a.coefs = d_coefs; a.status = d_status;
+    a.first_valid = ref;
+    a.shared_tables = env_int("IPX_JPEG_SHARED_TABLES", 1);
+    for (int i = 0; i < n && a.shared_tables; i++)
+        if (imgs[i].valid && (memcmp(tabs[i].lut, tabs[ref].lut, sizeof tabs[i].lut) || memcmp(tabs[i].maxcode, tabs[ref].maxcode, sizeof tabs[i].maxcode) ||
+                              memcmp(tabs[i].valoff, tabs[ref].valoff, sizeof tabs[i].valoff) || memcmp(tabs[i].vals, tabs[ref].vals, sizeof tabs[i].vals)))
+            a.shared_tables = 0;
     if (e == hipSuccess) e = launch_jpeg_huff(a, s);
     if (e == hipSuccess) e = launch_jpeg_idct(a, pl, s);
     std::vector<int> dev_status(n, 0);
@@ -1801,6 +1807,76 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     planes->y_frame_stride = pl.y_fs; planes->c_frame_stride = pl.c_fs;
     planes->ratio = R.ratio;
     *owner = own.release();
+    return IPX_OK;
+}
+
+}  // extern "C"
+
+
+// ---- compressed in, compressed out: image.Decode, the operators and jpeg.Encode without leaving the GPU ------
+extern "C" {
+
+int ipx_plan_run_jpeg_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_bytes *files, int quality, ipx_bytes *resize_out,
+                           ipx_bytes *thumb_out, ipx_bytes *wm_out, int *status, ipx_jpeg_result **result)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !files || !status || !result) { set_error("ipx_plan_run_jpeg_jpeg: bad argument"); return IPX_ERR_INVALID; }
+    *result = nullptr;
+    if (n == 0) return IPX_OK;
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    for (int i = 0; i < n; i++) {
+        if (resize_out) resize_out[i] = ipx_bytes{nullptr, 0};
+        if (thumb_out) thumb_out[i] = ipx_bytes{nullptr, 0};
+        if (wm_out) wm_out[i] = ipx_bytes{nullptr, 0};
+    }
+    LaneLease lane(ctx);
+    hipStream_t s = lane->stream;
+    int w = sw, h = sh;
+    ipx_ycbcr_batch planes;
+    ipx_jpeg_planes *owner = nullptr;
+    int rc = ipx_jpeg_decode_batch(ctx, s, files, n, &w, &h, &planes, status, &owner);
+    if (rc) return rc;
+    if (!planes.y) return IPX_OK;                         // nothing decodable: every status says why
+    struct Guard { ipx_ctx *c; ipx_jpeg_planes *o; ~Guard() { ipx_jpeg_planes_free(c, o); } } guard{ctx, owner};
+    const size_t fres = resize_out ? align256(pl->info.resize_bytes) : 0, fth = thumb_out ? align256(pl->info.thumb_bytes) : 0;
+    const size_t fwm = wm_out ? align256(pl->info.wm_bytes) : 0;
+    const size_t cres = fres ? ipx_jpeg_coef_count(pl->info.resize_w, pl->info.resize_h) * 2 : 0;
+    const size_t cth = fth ? ipx_jpeg_coef_count(pl->info.thumb_w, pl->info.thumb_h) * 2 : 0;
+    const size_t cwm = fwm ? ipx_jpeg_coef_count(sw, sh) * 2 : 0;
+    const size_t ccoef = align256(std::max(cres, std::max(cth, cwm)));
+    const size_t per_frame = fres + fth + fwm + ccoef;
+    if (per_frame == 0) return IPX_OK;
+    const int chunk = std::max(1, std::min(n, env_int("IPX_JPEG_JPEG_CHUNK", 256)));
+    rc = lane_reserve(lane.get(), per_frame * chunk + 256);
+    if (rc) return rc;
+    std::unique_ptr<ipx_jpeg_result> res(new ipx_jpeg_result);
+    std::vector<size_t> offs(chunk), lens(chunk);
+    for (int i0 = 0; i0 < n && !rc; i0 += chunk) {
+        const int m = std::min(chunk, n - i0);
+        uint8_t *base = (uint8_t *)(((uintptr_t)lane->dev + 255) & ~(uintptr_t)255);
+        uint8_t *dres = fres ? base : nullptr, *dth = fth ? base + fres * chunk : nullptr, *dwm = fwm ? base + (fres + fth) * chunk : nullptr;
+        int16_t *dcoef = (int16_t *)(base + (fres + fth + fwm) * chunk);
+        ipx_ycbcr_batch d = planes;
+        d.y += planes.y_frame_stride * i0; d.cb += planes.c_frame_stride * i0; d.cr += planes.c_frame_stride * i0;
+        rc = ipx_plan_run_dev_ycbcr(ctx, s, pl, m, &d, dres, fres, dth, fth, dwm, fwm);
+        struct Out { uint8_t *dev; size_t fs; int w, h; ipx_bytes *dst; };
+        const Out outs[3] = {{dres, fres, pl->info.resize_w, pl->info.resize_h, resize_out},
+                             {dth, fth, pl->info.thumb_w, pl->info.thumb_h, thumb_out},
+                             {dwm, fwm, sw, sh, wm_out}};
+        for (int k = 0; k < 3 && !rc; k++) {
+            const Out &o = outs[k];
+            if (!o.dev || o.w <= 0 || o.h <= 0) continue;
+            uint8_t *blob = nullptr;
+            rc = jpeg_encode_core(ctx, s, dcoef, o.dev, o.w, o.h, o.w * 4, o.fs, m, quality, &blob, offs.data(), lens.data());
+            if (rc) break;
+            res->blobs.push_back(blob);
+            for (int i = 0; i < m; i++)
+                if (status[i0 + i] == IPX_OK) { o.dst[i0 + i].data = blob + offs[i]; o.dst[i0 + i].len = lens[i]; }
+        }
+    }
+    (void)hipStreamSynchronize(s);
+    if (rc) { ipx_jpeg_result_free(ctx, res.release()); return rc; }
+    *result = res.release();
     return IPX_OK;
 }
 

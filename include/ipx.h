@@ -385,6 +385,13 @@ void ipx_jpeg_result_free(ipx_ctx *ctx, ipx_jpeg_result *result);
  * different from the batch's): the worker decodes those with Go as before.  planes->y == NULL when no
  * image was decodable.  Free the planes with ipx_jpeg_planes_free. */
 typedef struct ipx_jpeg_planes ipx_jpeg_planes;
+/* Compressed in, compressed out: the uploads as they arrive from the object store (image_processor.go:41-47), the
+ * objects as they go back (:76).  image.Decode, every operator of the plan and jpeg.Encode run on the GPU; the
+ * link carries ~0.3 MB up and ~0.5 MB down per 1080p image.  status[i] as for ipx_jpeg_decode_batch (the
+ * plan's frame size is the batch's size); outputs of undecodable files are {NULL, 0}. */
+int ipx_plan_run_jpeg_jpeg(ipx_ctx *ctx, const ipx_plan *plan, int n, const ipx_bytes *files, int quality,
+                           ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, int *status,
+                           ipx_jpeg_result **result);
 int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, int n, int *w, int *h,
                           ipx_ycbcr_batch *planes, int *status, ipx_jpeg_planes **owner);
 void ipx_jpeg_planes_free(ipx_ctx *ctx, ipx_jpeg_planes *owner);

@@ -108,6 +108,18 @@ def _check_batch(ctx, files, expect_status=None):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shared", ["1", "0"], ids=["shared-tables-kernel", "per-lane-tables-kernel"])
+def test_gpu_decode_same_tables_batch(ctx, shared, monkeypatch):
+    """A batch whose files all carry the Annex K tables takes the kernel with one shared table copy per workgroup (many waves
+    per CU); IPX_JPEG_SHARED_TABLES=0 forces the per-lane-table kernel on the same batch."""
+    monkeypatch.setenv("IPX_JPEG_SHARED_TABLES", shared)
+    for (w, h, n) in ((320, 200, 300), (1920, 1080, 3), (17, 9, 5)):
+        files = [pil_jpeg(picture(w, h, seed=i, noise=3.0 + 9 * (i % 5)), quality=[85, 60, 95][i % 3], **({"restart_marker_blocks": 7} if i % 4 == 0 else {}))
+                 for i in range(n)]
+        _check_batch(ctx, files)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sub", [0, 1, 2], ids=["444", "422", "420"])
 def test_gpu_decode_matches_oracle(ctx, sub):
     for (w, h) in ((150, 97), (640, 360), (16, 8), (1920, 1080)):
@@ -189,4 +201,37 @@ def test_decode_operators_encode_entirely_on_the_gpu(ctx):
         for key in streams:
             assert streams[key][k] == oracle.jpeg_encode_rgba(want[key], 85), (key, k)
     plan.close()
+    gs.close()
+
+
+@pytest.mark.gpu
+def test_compressed_in_compressed_out(ctx):
+    """ipx_plan_run_jpeg_jpeg: what the worker does per message (image_processor.go:41-77) for a batch, without the pixels ever
+    leaving HBM; files the GPU decoder refuses come back with a status and no outputs."""
+    from helpers import DEFAULT_COL, text_glyphs
+    from test_sources_gpu import _expect_ycbcr_ops
+    w, h = 320, 200
+    files = [pil_jpeg(picture(w, h, seed=40 + i), quality=80 + i) for i in range(7)]
+    files.insert(3, pil_jpeg(picture(w, h), progressive=True))
+    files.insert(5, pil_jpeg(picture(64, 64)))
+    glyphs = text_glyphs(w, h, n=6, width_px=150, height_px=30)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    import os
+    for chunk in ("256", "4"):
+        os.environ["IPX_JPEG_JPEG_CHUNK"] = chunk
+        plan = ctx.plan(w, h, resize=(512, 384, True), thumbnail=(100, True), watermark=gs)
+        got, st = plan.run_jpeg_jpeg(files)
+        assert st == [0, 0, 0, -4, 0, -4, 0, 0, 0]
+        for k, f in enumerate(files):
+            if st[k]:
+                assert all(got[key][k] is None for key in got)
+                continue
+            d = oracle.jpeg_decode(f)
+            ch, cw = (h + 1) // 2, (w + 1) // 2
+            want = _expect_ycbcr_ops(np.ascontiguousarray(d["y"][:h, :w]), np.ascontiguousarray(d["cb"][:ch, :cw]), np.ascontiguousarray(d["cr"][:ch, :cw]),
+                                     2, (512, 384, True), (100, True), glyphs, DEFAULT_COL)
+            for key in ("resize", "thumbnail", "watermark"):
+                assert got[key][k] == oracle.jpeg_encode_rgba(want[key], 85), (key, k)
+        plan.close()
+    os.environ.pop("IPX_JPEG_JPEG_CHUNK", None)
     gs.close()
