@@ -10,8 +10,13 @@
 //                      128 KiB per wave), falls back to the canonical mincode / maxcode search for longer codes, and
 //                      writes the non-zero quantised coefficients, de-zig-zagged, into a zeroed int16 array.  0xff00
 //                      unstuffing and RSTn handling follow F.1.2.3 / Go's processSOS (DC predictions and the bit reader
-//                      reset at every restart interval).  A single image gains nothing here; a batch of a few thousand
-//                      fills the chip, which is how the worker is fed anyway.
+//                      reset at every restart interval).  A single image gains nothing here: a lane needs ~0.4 us per
+//                      symbol step (a dependent chain of ~100 instructions, and a wave steps at the pace of its slowest
+//                      lane), i.e. ~0.5 s for a 1080p file whatever the batch size, so throughput = batch / 0.5 s until
+//                      the chip is full (16 k images with per-lane tables, more with shared ones).  Measured without the
+//                      coefficient stores and with 16-byte scan reads the time barely moves: it is instruction latency,
+//                      not memory.  The remedy is parallelism inside a file (restart intervals where present,
+//                      self-synchronising sub-sequences otherwise), not a faster lane.
 //   jpeg_idct_kernel   parallel over blocks: b[unzig[zig]] *= qt[zig]; idct (the Chen-Wang integer transform of
 //                      idct.go, row pass in registers, column pass through LDS); level shift, clip, 8-byte row stores
 //                      into the MCU-padded planes of image.NewYCbCr.
@@ -67,6 +72,19 @@ struct BitReader {
     }
     __device__ __forceinline__ void refill()
     {
+        // four bytes at once when none of them is 0xff (no stuffing, no marker) and they are all in the buffer
+        if (cnt <= 32 && have >= 4 && pos + 4 <= len) {
+            const uint32_t w4 = (uint32_t)lo, inv = ~w4;
+            if (((inv - 0x01010101u) & ~inv & 0x80808080u) == 0) {
+                acc = (acc << 32) | __builtin_bswap32(w4);
+                cnt += 32;
+                lo = (lo >> 32) | (hi << 32);
+                hi >>= 32;
+                have -= 4;
+                pos += 4;
+                if (cnt > 56) return;
+            }
+        }
         while (cnt <= 56 && !stop) {
             if (pos >= len) { stop = true; break; }
             const uint32_t c = peek_byte();
@@ -99,16 +117,19 @@ struct BitReader {
     }
 };
 
-__device__ __forceinline__ int decode_symbol(BitReader &br, const uint16_t *lut, const JpegDecTables *tab, int slot)
+// the canonical tables of the long codes (9..16 bits): in LDS for the shared-table kernel, in global memory otherwise
+struct SlowTables { const int32_t *maxcode, *valoff; const uint8_t *vals; };   // [4][18], [4][18], [4][256]
+
+__device__ __forceinline__ int decode_symbol(BitReader &br, const uint16_t *lut, const SlowTables &st, int slot)
 {
     const uint32_t bits = br.peek16();
     const uint32_t e = lut[bits >> 8];
     if (e) { br.skip((int)(e >> 8)); return (int)(e & 0xffu); }
     for (int len = 9; len <= 16; len++) {     // canonical search for the long codes
         const int code = (int)(bits >> (16 - len));
-        if (code <= tab->maxcode[slot][len]) {
+        if (code <= st.maxcode[slot * 18 + len]) {
             br.skip(len);
-            return tab->vals[slot][(tab->valoff[slot][len] + code) & 255];
+            return st.vals[slot * 256 + ((st.valoff[slot * 18 + len] + code) & 255)];
         }
     }
     br.err = true;    // "bad Huffman code"
@@ -128,11 +149,17 @@ __global__ __launch_bounds__(SHARED ? 256 : 64) void jpeg_huff_kernel(JpegDecArg
     uint16_t *lut = (uint16_t *)(SHARED ? lds : lds + lane * kLutStride);
     const JpegDecTables *tab = a.tab + (SHARED ? a.first_valid : (live ? img : 0));
     uint8_t *unz;
+    SlowTables st{&tab->maxcode[0][0], &tab->valoff[0][0], &tab->vals[0][0]};
     if (SHARED) {
         const uint2 *src = (const uint2 *)&tab->lut[0][0];
-        ((uint2 *)lds)[lane] = src[lane];                // 256 threads x 8 bytes = the four tables
+        ((uint2 *)lds)[lane] = src[lane];                // 256 threads x 8 bytes = the four first-level tables
         unz = lds + 2048;
         if (lane < 64) unz[lane] = c_unzig[lane];
+        int32_t *mc = (int32_t *)(lds + 2048 + 64), *vo = mc + 72;
+        uint8_t *vl = (uint8_t *)(vo + 72);
+        if (lane < 72) { mc[lane] = (&tab->maxcode[0][0])[lane]; vo[lane] = (&tab->valoff[0][0])[lane]; }
+        ((uint32_t *)vl)[lane] = ((const uint32_t *)&tab->vals[0][0])[lane];
+        st = SlowTables{mc, vo, vl};
     } else {
         if (live) {
             const uint4 *src = (const uint4 *)&tab->lut[0][0];
@@ -157,14 +184,14 @@ __global__ __launch_bounds__(SHARED ? 256 : 64) void jpeg_huff_kernel(JpegDecArg
         for (int bi = 0; bi < bpm; bi++) {
             const int c = bi < ybl ? 0 : bi - ybl + 1;
             int16_t *b = coefs + ((size_t)m * bpm + bi) * 64;
-            const int t = decode_symbol(br, lut + im.td[c] * 256, tab, im.td[c]);
+            const int t = decode_symbol(br, lut + im.td[c] * 256, st, im.td[c]);
             if (t > 16) { br.err = true; break; }        // "excessive DC component"
             dc[c] += br.receive_extend(t);
             if (dc[c] < -32768 || dc[c] > 32767) { br.err = true; break; }   // Go keeps int32; out of int16 = not a sane file
             if (dc[c]) b[0] = (int16_t)dc[c];
             const uint16_t *aclut = lut + im.ta[c] * 256;
             for (int zig = 1; zig < 64; zig++) {
-                const int v = decode_symbol(br, aclut, tab, im.ta[c]);
+                const int v = decode_symbol(br, aclut, st, im.ta[c]);
                 const int r = v >> 4, sz = v & 15;
                 if (sz) {
                     zig += r;
@@ -298,7 +325,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegDecArgs a, JpegPlane
 hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s)
 {
     if (a.shared_tables) {
-        hipLaunchKernelGGL(jpeg_huff_kernel<true>, dim3((a.n + 255) / 256), dim3(256), 2048 + 64, s, a);
+        hipLaunchKernelGGL(jpeg_huff_kernel<true>, dim3((a.n + 255) / 256), dim3(256), 2048 + 64 + 2 * 72 * 4 + 1024, s, a);
         return hipGetLastError();
     }
     const size_t lds = (size_t)64 * kLutStride + 64;
