@@ -182,14 +182,17 @@ struct JpegDecTables {         // per image, as the kernels read them
     uint8_t vals[4][256];
     uint16_t qnat[3][64];      // quantiser per component, natural order
 };
-struct JpegDecImage { unsigned long long scan_off; uint32_t scan_len, ri; uint8_t td[3], ta[3], valid, pad; };
+// one independently decodable piece of a scan: the whole scan, or one restart interval of it (DC predictions and the bit
+// reader start afresh after every RSTn, so intervals decode in parallel)
+struct JpegDecImage { unsigned long long scan_off; uint32_t scan_len, img, first_mcu, n_mcu; uint8_t td[3], ta[3], valid, pad; };
 struct JpegDecArgs {
     const uint8_t *blob; const JpegDecImage *img; const JpegDecTables *tab;
     int16_t *coefs; int *status;
-    int n, mxx, myy, h0, v0, nblk;
+    int n, mxx, myy, h0, v0, nblk;   // n = images
+    int nitems;                      // pieces to decode (>= images)
     int shared_tables, first_valid;   // every valid image carries the Huffman tables of image first_valid
 };
-struct JpegPlanes { uint8_t *y, *cb, *cr; int ystride, cstride; size_t y_fs, c_fs; };
+struct JpegPlanes { uint8_t *y, *cb, *cr; int ystride, cstride; size_t y_fs, c_fs; const uint8_t *valid; /* per image */ };
 int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *tab);
 hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s);
 hipError_t launch_jpeg_idct(const JpegDecArgs &a, const JpegPlanes &pl, hipStream_t s);

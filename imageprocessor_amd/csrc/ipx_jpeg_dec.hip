@@ -9,8 +9,9 @@
 //                      diverge).  Each lane keeps its four 8-bit first-level Huffman tables in LDS (2 KiB per image,
 //                      128 KiB per wave), falls back to the canonical mincode / maxcode search for longer codes, and
 //                      writes the non-zero quantised coefficients, de-zig-zagged, into a zeroed int16 array.  0xff00
-//                      unstuffing and RSTn handling follow F.1.2.3 / Go's processSOS (DC predictions and the bit reader
-//                      reset at every restart interval).  A single image gains nothing here: a lane needs ~0.4 us per
+//                      unstuffing follows F.1.2.3.  Where a file has restart intervals (DRI), the host cuts its scan at the
+//                      RSTn markers and every interval becomes a lane of its own: Go's processSOS resets the DC
+//                      predictions and the bit reader there, so the pieces are independent.  A single image gains nothing here: a lane needs ~0.4 us per
 //                      symbol step (a dependent chain of ~100 instructions, and a wave steps at the pace of its slowest
 //                      lane), i.e. ~0.5 s for a 1080p file whatever the batch size, so throughput = batch / 0.5 s until
 //                      the chip is full (16 k images with per-lane tables, more with shared ones).  Measured without the
@@ -137,28 +138,30 @@ __device__ __forceinline__ int decode_symbol(BitReader &br, const uint16_t *lut,
 }
 
 // SHARED: every image of the batch carries the same Huffman tables (the usual case: Annex K tables, or one encoder's
-// output), so one 2 KiB copy per workgroup serves all lanes and many waves fit on a CU; otherwise each lane keeps its own.
+// output), so one 3.7 KiB copy per (single-wave) workgroup serves all lanes and many waves fit on a CU; otherwise each lane
+// keeps its own first-level tables (128 KiB per wave, one wave per CU).
 template <bool SHARED>
-__global__ __launch_bounds__(SHARED ? 256 : 64) void jpeg_huff_kernel(JpegDecArgs a)
+__global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
 {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = (uint8_t *)lds_raw;
     const int lane = threadIdx.x;
-    const int img = blockIdx.x * (SHARED ? 256 : 64) + lane;
-    const bool live = img < a.n && a.img[img].valid;
+    const int item = blockIdx.x * 64 + lane;
+    const bool live = item < a.nitems && a.img[item].valid;
+    const int img = live ? (int)a.img[item].img : 0;
     uint16_t *lut = (uint16_t *)(SHARED ? lds : lds + lane * kLutStride);
     const JpegDecTables *tab = a.tab + (SHARED ? a.first_valid : (live ? img : 0));
     uint8_t *unz;
     SlowTables st{&tab->maxcode[0][0], &tab->valoff[0][0], &tab->vals[0][0]};
     if (SHARED) {
-        const uint2 *src = (const uint2 *)&tab->lut[0][0];
-        ((uint2 *)lds)[lane] = src[lane];                // 256 threads x 8 bytes = the four first-level tables
+        const uint4 *src = (const uint4 *)&tab->lut[0][0];
+        for (int i = lane; i < 128; i += 64) ((uint4 *)lds)[i] = src[i];   // the four first-level tables, 2 KiB
         unz = lds + 2048;
-        if (lane < 64) unz[lane] = c_unzig[lane];
+        unz[lane] = c_unzig[lane];
         int32_t *mc = (int32_t *)(lds + 2048 + 64), *vo = mc + 72;
         uint8_t *vl = (uint8_t *)(vo + 72);
-        if (lane < 72) { mc[lane] = (&tab->maxcode[0][0])[lane]; vo[lane] = (&tab->valoff[0][0])[lane]; }
-        ((uint32_t *)vl)[lane] = ((const uint32_t *)&tab->vals[0][0])[lane];
+        for (int i = lane; i < 72; i += 64) { mc[i] = (&tab->maxcode[0][0])[i]; vo[i] = (&tab->valoff[0][0])[i]; }
+        for (int i = lane; i < 256; i += 64) ((uint32_t *)vl)[i] = ((const uint32_t *)&tab->vals[0][0])[i];
         st = SlowTables{mc, vo, vl};
     } else {
         if (live) {
@@ -171,16 +174,16 @@ __global__ __launch_bounds__(SHARED ? 256 : 64) void jpeg_huff_kernel(JpegDecArg
     }
     __syncthreads();
     if (!live) return;                                   // no barrier below
-    const JpegDecImage im = a.img[img];
+    const JpegDecImage im = a.img[item];
     BitReader br;
     br.base = (const uint4 *)(a.blob + im.scan_off);
     br.len = im.scan_len;
+    for (int k = 0; k < (int)im.pad; k++) br.advance();   // the piece starts inside its first 16-byte chunk
     int16_t *coefs = a.coefs + (size_t)img * a.nblk * 64;
-    const int ybl = a.h0 * a.v0, bpm = ybl + 2, nmcu = a.mxx * a.myy;
+    const int ybl = a.h0 * a.v0, bpm = ybl + 2;
     int dc[3] = {0, 0, 0};
     int status = 0;
-    uint32_t expected_rst = 0xd0;
-    for (int m = 0; m < nmcu && !status; m++) {
+    for (int m = (int)im.first_mcu; m < (int)(im.first_mcu + im.n_mcu); m++) {
         for (int bi = 0; bi < bpm; bi++) {
             const int c = bi < ybl ? 0 : bi - ybl + 1;
             int16_t *b = coefs + ((size_t)m * bpm + bi) * 64;
@@ -207,17 +210,8 @@ __global__ __launch_bounds__(SHARED ? 256 : 64) void jpeg_huff_kernel(JpegDecArg
             if (br.err) break;
         }
         if (br.err) { status = IPX_ERR_INVALID; break; }
-        if (im.ri > 0 && (m + 1) % (int)im.ri == 0 && m + 1 < nmcu) {
-            // the RSTn marker sits on the next byte boundary: what is left in the accumulator must be padding only
-            if (br.cnt >= 8) { status = IPX_ERR_UNSUPPORTED; break; }
-            if (br.pos + 2 > br.len || br.peek_byte() != 0xff || br.peek_second() != expected_rst) { status = IPX_ERR_UNSUPPORTED; break; }
-            br.advance(); br.advance();
-            expected_rst = expected_rst == 0xd7 ? 0xd0 : expected_rst + 1;
-            br.acc = 0; br.cnt = 0; br.stop = false;
-            dc[0] = dc[1] = dc[2] = 0;
-        }
     }
-    a.status[img] = status;
+    if (status) atomicExch(&a.status[img], status);   // pieces of one image report into one word (zeroed by the host)
 }
 
 // ---- reconstruction -----------------------------------------------------------------------------------------
@@ -284,7 +278,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegDecArgs a, JpegPlane
     __shared__ __attribute__((aligned(8))) uint8_t ob[32 * 64];
     const int t = threadIdx.x, blk = t >> 3, r = t & 7;
     const int img = blockIdx.y;
-    if (!a.img[img].valid) return;                        // uniform over the workgroup
+    if (!pl.valid[img]) return;                           // uniform over the workgroup
     const int gb = blockIdx.x * 32 + blk;
     const bool live = gb < a.nblk;
     const int ybl = a.h0 * a.v0, bpm = ybl + 2;
@@ -325,7 +319,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegDecArgs a, JpegPlane
 hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s)
 {
     if (a.shared_tables) {
-        hipLaunchKernelGGL(jpeg_huff_kernel<true>, dim3((a.n + 255) / 256), dim3(256), 2048 + 64 + 2 * 72 * 4 + 1024, s, a);
+        hipLaunchKernelGGL(jpeg_huff_kernel<true>, dim3((a.nitems + 63) / 64), dim3(64), 2048 + 64 + 2 * 72 * 4 + 1024, s, a);
         return hipGetLastError();
     }
     const size_t lds = (size_t)64 * kLutStride + 64;
@@ -335,7 +329,7 @@ hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s)
         if (e != hipSuccess) return e;
         set = true;
     }
-    hipLaunchKernelGGL(jpeg_huff_kernel<false>, dim3((a.n + 63) / 64), dim3(64), lds, s, a);
+    hipLaunchKernelGGL(jpeg_huff_kernel<false>, dim3((a.nitems + 63) / 64), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 

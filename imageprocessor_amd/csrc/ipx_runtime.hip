@@ -1331,6 +1331,7 @@ int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_y
 
 // ---- jpeg.Encode: the entries that touch the device (tables / entropy coder: ipx_jpeg_host.cpp) ----------
 #include <atomic>
+#include <functional>
 #include <memory>
 #include <string>
 #include <thread>
@@ -1724,24 +1725,74 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     std::vector<JpegDecInfo> info(n);
     std::vector<JpegDecTables> tabs(n);
-    std::vector<JpegDecImage> imgs(n);
+    std::vector<JpegDecImage> items;
+    std::vector<uint8_t> valid(n, 0);
+    std::vector<size_t> blob_off(n, 0);
+    // host preparation runs on a few threads: parsing is trivial, but finding the RSTn markers and packing the scans walk
+    // every compressed byte (0.3 GB for a thousand 1080p files)
+    auto parallel_for = [&](int count, const std::function<void(int)> &fn) {
+        const int nt = std::max(1, std::min({count / 8, (int)std::thread::hardware_concurrency(), 16}));
+        std::atomic<int> next{0};
+        auto work = [&] { for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    };
+    // pieces of a scan: the whole scan, or one per restart interval.  Inside entropy-coded data 0xff is followed by 0x00 or by a
+    // marker, so every 0xff 0xd0..0xd7 pair is an RSTn.
+    std::vector<std::vector<uint32_t>> marks(n);
+    parallel_for(n, [&](int i) {
+        status[i] = jpegs[i].data ? jpeg_parse(jpegs[i].data, jpegs[i].len, &info[i], &tabs[i]) : IPX_ERR_INVALID;
+        if (status[i] != IPX_OK) return;
+        const JpegDecInfo &I = info[i];
+        const int nmcu = ((I.w + 8 * I.h0 - 1) / (8 * I.h0)) * ((I.h + 8 * I.v0 - 1) / (8 * I.v0));
+        if (I.ri <= 0 || nmcu <= I.ri) return;
+        const uint8_t *sd = jpegs[i].data + I.scan_off;
+        int expected = 0;
+        for (size_t k = 0; k + 1 < I.scan_len;) {
+            const uint8_t *q = (const uint8_t *)memchr(sd + k, 0xff, I.scan_len - 1 - k);
+            if (!q) break;
+            k = (size_t)(q - sd);
+            const uint8_t m2 = sd[k + 1];
+            if (m2 == 0x00) { k += 2; continue; }
+            if (m2 < 0xd0 || m2 > 0xd7) break;                        // EOI or another marker: the scan ends here
+            if (m2 != 0xd0 + expected) { status[i] = IPX_ERR_UNSUPPORTED; return; }
+            marks[i].push_back((uint32_t)k);
+            expected = (expected + 1) & 7;
+            k += 2;
+        }
+        if ((int)marks[i].size() != (nmcu + I.ri - 1) / I.ri - 1) status[i] = IPX_ERR_UNSUPPORTED;   // Go would try to resynchronise
+    });
     int ref = -1;
     size_t blob_bytes = 0;
     for (int i = 0; i < n; i++) {
-        status[i] = jpegs[i].data ? jpeg_parse(jpegs[i].data, jpegs[i].len, &info[i], &tabs[i]) : IPX_ERR_INVALID;
         if (status[i] == IPX_OK) {
             if (ref < 0 && (*w <= 0 || (info[i].w == *w && info[i].h == *h))) ref = i;
             if (ref >= 0 && (info[i].w != info[ref].w || info[i].h != info[ref].h || info[i].h0 != info[ref].h0 || info[i].v0 != info[ref].v0))
                 status[i] = IPX_ERR_UNSUPPORTED;
             else if (ref < 0) status[i] = IPX_ERR_UNSUPPORTED;   // a size other than the one asked for
         }
-        memset(&imgs[i], 0, sizeof imgs[i]);
-        if (status[i] == IPX_OK) {
-            imgs[i].scan_off = blob_bytes; imgs[i].scan_len = (uint32_t)info[i].scan_len; imgs[i].ri = (uint32_t)info[i].ri;
-            memcpy(imgs[i].td, info[i].td, 3); memcpy(imgs[i].ta, info[i].ta, 3);
-            imgs[i].valid = 1;
-            blob_bytes += (info[i].scan_len + 15) & ~(size_t)15;
-        }
+        if (status[i] != IPX_OK) continue;
+        const JpegDecInfo &I = info[i];
+        const int nmcu = ((I.w + 8 * I.h0 - 1) / (8 * I.h0)) * ((I.h + 8 * I.v0 - 1) / (8 * I.v0));
+        auto push = [&](size_t a0, size_t a1, int m0, int cnt) {
+            JpegDecImage it;
+            memset(&it, 0, sizeof it);
+            it.scan_off = blob_bytes + (a0 & ~(size_t)15); it.scan_len = (uint32_t)(a1 - (a0 & ~(size_t)15));
+            it.img = (uint32_t)i; it.first_mcu = (uint32_t)m0; it.n_mcu = (uint32_t)cnt;
+            memcpy(it.td, I.td, 3); memcpy(it.ta, I.ta, 3);
+            it.valid = 1;
+            it.pad = (uint8_t)(a0 & 15);           // bytes to skip: pieces start 16-byte aligned for the kernel's chunk loads
+            items.push_back(it);
+        };
+        size_t start = 0;
+        int mcu = 0;
+        for (uint32_t k : marks[i]) { push(start, k, mcu, I.ri); mcu += I.ri; start = (size_t)k + 2; }
+        push(start, I.scan_len, mcu, nmcu - mcu);
+        valid[i] = 1;
+        blob_off[i] = blob_bytes;
+        blob_bytes += (I.scan_len + 15 + 16) & ~(size_t)15;
     }
     if (ref < 0) return IPX_OK;
     const JpegDecInfo &R = info[ref];
@@ -1773,16 +1824,20 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     AsyncFree mem{s, {}};
     uint8_t *d_blob; JpegDecImage *d_img; JpegDecTables *d_tab; int16_t *d_coefs; int *d_status;
     if ((e = mem.get(&d_blob, blob_bytes + 16)) != hipSuccess) return fail(e, "scratch allocation");
-    if ((e = mem.get(&d_img, sizeof(JpegDecImage) * n)) != hipSuccess) return fail(e, "scratch allocation");
+    uint8_t *d_valid;
+    if ((e = mem.get(&d_img, sizeof(JpegDecImage) * items.size())) != hipSuccess) return fail(e, "scratch allocation");
+    if ((e = mem.get(&d_valid, (size_t)n)) != hipSuccess) return fail(e, "scratch allocation");
     if ((e = mem.get(&d_tab, sizeof(JpegDecTables) * n)) != hipSuccess) return fail(e, "scratch allocation");
     if ((e = mem.get(&d_coefs, (size_t)n * a.nblk * 128)) != hipSuccess) return fail(e, "scratch allocation");
     if ((e = mem.get(&d_status, sizeof(int) * n)) != hipSuccess) return fail(e, "scratch allocation");
     uint8_t *hblob = (uint8_t *)ipx_host_alloc(ctx, blob_bytes + 16);
     if (!hblob) { ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
-    for (int i = 0; i < n; i++)
-        if (imgs[i].valid) memcpy(hblob + imgs[i].scan_off, jpegs[i].data + info[i].scan_off, info[i].scan_len);
+    parallel_for(n, [&](int i) { if (valid[i]) memcpy(hblob + blob_off[i], jpegs[i].data + info[i].scan_off, info[i].scan_len); });
     e = hipMemcpyAsync(d_blob, hblob, blob_bytes, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_img, imgs.data(), sizeof(JpegDecImage) * n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_img, items.data(), sizeof(JpegDecImage) * items.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_valid, valid.data(), (size_t)n, hipMemcpyHostToDevice, s);
+    pl.valid = d_valid;
+    a.nitems = (int)items.size();
     if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tabs.data(), sizeof(JpegDecTables) * n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_coefs, 0, (size_t)n * a.nblk * 128, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int) * n, s);
@@ -1790,7 +1845,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     a.first_valid = ref;
     a.shared_tables = env_int("IPX_JPEG_SHARED_TABLES", 1);
     for (int i = 0; i < n && a.shared_tables; i++)
-        if (imgs[i].valid && (memcmp(tabs[i].lut, tabs[ref].lut, sizeof tabs[i].lut) || memcmp(tabs[i].maxcode, tabs[ref].maxcode, sizeof tabs[i].maxcode) ||
+        if (valid[i] && (memcmp(tabs[i].lut, tabs[ref].lut, sizeof tabs[i].lut) || memcmp(tabs[i].maxcode, tabs[ref].maxcode, sizeof tabs[i].maxcode) ||
                               memcmp(tabs[i].valoff, tabs[ref].valoff, sizeof tabs[i].valoff) || memcmp(tabs[i].vals, tabs[ref].vals, sizeof tabs[i].vals)))
             a.shared_tables = 0;
     if (e == hipSuccess) e = launch_jpeg_huff(a, s);
