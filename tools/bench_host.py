@@ -77,3 +77,25 @@ for _ in range(3):
 kb = sum(sum(v) for v in lens.values()) / n / 1e3
 print("decoded-JPEG planes (4:2:0) -> three JPEG streams, pinned source, %d lanes: %d frames in %.1f ms = %.0f images/s; 3.1 MB up, %.0f KB down per frame"
       % (lanes, n, best * 1e3, n / best, kb))
+
+# compressed in, compressed out: the worker's whole per-message job on the GPU
+import io
+from PIL import Image
+files, files_rst = [], []
+for k in range(4):
+    for dst, kw in ((files, {}), (files_rst, {"restart_marker_rows": 1})):
+        buf = io.BytesIO()
+        Image.fromarray(src[k, ..., :3]).save(buf, "JPEG", quality=85, **kw)
+        dst.append(buf.getvalue())
+for label, pool_ in (("no restart markers", files), ("one restart interval per MCU row", files_rst)):
+    for m in (n, 4 * n):
+        batch = [pool_[i % 4] for i in range(m)]
+        plan2.run_jpeg_jpeg(batch[:64], copy=False)
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            lens, st = plan2.run_jpeg_jpeg(batch, copy=False)
+            best = min(best, time.perf_counter() - t0)
+        assert not any(st)
+        print("JPEG files (%s, %.0f KB) -> decode + operators + three encodes on the GPU: %d files in %.1f ms = %.0f images/s"
+              % (label, len(batch[0]) / 1e3, m, best * 1e3, m / best))

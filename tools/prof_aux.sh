@@ -4,6 +4,7 @@ out=gpurun_out/prof_aux
 mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ycc -- python3 tools/bench_ycbcr.py 1024 > $out/ycc.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/jpeg -- python3 tools/bench_jpeg.py 256 > $out/jpeg.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/dec -- python3 tools/bench_jpeg_dec.py 1024 > $out/dec.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/jpeg_fetch -- python3 tools/bench_jpeg.py 256 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/jpeg_write -- python3 tools/bench_jpeg.py 256 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/ycc_fetch -- python3 tools/bench_ycbcr.py 1024 > /dev/null 2>&1
@@ -11,7 +12,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/ycc_write -- python3 tool
 python3 - $out <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-for tag in ("ycc", "jpeg"):
+for tag in ("ycc", "jpeg", "dec"):
     print("==", tag, open(out + "/" + tag + ".log").read().strip().replace("\n", "\n   "))
     for f in glob.glob(out + "/" + tag + "/*/*_kernel_stats.csv"):
         for r in csv.DictReader(open(f)):
