@@ -181,20 +181,26 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
     for (int k = 0; k < (int)im.pad; k++) br.advance();   // the piece starts inside its first 16-byte chunk
     int16_t *coefs = a.coefs + (size_t)img * a.nblk * 64;
     const int ybl = a.h0 * a.v0, bpm = ybl + 2;
-    int dc[3] = {0, 0, 0};
+    // table slots and DC predictions as scalars selected by the component: arrays indexed by c would live in scratch memory
+    // (a global-memory round trip per block)
+    const int td0 = im.td[0], td1 = im.td[1], td2 = im.td[2], ta0 = im.ta[0], ta1 = im.ta[1], ta2 = im.ta[2];
+    int dc0 = 0, dc1 = 0, dc2 = 0;
     int status = 0;
     for (int m = (int)im.first_mcu; m < (int)(im.first_mcu + im.n_mcu); m++) {
         for (int bi = 0; bi < bpm; bi++) {
             const int c = bi < ybl ? 0 : bi - ybl + 1;
             int16_t *b = coefs + ((size_t)m * bpm + bi) * 64;
-            const int t = decode_symbol(br, lut + im.td[c] * 256, st, im.td[c]);
+            const int td = c == 0 ? td0 : (c == 1 ? td1 : td2), ta = c == 0 ? ta0 : (c == 1 ? ta1 : ta2);
+            const int t = decode_symbol(br, lut + td * 256, st, td);
             if (t > 16) { br.err = true; break; }        // "excessive DC component"
-            dc[c] += br.receive_extend(t);
-            if (dc[c] < -32768 || dc[c] > 32767) { br.err = true; break; }   // Go keeps int32; out of int16 = not a sane file
-            if (dc[c]) b[0] = (int16_t)dc[c];
-            const uint16_t *aclut = lut + im.ta[c] * 256;
+            const int diff = br.receive_extend(t);
+            const int dcv = (c == 0 ? dc0 : (c == 1 ? dc1 : dc2)) + diff;
+            if (c == 0) dc0 = dcv; else if (c == 1) dc1 = dcv; else dc2 = dcv;
+            if (dcv < -32768 || dcv > 32767) { br.err = true; break; }   // Go keeps int32; out of int16 = not a sane file
+            if (dcv) b[0] = (int16_t)dcv;
+            const uint16_t *aclut = lut + ta * 256;
             for (int zig = 1; zig < 64; zig++) {
-                const int v = decode_symbol(br, aclut, st, im.ta[c]);
+                const int v = decode_symbol(br, aclut, st, ta);
                 const int r = v >> 4, sz = v & 15;
                 if (sz) {
                     zig += r;
