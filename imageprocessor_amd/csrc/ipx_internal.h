@@ -193,6 +193,25 @@ struct JpegDecArgs {
     int shared_tables, first_valid;   // every valid image carries the Huffman tables of image first_valid
 };
 struct JpegPlanes { uint8_t *y, *cb, *cr; int ystride, cstride; size_t y_fs, c_fs; const uint8_t *valid; /* per image */ };
+// Huffman decoding parallel inside a scan (ipx_jpeg_dec_par.hip): per image and per 1 KiB sub-sequence of its scan
+struct JpegParImage { unsigned long long scan_off; uint32_t scan_len, img, nsub; size_t sub_off; uint8_t td[3], ta[3], pad[2]; };
+struct JpegParArgs {
+    const uint8_t *blob; const JpegDecTables *tab; const JpegParImage *img;
+    uint8_t *ublob;                        // the scans without stuffing, same offsets as blob, zero filled
+    int nimg, max_nsub, bpm, ybl, nblk;
+    uint32_t *stuffed;                     // [nimg][max_nsub] stuffed zeros before each 1 KiB chunk (after the scan)
+    uint32_t *scan_end, *ulen;             // per image: first marker in the stuffed scan; bytes of the unstuffed scan
+    unsigned long long *entry, *exit_a, *exit_b;
+    uint32_t *ends, *total_ends;           // block ends per sub-sequence (after the scan: first block index); per image total
+    uint32_t *changed;
+    int16_t *coefs; int *status;
+};
+int jpeg_par_sub_bytes();
+hipError_t launch_par_count(const JpegParArgs &a, hipStream_t s);
+hipError_t launch_par_unstuff(const JpegParArgs &a, hipStream_t s);
+hipError_t launch_par_sync(const JpegParArgs &a, int round, hipStream_t s);
+hipError_t launch_par_write(const JpegParArgs &a, hipStream_t s);
+hipError_t launch_par_dc(const JpegParArgs &a, hipStream_t s);
 int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *tab);
 hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s);
 hipError_t launch_jpeg_idct(const JpegDecArgs &a, const JpegPlanes &pl, hipStream_t s);

@@ -1,0 +1,392 @@
+// ipx_jpeg_dec_par.hip -- Huffman decoding that is parallel INSIDE a scan (no restart markers needed).
+//
+// jpeg_huff_kernel (ipx_jpeg_dec.hip) gives a scan to one lane, and a lane needs ~0.45 s for a 1080p file.  The
+// classic remedy for variable-length codes is used here: Huffman streams resynchronise by themselves.  A decoder that
+// starts at an arbitrary bit with a guessed state produces garbage for a while, but once it happens to sit on a true
+// symbol boundary with the true (block-in-MCU, zig-zag index) state it stays correct for ever.  So:
+//
+//   0. unstuff the scan is copied without its stuffed 0x00 bytes and cut at the first marker (count per 1 KiB chunk, scan,
+//              copy): after that a position is a plain bit offset, a sub-sequence is a fixed 1 KiB window, and a lane
+//              refills its accumulator with one aligned 32-bit LDS read -- no per-byte 0xff tests in the hot loop (with
+//              them a wave spent ~8000 cycles per symbol step, because some lane was always in the byte loop);
+//   1. spec    one lane per sub-sequence decodes it from a guessed state (block 0, DC expected) -- except sub-sequence 0,
+//              whose state is known -- and records where and in which state it leaves: exit[t];
+//   2. sync    lane t takes exit[t-1] as its entry; if that differs from the entry it used last time it decodes its
+//              sub-sequence again.  Repeat until no entry changes.  entry[0] is true, so by induction every entry is true at
+//              the fixed point; because of the self-synchronisation most exits are already right after step 1 and the loop
+//              ends after a handful of rounds (the host reads one counter per round);
+//   3. write   block ends per sub-sequence -> exclusive scan = index of the block each lane starts in; the lanes decode once
+//              more, now storing coefficients (DC as the difference Go's processSOS would add to its running value);
+//   4. dc      per image and component, the running sum of the DC differences (F.2.1.3.1).
+// After that the coefficient array is what jpeg_huff_kernel would have left, and jpeg_idct_kernel finishes the job.
+// A workgroup is one wave = 64 consecutive sub-sequences of ONE image, staged in LDS (row stride 1028 bytes against bank
+// aliasing) next to that image's Huffman tables.
+#include "ipx_internal.h"
+
+namespace ipx {
+
+namespace {
+
+constexpr int kSub = 1024;            // bytes of scan per sub-sequence
+constexpr int kRow = kSub + 4;        // LDS bytes per staged sub-sequence
+constexpr uint32_t kEnd = 0xffffffffu;
+
+__constant__ uint8_t c_unzig_par[64] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// (unstuffed bit position, block-in-MCU index, next zig-zag index; 0 = DC expected)
+__device__ __forceinline__ unsigned long long pack_state(uint32_t p, int c, int z) { return (unsigned long long)p | (unsigned long long)c << 32 | (unsigned long long)z << 40; }
+
+struct Tables {          // LDS
+    const uint16_t *lut; const int32_t *maxcode, *valoff; const uint8_t *vals, *unz;
+};
+
+// Reads the UNSTUFFED scan of one image: bit position p <-> word p >> 5, most significant bit first within each byte.
+struct Reader {
+    const uint8_t *lds;      // staged rows of this workgroup's 64 sub-sequences (+ 16 bytes)
+    const uint8_t *g;        // the unstuffed scan in global memory (zero padded), for the words outside the staged window
+    uint32_t wg_base, wg_bytes;
+    uint32_t ubits;          // length of the unstuffed scan in bits
+    uint32_t widx = 0;       // next 32-bit word
+    unsigned long long acc = 0;
+    int cnt = 0;
+
+    __device__ __forceinline__ uint32_t word_at(uint32_t wi) const
+    {
+        const uint32_t i = wi * 4 - wg_base;
+        const uint32_t wv = i < wg_bytes ? *(const uint32_t *)(lds + (i >> 10) * kRow + (i & (kSub - 1))) : *(const uint32_t *)(g + (size_t)wi * 4);
+        return __builtin_bswap32(wv);
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (cnt <= 32) { acc = (acc << 32) | word_at(widx); widx++; cnt += 32; }
+    }
+    __device__ __forceinline__ uint32_t upos() const { return widx * 32u - (uint32_t)cnt; }
+    __device__ __forceinline__ bool exhausted() const { return upos() >= ubits; }
+    __device__ __forceinline__ uint32_t peek16()
+    {
+        refill();
+        return (uint32_t)(acc >> (cnt - 16)) & 0xffffu;      // cnt >= 33 after refill; past the end the buffer holds zeros
+    }
+    __device__ __forceinline__ bool skip(int n)      // false: the data ended inside this symbol
+    {
+        cnt -= n;
+        return upos() <= ubits;
+    }
+    __device__ __forceinline__ void seek(uint32_t p)
+    {
+        widx = p >> 5;
+        acc = 0; cnt = 0;
+        refill();
+        cnt -= (int)(p & 31u);
+    }
+};
+
+// one Huffman symbol; 0..255, or -1 (no such code: a speculative decoder just moves on by one bit), or -2 (out of data)
+__device__ __forceinline__ int symbol(Reader &r, const Tables &T, int slot)
+{
+    const uint32_t bits = r.peek16();
+    const uint32_t e = T.lut[slot * 256 + (bits >> 8)];
+    if (e) return r.skip((int)(e >> 8)) ? (int)(e & 0xffu) : -2;
+    for (int len = 9; len <= 16; len++) {
+        const int code = (int)(bits >> (16 - len));
+        if (code <= T.maxcode[slot * 18 + len]) return r.skip(len) ? (int)T.vals[slot * 256 + ((T.valoff[slot * 18 + len] + code) & 255)] : -2;
+    }
+    return r.skip(1) ? -1 : -2;
+}
+__device__ __forceinline__ bool extend(Reader &r, int t, int &out)   // receiveExtend; false: out of data
+{
+    out = 0;
+    if (t == 0) return true;
+    const uint32_t v = r.peek16() >> (16 - t);
+    if (!r.skip(t)) return false;
+    out = (int)v < (1 << (t - 1)) ? (int)v + (int)(0xffffffffu << t) + 1 : (int)v;
+    return true;
+}
+
+struct NoSink {
+    __device__ __forceinline__ void dc(int) {}
+    __device__ __forceinline__ void ac(int, int) {}
+    __device__ __forceinline__ bool end_block() { return true; }
+    __device__ __forceinline__ void bad() {}
+};
+
+// Decode from state (c, z) until the position reaches uend (or the data ends).  Returns the exit state; *ends counts blocks
+// that ended.  sink.end_block() returning false stops the lane (all blocks of the image are done).
+template <class Sink>
+__device__ __forceinline__ unsigned long long run(Reader &r, const Tables &T, const JpegParImage &im, int bpm, int ybl, int c, int z, uint32_t uend,
+                                                  Sink &sink, uint32_t *ends)
+{
+    uint32_t nend = 0;
+    unsigned long long out;
+    for (;;) {
+        const uint32_t p = r.upos();
+        if (p >= r.ubits) { out = pack_state(kEnd, 0, 0); break; }
+        if (p >= uend) { out = pack_state(p, c, z); break; }
+        const int comp = c < ybl ? 0 : c - ybl + 1;
+        bool block_done = false;
+        if (z == 0) {
+            const int t = symbol(r, T, comp == 0 ? im.td[0] : (comp == 1 ? im.td[1] : im.td[2]));
+            if (t == -2) { out = pack_state(kEnd, 0, 0); break; }
+            if (t < 0 || t > 16) { sink.bad(); continue; }
+            int diff;
+            if (!extend(r, t, diff)) { out = pack_state(kEnd, 0, 0); break; }
+            sink.dc(diff);
+            z = 1;
+        } else {
+            const int v = symbol(r, T, comp == 0 ? im.ta[0] : (comp == 1 ? im.ta[1] : im.ta[2]));
+            if (v == -2) { out = pack_state(kEnd, 0, 0); break; }
+            if (v < 0) { sink.bad(); continue; }
+            const int run_ = v >> 4, sz = v & 15;
+            if (sz) {
+                z += run_;
+                if (z > 63) block_done = true;       // Go: zig += val0; if zig > zigEnd { break } -- the value bits stay unread
+                else {
+                    int ac;
+                    if (!extend(r, sz, ac)) { out = pack_state(kEnd, 0, 0); break; }
+                    sink.ac(z, ac);
+                    z++;
+                    if (z > 63) block_done = true;
+                }
+            } else if (run_ != 15) {
+                block_done = true;                   // EOB
+            } else {
+                z += 16;
+                if (z > 63) block_done = true;
+            }
+        }
+        if (block_done) {
+            nend++;
+            c = c + 1 == bpm ? 0 : c + 1;
+            z = 0;
+            if (!sink.end_block()) { out = pack_state(kEnd, 0, 0); break; }
+        }
+    }
+    *ends = nend;
+    return out;
+}
+
+__device__ __forceinline__ Tables stage(uint8_t *lds, const JpegParArgs &a, const JpegParImage &im, int py, int lane, int first_sub, Reader &r)
+{
+    // tables of this image, then the workgroup's 64 sub-sequences (+ 16 bytes of look-ahead)
+    const JpegDecTables *tab = a.tab + im.img;
+    uint8_t *tb = lds;
+    for (int i = lane; i < 128; i += 64) ((uint4 *)tb)[i] = ((const uint4 *)&tab->lut[0][0])[i];
+    uint8_t *unz = tb + 2048;
+    unz[lane] = c_unzig_par[lane];
+    int32_t *mc = (int32_t *)(tb + 2048 + 64), *vo = mc + 72;
+    uint8_t *vl = (uint8_t *)(vo + 72);
+    for (int i = lane; i < 72; i += 64) { mc[i] = (&tab->maxcode[0][0])[i]; vo[i] = (&tab->valoff[0][0])[i]; }
+    for (int i = lane; i < 256; i += 64) ((uint32_t *)vl)[i] = ((const uint32_t *)&tab->vals[0][0])[i];
+    uint8_t *rows = tb + 4096;
+    const uint8_t *scan = a.ublob + im.scan_off;           // unstuffed copy: same offsets as the packed scans, zero padded
+    const uint32_t base = (uint32_t)first_sub * kSub;
+    const uint32_t cap = (im.scan_len + 15u) & ~15u;       // the unstuffed scan is no longer than the stuffed one
+    const uint32_t avail = cap > base ? min(cap - base, (uint32_t)(64 * kSub + 16)) : 0u;
+    for (uint32_t ch = lane; ch < (avail >> 4); ch += 64) {
+        const uint4 v = *(const uint4 *)(scan + base + ch * 16);
+        const uint32_t i = ch * 16;
+        uint32_t *d = (uint32_t *)(rows + (i >> 10) * kRow + (i & (kSub - 1)));   // 16-byte pieces never straddle a row; rows are only 4-byte aligned
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    r.lds = rows; r.g = scan; r.wg_base = base; r.wg_bytes = avail; r.ubits = a.ulen[py] * 8u;
+    return Tables{(const uint16_t *)tb, mc, vo, vl, unz};
+}
+
+constexpr size_t kParLds = 4096 + (size_t)65 * kRow + 64;
+
+// step 0a: stuffed zeros per 1 KiB chunk of the scan, and where the scan ends (the first 0xff not followed by 0x00)
+__global__ __launch_bounds__(256) void par_count_kernel(JpegParArgs a)
+{
+    const JpegParImage im = a.img[blockIdx.y];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int)im.nsub) return;
+    const uint8_t *scan = a.blob + im.scan_off;
+    const uint32_t b0 = (uint32_t)t * kSub, b1 = min(b0 + kSub, im.scan_len);
+    uint32_t n = 0, first_marker = 0xffffffffu;
+    uint32_t prev = b0 > 0 ? scan[b0 - 1] : 0u;
+    for (uint32_t j = b0; j < b1; j += 4) {                  // scans start 16-byte aligned, chunks are multiples of 4
+        const uint32_t wv = *(const uint32_t *)(scan + j);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t c = (wv >> (8 * k)) & 0xffu;
+            if (j + k < b1) {
+                n += (prev == 0xff && c == 0x00);
+                if (prev == 0xff && c != 0x00) first_marker = min(first_marker, j + k - 1);
+                prev = c;
+            }
+        }
+    }
+    if (b1 == im.scan_len && prev == 0xff) first_marker = min(first_marker, im.scan_len - 1);   // a lone 0xff at the very end
+    a.stuffed[im.sub_off + t] = n;
+    if (first_marker != 0xffffffffu) atomicMin(a.scan_end + blockIdx.y, first_marker);
+}
+
+// step 0b: the scan without its stuffed zeros, up to the marker (a.stuffed holds the exclusive scan of the counts)
+__global__ __launch_bounds__(256) void par_unstuff_kernel(JpegParArgs a)
+{
+    const JpegParImage im = a.img[blockIdx.y];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int)im.nsub) return;
+    const uint8_t *scan = a.blob + im.scan_off;
+    uint8_t *dst = a.ublob + im.scan_off;
+    const uint32_t end = min(a.scan_end[blockIdx.y], im.scan_len);
+    const uint32_t b0 = (uint32_t)t * kSub, b1 = min(b0 + kSub, end);
+    uint32_t o = b0 - a.stuffed[im.sub_off + t];
+    uint32_t prev = b0 > 0 ? scan[b0 - 1] : 0u;
+    for (uint32_t j = b0; j < b1; j++) {
+        const uint32_t c = scan[j];
+        if (!(prev == 0xff && c == 0x00)) dst[o++] = (uint8_t)c;
+        prev = c;
+    }
+    if (b0 < end && b1 == end) a.ulen[blockIdx.y] = o;       // the chunk that holds the last byte of the scan
+}
+
+// steps 1 and 2.  round 0: speculative; round >= 1: re-decode where the entry changed
+__global__ __launch_bounds__(64) void par_sync_kernel(JpegParArgs a, int round)
+{
+    extern __shared__ uint4 lds_raw[];
+    const JpegParImage im = a.img[blockIdx.y];
+    const int first = blockIdx.x * 64, lane = threadIdx.x, t = first + lane;
+    if (first >= (int)im.nsub) return;
+    Reader r;
+    const Tables T = stage((uint8_t *)lds_raw, a, im, blockIdx.y, lane, first, r);
+    if (t >= (int)im.nsub) return;
+    const size_t s = im.sub_off + t;
+    const unsigned long long *exit_prev = round & 1 ? a.exit_a : a.exit_b;
+    unsigned long long *exit_next = round & 1 ? a.exit_b : a.exit_a;
+    const uint32_t ustart = (uint32_t)t * kSub * 8u, uend = min(ustart + kSub * 8u, r.ubits);
+    unsigned long long entry;
+    if (round == 0) entry = ustart < r.ubits ? pack_state(ustart, 0, 0) : pack_state(kEnd, 0, 0);   // t == 0: the truth; t > 0: a guess
+    else if (t == 0) { exit_next[s] = exit_prev[s]; return; }
+    else {
+        entry = exit_prev[s - 1];
+        if (entry == a.entry[s]) { exit_next[s] = exit_prev[s]; return; }
+        atomicAdd(a.changed, 1u);
+    }
+    a.entry[s] = entry;
+    const uint32_t p = (uint32_t)entry;
+    uint32_t ends = 0;
+    unsigned long long out;
+    if (p == kEnd || p >= uend) out = p >= r.ubits ? pack_state(kEnd, 0, 0) : entry;   // nothing of this sub-sequence is left to decode
+    else {
+        r.seek(p);
+        NoSink sink;
+        out = run(r, T, im, a.bpm, a.ybl, (int)(entry >> 32) & 0xff, (int)(entry >> 40) & 0xff, uend, sink, &ends);
+    }
+    exit_next[s] = out;
+    a.ends[(size_t)blockIdx.y * a.max_nsub + t] = ends;
+}
+
+struct CoefSink {
+    int16_t *coefs; const uint8_t *unz;
+    uint32_t g, nblk;
+    int *status;
+    __device__ __forceinline__ void dc(int d)
+    {
+        if (g >= nblk) return;
+        if (d < -32768 || d > 32767) { atomicExch(status, IPX_ERR_INVALID); return; }
+        if (d) coefs[(size_t)g * 64] = (int16_t)d;
+    }
+    __device__ __forceinline__ void ac(int z, int v) { if (g < nblk) coefs[(size_t)g * 64 + unz[z]] = (int16_t)v; }
+    __device__ __forceinline__ bool end_block() { g++; return g < nblk; }
+    __device__ __forceinline__ void bad() { if (g < nblk) atomicExch(status, IPX_ERR_INVALID); }   // "bad Huffman code" in real data
+};
+
+// step 3: a.ends holds the exclusive scan of the block ends = the block each lane starts in
+__global__ __launch_bounds__(64) void par_write_kernel(JpegParArgs a)
+{
+    extern __shared__ uint4 lds_raw[];
+    const JpegParImage im = a.img[blockIdx.y];
+    const int first = blockIdx.x * 64, lane = threadIdx.x, t = first + lane;
+    if (first >= (int)im.nsub) return;
+    Reader r;
+    const Tables T = stage((uint8_t *)lds_raw, a, im, blockIdx.y, lane, first, r);
+    if (t >= (int)im.nsub) return;
+    const size_t s = im.sub_off + t;
+    const unsigned long long entry = a.entry[s];
+    const uint32_t p = (uint32_t)entry;
+    const uint32_t uend = min(((uint32_t)t + 1) * kSub * 8u, r.ubits);
+    if (p == kEnd || p >= uend) return;
+    CoefSink sink{a.coefs + (size_t)im.img * a.nblk * 64, T.unz, a.ends[(size_t)blockIdx.y * a.max_nsub + t], (uint32_t)a.nblk, a.status + im.img};
+    if (sink.g >= sink.nblk) return;
+    r.seek(p);
+    uint32_t ends;
+    (void)run(r, T, im, a.bpm, a.ybl, (int)(entry >> 32) & 0xff, (int)(entry >> 40) & 0xff, uend, sink, &ends);
+}
+
+// step 4: DC differences -> DC values, per component in scan order; also the "scan ran out of data" verdict
+__global__ __launch_bounds__(256) void par_dc_kernel(JpegParArgs a)
+{
+    __shared__ int part[256][3];
+    const JpegParImage im = a.img[blockIdx.x];
+    int16_t *coefs = a.coefs + (size_t)im.img * a.nblk * 64;
+    const int t = threadIdx.x, nmcu = a.nblk / a.bpm;
+    if (t == 0 && a.total_ends[blockIdx.x] < (uint32_t)a.nblk) atomicExch(a.status + im.img, IPX_ERR_INVALID);   // "short Huffman data"
+    const int per = (nmcu + 255) / 256, m0 = min(nmcu, t * per), m1 = min(nmcu, m0 + per);
+    int sum[3] = {0, 0, 0};
+    for (int m = m0; m < m1; m++)
+        for (int bi = 0; bi < a.bpm; bi++) sum[bi < a.ybl ? 0 : bi - a.ybl + 1] += coefs[((size_t)m * a.bpm + bi) * 64];
+    for (int k = 0; k < 3; k++) part[t][k] = sum[k];
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        int add[3] = {0, 0, 0};
+        if (t >= d) for (int k = 0; k < 3; k++) add[k] = part[t - d][k];
+        __syncthreads();
+        for (int k = 0; k < 3; k++) part[t][k] += add[k];
+        __syncthreads();
+    }
+    int run_[3];
+    for (int k = 0; k < 3; k++) run_[k] = part[t][k] - sum[k];
+    bool bad = false;
+    for (int m = m0; m < m1; m++)
+        for (int bi = 0; bi < a.bpm; bi++) {
+            const int k = bi < a.ybl ? 0 : bi - a.ybl + 1;
+            int16_t *b = coefs + ((size_t)m * a.bpm + bi) * 64;
+            run_[k] += b[0];
+            bad |= run_[k] < -32768 || run_[k] > 32767;
+            b[0] = (int16_t)run_[k];
+        }
+    if (bad) atomicExch(a.status + im.img, IPX_ERR_INVALID);
+}
+
+}  // namespace
+
+int jpeg_par_sub_bytes() { return kSub; }
+
+hipError_t launch_par_count(const JpegParArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(par_count_kernel, dim3((a.max_nsub + 255) / 256, a.nimg), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_par_unstuff(const JpegParArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(par_unstuff_kernel, dim3((a.max_nsub + 255) / 256, a.nimg), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_par_sync(const JpegParArgs &a, int round, hipStream_t s)
+{
+    static thread_local bool set = false;
+    if (!set) {
+        hipError_t e = hipFuncSetAttribute((const void *)par_sync_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kParLds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)par_write_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kParLds);
+        if (e != hipSuccess) return e;
+        set = true;
+    }
+    hipLaunchKernelGGL(par_sync_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), kParLds, s, a, round);
+    return hipGetLastError();
+}
+hipError_t launch_par_write(const JpegParArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(par_write_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), kParLds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_par_dc(const JpegParArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(par_dc_kernel, dim3(a.nimg), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ipx

@@ -1766,6 +1766,8 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     });
     int ref = -1;
     size_t blob_bytes = 0;
+    std::vector<JpegParImage> par;
+    const bool use_par = env_int("IPX_JPEG_PAR", 1) != 0;
     for (int i = 0; i < n; i++) {
         if (status[i] == IPX_OK) {
             if (ref < 0 && (*w <= 0 || (info[i].w == *w && info[i].h == *h))) ref = i;
@@ -1789,7 +1791,17 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         size_t start = 0;
         int mcu = 0;
         for (uint32_t k : marks[i]) { push(start, k, mcu, I.ri); mcu += I.ri; start = (size_t)k + 2; }
-        push(start, I.scan_len, mcu, nmcu - mcu);
+        if (marks[i].empty() && use_par && I.scan_len >= (size_t)4 * jpeg_par_sub_bytes() && I.scan_len < ((size_t)1 << 28)) {
+            // a long scan without restart markers: decoded in parallel inside the scan (ipx_jpeg_dec_par.hip)
+            JpegParImage pi;
+            memset(&pi, 0, sizeof pi);
+            pi.scan_off = blob_bytes; pi.scan_len = (uint32_t)I.scan_len; pi.img = (uint32_t)i;
+            pi.nsub = (uint32_t)((I.scan_len + jpeg_par_sub_bytes() - 1) / jpeg_par_sub_bytes());
+            memcpy(pi.td, I.td, 3); memcpy(pi.ta, I.ta, 3);
+            par.push_back(pi);
+        } else {
+            push(start, I.scan_len, mcu, nmcu - mcu);
+        }
         valid[i] = 1;
         blob_off[i] = blob_bytes;
         blob_bytes += (I.scan_len + 15 + 16) & ~(size_t)15;
@@ -1848,7 +1860,73 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         if (valid[i] && (memcmp(tabs[i].lut, tabs[ref].lut, sizeof tabs[i].lut) || memcmp(tabs[i].maxcode, tabs[ref].maxcode, sizeof tabs[i].maxcode) ||
                               memcmp(tabs[i].valoff, tabs[ref].valoff, sizeof tabs[i].valoff) || memcmp(tabs[i].vals, tabs[ref].vals, sizeof tabs[i].vals)))
             a.shared_tables = 0;
-    if (e == hipSuccess) e = launch_jpeg_huff(a, s);
+    if (e == hipSuccess && a.nitems > 0) e = launch_jpeg_huff(a, s);
+    if (e == hipSuccess && !par.empty()) {
+        JpegParArgs P{};
+        P.blob = d_blob; P.tab = d_tab; P.nimg = (int)par.size(); P.bpm = R.h0 * R.v0 + 2; P.ybl = R.h0 * R.v0; P.nblk = a.nblk;
+        P.coefs = d_coefs; P.status = d_status;
+        for (auto &pi : par) P.max_nsub = std::max(P.max_nsub, (int)pi.nsub);
+        for (size_t k = 0; k < par.size(); k++) par[k].sub_off = k * (size_t)P.max_nsub;
+        const size_t nsubs = par.size() * (size_t)P.max_nsub;
+        JpegParImage *d_par = nullptr; uint32_t *d_tot = nullptr;
+        if (e == hipSuccess) e = mem.get(&d_par, sizeof(JpegParImage) * par.size());
+        if (e == hipSuccess) e = mem.get(&P.stuffed, nsubs * 4);
+        if (e == hipSuccess) e = mem.get(&P.entry, nsubs * 8);
+        if (e == hipSuccess) e = mem.get(&P.exit_a, nsubs * 8);
+        if (e == hipSuccess) e = mem.get(&P.exit_b, nsubs * 8);
+        if (e == hipSuccess) e = mem.get(&P.ends, nsubs * 4);
+        if (e == hipSuccess) e = mem.get(&P.total_ends, par.size() * 4);
+        if (e == hipSuccess) e = mem.get(&d_tot, par.size() * 4);
+        if (e == hipSuccess) e = mem.get(&P.changed, 4);
+        P.img = d_par;
+        if (e == hipSuccess) e = hipMemcpyAsync(d_par, par.data(), sizeof(JpegParImage) * par.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemsetAsync(P.stuffed, 0, nsubs * 4, s);
+        if (e == hipSuccess) e = hipMemsetAsync(P.entry, 0xff, nsubs * 8, s);
+        if (e == hipSuccess) e = hipMemsetAsync(P.ends, 0, nsubs * 4, s);
+        if (e == hipSuccess) e = mem.get(&P.ublob, blob_bytes + 64);
+        if (e == hipSuccess) e = mem.get(&P.scan_end, par.size() * 4);
+        if (e == hipSuccess) e = mem.get(&P.ulen, par.size() * 4);
+        if (e == hipSuccess) e = hipMemsetAsync(P.ublob, 0, blob_bytes + 64, s);
+        if (e == hipSuccess) e = hipMemsetAsync(P.scan_end, 0xff, par.size() * 4, s);
+        if (e == hipSuccess) e = hipMemsetAsync(P.ulen, 0, par.size() * 4, s);
+        if (e == hipSuccess) e = launch_par_count(P, s);
+        if (e == hipSuccess) e = launch_scan(P.stuffed, P.max_nsub, P.nimg, d_tot, s);
+        if (e == hipSuccess) e = launch_par_unstuff(P, s);
+        if (e == hipSuccess) e = launch_par_sync(P, 0, s);
+        bool converged = false;
+        const int max_rounds = env_int("IPX_JPEG_PAR_ROUNDS", 96);
+        for (int round = 1; e == hipSuccess && round <= max_rounds; round++) {
+            uint32_t changed = 0;
+            e = hipMemsetAsync(P.changed, 0, 4, s);
+            if (e == hipSuccess) e = launch_par_sync(P, round, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(&changed, P.changed, 4, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess && changed == 0) { converged = true; break; }
+        }
+        if (e == hipSuccess && !converged) {
+            // a scan that never settled (it would take a pathological file): hand these images to the serial kernel
+            std::vector<JpegDecImage> serial;
+            for (auto &pi : par) {
+                JpegDecImage it;
+                memset(&it, 0, sizeof it);
+                it.scan_off = pi.scan_off; it.scan_len = pi.scan_len; it.img = pi.img; it.first_mcu = 0; it.n_mcu = (uint32_t)(a.mxx * a.myy);
+                memcpy(it.td, pi.td, 3); memcpy(it.ta, pi.ta, 3);
+                it.valid = 1;
+                serial.push_back(it);
+            }
+            JpegDecImage *d_serial;
+            e = mem.get(&d_serial, sizeof(JpegDecImage) * serial.size());
+            if (e == hipSuccess) e = hipMemcpyAsync(d_serial, serial.data(), sizeof(JpegDecImage) * serial.size(), hipMemcpyHostToDevice, s);
+            JpegDecArgs a2 = a;
+            a2.img = d_serial; a2.nitems = (int)serial.size();
+            if (e == hipSuccess) e = launch_jpeg_huff(a2, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);   // `serial` must outlive the copy
+        } else if (e == hipSuccess) {
+            e = launch_scan(P.ends, P.max_nsub, P.nimg, P.total_ends, s);
+            if (e == hipSuccess) e = launch_par_write(P, s);
+            if (e == hipSuccess) e = launch_par_dc(P, s);
+        }
+    }
     if (e == hipSuccess) e = launch_jpeg_idct(a, pl, s);
     std::vector<int> dev_status(n, 0);
     if (e == hipSuccess) e = hipMemcpyAsync(dev_status.data(), d_status, sizeof(int) * n, hipMemcpyDeviceToHost, s);

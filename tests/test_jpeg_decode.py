@@ -235,3 +235,36 @@ def test_compressed_in_compressed_out(ctx):
         plan.close()
     os.environ.pop("IPX_JPEG_JPEG_CHUNK", None)
     gs.close()
+
+
+@pytest.mark.gpu
+def test_randomised_codec_sweep(ctx):
+    """Seeded sweep over sizes (1..200 px, partial MCUs in both directions), samplings, qualities 1..100, restart intervals and
+    optimised tables: decode on the GPU == oracle decoder, and re-encoding the decoded picture on the GPU == oracle encoder."""
+    rng = np.random.default_rng(20261004)
+    by_shape = {}
+    for t in range(60):
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        sub = int(rng.integers(0, 3))
+        kw = {"quality": int(rng.integers(1, 101)), "subsampling": sub}
+        r = rng.random()
+        if r < 0.3:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 9))
+        elif r < 0.5:
+            kw["restart_marker_rows"] = int(rng.integers(1, 3))
+        if rng.random() < 0.3:
+            kw["optimize"] = True
+        noise = float(rng.choice([0.0, 3.0, 25.0, 90.0]))
+        by_shape.setdefault((w, h, sub), []).append(pil_jpeg(picture(w, h, seed=t, noise=noise), **kw))
+        if rng.random() < 0.5:   # a second file of the same shape with other tables / quality: exercises the per-lane-table kernel
+            kw2 = dict(kw, quality=int(rng.integers(1, 101)), optimize=True)
+            by_shape[(w, h, sub)].append(pil_jpeg(picture(w, h, seed=t + 100, noise=noise), **kw2))
+    for (w, h, sub), files in by_shape.items():
+        info, st = _check_batch(ctx, files)
+        # re-encode the first decoded picture (as RGBA through the oracle's DrawYCbCr) on the GPU
+        d = oracle.jpeg_decode(files[0])
+        chh, cww = {0: (h, w), 1: (h, (w + 1) // 2), 2: ((h + 1) // 2, (w + 1) // 2)}[sub]
+        rgba = oracle.draw_ycbcr(np.zeros((h, w, 4), np.uint8), (0, 0, w, h), np.ascontiguousarray(d["y"][:h, :w]),
+                                 np.ascontiguousarray(d["cb"][:chh, :cww]), np.ascontiguousarray(d["cr"][:chh, :cww]), sub)
+        q = int(rng.integers(1, 101))
+        assert ctx.jpeg_encode(rgba, q) == oracle.jpeg_encode_rgba(rgba, q), (w, h, sub, q)
