@@ -19,8 +19,9 @@
 //              more, now storing coefficients (DC as the difference Go's processSOS would add to its running value);
 //   4. dc      per image and component, the running sum of the DC differences (F.2.1.3.1).
 // After that the coefficient array is what jpeg_huff_kernel would have left, and jpeg_idct_kernel finishes the job.
-// A workgroup is one wave = 64 consecutive sub-sequences of ONE image, staged in LDS (row stride 1028 bytes against bank
-// aliasing) next to that image's Huffman tables.
+// A workgroup is one wave = 64 consecutive sub-sequences of ONE image, with that image's Huffman tables in LDS.  The scan
+// words are read through L1 / L2 (a lane walks its own KiB sequentially); staging the 64 KiB in LDS (IPX_JPEG_PAR_STAGE=1,
+// row stride 1028 bytes against bank aliasing) leaves two waves per CU and is 2.2x slower than the occupancy it costs.
 #include "ipx_internal.h"
 
 namespace ipx {
@@ -183,7 +184,7 @@ __device__ __forceinline__ Tables stage(uint8_t *lds, const JpegParArgs &a, cons
     const uint8_t *scan = a.ublob + im.scan_off;           // unstuffed copy: same offsets as the packed scans, zero padded
     const uint32_t base = (uint32_t)first_sub * kSub;
     const uint32_t cap = (im.scan_len + 15u) & ~15u;       // the unstuffed scan is no longer than the stuffed one
-    const uint32_t avail = cap > base ? min(cap - base, (uint32_t)(64 * kSub + 16)) : 0u;
+    const uint32_t avail = a.stage_rows && cap > base ? min(cap - base, (uint32_t)(64 * kSub + 16)) : 0u;
     for (uint32_t ch = lane; ch < (avail >> 4); ch += 64) {
         const uint4 v = *(const uint4 *)(scan + base + ch * 16);
         const uint32_t i = ch * 16;
@@ -375,12 +376,12 @@ hipError_t launch_par_sync(const JpegParArgs &a, int round, hipStream_t s)
         if (e != hipSuccess) return e;
         set = true;
     }
-    hipLaunchKernelGGL(par_sync_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), kParLds, s, a, round);
+    hipLaunchKernelGGL(par_sync_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows ? kParLds : 4096, s, a, round);
     return hipGetLastError();
 }
 hipError_t launch_par_write(const JpegParArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(par_write_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), kParLds, s, a);
+    hipLaunchKernelGGL(par_write_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows ? kParLds : 4096, s, a);
     return hipGetLastError();
 }
 hipError_t launch_par_dc(const JpegParArgs &a, hipStream_t s)

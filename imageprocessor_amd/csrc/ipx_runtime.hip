@@ -1865,6 +1865,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         JpegParArgs P{};
         P.blob = d_blob; P.tab = d_tab; P.nimg = (int)par.size(); P.bpm = R.h0 * R.v0 + 2; P.ybl = R.h0 * R.v0; P.nblk = a.nblk;
         P.coefs = d_coefs; P.status = d_status;
+        P.stage_rows = env_int("IPX_JPEG_PAR_STAGE", 0);   // measured: 109 ms staged (2 waves per CU) against 49 ms through L1 / L2 (1024 x 1080p)
         for (auto &pi : par) P.max_nsub = std::max(P.max_nsub, (int)pi.nsub);
         for (size_t k = 0; k < par.size(); k++) par[k].sub_off = k * (size_t)P.max_nsub;
         const size_t nsubs = par.size() * (size_t)P.max_nsub;
@@ -1901,6 +1902,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
             if (e == hipSuccess) e = launch_par_sync(P, round, s);
             if (e == hipSuccess) e = hipMemcpyAsync(&changed, P.changed, 4, hipMemcpyDeviceToHost, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (getenv("IPX_DEBUG")) fprintf(stderr, "[ipx] jpeg par sync round %d: %u entries changed\n", round, changed);
             if (e == hipSuccess && changed == 0) { converged = true; break; }
         }
         if (e == hipSuccess && !converged) {
