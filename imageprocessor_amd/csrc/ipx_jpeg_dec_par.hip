@@ -237,11 +237,42 @@ __global__ __launch_bounds__(256) void par_unstuff_kernel(JpegParArgs a)
     const uint32_t b0 = (uint32_t)t * kSub, b1 = min(b0 + kSub, end);
     uint32_t o = b0 - a.stuffed[im.sub_off + t];
     uint32_t prev = b0 > 0 ? scan[b0 - 1] : 0u;
-    for (uint32_t j = b0; j < b1; j++) {
-        const uint32_t c = scan[j];
-        if (!(prev == 0xff && c == 0x00)) dst[o++] = (uint8_t)c;
-        prev = c;
+    // whole input words (chunks start 4-byte aligned) through a small byte queue; output words are stored whole only when
+    // this thread owns all four bytes and they are aligned, the ragged ends go out byte by byte (the neighbours' do too)
+    unsigned long long q = 0;
+    int nq = 0;
+    uint32_t j = b0;
+    auto push = [&](uint32_t c) { q |= (unsigned long long)c << (8 * nq); nq++; };
+    auto drain = [&](bool all) {
+        while (nq >= 4 || (all && nq > 0)) {
+            if (nq >= 4 && (o & 3u) == 0) { *(uint32_t *)(dst + o) = (uint32_t)q; q >>= 32; nq -= 4; o += 4; }
+            else { dst[o++] = (uint8_t)q; q >>= 8; nq--; }
+        }
+    };
+    for (; j + 4 <= b1; j += 4) {
+        const uint32_t wv = *(const uint32_t *)(scan + j);
+        const uint32_t inv = ~wv;
+        if (prev != 0xff && ((inv - 0x01010101u) & ~inv & 0x80808080u) == 0) {   // no 0xff in sight: nothing to drop
+            q |= (unsigned long long)wv << (8 * nq);
+            nq += 4;
+            prev = wv >> 24;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t c = (wv >> (8 * k)) & 0xffu;
+                if (!(prev == 0xff && c == 0x00)) push(c);
+                prev = c;
+            }
+        }
+        drain(false);
     }
+    for (; j < b1; j++) {
+        const uint32_t c = scan[j];
+        if (!(prev == 0xff && c == 0x00)) push(c);
+        prev = c;
+        drain(false);
+    }
+    drain(true);
     if (b0 < end && b1 == end) a.ulen[blockIdx.y] = o;       // the chunk that holds the last byte of the scan
 }
 

@@ -99,3 +99,21 @@ for label, pool_ in (("no restart markers", files), ("one restart interval per M
         assert not any(st)
         print("JPEG files (%s, %.0f KB) -> decode + operators + three encodes on the GPU: %d files in %.1f ms = %.0f images/s"
               % (label, len(batch[0]) / 1e3, m, best * 1e3, m / best))
+
+# two callers at once (the worker's goroutines): each call leases its own lane, so one batch decodes while the other encodes
+import threading
+batch = [files[i % 4] for i in range(1024)]
+def call():
+    out, st = plan2.run_jpeg_jpeg(batch, copy=False)
+    assert not any(st)
+for nthreads in (2, 3):
+    best = 1e9
+    for _ in range(2):
+        ths = [threading.Thread(target=call) for _ in range(nthreads)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        best = min(best, time.perf_counter() - t0)
+    print("JPEG files -> JPEG streams, %d concurrent callers x 1024 files: %.1f ms = %.0f images/s" % (nthreads, best * 1e3, nthreads * 1024 / best))
