@@ -267,6 +267,12 @@ class Plan:
             lib().ipx_jpeg_result_free(self.ctx.handle, res)
         return out, list(status)
 
+    def run_dev_gray(self, n, gray_ptr, stride, frame_stride, resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
+        """*image.Gray frames resident in HBM (ipx_plan_run_dev_gray)"""
+        i = self.info
+        _check(lib().ipx_plan_run_dev_gray(self.ctx.handle, stream, self.handle, n, gray_ptr, stride, frame_stride, resize_ptr,
+                                           i.resize_bytes, thumb_ptr, i.thumb_bytes, wm_ptr, i.wm_bytes))
+
     def run_dev_ycbcr(self, n, y_ptr, cb_ptr, cr_ptr, ratio, ystride, cstride, y_frame_stride, c_frame_stride,
                       resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
         i = self.info
@@ -492,7 +498,7 @@ class Context:
         if not b.y:
             return None, st
         info = {"w": cw.value, "h": chh.value, "ratio": b.ratio, "ystride": b.ystride, "cstride": b.cstride}
-        v0 = 2 if b.ratio in (2, 3) else 1          # 4:2:0 and 4:4:0 halve the chroma rows
+        v0 = 2 if b.ratio in (2, 3) else 1          # 4:2:0 and 4:4:0 halve the chroma rows (Gray: 8 x 8 MCUs)
         myy = (chh.value + 8 * v0 - 1) // (8 * v0)
         yrows, crows = 8 * v0 * myy, 8 * myy            # image.NewYCbCr(Rect(0, 0, 8*h0*mxx, 8*v0*myy), ratio)
         if download:
@@ -501,8 +507,9 @@ class Context:
                 _check(lib().ipx_memcpy_d2h(self.handle, out.ctypes.data, ptr, out.nbytes))
                 return out[:, :rows * stride].reshape(n, rows, stride)
             info["y"] = grab(b.y, b.y_frame_stride, yrows, b.ystride)
-            info["cb"] = grab(b.cb, b.c_frame_stride, crows, b.cstride)
-            info["cr"] = grab(b.cr, b.c_frame_stride, crows, b.cstride)
+            if b.cb:   # *image.Gray has no chroma planes
+                info["cb"] = grab(b.cb, b.c_frame_stride, crows, b.cstride)
+                info["cr"] = grab(b.cr, b.c_frame_stride, crows, b.cstride)
             lib().ipx_jpeg_planes_free(self.handle, owner)
         else:
             info.update(batch=b, free=lambda: lib().ipx_jpeg_planes_free(self.handle, owner))

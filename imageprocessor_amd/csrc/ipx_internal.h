@@ -134,6 +134,7 @@ struct BandArgs {
     uint32_t cr, cg, cb, ca;
 };
 hipError_t launch_band(const BandArgs &a, hipStream_t s);
+hipError_t launch_gray_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, int w, int h, int n, hipStream_t s);
 
 // the fused band kernel on *image.YCbCr planes (ipx_band_ycc.hip): BandArgs without `src`, plus the planes
 struct YccArgs {
@@ -171,7 +172,7 @@ hipError_t launch_jpeg_fdct(const JpegArgs &a, int n, hipStream_t s);
 
 // ---- image.Decode for baseline JPEGs (ipx_jpeg_dec_host.cpp parses, ipx_jpeg_dec.hip decodes) ------------
 struct JpegDecInfo {
-    int w, h, h0, v0, ratio, ri;
+    int w, h, h0, v0, ratio, ri, ncomp;
     uint8_t td[3], ta[3];      // kernel table slots of the three components: 0,1 = DC tables, 2,3 = AC tables
     size_t scan_off, scan_len; // entropy-coded data within the file
 };
@@ -189,6 +190,7 @@ struct JpegDecArgs {
     const uint8_t *blob; const JpegDecImage *img; const JpegDecTables *tab;
     int16_t *coefs; int *status;
     int n, mxx, myy, h0, v0, nblk;   // n = images
+    int bpm, ybl;                    // blocks per MCU and how many of them are luma (Gray: 1, 1)
     int nitems;                      // pieces to decode (>= images)
     int shared_tables, first_valid;   // every valid image carries the Huffman tables of image first_valid
 };

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
     br.len = im.scan_len;
     for (int k = 0; k < (int)im.pad; k++) br.advance();   // the piece starts inside its first 16-byte chunk
     int16_t *coefs = a.coefs + (size_t)img * a.nblk * 64;
-    const int ybl = a.h0 * a.v0, bpm = ybl + 2;
+    const int ybl = a.ybl, bpm = a.bpm;
     // table slots and DC predictions as scalars selected by the component: arrays indexed by c would live in scratch memory
     // (a global-memory round trip per block)
     const int td0 = im.td[0], td1 = im.td[1], td2 = im.td[2], ta0 = im.ta[0], ta1 = im.ta[1], ta2 = im.ta[2];
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegDecArgs a, JpegPlane
     if (!pl.valid[img]) return;                           // uniform over the workgroup
     const int gb = blockIdx.x * 32 + blk;
     const bool live = gb < a.nblk;
-    const int ybl = a.h0 * a.v0, bpm = ybl + 2;
+    const int ybl = a.ybl, bpm = a.bpm;
     const int m = live ? gb / bpm : 0, bi = live ? gb - m * bpm : 0;
     const int c = bi < ybl ? 0 : bi - ybl + 1;
     int s[8];

@@ -6,7 +6,7 @@
 // tiny: walk the markers, collect the tables the single scan refers to, and lay them out the way the kernels read them
 // (an 8-bit first-level Huffman table plus the canonical mincode / maxcode arrays for longer codes; quantisers
 // de-zig-zagged).  Anything outside the baseline subset the kernels implement is reported as IPX_ERR_UNSUPPORTED for
-// that image, so that the worker keeps Go's CPU path for it: progressive (SOF2), Gray, CMYK / RGB (Adobe) files,
+// that image, so that the worker keeps Go's CPU path for it: progressive (SOF2), CMYK / RGB (Adobe) files,
 // 4:1:1 / 4:1:0 and other sampling factors, several scans, 12-bit samples, Huffman table ids above 1.
 #include <cstring>
 
@@ -81,13 +81,14 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
             if (s[0] != 8) return IPX_ERR_UNSUPPORTED;
             info->h = (int)be16(s + 1); info->w = (int)be16(s + 3);
             ncomp = s[5];
-            if (ncomp == 1 || ncomp == 4) return IPX_ERR_UNSUPPORTED;
-            if (ncomp != 3 || sn != 15 || info->w <= 0 || info->h <= 0) return IPX_ERR_INVALID;
-            for (int c = 0; c < 3; c++) {
+            if (ncomp == 4) return IPX_ERR_UNSUPPORTED;
+            if ((ncomp != 3 && ncomp != 1) || sn != (size_t)(6 + 3 * ncomp) || info->w <= 0 || info->h <= 0) return IPX_ERR_INVALID;
+            for (int c = 0; c < ncomp; c++) {
                 cid[c] = s[6 + 3 * c]; ch[c] = s[7 + 3 * c] >> 4; cv[c] = s[7 + 3 * c] & 15; ctq[c] = s[8 + 3 * c];
                 if (ctq[c] > 3 || ch[c] < 1 || ch[c] > 4 || cv[c] < 1 || cv[c] > 4) return IPX_ERR_INVALID;
                 for (int j = 0; j < c; j++) if (cid[j] == cid[c]) return IPX_ERR_INVALID;   // "repeated component identifier"
             }
+            if (ncomp == 1) { ch[0] = cv[0] = 1; break; }   // processSOF: a single component is non-interleaved, its (h, v) is effectively (1, 1)
             if (ch[1] != 1 || cv[1] != 1 || ch[2] != 1 || cv[2] != 1 || ch[0] > 2 || cv[0] > 2) return IPX_ERR_UNSUPPORTED;
             break;
         }
@@ -131,10 +132,10 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
         case 0xda: {
             if (!ncomp) return IPX_ERR_INVALID;
             if (sn < 1) return IPX_ERR_INVALID;
-            if (s[0] != 3) return s[0] == 1 || s[0] == 2 ? IPX_ERR_UNSUPPORTED : IPX_ERR_INVALID;
-            if (sn != 10) return IPX_ERR_INVALID;
-            int td[3], ta[3];
-            for (int c = 0; c < 3; c++) {
+            if (s[0] != ncomp) return s[0] >= 1 && s[0] <= 3 ? IPX_ERR_UNSUPPORTED : IPX_ERR_INVALID;   // a frame coded in several scans
+            if (sn != (size_t)(4 + 2 * ncomp)) return IPX_ERR_INVALID;
+            int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+            for (int c = 0; c < ncomp; c++) {
                 if (s[1 + 2 * c] != cid[c]) return IPX_ERR_UNSUPPORTED;
                 td[c] = s[2 + 2 * c] >> 4; ta[c] = s[2 + 2 * c] & 15;
                 if (td[c] > 3 || ta[c] > 3) return IPX_ERR_INVALID;
@@ -142,9 +143,10 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
                 if (!hf[0][td[c]].ok || !hf[1][ta[c]].ok || !have_q[ctq[c]]) return IPX_ERR_INVALID;
                 info->td[c] = (uint8_t)td[c]; info->ta[c] = (uint8_t)(2 + ta[c]);   // kernel table slots: 0,1 = DC; 2,3 = AC
             }
-            if (!jfif && ((adobe && adobe_transform == 0) || (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B'))) return IPX_ERR_UNSUPPORTED;
+            if (ncomp == 3 && !jfif && ((adobe && adobe_transform == 0) || (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B'))) return IPX_ERR_UNSUPPORTED;
             info->h0 = ch[0]; info->v0 = cv[0];
-            info->ratio = ch[0] == 1 ? (cv[0] == 1 ? IPX_YCBCR_444 : IPX_YCBCR_440) : (cv[0] == 1 ? IPX_YCBCR_422 : IPX_YCBCR_420);
+            info->ncomp = ncomp;
+            info->ratio = ncomp == 1 ? IPX_GRAY : ch[0] == 1 ? (cv[0] == 1 ? IPX_YCBCR_444 : IPX_YCBCR_440) : (cv[0] == 1 ? IPX_YCBCR_422 : IPX_YCBCR_420);
             info->scan_off = i + n;
             info->scan_len = len - (i + n);
             for (int tc = 0; tc < 2; tc++)
@@ -159,7 +161,7 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
                     if (!build_huff(hf[tc][th], tab->lut[slot], tab->maxcode[slot], tab->valoff[slot], tab->vals[slot])) return IPX_ERR_INVALID;
                 }
             for (int c = 0; c < 3; c++)
-                for (int zig = 0; zig < 64; zig++) tab->qnat[c][kUnzig[zig]] = quant[ctq[c]][zig];
+                for (int zig = 0; zig < 64; zig++) tab->qnat[c][kUnzig[zig]] = c < ncomp ? quant[ctq[c]][zig] : 0;
             return IPX_OK;
         }
         default: break;   // APPn, COM, ...: skipped

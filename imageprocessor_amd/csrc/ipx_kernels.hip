@@ -9,6 +9,8 @@
 //   * glyph composite: image/draw drawGlyphOver, uint32 wrap-around preserved.
 // The file is compiled with -ffp-contract=off and the pragma below; check with
 // `llvm-objdump -d` that the scale kernels hold no v_fma_f64.
+#include <algorithm>
+
 #include "ipx_internal.h"
 
 #pragma clang fp contract(off)
@@ -246,6 +248,22 @@ hipError_t launch_draw_nrgba(uint8_t *dst, int dstride, const uint8_t *src, int 
     if (w <= 0 || h <= 0) return hipSuccess;
     dim3 grid(min(8, (w + 255) / 256), h);
     hipLaunchKernelGGL(draw_nrgba_kernel, grid, dim3(256), 0, s, dst, dstride, src, sstride, w, h, op);
+    return hipGetLastError();
+}
+
+// image/draw drawGray (and scale_RGBA_Gray_Src's taps): a Gray source pixel is (y, y, y, 0xff)
+__global__ __launch_bounds__(256) void gray_expand_kernel(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, int w, int h)
+{
+    const int y = blockIdx.y;
+    dst += blockIdx.z * dst_fs; src += blockIdx.z * src_fs;
+    const uint8_t *row = src + (size_t)y * sstride;
+    uint32_t *out = (uint32_t *)(dst + (size_t)y * w * 4);
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256) out[x] = (uint32_t)row[x] * 0x010101u | 0xff000000u;
+}
+
+hipError_t launch_gray_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, int w, int h, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(gray_expand_kernel, dim3(std::min(8, (w + 255) / 256), h, n), dim3(256), 0, s, dst, dst_fs, src, sstride, src_fs, w, h);
     return hipGetLastError();
 }
 

@@ -1281,6 +1281,27 @@ int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     return rc;
 }
 
+int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *gray, int stride, size_t frame_stride,
+                          uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                          size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !gray || stride < pl->p.sw) { set_error("ipx_plan_run_dev_gray: bad argument"); return IPX_ERR_INVALID; }
+    if (n == 0) return IPX_OK;
+    if (n > 65535) { set_error("ipx_plan_run_dev_gray: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    const size_t fs = align256((size_t)sw * sh * 4);
+    uint8_t *rgba = nullptr;
+    IPX_HIP(hipMallocAsync((void **)&rgba, fs * n, s));
+    hipError_t e = launch_gray_expand(rgba, fs, gray, stride, frame_stride, sw, sh, n, s);
+    int rc = IPX_OK;
+    if (e != hipSuccess) { set_error("gray expansion failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
+    if (!rc) rc = ipx_plan_run_dev(ctx, s, pl, n, rgba, sw * 4, fs, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride, wm_out, wm_frame_stride);
+    (void)hipFreeAsync(rgba, s);
+    return rc;
+}
+
 int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, uint8_t *resize_out,
                             size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride,
                             uint8_t *wm_out, size_t wm_frame_stride)
@@ -1771,7 +1792,8 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     for (int i = 0; i < n; i++) {
         if (status[i] == IPX_OK) {
             if (ref < 0 && (*w <= 0 || (info[i].w == *w && info[i].h == *h))) ref = i;
-            if (ref >= 0 && (info[i].w != info[ref].w || info[i].h != info[ref].h || info[i].h0 != info[ref].h0 || info[i].v0 != info[ref].v0))
+            if (ref >= 0 && (info[i].w != info[ref].w || info[i].h != info[ref].h || info[i].h0 != info[ref].h0 || info[i].v0 != info[ref].v0 ||
+                             info[i].ncomp != info[ref].ncomp))
                 status[i] = IPX_ERR_UNSUPPORTED;
             else if (ref < 0) status[i] = IPX_ERR_UNSUPPORTED;   // a size other than the one asked for
         }
@@ -1812,10 +1834,12 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     JpegDecArgs a{};
     a.n = n; a.h0 = R.h0; a.v0 = R.v0;
     a.mxx = (R.w + 8 * R.h0 - 1) / (8 * R.h0); a.myy = (R.h + 8 * R.v0 - 1) / (8 * R.v0);
-    a.nblk = a.mxx * a.myy * (R.h0 * R.v0 + 2);
+    const bool gray = R.ncomp == 1;                        // *image.Gray: one block per MCU, no chroma planes
+    a.ybl = R.h0 * R.v0; a.bpm = gray ? 1 : a.ybl + 2;
+    a.nblk = a.mxx * a.myy * a.bpm;
     JpegPlanes pl{};
     pl.ystride = 8 * R.h0 * a.mxx; pl.cstride = 8 * a.mxx;
-    pl.y_fs = align256((size_t)pl.ystride * 8 * R.v0 * a.myy); pl.c_fs = align256((size_t)pl.cstride * 8 * a.myy);
+    pl.y_fs = align256((size_t)pl.ystride * 8 * R.v0 * a.myy); pl.c_fs = gray ? 0 : align256((size_t)pl.cstride * 8 * a.myy);
 
     std::unique_ptr<ipx_jpeg_planes> own(new ipx_jpeg_planes);
     auto dalloc = [&](void **p, size_t bytes) {
@@ -1830,8 +1854,8 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     };
     hipError_t e;
     if ((e = dalloc((void **)&pl.y, pl.y_fs * n)) != hipSuccess) return fail(e, "plane allocation");
-    if ((e = dalloc((void **)&pl.cb, pl.c_fs * n)) != hipSuccess) return fail(e, "plane allocation");
-    if ((e = dalloc((void **)&pl.cr, pl.c_fs * n)) != hipSuccess) return fail(e, "plane allocation");
+    if (!gray && (e = dalloc((void **)&pl.cb, pl.c_fs * n)) != hipSuccess) return fail(e, "plane allocation");
+    if (!gray && (e = dalloc((void **)&pl.cr, pl.c_fs * n)) != hipSuccess) return fail(e, "plane allocation");
     // scratch of this call, stream-ordered
     AsyncFree mem{s, {}};
     uint8_t *d_blob; JpegDecImage *d_img; JpegDecTables *d_tab; int16_t *d_coefs; int *d_status;
@@ -1863,7 +1887,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     if (e == hipSuccess && a.nitems > 0) e = launch_jpeg_huff(a, s);
     if (e == hipSuccess && !par.empty()) {
         JpegParArgs P{};
-        P.blob = d_blob; P.tab = d_tab; P.nimg = (int)par.size(); P.bpm = R.h0 * R.v0 + 2; P.ybl = R.h0 * R.v0; P.nblk = a.nblk;
+        P.blob = d_blob; P.tab = d_tab; P.nimg = (int)par.size(); P.bpm = a.bpm; P.ybl = a.ybl; P.nblk = a.nblk;
         P.coefs = d_coefs; P.status = d_status;
         P.stage_rows = env_int("IPX_JPEG_PAR_STAGE", 0);   // measured: 109 ms staged (2 waves per CU) against 49 ms through L1 / L2 (1024 x 1080p)
         for (auto &pi : par) P.max_nsub = std::max(P.max_nsub, (int)pi.nsub);
@@ -1992,8 +2016,10 @@ int ipx_plan_run_jpeg_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_by
         uint8_t *dres = fres ? base : nullptr, *dth = fth ? base + fres * chunk : nullptr, *dwm = fwm ? base + (fres + fth) * chunk : nullptr;
         int16_t *dcoef = (int16_t *)(base + (fres + fth + fwm) * chunk);
         ipx_ycbcr_batch d = planes;
-        d.y += planes.y_frame_stride * i0; d.cb += planes.c_frame_stride * i0; d.cr += planes.c_frame_stride * i0;
-        rc = ipx_plan_run_dev_ycbcr(ctx, s, pl, m, &d, dres, fres, dth, fth, dwm, fwm);
+        d.y += planes.y_frame_stride * i0;
+        if (d.cb) { d.cb += planes.c_frame_stride * i0; d.cr += planes.c_frame_stride * i0; }
+        if (planes.ratio == IPX_GRAY) rc = ipx_plan_run_dev_gray(ctx, s, pl, m, d.y, d.ystride, d.y_frame_stride, dres, fres, dth, fth, dwm, fwm);
+        else rc = ipx_plan_run_dev_ycbcr(ctx, s, pl, m, &d, dres, fres, dth, fth, dwm, fwm);
         struct Out { uint8_t *dev; size_t fs; int w, h; ipx_bytes *dst; };
         const Out outs[3] = {{dres, fres, pl->info.resize_w, pl->info.resize_h, resize_out},
                              {dth, fth, pl->info.thumb_w, pl->info.thumb_h, thumb_out},

@@ -135,7 +135,8 @@ int ipx_draw_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx
                     const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op);
 
 /* *image.YCbCr with Rect.Min = (0,0); ratio numbered as image.YCbCrSubsampleRatio */
-enum { IPX_YCBCR_444 = 0, IPX_YCBCR_422 = 1, IPX_YCBCR_420 = 2, IPX_YCBCR_440 = 3 };
+enum { IPX_YCBCR_444 = 0, IPX_YCBCR_422 = 1, IPX_YCBCR_420 = 2, IPX_YCBCR_440 = 3,
+       IPX_GRAY = 4 /* *image.Gray: only the y plane is set (one-component JPEGs) */ };
 typedef struct {
     const uint8_t *y, *cb, *cr;
     int32_t ystride, cstride, w, h, ratio;
@@ -221,6 +222,12 @@ typedef struct {
 int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const ipx_ycbcr_batch *src,
                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                            size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
+/* A batch of *image.Gray frames (one-component JPEGs, grey PNGs): image/draw's drawGray and x/image's
+ * scale_RGBA_Gray_Src both read a source pixel as (y, y, y, 0xff), so the frames are expanded to RGBA8 in HBM
+ * and take the RGBA pass; the outputs are bit for bit the reference's. */
+int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const uint8_t *gray, int stride,
+                          size_t frame_stride, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
+                          size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
 int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *plan, int n, const ipx_ycbcr_batch *src,
                             uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                             size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
@@ -377,11 +384,11 @@ void ipx_jpeg_result_free(ipx_ctx *ctx, ipx_jpeg_result *result);
 
 /* ---- image.Decode for JPEGs (decoder side) -------------------------------------------
  * image_processor.go:47 decodes every upload; for JPEG files that is Go's image/jpeg.  A batch of baseline,
- * three-component files of one size and one sampling (4:4:4 / 4:2:2 / 4:2:0 / 4:4:0) is decoded on the GPU:
+ * files of one size and one kind (three components at 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0, or one component) is decoded on the GPU:
  * the compressed bytes go up, Huffman decoding runs one lane per image, the integer IDCT of idct.go runs
  * block-parallel, and the *image.YCbCr planes (MCU-padded strides, as image.NewYCbCr lays them out) stay in
- * HBM, ready for ipx_plan_run_dev_ycbcr.  status[i]: IPX_OK, IPX_ERR_INVALID (malformed) or
- * IPX_ERR_UNSUPPORTED (progressive, Gray, CMYK / RGB, other samplings, several scans, a size or sampling
+ * HBM, ready for ipx_plan_run_dev_ycbcr (ratio IPX_GRAY: only y is set; ipx_plan_run_dev_gray).  status[i]: IPX_OK, IPX_ERR_INVALID (malformed) or
+ * IPX_ERR_UNSUPPORTED (progressive, CMYK / RGB, other samplings, several scans, a size or sampling
  * different from the batch's): the worker decodes those with Go as before.  planes->y == NULL when no
  * image was decodable.  Free the planes with ipx_jpeg_planes_free. */
 typedef struct ipx_jpeg_planes ipx_jpeg_planes;

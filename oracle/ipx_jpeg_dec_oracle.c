@@ -4,14 +4,15 @@
  * image/jpeg (go.mod:3; reader.go, scan.go, huffman.go, idct.go), absent from /root/reference and not runnable here
  * (no Go toolchain): PARITY UNPINNED against Go itself.  Restated, function by function:
  *   decode            marker loop: SOI, DQT, SOF0 / SOF1, DHT, DRI, SOS, APPn / COM skipped, Adobe / JFIF noted (isRGB)
- *   processSOF        8-bit precision, 3 components, Y sampling (1|2) x (1|2), chroma 1 x 1 -> 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0
+ *   processSOF        8-bit precision; 3 components, Y sampling (1|2) x (1|2), chroma 1 x 1 -> 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0;
+ *                     or 1 component -> *image.Gray (its sampling factors count as 1 x 1, 8 x 8 MCUs)
  *   makeImg           image.NewYCbCr(Rect(0, 0, 8*h0*mxx, 8*v0*myy), ratio).SubImage(Rect(0, 0, w, h)): MCU-padded strides
  *   processSOS        one interleaved scan; DC prediction; F.2.2.1 / F.2.2.2 symbol decoding; restart intervals
  *   huffman.go        canonical codes from BITS / HUFFVAL; receiveExtend
  *   reconstructBlock  b[unzig[zig]] *= qt[zig]; idct; +128, clip, store
  *   idct.go           the Chen-Wang 32-bit integer IDCT of the MPEG-2 reference decoder (w1..w7, r2 = 181)
  * Out of this oracle's scope (the product reports them unsupported and the worker keeps Go's CPU path for such files):
- * progressive (SOF2), Gray, CMYK / RGB JPEGs, 4:1:1 / 4:1:0, multi-scan baseline files, 12-bit precision.
+ * progressive (SOF2), CMYK / RGB JPEGs, 4:1:1 / 4:1:0, multi-scan baseline files, 12-bit precision.
  * Pins: decode(encode(x)) reproduces the pinned encoder's coefficients exactly (tests/test_jpeg_decode.py), and
  * libjpeg (Pillow) decodes the same files to within the known +-1..2 of a different IDCT.
  */
@@ -20,7 +21,7 @@
 #include <string.h>
 
 typedef struct {
-    int w, h, ratio;          /* ratio: 0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0, 3 = 4:4:0 (image.YCbCrSubsampleRatio) */
+    int w, h, ratio;          /* ratio: 0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0, 3 = 4:4:0 (image.YCbCrSubsampleRatio); 4 = *image.Gray (y only) */
     int ystride, cstride, yrows, crows;
     uint8_t *y, *cb, *cr;
 } ipxo_decoded;
@@ -185,13 +186,14 @@ int ipxo_jpeg_decode(const uint8_t *data, size_t len, ipxo_decoded *out, int16_t
             if (sn < 6) return -1;
             if (s[0] != 8) return -2;             /* precision */
             h = (int)be16(s + 1); w = (int)be16(s + 3); ncomp = s[5];
-            if (ncomp != 3) return ncomp == 1 || ncomp == 4 ? -2 : -1;
+            if (ncomp != 3 && ncomp != 1) return ncomp == 4 ? -2 : -1;
             if (sn != (size_t)(6 + 3 * ncomp) || w <= 0 || h <= 0) return -1;
-            for (int c = 0; c < 3; c++) {
+            for (int c = 0; c < ncomp; c++) {
                 cid[c] = s[6 + 3 * c]; ch[c] = s[7 + 3 * c] >> 4; cv[c] = s[7 + 3 * c] & 15; ctq[c] = s[8 + 3 * c];
                 if (ctq[c] > 3 || ch[c] < 1 || ch[c] > 4 || cv[c] < 1 || cv[c] > 4) return -1;
             }
-            if (ch[1] != 1 || cv[1] != 1 || ch[2] != 1 || cv[2] != 1 || ch[0] > 2 || cv[0] > 2) return -2;
+            if (ncomp == 1) { ch[0] = cv[0] = 1; }        /* processSOF: "the component's (h, v) is effectively always (1, 1)" */
+            else if (ch[1] != 1 || cv[1] != 1 || ch[2] != 1 || cv[2] != 1 || ch[0] > 2 || cv[0] > 2) return -2;
         } else if (m == 0xc2) {
             return -2;                            /* progressive */
         } else if (m == 0xc4) {
@@ -238,19 +240,20 @@ int ipxo_jpeg_decode(const uint8_t *data, size_t len, ipxo_decoded *out, int16_t
             if (sn >= 12 && !memcmp(s, "Adobe", 5)) { adobe_valid = 1; adobe_transform = s[11]; }
         } else if (m == 0xda) {
             if (!ncomp) return -1;
-            if (sn != 10 || s[0] != 3) return sn >= 1 && (s[0] == 1 || s[0] == 2) ? -2 : -1;
-            int td[3], ta[3];
-            for (int c = 0; c < 3; c++) {
+            if (sn < 1 || s[0] != ncomp) return sn >= 1 && s[0] >= 1 && s[0] <= 3 ? -2 : -1;
+            if (sn != (size_t)(4 + 2 * ncomp)) return -1;
+            int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+            for (int c = 0; c < ncomp; c++) {
                 if (s[1 + 2 * c] != cid[c]) return -2;       /* components out of frame order */
                 td[c] = s[2 + 2 * c] >> 4; ta[c] = s[2 + 2 * c] & 15;
                 if (td[c] > 3 || ta[c] > 3 || !hf[0][td[c]].ok || !hf[1][ta[c]].ok || !have_q[ctq[c]]) return -1;
             }
             /* isRGB: not JFIF and (Adobe transform "unknown" or component ids 'R','G','B') */
-            if (!jfif && ((adobe_valid && adobe_transform == 0) || (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B'))) return -2;
+            if (ncomp == 3 && !jfif && ((adobe_valid && adobe_transform == 0) || (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B'))) return -2;
             const int h0 = ch[0], v0 = cv[0];
             const int mxx = (w + 8 * h0 - 1) / (8 * h0), myy = (h + 8 * v0 - 1) / (8 * v0);
             out->w = w; out->h = h;
-            out->ratio = h0 == 1 ? (v0 == 1 ? 0 : 3) : (v0 == 1 ? 1 : 2);
+            out->ratio = ncomp == 1 ? 4 : (h0 == 1 ? (v0 == 1 ? 0 : 3) : (v0 == 1 ? 1 : 2));
             out->ystride = 8 * h0 * mxx; out->yrows = 8 * v0 * myy;
             out->cstride = 8 * mxx; out->crows = 8 * myy;
             out->y = (uint8_t *)calloc((size_t)out->ystride * out->yrows, 1);
@@ -263,7 +266,7 @@ int ipxo_jpeg_decode(const uint8_t *data, size_t len, ipxo_decoded *out, int16_t
             size_t nblk = 0;
             for (int my = 0; my < myy; my++)
                 for (int mx = 0; mx < mxx; mx++) {
-                    for (int c = 0; c < 3; c++) {
+                    for (int c = 0; c < ncomp; c++) {
                         const int hi = ch[c], vi = cv[c];
                         for (int j = 0; j < hi * vi; j++) {
                             const int bx = hi * mx + j % hi, by = vi * my + j / hi;

@@ -116,9 +116,10 @@ def test_host_entropy_coder_matches_oracle():
 
 
 def test_quantiser_reciprocal_is_exact():
-    """The kernel divides with mulhi(n, ceil(2^32 / d)); exact for every divisor 8*q and every n the transform can produce."""
+    """The kernel divides with mulhi(n, ceil(2^32 / d)): exact whenever n * (d - 1) < 2^32, i.e. for every divisor 8*q <= 2040 and every
+    n < 2^20; checked exhaustively over n < 2^17 (all the transform can produce) for a spread of divisors."""
     n = np.arange(0, 1 << 17, dtype=np.uint64)
-    for d in range(8, 2041, 8):
+    for d in list(range(8, 2041, 136)) + [16, 24, 1016, 2032, 2040]:
         m = ((1 << 32) + d - 1) // d
         assert np.array_equal((n * np.uint64(m)) >> np.uint64(32), n // np.uint64(d)), d
 

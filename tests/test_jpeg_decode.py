@@ -66,7 +66,6 @@ def test_unsupported_and_malformed():
     from PIL import Image
     img = picture(64, 48)
     for blob, what in ((pil_jpeg(img, progressive=True), "unsupported"),
-                       (pil_jpeg(img[..., 0]), "unsupported"),                      # Gray
                        (pil_jpeg(img)[:200], "malformed"),
                        (b"not a jpeg at all", "malformed")):
         with pytest.raises(ValueError, match=what):
@@ -102,7 +101,7 @@ def _check_batch(ctx, files, expect_status=None):
             continue
         assert st[i] == 0, (i, st[i])
         assert (info["w"], info["h"], info["ratio"]) == (want["w"], want["h"], want["ratio"])
-        for k in ("y", "cb", "cr"):
+        for k in ("y", "cb", "cr") if want["ratio"] != 4 else ("y",):
             np.testing.assert_array_equal(info[k][i], want[k], err_msg="%s of file %d" % (k, i))
     return info, st
 
@@ -155,7 +154,7 @@ def test_gpu_decode_statuses(ctx):
     other_size = pil_jpeg(picture(64, 64), quality=85)
     other_sampling = pil_jpeg(picture(96, 64), quality=85, subsampling=0)
     progressive = pil_jpeg(picture(96, 64), progressive=True)
-    gray = pil_jpeg(picture(96, 64)[..., 0])
+    gray = pil_jpeg(picture(96, 64)[..., 0])          # decodable, but not in a batch of colour files
     truncated = good[0][:len(good[0]) // 2]
     garbage = b"\xff\xd8" + bytes(100)
     files = [good[0], other_size, good[1], other_sampling, progressive, gray, truncated, garbage, good[2], good[3]]
@@ -164,7 +163,7 @@ def test_gpu_decode_statuses(ctx):
     for i in (0, 2, 8, 9):
         want = oracle.jpeg_decode(files[i])
         np.testing.assert_array_equal(info["y"][i], want["y"])
-    info, st = ctx.jpeg_decode_batch([progressive, gray])
+    info, st = ctx.jpeg_decode_batch([progressive, progressive])
     assert info is None and st == [-4, -4]
     # asking for a size: everything else is refused
     info, st = ctx.jpeg_decode_batch([other_size, good[0]], w=96, h=64)
@@ -268,3 +267,41 @@ def test_randomised_codec_sweep(ctx):
                                  np.ascontiguousarray(d["cb"][:chh, :cww]), np.ascontiguousarray(d["cr"][:chh, :cww]), sub)
         q = int(rng.integers(1, 101))
         assert ctx.jpeg_encode(rgba, q) == oracle.jpeg_encode_rgba(rgba, q), (w, h, sub, q)
+
+
+def test_gray_close_to_libjpeg():
+    from PIL import Image
+    g = picture(150, 97, seed=2)[..., 0]
+    for kw in ({}, {"restart_marker_blocks": 4}, {"optimize": True, "quality": 40}):
+        b = pil_jpeg(g, **{"quality": 85, **kw})
+        d = oracle.jpeg_decode(b)
+        assert d["ratio"] == 4 and d["y"].shape == (104, 152)     # *image.Gray with Stride 8 * mxx
+        diff = np.abs(d["y"][:97, :150].astype(int) - np.asarray(Image.open(io.BytesIO(b))).astype(int))
+        assert diff.max() <= 2 and diff.mean() < 0.1
+
+
+@pytest.mark.gpu
+def test_gray_jpegs_on_the_gpu(ctx):
+    """One-component files: decoded on the GPU into an *image.Gray plane, expanded to (y, y, y, 0xff) -- what image/draw's drawGray and
+    x/image's scale_RGBA_Gray_Src read -- and run through the RGBA pass; against the oracle on the expanded frame."""
+    from helpers import DEFAULT_COL, text_glyphs
+    w, h = 320, 200
+    files = [pil_jpeg(picture(w, h, seed=60 + i)[..., 0], quality=70 + 5 * i, **({"restart_marker_rows": 2} if i == 1 else {})) for i in range(5)]
+    files.append(pil_jpeg(picture(w, h, seed=3)))                       # a colour file in a Gray batch: refused
+    info, st = _check_batch(ctx, files, expect_status=[0, 0, 0, 0, 0, -4])
+    assert st == [0, 0, 0, 0, 0, -4] and info["ratio"] == 4
+    for big in ((1920, 1080), (17, 9)):
+        _check_batch(ctx, [pil_jpeg(picture(*big, seed=5)[..., 0], quality=85)] * 2)
+    glyphs = text_glyphs(w, h, n=6, width_px=150, height_px=30)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(w, h, resize=(512, 384, True), thumbnail=(100, True), watermark=gs)
+    got, st = plan.run_jpeg_jpeg(files)
+    assert st == [0, 0, 0, 0, 0, -4]
+    for k in range(5):
+        y = oracle.jpeg_decode(files[k])["y"][:h, :w]
+        rgba = np.dstack([y, y, y, np.full_like(y, 255)])
+        want = oracle.process(rgba, resize=(512, 384, True), thumb=(100, True), glyphs=glyphs, col=DEFAULT_COL)
+        for key in ("resize", "thumbnail", "watermark"):
+            assert got[key][k] == oracle.jpeg_encode_rgba(want[key], 85), (key, k)
+    plan.close()
+    gs.close()
