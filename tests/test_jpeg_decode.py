@@ -216,8 +216,9 @@ def test_compressed_in_compressed_out(ctx):
     glyphs = text_glyphs(w, h, n=6, width_px=150, height_px=30)
     gs = ctx.glyphset(glyphs, DEFAULT_COL)
     import os
-    for chunk in ("256", "4"):
+    for chunk, part in (("256", "384"), ("4", "384"), ("256", "3")):   # the last one splits the nine files over three lanes
         os.environ["IPX_JPEG_JPEG_CHUNK"] = chunk
+        os.environ["IPX_JPEG_JPEG_PART"] = part
         plan = ctx.plan(w, h, resize=(512, 384, True), thumbnail=(100, True), watermark=gs)
         got, st = plan.run_jpeg_jpeg(files)
         assert st == [0, 0, 0, -4, 0, -4, 0, 0, 0]
@@ -233,6 +234,7 @@ def test_compressed_in_compressed_out(ctx):
                 assert got[key][k] == oracle.jpeg_encode_rgba(want[key], 85), (key, k)
         plan.close()
     os.environ.pop("IPX_JPEG_JPEG_CHUNK", None)
+    os.environ.pop("IPX_JPEG_JPEG_PART", None)
     gs.close()
 
 
