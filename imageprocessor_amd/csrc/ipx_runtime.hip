@@ -1743,6 +1743,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     *owner = nullptr;
     memset(planes, 0, sizeof *planes);
     if (n == 0) return IPX_OK;
+    if (n > 65535) { set_error("ipx_jpeg_decode_batch: at most 65535 files per call"); return IPX_ERR_UNSUPPORTED; }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     std::vector<JpegDecInfo> info(n);
     std::vector<JpegDecTables> tabs(n);
@@ -1764,7 +1765,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     // marker, so every 0xff 0xd0..0xd7 pair is an RSTn.
     std::vector<std::vector<uint32_t>> marks(n);
     parallel_for(n, [&](int i) {
-        status[i] = jpegs[i].data ? jpeg_parse(jpegs[i].data, jpegs[i].len, &info[i], &tabs[i]) : IPX_ERR_INVALID;
+        status[i] = !jpegs[i].data ? IPX_ERR_INVALID : (jpegs[i].len >= ((size_t)1 << 30) ? IPX_ERR_UNSUPPORTED : jpeg_parse(jpegs[i].data, jpegs[i].len, &info[i], &tabs[i]));
         if (status[i] != IPX_OK) return;
         const JpegDecInfo &I = info[i];
         const int nmcu = ((I.w + 8 * I.h0 - 1) / (8 * I.h0)) * ((I.h + 8 * I.v0 - 1) / (8 * I.v0));

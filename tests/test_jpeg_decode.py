@@ -307,3 +307,26 @@ def test_gray_jpegs_on_the_gpu(ctx):
             assert got[key][k] == oracle.jpeg_encode_rgba(want[key], 85), (key, k)
     plan.close()
     gs.close()
+
+
+@pytest.mark.gpu
+def test_baseline_config_1_single_jpeg_to_thumbnail(ctx):
+    """BASELINE.json configs[0]: "Single 640x480 JPEG -> 200x200 thumbnail" as the worker does it (image.Decode, Thumbnailer with
+    crop_to_fit, jpeg.Encode at 85), here entirely on the GPU: file in, file out, against the oracle's decoder, crop-copy + scale and
+    encoder.  (The crop thumbnail of a YCbCr source converts the crop to RGBA8 first: thumbnail.go:128-131.)"""
+    from PIL import Image
+    w, h = 640, 480
+    f = pil_jpeg(picture(w, h, seed=99, noise=5.0), quality=90)
+    plan = ctx.plan(w, h, resize=None, thumbnail=(200, True))
+    got, st = plan.run_jpeg_jpeg([f])
+    assert st == [0] and set(got) == {"thumbnail"}
+    d = oracle.jpeg_decode(f)
+    crop, tw, th = oracle.thumb_geometry(w, h, 200, True)
+    assert crop == (80, 0, 560, 480) and (tw, th) == (200, 200)
+    cs = crop[2] - crop[0]
+    cropped = oracle.scale_bilinear_ycbcr(np.ascontiguousarray(d["y"][:h, :w]), np.ascontiguousarray(d["cb"][:h // 2, :w // 2]),
+                                          np.ascontiguousarray(d["cr"][:h // 2, :w // 2]), 2, cs, cs, sr=crop)
+    want = oracle.jpeg_encode_rgba(oracle.scale_bilinear(cropped, tw, th), 85)
+    assert got["thumbnail"][0] == want
+    assert Image.open(io.BytesIO(got["thumbnail"][0])).size == (200, 200)
+    plan.close()
