@@ -185,7 +185,11 @@ struct JpegDecTables {         // per image, as the kernels read them
 };
 // one independently decodable piece of a scan: the whole scan, or one restart interval of it (DC predictions and the bit
 // reader start afresh after every RSTn, so intervals decode in parallel)
-struct JpegDecImage { unsigned long long scan_off; uint32_t scan_len, img, first_mcu, n_mcu; uint8_t td[3], ta[3], valid, pad; };
+struct JpegDecImage {
+    unsigned long long scan_off; uint32_t scan_len, img, first_mcu, n_mcu;
+    uint8_t td[3], ta[3], valid, pad;   // pad: bytes to skip at the start (pieces are read in aligned 16-byte chunks)
+    uint8_t strict_end, rsv[3];         // a restart interval must end exactly at its RSTn marker (Go would resynchronise: not ours to guess)
+};
 struct JpegDecArgs {
     const uint8_t *blob; const JpegDecImage *img; const JpegDecTables *tab;
     int16_t *coefs; int *status;

@@ -217,6 +217,9 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
         }
         if (br.err) { status = IPX_ERR_INVALID; break; }
     }
+    // An interval that does not end exactly at its marker (damaged data: too few or too many bits) is where Go's processSOS starts
+    // searching for the next RSTn (findRST); that heuristic is not restated here -- the file goes back to the CPU path.
+    if (!status && im.strict_end && !(br.cnt < 8 && br.pos >= br.len)) status = IPX_ERR_UNSUPPORTED;
     if (status) atomicExch(&a.status[img], status);   // pieces of one image report into one word (zeroed by the host)
 }
 

@@ -83,6 +83,7 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
             ncomp = s[5];
             if (ncomp == 4) return IPX_ERR_UNSUPPORTED;
             if ((ncomp != 3 && ncomp != 1) || sn != (size_t)(6 + 3 * ncomp) || info->w <= 0 || info->h <= 0) return IPX_ERR_INVALID;
+            if ((long long)info->w * info->h > (1LL << 28)) return IPX_ERR_UNSUPPORTED;   // 268 Mpixel: beyond any batch this path is meant for
             for (int c = 0; c < ncomp; c++) {
                 cid[c] = s[6 + 3 * c]; ch[c] = s[7 + 3 * c] >> 4; cv[c] = s[7 + 3 * c] & 15; ctq[c] = s[8 + 3 * c];
                 if (ctq[c] > 3 || ch[c] < 1 || ch[c] > 4 || cv[c] < 1 || cv[c] > 4) return IPX_ERR_INVALID;

@@ -1813,7 +1813,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         };
         size_t start = 0;
         int mcu = 0;
-        for (uint32_t k : marks[i]) { push(start, k, mcu, I.ri); mcu += I.ri; start = (size_t)k + 2; }
+        for (uint32_t k : marks[i]) { push(start, k, mcu, I.ri); items.back().strict_end = 1; mcu += I.ri; start = (size_t)k + 2; }
         if (marks[i].empty() && use_par && I.scan_len >= (size_t)4 * jpeg_par_sub_bytes() && I.scan_len < ((size_t)1 << 28)) {
             // a long scan without restart markers: decoded in parallel inside the scan (ipx_jpeg_dec_par.hip)
             JpegParImage pi;

@@ -330,3 +330,44 @@ def test_baseline_config_1_single_jpeg_to_thumbnail(ctx):
     assert got["thumbnail"][0] == want
     assert Image.open(io.BytesIO(got["thumbnail"][0])).size == (200, 200)
     plan.close()
+
+
+@pytest.mark.gpu
+def test_damaged_files_never_disagree(ctx):
+    """Bit flips, random bytes, truncation and missing chunks (tools/fuzz_corrupt.py holds the long version: 800 cases, no mismatch):
+    the GPU decoder agrees with the oracle's verdict -- or hands the file back to Go's decoder (-4) where the oracle says malformed --
+    and where a damaged file still decodes, every byte matches (the self-synchronising decoder converges to the serial decoding of
+    whatever bits there are)."""
+    rng = np.random.default_rng(5)
+    img = picture(333, 250, seed=8, noise=10.0)
+    clean = [pil_jpeg(img, quality=85), pil_jpeg(img, quality=85, restart_marker_rows=1), pil_jpeg(img, quality=90, subsampling=0, optimize=True),
+             pil_jpeg(img[..., 0], quality=80)]
+    for t in range(40):
+        f = bytearray(clean[t % 4])
+        sos = f.index(b"\xff\xda")
+        kind = t % 5
+        if kind == 0:
+            for _ in range(3):
+                f[int(rng.integers(sos + 14, len(f) - 2))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            f[int(rng.integers(sos + 14, len(f) - 2))] = int(rng.integers(0, 256))
+        elif kind == 2:
+            f[int(rng.integers(2, sos + 14))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 3:
+            f = f[:int(rng.integers(sos, len(f)))]
+        else:
+            a = int(rng.integers(sos + 14, len(f) - 10))
+            del f[a:a + int(rng.integers(1, 1500))]
+        f = bytes(f)
+        try:
+            want, exp = oracle.jpeg_decode(f), 0
+        except ValueError as e:
+            want, exp = None, -1 if "malformed" in str(e) else -4
+        info, st = ctx.jpeg_decode_batch([f, clean[t % 4]])
+        if want is not None and info is not None and (want["w"], want["h"], want["ratio"]) != (info["w"], info["h"], info["ratio"]):
+            continue                      # the damage changed the size or kind: the one-size-per-batch rule decides, not the decoder
+        assert st[0] == exp or (exp == -1 and st[0] == -4), (t, kind, exp, st)
+        assert st[1] == 0
+        if exp == 0:
+            for k in ("y", "cb", "cr") if want["ratio"] != 4 else ("y",):
+                np.testing.assert_array_equal(info[k][0], want[k], err_msg="case %d plane %s" % (t, k))
