@@ -267,6 +267,12 @@ class Plan:
             lib().ipx_jpeg_result_free(self.ctx.handle, res)
         return out, list(status)
 
+    def run_dev_nrgba(self, n, src_ptr, resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
+        """*image.NRGBA frames (tightly packed) resident in HBM (ipx_plan_run_dev_nrgba)"""
+        i = self.info
+        _check(lib().ipx_plan_run_dev_nrgba(self.ctx.handle, stream, self.handle, n, src_ptr, self._sw * 4, self._sw * self._sh * 4,
+                                            resize_ptr, i.resize_bytes, thumb_ptr, i.thumb_bytes, wm_ptr, i.wm_bytes))
+
     def run_dev_gray(self, n, gray_ptr, stride, frame_stride, resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
         """*image.Gray frames resident in HBM (ipx_plan_run_dev_gray)"""
         i = self.info

@@ -85,7 +85,7 @@ hipError_t launch_opaque_scan(const uint8_t *src, int sw, int sh, int sstride, i
 hipError_t launch_draw(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h,
                        int op, hipStream_t s);
 hipError_t launch_draw_nrgba(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h, int op,
-                             hipStream_t s);
+                             hipStream_t s, int nframes = 1, size_t dst_fs = 0, size_t src_fs = 0);
 hipError_t launch_draw_ycbcr(uint8_t *dst, int dstride, const uint8_t *y, int ystride, const uint8_t *cb,
                              const uint8_t *cr, int cstride, int ratio, int spx, int spy, int w, int h, hipStream_t s,
                              int nframes = 1, size_t dst_fs = 0, size_t y_fs = 0, size_t c_fs = 0);

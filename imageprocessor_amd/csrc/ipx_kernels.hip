@@ -155,10 +155,11 @@ __global__ __launch_bounds__(256) void draw_px_kernel(uint8_t *dst, int dstride,
 
 // drawNRGBASrc / drawNRGBAOver: premultiply each source pixel, then as drawCopySrc / drawCopyOver
 __global__ __launch_bounds__(256) void draw_nrgba_kernel(uint8_t *dst, int dstride, const uint8_t *src,
-                                                         int sstride, int w, int h, int op)
+                                                         int sstride, int w, int h, int op, size_t dst_fs, size_t src_fs)
 {
     const int y = blockIdx.y;
     if (y >= h) return;
+    dst += blockIdx.z * dst_fs; src += blockIdx.z * src_fs;   // frame of a batch
     for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256) {
         const uint32_t s = *(const uint32_t *)(src + (size_t)y * sstride + (size_t)x * 4);
         uint32_t *dp = (uint32_t *)(dst + (size_t)y * dstride + (size_t)x * 4);
@@ -243,11 +244,11 @@ hipError_t launch_scale_generic(const ScaleArgs &a, hipStream_t s)
 }
 
 hipError_t launch_draw_nrgba(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h, int op,
-                             hipStream_t s)
+                             hipStream_t s, int nframes, size_t dst_fs, size_t src_fs)
 {
-    if (w <= 0 || h <= 0) return hipSuccess;
-    dim3 grid(min(8, (w + 255) / 256), h);
-    hipLaunchKernelGGL(draw_nrgba_kernel, grid, dim3(256), 0, s, dst, dstride, src, sstride, w, h, op);
+    if (w <= 0 || h <= 0 || nframes <= 0) return hipSuccess;
+    dim3 grid(min(8, (w + 255) / 256), h, nframes);
+    hipLaunchKernelGGL(draw_nrgba_kernel, grid, dim3(256), 0, s, dst, dstride, src, sstride, w, h, op, dst_fs, src_fs);
     return hipGetLastError();
 }
 

@@ -213,7 +213,7 @@ int dev_draw_src(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect 
                                   r.dx(), r.dy(), s, src.nframes, dst_fs, src.frame_stride, src.c_frame_stride));
     else if (src.kind == IPX_SRC_NRGBA)
         IPX_HIP(launch_draw_nrgba(d, dstride, src.pix + (size_t)spy * src.stride + (size_t)spx * 4, src.stride, r.dx(),
-                                  r.dy(), op, s));
+                                  r.dy(), op, s, src.nframes, dst_fs, src.frame_stride));
     else
         IPX_HIP(launch_draw(d, dstride, src.pix + (size_t)spy * src.stride + (size_t)spx * 4, src.stride, r.dx(), r.dy(),
                             op, s));
@@ -1276,6 +1276,68 @@ int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
         const size_t ofs = k == 0 ? resize_frame_stride : thumb_frame_stride;
         if (!o || ps.dw <= 0 || ps.dh <= 0) continue;
         rc = dev_scale_src(s, nullptr, o, ps.dw, ps.dh, ps.dw * 4, Rect{0, 0, ps.dw, ps.dh}, ysrc, ps.sr, IPX_OP_SRC, ofs);
+    }
+    if (scratch) (void)hipFreeAsync(scratch, s);
+    return rc;
+}
+
+int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
+                           uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                           size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * 4) { set_error("ipx_plan_run_dev_nrgba: bad argument"); return IPX_ERR_INVALID; }
+    if (n == 0) return IPX_OK;
+    if (n > 65535) { set_error("ipx_plan_run_dev_nrgba: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    uint8_t *res = pl->sc[0].on ? resize_out : nullptr;
+    uint8_t *th = pl->sc[1].on ? thumb_out : nullptr;
+    uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
+    const bool crop_thumb = th && pl->p.crop_to_fit;
+    // premultiplied RGBA8 of the whole batch (drawNRGBASrc == drawNRGBAOver onto a zeroed frame), into the watermark frames when wanted
+    uint8_t *conv = wm;
+    size_t conv_fs = wm_frame_stride;
+    uint8_t *scratch = nullptr;
+    if (!conv && crop_thumb) {
+        conv_fs = (size_t)sw * sh * 4;
+        IPX_HIP(hipMallocAsync((void **)&scratch, conv_fs * n, s));
+        conv = scratch;
+    }
+    int rc = IPX_OK;
+    if (conv) {
+        hipError_t e = launch_draw_nrgba(conv, sw * 4, src, sstride, sw, sh, IPX_OP_SRC, s, n, conv_fs, src_frame_stride);
+        if (e != hipSuccess) { set_error("premultiply launch failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
+    }
+    if (!rc && crop_thumb) {
+        ipx_plan *sub = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(pl->mu);
+            if (!pl->thumb_only) {
+                ipx_plan_params tp;
+                memset(&tp, 0, sizeof tp);
+                tp.sw = sw; tp.sh = sh; tp.do_thumbnail = 1; tp.thumb_size = pl->p.thumb_size; tp.crop_to_fit = 1;
+                rc = ipx_plan_create(ctx, &tp, &pl->thumb_only);
+            }
+            sub = pl->thumb_only;
+        }
+        if (!rc) rc = ipx_plan_run_dev(ctx, s, sub, n, conv, sw * 4, conv_fs, nullptr, 0, th, thumb_frame_stride, nullptr, 0);
+    }
+    if (!rc && wm && pl->glyphs.n && pl->p.glyphs) {
+        const uint8_t *c = pl->p.glyphs->col;
+        hipError_t e = launch_composite(wm, sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox,
+                                        c[0] * 0x101u, c[1] * 0x101u, c[2] * 0x101u, c[3] * 0x101u, s);
+        if (e != hipSuccess) { set_error("composite launch failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
+    }
+    DevSrc nsrc;
+    nsrc.kind = IPX_SRC_NRGBA; nsrc.pix = src; nsrc.stride = sstride; nsrc.w = sw; nsrc.h = sh;
+    nsrc.nframes = n; nsrc.frame_stride = src_frame_stride;
+    for (int k = 0; k < 2 && !rc; k++) {   // 16-bit premultiplied taps straight from the source; Over onto the zeroed frame == Src
+        const PlanScale &ps = pl->sc[k];
+        uint8_t *o = k == 0 ? res : (crop_thumb ? nullptr : th);
+        const size_t ofs = k == 0 ? resize_frame_stride : thumb_frame_stride;
+        if (!o || ps.dw <= 0 || ps.dh <= 0) continue;
+        rc = dev_scale_src(s, nullptr, o, ps.dw, ps.dh, ps.dw * 4, Rect{0, 0, ps.dw, ps.dh}, nsrc, ps.sr, IPX_OP_SRC, ofs);
     }
     if (scratch) (void)hipFreeAsync(scratch, s);
     return rc;

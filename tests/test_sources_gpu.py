@@ -159,3 +159,40 @@ def test_ycbcr_batch_plan(ctx, case, fused, monkeypatch):
         p2.close()
     plan.close()
     gs.close()
+
+
+@pytest.mark.parametrize("case", [(640, 360, 3, (1024, 768, True), (200, True)), (333, 251, 2, (200, 100, False), (64, False)),
+                                  (200, 200, 2, (200, 200, False), (100, True))], ids=lambda c: "%dx%d" % (c[0], c[1]))
+def test_nrgba_batch_plan(ctx, case):
+    """ipx_plan_run_dev_nrgba: a batch of *image.NRGBA frames (PNGs with alpha), per operator as the reference's helpers treat the
+    type: 16-bit premultiplied taps for resizeImage, drawNRGBA* first for the crop thumbnail and the watermark."""
+    from helpers import DEFAULT_COL, text_glyphs
+    w, h, n, resize, thumb = case
+    rng = np.random.default_rng(w)
+    frames = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)          # non-premultiplied: colour may exceed alpha
+    frames[0, :, : w // 2, 3] = 255
+    glyphs = text_glyphs(w, h, n=6, width_px=min(150, w), height_px=min(30, h))
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(w, h, resize=resize, thumbnail=thumb, watermark=gs)
+    i = plan.info
+    src = ctx.alloc(frames.nbytes).upload(frames)
+    res, th, wm = ctx.alloc(n * i.resize_bytes), ctx.alloc(n * i.thumb_bytes), ctx.alloc(n * i.wm_bytes)
+    plan.run_dev_nrgba(n, src.ptr, res.ptr, th.ptr, wm.ptr)
+    ctx.sync()
+    got = {"resize": res.download((n, i.resize_h, i.resize_w, 4)), "thumbnail": th.download((n, i.thumb_h, i.thumb_w, 4)),
+           "watermark": wm.download((n, h, w, 4))}
+    for k in range(n):
+        nw, nh = oracle.resize_dims(w, h, *resize)
+        np.testing.assert_array_equal(got["resize"][k], oracle.scale_bilinear_nrgba(frames[k], nw, nh), err_msg="resize %d" % k)
+        crop, tw, thh = oracle.thumb_geometry(w, h, *thumb)
+        if thumb[1]:
+            cs = crop[2] - crop[0]
+            cropped = oracle.scale_bilinear_nrgba(frames[k], cs, cs, sr=crop)       # equal size: Copy = drawNRGBAOver onto zeros
+            want_t = oracle.scale_bilinear(cropped, tw, thh)
+        else:
+            want_t = oracle.scale_bilinear_nrgba(frames[k], tw, thh)
+        np.testing.assert_array_equal(got["thumbnail"][k], want_t, err_msg="thumbnail %d" % k)
+        want_w = oracle.draw_nrgba(np.zeros((h, w, 4), np.uint8), (0, 0, w, h), frames[k])
+        np.testing.assert_array_equal(got["watermark"][k], oracle.composite_glyphs(want_w, glyphs, DEFAULT_COL), err_msg="watermark %d" % k)
+    plan.close()
+    gs.close()
