@@ -14,147 +14,14 @@
 #include <utility>
 #include <vector>
 
-#include "ipx_internal.h"
+#include "ipx_runtime_internal.h"
 
 #ifndef IPX_DIAG
 #define IPX_DIAG 0
 #endif
 
-using namespace ipx;
-
-// ---------------------------------------------------------------------------------------------
-struct Lane {
-    hipStream_t stream = nullptr;
-    uint8_t *dev = nullptr;   // device scratch
-    size_t dev_bytes = 0;
-    int *flag = nullptr;      // device int for the opaque() scan
-    bool busy = false;
-};
-
-struct ipx_ctx {
-    int device = 0;
-    int cus = 256;                 // compute units of the device
-    hipStream_t stream = nullptr;  // default stream for device-pointer calls
-    std::vector<Lane> lanes;
-    size_t lane_bytes = 0;
-    std::mutex mu;
-    std::condition_variable cv;
-    // pinned host blocks: hipHostMalloc / hipHostFree cost milliseconds each, and the encoder hands out one block per
-    // batch and output, so freed blocks are kept (up to host_cache_limit bytes) and reused for requests they fit
-    std::mutex host_mu;
-    std::map<void *, size_t> host_size;            // every live block handed out by ipx_host_alloc
-    std::multimap<size_t, void *> host_free_blocks;
-    size_t host_cached = 0, host_cache_limit = (size_t)2 << 30;
-};
-
-struct GlyphHost {
-    size_t mask_off;  // offset of this glyph's mask in the packed blob
-    int mw, mh;
-    Rect dr;
-    int mpx, mpy;
-};
-
-struct ClippedGlyphs {
-    DevGlyph *dev = nullptr;
-    int n = 0;
-    Rect bbox{0, 0, 0, 0};
-};
-
-struct ipx_glyphset {
-    int device = 0;
-    std::vector<GlyphHost> g;
-    uint8_t *masks_dev = nullptr;
-    size_t masks_bytes = 0;
-    uint8_t col[4] = {0, 0, 0, 0};
-    mutable std::mutex mu;
-    mutable std::map<std::pair<int, int>, ClippedGlyphs> clipped;  // per frame size
-};
-
-struct PlanScale {
-    bool on = false;
-    int dw = 0, dh = 0;
-    Rect sr{0, 0, 0, 0};
-    AxisTap *xt = nullptr, *yt = nullptr;
-    int *row_begin = nullptr, *col_begin = nullptr;
-    int dyadic_shift = -1;
-    int kx = -1, ky = -1;   // dyadic bits per axis (dyadic_shift = kx + ky), -1 = not dyadic
-};
-
-struct ipx_plan {
-    ipx_plan_params p{};
-    ipx_plan_info info{};
-    bool fused = false;
-    int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0;
-    int nx_out[2] = {0, 0}; // per output: ceil(widest column block / 256)
-    int most_rows = 0;    // most destination rows any band owns, over the scaled outputs
-    PlanScale sc[2];      // 0 = resize, 1 = thumbnail
-    uint8_t *blob = nullptr;
-    ClippedGlyphs glyphs;
-    mutable std::mutex mu;
-    mutable ipx_plan *thumb_only = nullptr;   // RGBA sub-plan for YCbCr batches (thumbnail of the converted frame)
-};
-
 namespace {
 
-int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
-struct DeviceGuard {  // hipSetDevice is per-thread; callers may arrive on any OS thread
-    explicit DeviceGuard(int dev) { ok = hipSetDevice(dev) == hipSuccess; }
-    bool ok;
-};
-
-#define IPX_ENTER(ctx)                                                         \
-    clear_error();                                                             \
-    if (!(ctx)) { set_error("%s: null context", __func__); return IPX_ERR_INVALID; } \
-    DeviceGuard guard_((ctx)->device);                                         \
-    if (!guard_.ok) { set_error("hipSetDevice(%d) failed", (ctx)->device); return IPX_ERR_HIP; }
-
-class LaneLease {
-public:
-    explicit LaneLease(ipx_ctx *c) : c_(c)
-    {
-        std::unique_lock<std::mutex> lk(c->mu);
-        c->cv.wait(lk, [&] {
-            for (auto &l : c->lanes) if (!l.busy) return true;
-            return false;
-        });
-        for (auto &l : c->lanes) if (!l.busy) { l.busy = true; lane_ = &l; break; }
-    }
-    ~LaneLease()
-    {
-        {
-            std::lock_guard<std::mutex> lk(c_->mu);
-            lane_->busy = false;
-        }
-        c_->cv.notify_one();
-    }
-    Lane *operator->() { return lane_; }
-    Lane &get() { return *lane_; }
-private:
-    ipx_ctx *c_;
-    Lane *lane_ = nullptr;
-};
-
-int lane_reserve(Lane &l, size_t bytes)
-{
-    if (bytes <= l.dev_bytes) return IPX_OK;
-    if (l.dev) { IPX_HIP(hipStreamSynchronize(l.stream)); IPX_HIP(hipFree(l.dev)); l.dev = nullptr; l.dev_bytes = 0; }
-    const size_t want = std::max(bytes, l.dev_bytes * 2);
-    hipError_t e = hipMalloc((void **)&l.dev, want);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        set_error("device allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
-        return IPX_ERR_NOMEM;
-    }
-    l.dev_bytes = want;
-    return IPX_OK;
-}
-
-size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 bool frame_args_ok(const void *p, int w, int h, int stride)
 {
@@ -1406,735 +1273,6 @@ int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_y
             IPX_HIP(hipMemcpyAsync(wm_out + wm_frame_stride * i, dwm + fwm * i, pl->info.wm_bytes, hipMemcpyDeviceToHost, s));
     }
     IPX_HIP(hipStreamSynchronize(s));
-    return IPX_OK;
-}
-
-}  // extern "C"
-
-
-// ---- jpeg.Encode: the entries that touch the device (tables / entropy coder: ipx_jpeg_host.cpp) ----------
-#include <atomic>
-#include <functional>
-#include <memory>
-#include <string>
-#include <thread>
-
-extern "C" {
-
-int ipx_dev_jpeg_fdct_rgba8(ipx_ctx *ctx, void *stream, const uint8_t *src, int w, int h, int stride, size_t frame_stride,
-                            int n, int quality, int16_t *coefs)
-{
-    IPX_ENTER(ctx);
-    if (!src || !coefs || n < 0 || w <= 0 || h <= 0 || (long long)stride < (long long)w * 4) {
-        set_error("ipx_dev_jpeg_fdct_rgba8: bad argument");
-        return IPX_ERR_INVALID;
-    }
-    if (w >= 1 << 16 || h >= 1 << 16) { set_error("jpeg: image is too large to encode"); return IPX_ERR_INVALID; }
-    if (n == 0) return IPX_OK;
-    if (n > 65535) { set_error("ipx_dev_jpeg_fdct_rgba8: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
-    JpegTables t;
-    jpeg_tables(quality, &t);
-    JpegArgs a;
-    a.src = src; a.frame_stride = frame_stride; a.stride = stride; a.w = w; a.h = h;
-    a.aligned16 = ((((uintptr_t)src) | (uintptr_t)stride | frame_stride) & 15) == 0;
-    a.coefs = coefs; a.mcus_per_frame = ((w + 15) / 16) * ((h + 15) / 16);
-    memcpy(a.recip, t.recip, sizeof a.recip);
-    memcpy(a.div8, t.div8, sizeof a.div8);
-    IPX_HIP(launch_jpeg_fdct(a, n, stream ? (hipStream_t)stream : ctx->stream));
-    return IPX_OK;
-}
-
-}  // extern "C"
-
-// host entropy coding of a downloaded coefficient batch (IPX_JPEG_HOST_ENTROPY=1, and the reference point of tools/bench_jpeg.py)
-static int jpeg_batch_host_entropy(ipx_ctx *ctx, Lane &lane, const int16_t *dcoefs, int w, int h, int n, int quality,
-                                   uint8_t **blob, size_t *offs, size_t *lens)
-{
-    const size_t per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
-    hipStream_t s = lane.stream;
-    int16_t *host = nullptr;
-    IPX_HIP(hipHostMalloc((void **)&host, per * n, hipHostMallocDefault));
-    hipError_t e = hipMemcpyAsync(host, dcoefs, per * n, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { (void)hipHostFree(host); set_error("coefficient download failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
-    JpegTables t;
-    jpeg_tables(quality, &t);
-    const int nt = std::max(1, std::min((int)std::thread::hardware_concurrency(), n));
-    std::vector<std::vector<uint8_t>> streams(n);
-    std::atomic<int> next{0};
-    auto work = [&] {
-        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1))
-            jpeg_write_stream(host + (per / sizeof(int16_t)) * (size_t)i, w, h, t, &streams[i]);
-    };
-    std::vector<std::thread> pool;
-    for (int i = 1; i < nt; i++) pool.emplace_back(work);
-    work();
-    for (auto &th : pool) th.join();
-    (void)hipHostFree(host);
-    size_t total = 0;
-    for (int i = 0; i < n; i++) { offs[i] = total; lens[i] = streams[i].size(); total += (lens[i] + 15) & ~(size_t)15; }
-    uint8_t *b = (uint8_t *)ipx_host_alloc(ctx, total ? total : 1);
-    if (!b) return IPX_ERR_NOMEM;
-    for (int i = 0; i < n; i++) memcpy(b + offs[i], streams[i].data(), lens[i]);
-    *blob = b;
-    return IPX_OK;
-}
-
-namespace {
-struct AsyncFree {   // stream-ordered scratch of one call
-    hipStream_t s;
-    std::vector<void *> p;
-    ~AsyncFree() { for (void *q : p) (void)hipFreeAsync(q, s); }
-    template <class T> hipError_t get(T **out, size_t bytes)
-    {
-        void *q = nullptr;
-        hipError_t e = hipMallocAsync(&q, bytes ? bytes : 1, s);
-        if (e == hipSuccess) p.push_back(q);
-        *out = (T *)q;
-        return e;
-    }
-};
-}  // namespace
-
-extern "C" {
-
-}  // extern "C"
-
-// n frames in HBM -> streams in one pinned block, everything on stream s; dcoefs = n * ipx_jpeg_coef_count int16 of scratch
-static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const uint8_t *src, int w, int h, int stride, size_t frame_stride,
-                            int n, int quality, uint8_t **blob, size_t *offs, size_t *lens);
-
-extern "C" {
-
-int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, int stride, size_t frame_stride, int n,
-                              int quality, uint8_t **blob, size_t *offs, size_t *lens)
-{
-    IPX_ENTER(ctx);
-    if (!blob || !offs || !lens || n < 0) { set_error("ipx_jpeg_encode_batch_dev: bad argument"); return IPX_ERR_INVALID; }
-    *blob = nullptr;
-    if (n == 0) return IPX_OK;
-    const size_t per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
-    LaneLease lane(ctx);
-    int rc = lane_reserve(lane.get(), per * n);
-    if (rc) return rc;
-    int16_t *dcoefs = (int16_t *)lane->dev;
-    if (env_int("IPX_JPEG_HOST_ENTROPY", 0)) {
-        rc = ipx_dev_jpeg_fdct_rgba8(ctx, lane->stream, src, w, h, stride, frame_stride, n, quality, dcoefs);
-        if (rc) return rc;
-        return jpeg_batch_host_entropy(ctx, lane.get(), dcoefs, w, h, n, quality, blob, offs, lens);
-    }
-    return jpeg_encode_core(ctx, lane->stream, dcoefs, src, w, h, stride, frame_stride, n, quality, blob, offs, lens);
-}
-
-}  // extern "C"
-
-static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const uint8_t *src, int w, int h, int stride, size_t frame_stride,
-                            int n, int quality, uint8_t **blob, size_t *offs, size_t *lens)
-{
-    const size_t per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
-    int rc = ipx_dev_jpeg_fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, dcoefs);
-    if (rc) return rc;
-
-    // ---- entropy coding on the GPU: size, scan, place, stuff (ipx_jpeg_entropy.hip); two small read-backs ----
-    const int nblk = (int)(per / 128);
-    JpegTables t;
-    jpeg_tables(quality, &t);
-    std::vector<uint8_t> hdr;
-    jpeg_write_header(w, h, t, &hdr);
-    uint32_t packed[1024];
-    jpeg_huff_packed(packed);
-    AsyncFree mem{s, {}};
-    uint32_t *d_tab, *d_len, *d_tot, *d_ubytes, *d_ff, *d_fftot;
-    unsigned long long *d_ubase, *d_obase;
-    uint8_t *d_hdr, *d_ustream = nullptr, *d_ostream = nullptr;
-    IPX_HIP(mem.get(&d_tab, sizeof packed));
-    IPX_HIP(mem.get(&d_len, (size_t)n * nblk * 4));
-    IPX_HIP(mem.get(&d_tot, (size_t)n * 4));
-    IPX_HIP(mem.get(&d_ubytes, (size_t)n * 4));
-    IPX_HIP(mem.get(&d_fftot, (size_t)n * 4));
-    IPX_HIP(mem.get(&d_ubase, (size_t)n * 8));
-    IPX_HIP(mem.get(&d_obase, (size_t)n * 8));
-    IPX_HIP(mem.get(&d_hdr, hdr.size()));
-    IPX_HIP(hipMemcpyAsync(d_tab, packed, sizeof packed, hipMemcpyHostToDevice, s));
-    IPX_HIP(hipMemcpyAsync(d_hdr, hdr.data(), hdr.size(), hipMemcpyHostToDevice, s));
-    IPX_HIP(launch_jpeg_len(dcoefs, nblk, n, d_tab, d_len, s));
-    IPX_HIP(launch_scan(d_len, nblk, n, d_tot, s));
-    std::vector<uint32_t> tot(n), ubytes(n), ff(n);
-    IPX_HIP(hipMemcpyAsync(tot.data(), d_tot, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    IPX_HIP(hipStreamSynchronize(s));
-    std::vector<unsigned long long> ubase(n), obase(n);
-    unsigned long long utotal = 0;
-    uint32_t umax = 0;
-    for (int i = 0; i < n; i++) {
-        ubytes[i] = (tot[i] + 7) / 8;
-        ubase[i] = utotal;
-        utotal += align256((size_t)ubytes[i] + 8);
-        umax = std::max(umax, ubytes[i]);
-    }
-    const int chunk = jpeg_chunk_bytes();
-    const int max_chunks = (int)((umax + chunk - 1) / chunk);
-    IPX_HIP(mem.get(&d_ustream, (size_t)utotal));
-    IPX_HIP(mem.get(&d_ff, (size_t)n * max_chunks * 4));
-    IPX_HIP(hipMemsetAsync(d_ustream, 0, (size_t)utotal, s));
-    IPX_HIP(hipMemcpyAsync(d_ubase, ubase.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
-    IPX_HIP(hipMemcpyAsync(d_ubytes, ubytes.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    IPX_HIP(launch_jpeg_bits(dcoefs, nblk, n, d_tab, d_len, d_tot, d_ubase, d_ustream, s));
-    IPX_HIP(launch_jpeg_ffcount(d_ustream, d_ubase, d_ubytes, max_chunks, n, d_ff, s));
-    IPX_HIP(launch_scan(d_ff, max_chunks, n, d_fftot, s));
-    IPX_HIP(hipMemcpyAsync(ff.data(), d_fftot, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-    IPX_HIP(hipStreamSynchronize(s));
-    unsigned long long ototal = 0;
-    for (int i = 0; i < n; i++) {
-        lens[i] = hdr.size() + ubytes[i] + ff[i] + 2;
-        obase[i] = ototal;
-        offs[i] = (size_t)ototal;
-        ototal += (lens[i] + 15) & ~(size_t)15;
-    }
-    IPX_HIP(mem.get(&d_ostream, (size_t)ototal));
-    IPX_HIP(hipMemcpyAsync(d_obase, obase.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
-    IPX_HIP(launch_jpeg_stuff(d_ustream, d_ubase, d_ubytes, max_chunks, n, d_ff, d_hdr, (int)hdr.size(), d_obase, d_ostream, s));
-    uint8_t *host = (uint8_t *)ipx_host_alloc(ctx, (size_t)ototal ? (size_t)ototal : 1);   // pinned: the download runs at link speed
-    if (!host) return IPX_ERR_NOMEM;
-    hipError_t e = hipMemcpyAsync(host, d_ostream, (size_t)ototal, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { (void)ipx_host_free(ctx, host); set_error("stream download failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
-    *blob = host;
-    return IPX_OK;
-}
-
-// ---- host frames in, JPEG streams out: the worker's whole GPU leg ----------------------------------------
-struct ipx_jpeg_result { std::vector<uint8_t *> blobs; };
-
-extern "C" {
-
-void ipx_jpeg_result_free(ipx_ctx *ctx, ipx_jpeg_result *r)
-{
-    if (!r) return;
-    for (uint8_t *b : r->blobs) (void)ipx_host_free(ctx, b);
-    delete r;
-}
-
-}  // extern "C"
-
-// one implementation for both source kinds: ysrc == nullptr -> RGBA frames at src
-static int run_host_jpeg_impl(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
-                              const ipx_ycbcr_batch *ysrc, int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out,
-                              ipx_jpeg_result **result)
-{
-    *result = nullptr;
-    if (n == 0) return IPX_OK;
-    const int sw = pl->p.sw, sh = pl->p.sh;
-    const int cw = ysrc ? ((ysrc->ratio == IPX_YCBCR_422 || ysrc->ratio == IPX_YCBCR_420) ? (sw + 1) / 2 : sw) : 0;
-    const int ch = ysrc ? ((ysrc->ratio == IPX_YCBCR_420 || ysrc->ratio == IPX_YCBCR_440) ? (sh + 1) / 2 : sh) : 0;
-    const size_t yb = ysrc ? align256((size_t)sw * sh) : 0, cbb = ysrc ? align256((size_t)cw * ch) : 0;
-    const size_t fsrc = ysrc ? yb + 2 * cbb : align256((size_t)sw * sh * 4);
-    const size_t fres = resize_out ? align256(pl->info.resize_bytes) : 0, fth = thumb_out ? align256(pl->info.thumb_bytes) : 0;
-    const size_t fwm = wm_out ? align256(pl->info.wm_bytes) : 0;
-    const size_t cres = fres ? ipx_jpeg_coef_count(pl->info.resize_w, pl->info.resize_h) * 2 : 0;
-    const size_t cth = fth ? ipx_jpeg_coef_count(pl->info.thumb_w, pl->info.thumb_h) * 2 : 0;
-    const size_t cwm = fwm ? ipx_jpeg_coef_count(sw, sh) * 2 : 0;
-    const size_t ccoef = align256(std::max(cres, std::max(cth, cwm)));
-    const size_t per_frame = fsrc + fres + fth + fwm + ccoef;
-    // every lane runs its own host thread: upload, operators, three encodes (each with two small read-backs) --
-    // the threads block independently, so copies and kernels of different chunks overlap
-    std::vector<Lane *> lanes;
-    {
-        std::unique_lock<std::mutex> lk(ctx->mu);
-        ctx->cv.wait(lk, [&] { for (auto &l : ctx->lanes) if (l.busy) return false; return true; });
-        for (auto &l : ctx->lanes) { l.busy = true; lanes.push_back(&l); }
-    }
-    const int nl = (int)lanes.size();
-    int chunk = std::max(1, (n + 2 * nl - 1) / (2 * nl));
-    chunk = (int)std::min<size_t>((size_t)chunk, std::max<size_t>(1, ctx->lane_bytes / per_frame));
-    chunk = std::max(1, std::min(chunk, env_int("IPX_HOST_CHUNK_JPEG", 32)));
-    std::unique_ptr<ipx_jpeg_result> res(new ipx_jpeg_result);
-    std::mutex res_mu;
-    std::atomic<int> next{0};
-    std::atomic<int> status{IPX_OK};
-    std::string err_text;
-    const int nchunks = (n + chunk - 1) / chunk;
-    auto worker = [&](Lane *l) {
-        if (hipSetDevice(ctx->device) != hipSuccess) { status = IPX_ERR_HIP; return; }
-        int rc = lane_reserve(*l, per_frame * chunk + 256);
-        std::vector<size_t> offs(chunk), lens(chunk);
-        for (int c = next.fetch_add(1); !rc && c < nchunks && status == IPX_OK; c = next.fetch_add(1)) {
-            const int i0 = c * chunk, m = std::min(chunk, n - i0);
-            uint8_t *dsrc = (uint8_t *)(((uintptr_t)l->dev + 255) & ~(uintptr_t)255);
-            uint8_t *dres = fres ? dsrc + fsrc * chunk : nullptr;
-            uint8_t *dth = fth ? dsrc + (fsrc + fres) * chunk : nullptr;
-            uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * chunk : nullptr;
-            int16_t *dcoef = (int16_t *)(dsrc + (fsrc + fres + fth + fwm) * chunk);
-            hipError_t e = hipSuccess;
-            if (ysrc) {
-                // planes of the chunk: [m x Y][m x Cb][m x Cr]
-                uint8_t *dy = dsrc, *dcb = dy + yb * chunk, *dcr = dcb + cbb * chunk;
-                auto up = [&](uint8_t *d, size_t dfs, int w, int h, const uint8_t *hsrc, int hstride, size_t hfs) {
-                    if (hstride == w && hfs == dfs) return hipMemcpyAsync(d, hsrc + hfs * i0, dfs * m, hipMemcpyHostToDevice, l->stream);
-                    hipError_t r = hipSuccess;
-                    for (int i = 0; i < m && r == hipSuccess; i++)
-                        r = hipMemcpy2DAsync(d + dfs * i, w, hsrc + hfs * (size_t)(i0 + i), hstride, w, h, hipMemcpyHostToDevice, l->stream);
-                    return r;
-                };
-                e = up(dy, yb, sw, sh, ysrc->y, ysrc->ystride, ysrc->y_frame_stride);
-                if (e == hipSuccess) e = up(dcb, cbb, cw, ch, ysrc->cb, ysrc->cstride, ysrc->c_frame_stride);
-                if (e == hipSuccess) e = up(dcr, cbb, cw, ch, ysrc->cr, ysrc->cstride, ysrc->c_frame_stride);
-                if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; break; }
-                ipx_ycbcr_batch d;
-                d.y = dy; d.cb = dcb; d.cr = dcr; d.ystride = sw; d.cstride = cw; d.y_frame_stride = yb; d.c_frame_stride = cbb;
-                d.ratio = ysrc->ratio;
-                rc = ipx_plan_run_dev_ycbcr(ctx, l->stream, pl, m, &d, dres, fres, dth, fth, dwm, fwm);
-            } else {
-                if (sstride == sw * 4 && src_frame_stride == fsrc)
-                    e = hipMemcpyAsync(dsrc, src + (size_t)i0 * src_frame_stride, fsrc * m, hipMemcpyHostToDevice, l->stream);
-                else
-                    for (int i = 0; i < m && e == hipSuccess; i++)
-                        e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * 4, src + (size_t)(i0 + i) * src_frame_stride, sstride,
-                                             (size_t)sw * 4, sh, hipMemcpyHostToDevice, l->stream);
-                if (e != hipSuccess) { set_error("upload failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; break; }
-                rc = ipx_plan_run_dev(ctx, l->stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm);
-            }
-            struct Out { uint8_t *dev; size_t fs; int w, h; ipx_bytes *dst; };
-            const Out outs[3] = {{dres, fres, pl->info.resize_w, pl->info.resize_h, resize_out},
-                                 {dth, fth, pl->info.thumb_w, pl->info.thumb_h, thumb_out},
-                                 {dwm, fwm, sw, sh, wm_out}};
-            for (int k = 0; k < 3 && !rc; k++) {
-                const Out &o = outs[k];
-                if (!o.dev || o.w <= 0 || o.h <= 0) continue;
-                uint8_t *blob = nullptr;
-                rc = jpeg_encode_core(ctx, l->stream, dcoef, o.dev, o.w, o.h, o.w * 4, o.fs, m, quality, &blob, offs.data(), lens.data());
-                if (rc) break;
-                for (int i = 0; i < m; i++) { o.dst[i0 + i].data = blob + offs[i]; o.dst[i0 + i].len = lens[i]; }
-                std::lock_guard<std::mutex> lk(res_mu);
-                res->blobs.push_back(blob);
-            }
-        }
-        if (rc) {
-            std::lock_guard<std::mutex> lk(res_mu);
-            if (status == IPX_OK) { status = rc; err_text = ipx_last_error(); }
-        }
-        (void)hipStreamSynchronize(l->stream);
-    };
-    std::vector<std::thread> pool;
-    for (int i = 1; i < nl; i++) pool.emplace_back(worker, lanes[i]);
-    worker(lanes[0]);
-    for (auto &t : pool) t.join();
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        for (auto *l : lanes) l->busy = false;
-    }
-    ctx->cv.notify_all();
-    if (status != IPX_OK) {
-        ipx_jpeg_result_free(ctx, res.release());
-        set_error("%s", err_text.c_str());
-        return status;
-    }
-    *result = res.release();
-    return IPX_OK;
-}
-
-extern "C" {
-
-int ipx_plan_run_host_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
-                           int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, ipx_jpeg_result **result)
-{
-    IPX_ENTER(ctx);
-    if (!pl || n < 0 || !src || !result || (long long)sstride < (long long)pl->p.sw * 4) {
-        set_error("ipx_plan_run_host_jpeg: bad argument");
-        return IPX_ERR_INVALID;
-    }
-    return run_host_jpeg_impl(ctx, pl, n, src, sstride, src_frame_stride, nullptr, quality, resize_out, thumb_out, wm_out, result);
-}
-
-int ipx_plan_run_host_ycbcr_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, int quality,
-                                 ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, ipx_jpeg_result **result)
-{
-    IPX_ENTER(ctx);
-    if (!pl || n < 0 || !result || !src || !src->y || !src->cb || !src->cr || src->ratio < 0 || src->ratio > IPX_YCBCR_440 ||
-        src->ystride < pl->p.sw) {
-        set_error("ipx_plan_run_host_ycbcr_jpeg: bad argument");
-        return IPX_ERR_INVALID;
-    }
-    return run_host_jpeg_impl(ctx, pl, n, nullptr, 0, 0, src, quality, resize_out, thumb_out, wm_out, result);
-}
-
-int ipx_jpeg_encode_rgba8(ipx_ctx *ctx, const uint8_t *pix, int w, int h, int stride, int quality, uint8_t **out, size_t *len)
-{
-    IPX_ENTER(ctx);
-    if (!pix || !out || !len || w <= 0 || h <= 0 || (long long)stride < (long long)w * 4) {
-        set_error("ipx_jpeg_encode_rgba8: bad argument");
-        return IPX_ERR_INVALID;
-    }
-    if (w >= 1 << 16 || h >= 1 << 16) { set_error("jpeg: image is too large to encode"); return IPX_ERR_INVALID; }
-    const size_t fbytes = align256((size_t)w * h * 4), per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
-    std::vector<int16_t> host(per / sizeof(int16_t));
-    {
-        LaneLease lane(ctx);
-        int rc = lane_reserve(lane.get(), fbytes + per);
-        if (rc) return rc;
-        hipStream_t s = lane->stream;
-        IPX_HIP(hipMemcpy2DAsync(lane->dev, (size_t)w * 4, pix, stride, (size_t)w * 4, h, hipMemcpyHostToDevice, s));
-        rc = ipx_dev_jpeg_fdct_rgba8(ctx, s, lane->dev, w, h, w * 4, fbytes, 1, quality, (int16_t *)(lane->dev + fbytes));
-        if (rc) { (void)hipStreamSynchronize(s); return rc; }
-        IPX_HIP(hipMemcpyAsync(host.data(), lane->dev + fbytes, per, hipMemcpyDeviceToHost, s));
-        IPX_HIP(hipStreamSynchronize(s));
-    }
-    return ipx_jpeg_entropy_encode(host.data(), w, h, quality, out, len);
-}
-
-}  // extern "C"
-
-
-// ---- image.Decode for JPEG batches -----------------------------------------------------------------------
-struct ipx_jpeg_planes { std::vector<void *> dev; };
-
-extern "C" {
-
-void ipx_jpeg_planes_free(ipx_ctx *ctx, ipx_jpeg_planes *o)
-{
-    if (!o) return;
-    if (ctx) (void)hipSetDevice(ctx->device);
-    for (void *p : o->dev) (void)hipFree(p);
-    delete o;
-}
-
-int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, int n, int *w, int *h, ipx_ycbcr_batch *planes,
-                          int *status, ipx_jpeg_planes **owner)
-{
-    IPX_ENTER(ctx);
-    if (!jpegs || n < 0 || !w || !h || !planes || !status || !owner) { set_error("ipx_jpeg_decode_batch: bad argument"); return IPX_ERR_INVALID; }
-    *owner = nullptr;
-    memset(planes, 0, sizeof *planes);
-    if (n == 0) return IPX_OK;
-    if (n > 65535) { set_error("ipx_jpeg_decode_batch: at most 65535 files per call"); return IPX_ERR_UNSUPPORTED; }
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    std::vector<JpegDecInfo> info(n);
-    std::vector<JpegDecTables> tabs(n);
-    std::vector<JpegDecImage> items;
-    std::vector<uint8_t> valid(n, 0);
-    std::vector<size_t> blob_off(n, 0);
-    // host preparation runs on a few threads: parsing is trivial, but finding the RSTn markers and packing the scans walk
-    // every compressed byte (0.3 GB for a thousand 1080p files)
-    auto parallel_for = [&](int count, const std::function<void(int)> &fn) {
-        const int nt = std::max(1, std::min({count / 8, (int)std::thread::hardware_concurrency(), 16}));
-        std::atomic<int> next{0};
-        auto work = [&] { for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
-    };
-    // pieces of a scan: the whole scan, or one per restart interval.  Inside entropy-coded data 0xff is followed by 0x00 or by a
-    // marker, so every 0xff 0xd0..0xd7 pair is an RSTn.
-    std::vector<std::vector<uint32_t>> marks(n);
-    parallel_for(n, [&](int i) {
-        status[i] = !jpegs[i].data ? IPX_ERR_INVALID : (jpegs[i].len >= ((size_t)1 << 30) ? IPX_ERR_UNSUPPORTED : jpeg_parse(jpegs[i].data, jpegs[i].len, &info[i], &tabs[i]));
-        if (status[i] != IPX_OK) return;
-        const JpegDecInfo &I = info[i];
-        const int nmcu = ((I.w + 8 * I.h0 - 1) / (8 * I.h0)) * ((I.h + 8 * I.v0 - 1) / (8 * I.v0));
-        if (I.ri <= 0 || nmcu <= I.ri) return;
-        const uint8_t *sd = jpegs[i].data + I.scan_off;
-        int expected = 0;
-        for (size_t k = 0; k + 1 < I.scan_len;) {
-            const uint8_t *q = (const uint8_t *)memchr(sd + k, 0xff, I.scan_len - 1 - k);
-            if (!q) break;
-            k = (size_t)(q - sd);
-            const uint8_t m2 = sd[k + 1];
-            if (m2 == 0x00) { k += 2; continue; }
-            if (m2 < 0xd0 || m2 > 0xd7) break;                        // EOI or another marker: the scan ends here
-            if (m2 != 0xd0 + expected) { status[i] = IPX_ERR_UNSUPPORTED; return; }
-            marks[i].push_back((uint32_t)k);
-            expected = (expected + 1) & 7;
-            k += 2;
-        }
-        if ((int)marks[i].size() != (nmcu + I.ri - 1) / I.ri - 1) status[i] = IPX_ERR_UNSUPPORTED;   // Go would try to resynchronise
-    });
-    int ref = -1;
-    size_t blob_bytes = 0;
-    std::vector<JpegParImage> par;
-    const bool use_par = env_int("IPX_JPEG_PAR", 1) != 0;
-    for (int i = 0; i < n; i++) {
-        if (status[i] == IPX_OK) {
-            if (ref < 0 && (*w <= 0 || (info[i].w == *w && info[i].h == *h))) ref = i;
-            if (ref >= 0 && (info[i].w != info[ref].w || info[i].h != info[ref].h || info[i].h0 != info[ref].h0 || info[i].v0 != info[ref].v0 ||
-                             info[i].ncomp != info[ref].ncomp))
-                status[i] = IPX_ERR_UNSUPPORTED;
-            else if (ref < 0) status[i] = IPX_ERR_UNSUPPORTED;   // a size other than the one asked for
-        }
-        if (status[i] != IPX_OK) continue;
-        const JpegDecInfo &I = info[i];
-        const int nmcu = ((I.w + 8 * I.h0 - 1) / (8 * I.h0)) * ((I.h + 8 * I.v0 - 1) / (8 * I.v0));
-        auto push = [&](size_t a0, size_t a1, int m0, int cnt) {
-            JpegDecImage it;
-            memset(&it, 0, sizeof it);
-            it.scan_off = blob_bytes + (a0 & ~(size_t)15); it.scan_len = (uint32_t)(a1 - (a0 & ~(size_t)15));
-            it.img = (uint32_t)i; it.first_mcu = (uint32_t)m0; it.n_mcu = (uint32_t)cnt;
-            memcpy(it.td, I.td, 3); memcpy(it.ta, I.ta, 3);
-            it.valid = 1;
-            it.pad = (uint8_t)(a0 & 15);           // bytes to skip: pieces start 16-byte aligned for the kernel's chunk loads
-            items.push_back(it);
-        };
-        size_t start = 0;
-        int mcu = 0;
-        for (uint32_t k : marks[i]) { push(start, k, mcu, I.ri); items.back().strict_end = 1; mcu += I.ri; start = (size_t)k + 2; }
-        if (marks[i].empty() && use_par && I.scan_len >= (size_t)4 * jpeg_par_sub_bytes() && I.scan_len < ((size_t)1 << 28)) {
-            // a long scan without restart markers: decoded in parallel inside the scan (ipx_jpeg_dec_par.hip)
-            JpegParImage pi;
-            memset(&pi, 0, sizeof pi);
-            pi.scan_off = blob_bytes; pi.scan_len = (uint32_t)I.scan_len; pi.img = (uint32_t)i;
-            pi.nsub = (uint32_t)((I.scan_len + jpeg_par_sub_bytes() - 1) / jpeg_par_sub_bytes());
-            memcpy(pi.td, I.td, 3); memcpy(pi.ta, I.ta, 3);
-            par.push_back(pi);
-        } else {
-            push(start, I.scan_len, mcu, nmcu - mcu);
-        }
-        valid[i] = 1;
-        blob_off[i] = blob_bytes;
-        blob_bytes += (I.scan_len + 15 + 16) & ~(size_t)15;
-    }
-    if (ref < 0) return IPX_OK;
-    const JpegDecInfo &R = info[ref];
-    *w = R.w; *h = R.h;
-    JpegDecArgs a{};
-    a.n = n; a.h0 = R.h0; a.v0 = R.v0;
-    a.mxx = (R.w + 8 * R.h0 - 1) / (8 * R.h0); a.myy = (R.h + 8 * R.v0 - 1) / (8 * R.v0);
-    const bool gray = R.ncomp == 1;                        // *image.Gray: one block per MCU, no chroma planes
-    a.ybl = R.h0 * R.v0; a.bpm = gray ? 1 : a.ybl + 2;
-    a.nblk = a.mxx * a.myy * a.bpm;
-    JpegPlanes pl{};
-    pl.ystride = 8 * R.h0 * a.mxx; pl.cstride = 8 * a.mxx;
-    pl.y_fs = align256((size_t)pl.ystride * 8 * R.v0 * a.myy); pl.c_fs = gray ? 0 : align256((size_t)pl.cstride * 8 * a.myy);
-
-    std::unique_ptr<ipx_jpeg_planes> own(new ipx_jpeg_planes);
-    auto dalloc = [&](void **p, size_t bytes) {
-        hipError_t e = hipMalloc(p, bytes ? bytes : 1);
-        if (e == hipSuccess) own->dev.push_back(*p);
-        return e;
-    };
-    auto fail = [&](hipError_t e, const char *what) {
-        set_error("%s: %s", what, hipGetErrorString(e));
-        ipx_jpeg_planes_free(ctx, own.release());
-        return IPX_ERR_HIP;
-    };
-    hipError_t e;
-    if ((e = dalloc((void **)&pl.y, pl.y_fs * n)) != hipSuccess) return fail(e, "plane allocation");
-    if (!gray && (e = dalloc((void **)&pl.cb, pl.c_fs * n)) != hipSuccess) return fail(e, "plane allocation");
-    if (!gray && (e = dalloc((void **)&pl.cr, pl.c_fs * n)) != hipSuccess) return fail(e, "plane allocation");
-    // scratch of this call, stream-ordered
-    AsyncFree mem{s, {}};
-    uint8_t *d_blob; JpegDecImage *d_img; JpegDecTables *d_tab; int16_t *d_coefs; int *d_status;
-    if ((e = mem.get(&d_blob, blob_bytes + 16)) != hipSuccess) return fail(e, "scratch allocation");
-    uint8_t *d_valid;
-    if ((e = mem.get(&d_img, sizeof(JpegDecImage) * items.size())) != hipSuccess) return fail(e, "scratch allocation");
-    if ((e = mem.get(&d_valid, (size_t)n)) != hipSuccess) return fail(e, "scratch allocation");
-    if ((e = mem.get(&d_tab, sizeof(JpegDecTables) * n)) != hipSuccess) return fail(e, "scratch allocation");
-    if ((e = mem.get(&d_coefs, (size_t)n * a.nblk * 128)) != hipSuccess) return fail(e, "scratch allocation");
-    if ((e = mem.get(&d_status, sizeof(int) * n)) != hipSuccess) return fail(e, "scratch allocation");
-    uint8_t *hblob = (uint8_t *)ipx_host_alloc(ctx, blob_bytes + 16);
-    if (!hblob) { ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
-    parallel_for(n, [&](int i) { if (valid[i]) memcpy(hblob + blob_off[i], jpegs[i].data + info[i].scan_off, info[i].scan_len); });
-    e = hipMemcpyAsync(d_blob, hblob, blob_bytes, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_img, items.data(), sizeof(JpegDecImage) * items.size(), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_valid, valid.data(), (size_t)n, hipMemcpyHostToDevice, s);
-    pl.valid = d_valid;
-    a.nitems = (int)items.size();
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tabs.data(), sizeof(JpegDecTables) * n, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_coefs, 0, (size_t)n * a.nblk * 128, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int) * n, s);
-    a.blob = d_blob; a.img = d_img; a.tab = d_tab; a.coefs = d_coefs; a.status = d_status;
-    a.first_valid = ref;
-    a.shared_tables = env_int("IPX_JPEG_SHARED_TABLES", 1);
-    for (int i = 0; i < n && a.shared_tables; i++)
-        if (valid[i] && (memcmp(tabs[i].lut, tabs[ref].lut, sizeof tabs[i].lut) || memcmp(tabs[i].maxcode, tabs[ref].maxcode, sizeof tabs[i].maxcode) ||
-                              memcmp(tabs[i].valoff, tabs[ref].valoff, sizeof tabs[i].valoff) || memcmp(tabs[i].vals, tabs[ref].vals, sizeof tabs[i].vals)))
-            a.shared_tables = 0;
-    if (e == hipSuccess && a.nitems > 0) e = launch_jpeg_huff(a, s);
-    if (e == hipSuccess && !par.empty()) {
-        JpegParArgs P{};
-        P.blob = d_blob; P.tab = d_tab; P.nimg = (int)par.size(); P.bpm = a.bpm; P.ybl = a.ybl; P.nblk = a.nblk;
-        P.coefs = d_coefs; P.status = d_status;
-        P.stage_rows = env_int("IPX_JPEG_PAR_STAGE", 0);   // measured: 109 ms staged (2 waves per CU) against 49 ms through L1 / L2 (1024 x 1080p)
-        for (auto &pi : par) P.max_nsub = std::max(P.max_nsub, (int)pi.nsub);
-        for (size_t k = 0; k < par.size(); k++) par[k].sub_off = k * (size_t)P.max_nsub;
-        const size_t nsubs = par.size() * (size_t)P.max_nsub;
-        JpegParImage *d_par = nullptr; uint32_t *d_tot = nullptr;
-        if (e == hipSuccess) e = mem.get(&d_par, sizeof(JpegParImage) * par.size());
-        if (e == hipSuccess) e = mem.get(&P.stuffed, nsubs * 4);
-        if (e == hipSuccess) e = mem.get(&P.entry, nsubs * 8);
-        if (e == hipSuccess) e = mem.get(&P.exit_a, nsubs * 8);
-        if (e == hipSuccess) e = mem.get(&P.exit_b, nsubs * 8);
-        if (e == hipSuccess) e = mem.get(&P.ends, nsubs * 4);
-        if (e == hipSuccess) e = mem.get(&P.total_ends, par.size() * 4);
-        if (e == hipSuccess) e = mem.get(&d_tot, par.size() * 4);
-        if (e == hipSuccess) e = mem.get(&P.changed, 4);
-        P.img = d_par;
-        if (e == hipSuccess) e = hipMemcpyAsync(d_par, par.data(), sizeof(JpegParImage) * par.size(), hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemsetAsync(P.stuffed, 0, nsubs * 4, s);
-        if (e == hipSuccess) e = hipMemsetAsync(P.entry, 0xff, nsubs * 8, s);
-        if (e == hipSuccess) e = hipMemsetAsync(P.ends, 0, nsubs * 4, s);
-        if (e == hipSuccess) e = mem.get(&P.ublob, blob_bytes + 64);
-        if (e == hipSuccess) e = mem.get(&P.scan_end, par.size() * 4);
-        if (e == hipSuccess) e = mem.get(&P.ulen, par.size() * 4);
-        if (e == hipSuccess) e = hipMemsetAsync(P.ublob, 0, blob_bytes + 64, s);
-        if (e == hipSuccess) e = hipMemsetAsync(P.scan_end, 0xff, par.size() * 4, s);
-        if (e == hipSuccess) e = hipMemsetAsync(P.ulen, 0, par.size() * 4, s);
-        if (e == hipSuccess) e = launch_par_count(P, s);
-        if (e == hipSuccess) e = launch_scan(P.stuffed, P.max_nsub, P.nimg, d_tot, s);
-        if (e == hipSuccess) e = launch_par_unstuff(P, s);
-        if (e == hipSuccess) e = launch_par_sync(P, 0, s);
-        bool converged = false;
-        const int max_rounds = env_int("IPX_JPEG_PAR_ROUNDS", 96);
-        for (int round = 1; e == hipSuccess && round <= max_rounds; round++) {
-            uint32_t changed = 0;
-            e = hipMemsetAsync(P.changed, 0, 4, s);
-            if (e == hipSuccess) e = launch_par_sync(P, round, s);
-            if (e == hipSuccess) e = hipMemcpyAsync(&changed, P.changed, 4, hipMemcpyDeviceToHost, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (getenv("IPX_DEBUG")) fprintf(stderr, "[ipx] jpeg par sync round %d: %u entries changed\n", round, changed);
-            if (e == hipSuccess && changed == 0) { converged = true; break; }
-        }
-        if (e == hipSuccess && !converged) {
-            // a scan that never settled (it would take a pathological file): hand these images to the serial kernel
-            std::vector<JpegDecImage> serial;
-            for (auto &pi : par) {
-                JpegDecImage it;
-                memset(&it, 0, sizeof it);
-                it.scan_off = pi.scan_off; it.scan_len = pi.scan_len; it.img = pi.img; it.first_mcu = 0; it.n_mcu = (uint32_t)(a.mxx * a.myy);
-                memcpy(it.td, pi.td, 3); memcpy(it.ta, pi.ta, 3);
-                it.valid = 1;
-                serial.push_back(it);
-            }
-            JpegDecImage *d_serial;
-            e = mem.get(&d_serial, sizeof(JpegDecImage) * serial.size());
-            if (e == hipSuccess) e = hipMemcpyAsync(d_serial, serial.data(), sizeof(JpegDecImage) * serial.size(), hipMemcpyHostToDevice, s);
-            JpegDecArgs a2 = a;
-            a2.img = d_serial; a2.nitems = (int)serial.size();
-            if (e == hipSuccess) e = launch_jpeg_huff(a2, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);   // `serial` must outlive the copy
-        } else if (e == hipSuccess) {
-            e = launch_scan(P.ends, P.max_nsub, P.nimg, P.total_ends, s);
-            if (e == hipSuccess) e = launch_par_write(P, s);
-            if (e == hipSuccess) e = launch_par_dc(P, s);
-        }
-    }
-    if (e == hipSuccess) e = launch_jpeg_idct(a, pl, s);
-    std::vector<int> dev_status(n, 0);
-    if (e == hipSuccess) e = hipMemcpyAsync(dev_status.data(), d_status, sizeof(int) * n, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);   // the host tables and the blob may go now
-    (void)ipx_host_free(ctx, hblob);
-    if (e != hipSuccess) return fail(e, "jpeg decode");
-    for (int i = 0; i < n; i++)
-        if (status[i] == IPX_OK && dev_status[i]) status[i] = dev_status[i];
-    planes->y = pl.y; planes->cb = pl.cb; planes->cr = pl.cr;
-    planes->ystride = pl.ystride; planes->cstride = pl.cstride;
-    planes->y_frame_stride = pl.y_fs; planes->c_frame_stride = pl.c_fs;
-    planes->ratio = R.ratio;
-    *owner = own.release();
-    return IPX_OK;
-}
-
-}  // extern "C"
-
-
-// ---- compressed in, compressed out: image.Decode, the operators and jpeg.Encode without leaving the GPU ------
-extern "C" {
-
-static int run_jpeg_jpeg_one(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_bytes *files, int quality, ipx_bytes *resize_out,
-                             ipx_bytes *thumb_out, ipx_bytes *wm_out, int *status, ipx_jpeg_result **result)
-{
-    IPX_ENTER(ctx);
-    *result = nullptr;
-    if (n == 0) return IPX_OK;
-    const int sw = pl->p.sw, sh = pl->p.sh;
-    for (int i = 0; i < n; i++) {
-        if (resize_out) resize_out[i] = ipx_bytes{nullptr, 0};
-        if (thumb_out) thumb_out[i] = ipx_bytes{nullptr, 0};
-        if (wm_out) wm_out[i] = ipx_bytes{nullptr, 0};
-    }
-    LaneLease lane(ctx);
-    hipStream_t s = lane->stream;
-    int w = sw, h = sh;
-    ipx_ycbcr_batch planes;
-    ipx_jpeg_planes *owner = nullptr;
-    int rc = ipx_jpeg_decode_batch(ctx, s, files, n, &w, &h, &planes, status, &owner);
-    if (rc) return rc;
-    if (!planes.y) return IPX_OK;                         // nothing decodable: every status says why
-    struct Guard { ipx_ctx *c; ipx_jpeg_planes *o; ~Guard() { ipx_jpeg_planes_free(c, o); } } guard{ctx, owner};
-    const size_t fres = resize_out ? align256(pl->info.resize_bytes) : 0, fth = thumb_out ? align256(pl->info.thumb_bytes) : 0;
-    const size_t fwm = wm_out ? align256(pl->info.wm_bytes) : 0;
-    const size_t cres = fres ? ipx_jpeg_coef_count(pl->info.resize_w, pl->info.resize_h) * 2 : 0;
-    const size_t cth = fth ? ipx_jpeg_coef_count(pl->info.thumb_w, pl->info.thumb_h) * 2 : 0;
-    const size_t cwm = fwm ? ipx_jpeg_coef_count(sw, sh) * 2 : 0;
-    const size_t ccoef = align256(std::max(cres, std::max(cth, cwm)));
-    const size_t per_frame = fres + fth + fwm + ccoef;
-    if (per_frame == 0) return IPX_OK;
-    const int chunk = std::max(1, std::min(n, env_int("IPX_JPEG_JPEG_CHUNK", 256)));
-    rc = lane_reserve(lane.get(), per_frame * chunk + 256);
-    if (rc) return rc;
-    std::unique_ptr<ipx_jpeg_result> res(new ipx_jpeg_result);
-    std::vector<size_t> offs(chunk), lens(chunk);
-    for (int i0 = 0; i0 < n && !rc; i0 += chunk) {
-        const int m = std::min(chunk, n - i0);
-        uint8_t *base = (uint8_t *)(((uintptr_t)lane->dev + 255) & ~(uintptr_t)255);
-        uint8_t *dres = fres ? base : nullptr, *dth = fth ? base + fres * chunk : nullptr, *dwm = fwm ? base + (fres + fth) * chunk : nullptr;
-        int16_t *dcoef = (int16_t *)(base + (fres + fth + fwm) * chunk);
-        ipx_ycbcr_batch d = planes;
-        d.y += planes.y_frame_stride * i0;
-        if (d.cb) { d.cb += planes.c_frame_stride * i0; d.cr += planes.c_frame_stride * i0; }
-        if (planes.ratio == IPX_GRAY) rc = ipx_plan_run_dev_gray(ctx, s, pl, m, d.y, d.ystride, d.y_frame_stride, dres, fres, dth, fth, dwm, fwm);
-        else rc = ipx_plan_run_dev_ycbcr(ctx, s, pl, m, &d, dres, fres, dth, fth, dwm, fwm);
-        struct Out { uint8_t *dev; size_t fs; int w, h; ipx_bytes *dst; };
-        const Out outs[3] = {{dres, fres, pl->info.resize_w, pl->info.resize_h, resize_out},
-                             {dth, fth, pl->info.thumb_w, pl->info.thumb_h, thumb_out},
-                             {dwm, fwm, sw, sh, wm_out}};
-        for (int k = 0; k < 3 && !rc; k++) {
-            const Out &o = outs[k];
-            if (!o.dev || o.w <= 0 || o.h <= 0) continue;
-            uint8_t *blob = nullptr;
-            rc = jpeg_encode_core(ctx, s, dcoef, o.dev, o.w, o.h, o.w * 4, o.fs, m, quality, &blob, offs.data(), lens.data());
-            if (rc) break;
-            res->blobs.push_back(blob);
-            for (int i = 0; i < m; i++)
-                if (status[i0 + i] == IPX_OK) { o.dst[i0 + i].data = blob + offs[i]; o.dst[i0 + i].len = lens[i]; }
-        }
-    }
-    (void)hipStreamSynchronize(s);
-    if (rc) { ipx_jpeg_result_free(ctx, res.release()); return rc; }
-    *result = res.release();
-    return IPX_OK;
-}
-
-
-int ipx_plan_run_jpeg_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_bytes *files, int quality, ipx_bytes *resize_out,
-                           ipx_bytes *thumb_out, ipx_bytes *wm_out, int *status, ipx_jpeg_result **result)
-{
-    IPX_ENTER(ctx);
-    if (!pl || n < 0 || !files || !status || !result) { set_error("ipx_plan_run_jpeg_jpeg: bad argument"); return IPX_ERR_INVALID; }
-    *result = nullptr;
-    // a large batch is cut into parts that run on lanes of their own, one host thread each: while one part is in its (host-paced)
-    // encode read-backs another decodes.  Two callers with 1024 files each measured 15 k images/s against 11.7 k for one.
-    const int parts = std::max(1, std::min({(int)ctx->lanes.size(), n / std::max(1, env_int("IPX_JPEG_JPEG_PART", 384)), 3}));
-    if (parts == 1) return run_jpeg_jpeg_one(ctx, pl, n, files, quality, resize_out, thumb_out, wm_out, status, result);
-    std::vector<ipx_jpeg_result *> res(parts, nullptr);
-    std::vector<int> rcs(parts, IPX_OK);
-    std::vector<std::string> errs(parts);
-    auto work = [&](int k) {
-        const int i0 = (int)((long long)n * k / parts), i1 = (int)((long long)n * (k + 1) / parts);
-        rcs[k] = run_jpeg_jpeg_one(ctx, pl, i1 - i0, files + i0, quality, resize_out ? resize_out + i0 : nullptr, thumb_out ? thumb_out + i0 : nullptr,
-                                   wm_out ? wm_out + i0 : nullptr, status + i0, &res[k]);
-        if (rcs[k]) errs[k] = ipx_last_error();
-    };
-    std::vector<std::thread> pool;
-    for (int k = 1; k < parts; k++) pool.emplace_back(work, k);
-    work(0);
-    for (auto &t : pool) t.join();
-    std::unique_ptr<ipx_jpeg_result> all(new ipx_jpeg_result);
-    int rc = IPX_OK;
-    for (int k = 0; k < parts; k++) {
-        if (res[k]) { all->blobs.insert(all->blobs.end(), res[k]->blobs.begin(), res[k]->blobs.end()); delete res[k]; }
-        if (rcs[k] && !rc) { rc = rcs[k]; set_error("%s", errs[k].c_str()); }
-    }
-    if (rc) { ipx_jpeg_result_free(ctx, all.release()); return rc; }
-    *result = all.release();
     return IPX_OK;
 }
 

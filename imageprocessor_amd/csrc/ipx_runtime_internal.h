@@ -1,0 +1,163 @@
+// ipx_runtime_internal.h -- the runtime's own types (context, lanes, glyph sets, plans) and the small helpers every
+// translation unit that implements ABI entries needs (ipx_runtime.hip, ipx_jpeg_runtime.hip).  Not part of the ABI.
+#pragma once
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "ipx_internal.h"
+
+using namespace ipx;
+
+// ---------------------------------------------------------------------------------------------
+struct Lane {
+    hipStream_t stream = nullptr;
+    uint8_t *dev = nullptr;   // device scratch
+    size_t dev_bytes = 0;
+    int *flag = nullptr;      // device int for the opaque() scan
+    bool busy = false;
+};
+
+struct ipx_ctx {
+    int device = 0;
+    int cus = 256;                 // compute units of the device
+    hipStream_t stream = nullptr;  // default stream for device-pointer calls
+    std::vector<Lane> lanes;
+    size_t lane_bytes = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    // pinned host blocks: hipHostMalloc / hipHostFree cost milliseconds each, and the encoder hands out one block per
+    // batch and output, so freed blocks are kept (up to host_cache_limit bytes) and reused for requests they fit
+    std::mutex host_mu;
+    std::map<void *, size_t> host_size;            // every live block handed out by ipx_host_alloc
+    std::multimap<size_t, void *> host_free_blocks;
+    size_t host_cached = 0, host_cache_limit = (size_t)2 << 30;
+};
+
+struct GlyphHost {
+    size_t mask_off;  // offset of this glyph's mask in the packed blob
+    int mw, mh;
+    Rect dr;
+    int mpx, mpy;
+};
+
+struct ClippedGlyphs {
+    DevGlyph *dev = nullptr;
+    int n = 0;
+    Rect bbox{0, 0, 0, 0};
+};
+
+struct ipx_glyphset {
+    int device = 0;
+    std::vector<GlyphHost> g;
+    uint8_t *masks_dev = nullptr;
+    size_t masks_bytes = 0;
+    uint8_t col[4] = {0, 0, 0, 0};
+    mutable std::mutex mu;
+    mutable std::map<std::pair<int, int>, ClippedGlyphs> clipped;  // per frame size
+};
+
+struct PlanScale {
+    bool on = false;
+    int dw = 0, dh = 0;
+    Rect sr{0, 0, 0, 0};
+    AxisTap *xt = nullptr, *yt = nullptr;
+    int *row_begin = nullptr, *col_begin = nullptr;
+    int dyadic_shift = -1;
+    int kx = -1, ky = -1;   // dyadic bits per axis (dyadic_shift = kx + ky), -1 = not dyadic
+};
+
+struct ipx_plan {
+    ipx_plan_params p{};
+    ipx_plan_info info{};
+    bool fused = false;
+    int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0;
+    int nx_out[2] = {0, 0}; // per output: ceil(widest column block / 256)
+    int most_rows = 0;    // most destination rows any band owns, over the scaled outputs
+    PlanScale sc[2];      // 0 = resize, 1 = thumbnail
+    uint8_t *blob = nullptr;
+    ClippedGlyphs glyphs;
+    mutable std::mutex mu;
+    mutable ipx_plan *thumb_only = nullptr;   // RGBA sub-plan for YCbCr batches (thumbnail of the converted frame)
+};
+
+inline int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+struct DeviceGuard {  // hipSetDevice is per-thread; callers may arrive on any OS thread
+    explicit DeviceGuard(int dev) { ok = hipSetDevice(dev) == hipSuccess; }
+    bool ok;
+};
+
+#define IPX_ENTER(ctx)                                                         \
+    clear_error();                                                             \
+    if (!(ctx)) { set_error("%s: null context", __func__); return IPX_ERR_INVALID; } \
+    DeviceGuard guard_((ctx)->device);                                         \
+    if (!guard_.ok) { set_error("hipSetDevice(%d) failed", (ctx)->device); return IPX_ERR_HIP; }
+
+class LaneLease {
+public:
+    explicit LaneLease(ipx_ctx *c) : c_(c)
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        c->cv.wait(lk, [&] {
+            for (auto &l : c->lanes) if (!l.busy) return true;
+            return false;
+        });
+        for (auto &l : c->lanes) if (!l.busy) { l.busy = true; lane_ = &l; break; }
+    }
+    ~LaneLease()
+    {
+        {
+            std::lock_guard<std::mutex> lk(c_->mu);
+            lane_->busy = false;
+        }
+        c_->cv.notify_one();
+    }
+    Lane *operator->() { return lane_; }
+    Lane &get() { return *lane_; }
+private:
+    ipx_ctx *c_;
+    Lane *lane_ = nullptr;
+};
+
+inline int lane_reserve(Lane &l, size_t bytes)
+{
+    if (bytes <= l.dev_bytes) return IPX_OK;
+    if (l.dev) { IPX_HIP(hipStreamSynchronize(l.stream)); IPX_HIP(hipFree(l.dev)); l.dev = nullptr; l.dev_bytes = 0; }
+    const size_t want = std::max(bytes, l.dev_bytes * 2);
+    hipError_t e = hipMalloc((void **)&l.dev, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("device allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return IPX_ERR_NOMEM;
+    }
+    l.dev_bytes = want;
+    return IPX_OK;
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// stream-ordered scratch of one call: freed (in stream order) when the call returns
+struct AsyncFree {
+    hipStream_t s;
+    std::vector<void *> p;
+    ~AsyncFree() { for (void *q : p) (void)hipFreeAsync(q, s); }
+    template <class T> hipError_t get(T **out, size_t bytes)
+    {
+        void *q = nullptr;
+        hipError_t e = hipMallocAsync(&q, bytes ? bytes : 1, s);
+        if (e == hipSuccess) p.push_back(q);
+        *out = (T *)q;
+        return e;
+    }
+};
