@@ -198,6 +198,13 @@ struct JpegDecArgs {
     int nitems;                      // pieces to decode (>= images)
     int shared_tables, first_valid;   // every valid image carries the Huffman tables of image first_valid
 };
+// the per-image status word of the decoder kernels: 0, or a negative key whose low three bits are -IPX_ERR_* and whose upper bits order
+// the reporting pieces so that atomicMin keeps the verdict of the piece a sequential decoder would have reached first
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int jpeg_status_key(uint32_t first_mcu, int status) { return -(int)(((0x3ffffffu - (first_mcu & 0x3ffffffu)) << 3) | (uint32_t)(-status)); }
+inline int jpeg_status_of(int key) { return key >= 0 ? 0 : -(int)((uint32_t)(-key) & 7u); }
 struct JpegPlanes { uint8_t *y, *cb, *cr; int ystride, cstride; size_t y_fs, c_fs; const uint8_t *valid; /* per image */ };
 // Huffman decoding parallel inside a scan (ipx_jpeg_dec_par.hip): per image and per 1 KiB sub-sequence of its scan
 struct JpegParImage { unsigned long long scan_off; uint32_t scan_len, img, nsub; size_t sub_off; uint8_t td[3], ta[3], pad[2]; };

@@ -220,7 +220,9 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
     // An interval that does not end exactly at its marker (damaged data: too few or too many bits) is where Go's processSOS starts
     // searching for the next RSTn (findRST); that heuristic is not restated here -- the file goes back to the CPU path.
     if (!status && im.strict_end && !(br.cnt < 8 && br.pos >= br.len)) status = IPX_ERR_UNSUPPORTED;
-    if (status) atomicExch(&a.status[img], status);   // pieces of one image report into one word (zeroed by the host)
+    // Pieces of one image report into one word (zeroed by the host).  A sequential decoder stops at the FIRST interval that fails, so the
+    // earliest piece's verdict is the image's: negative keys ordered by first_mcu, combined with atomicMin (jpeg_status_of unpacks).
+    if (status) atomicMin(&a.status[img], jpeg_status_key(im.first_mcu, status));
 }
 
 // ---- reconstruction -----------------------------------------------------------------------------------------

@@ -600,7 +600,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     (void)ipx_host_free(ctx, hblob);
     if (e != hipSuccess) return fail(e, "jpeg decode");
     for (int i = 0; i < n; i++)
-        if (status[i] == IPX_OK && dev_status[i]) status[i] = dev_status[i];
+        if (status[i] == IPX_OK && dev_status[i]) status[i] = jpeg_status_of(dev_status[i]);
     planes->y = pl.y; planes->cb = pl.cb; planes->cr = pl.cr;
     planes->ystride = pl.ystride; planes->cstride = pl.cstride;
     planes->y_frame_stride = pl.y_fs; planes->c_frame_stride = pl.c_fs;

@@ -371,3 +371,43 @@ def test_damaged_files_never_disagree(ctx):
         if exp == 0:
             for k in ("y", "cb", "cr") if want["ratio"] != 4 else ("y",):
                 np.testing.assert_array_equal(info[k][0], want[k], err_msg="case %d plane %s" % (t, k))
+
+
+@pytest.mark.gpu
+def test_first_failing_restart_interval_decides(ctx):
+    """Two damaged restart intervals in one file: a sequential decoder (Go's, the oracle) stops at the first, so the first one's verdict is
+    the file's -- whichever of the independently decoded pieces reports last on the GPU (found by tools/fuzz_corrupt.py seed 29)."""
+    rng = np.random.default_rng(2)
+    img = picture(200, 128, seed=4, noise=10.0)
+    clean = pil_jpeg(img, quality=85, restart_marker_rows=1)
+    sos = clean.index(b"\xff\xda") + 14
+    marks = [i for i in range(sos, len(clean) - 2) if clean[i] == 0xff and 0xd0 <= clean[i + 1] <= 0xd7]
+    assert len(marks) == 7
+
+    def verdict(f):
+        try:
+            oracle.jpeg_decode(f)
+            return 0
+        except ValueError as e:
+            return -1 if "malformed" in str(e) else -4
+
+    def damage(lo, hi, want):      # one changed byte between lo and hi that gives the verdict `want` on its own
+        for _ in range(4000):
+            f = bytearray(clean)
+            p = int(rng.integers(lo, hi))
+            f[p] = int(rng.integers(0, 255))
+            if f[p] == 0xff or f[p] == clean[p] or f[p - 1] == 0xff:
+                continue
+            if verdict(bytes(f)) == want:
+                return p, f[p]
+        raise AssertionError("no such damage found")
+
+    for first, second in ((-4, -1), (-1, -4)):
+        p0, v0 = damage(marks[1] + 2, marks[2], first)
+        p1, v1 = damage(marks[4] + 2, marks[5], second)
+        f = bytearray(clean)
+        f[p0], f[p1] = v0, v1
+        f = bytes(f)
+        assert verdict(f) == first
+        _, st = ctx.jpeg_decode_batch([f, clean])
+        assert list(st) == [first, 0], (first, second, st)
