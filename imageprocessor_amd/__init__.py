@@ -279,6 +279,12 @@ class Plan:
         _check(lib().ipx_plan_run_dev_gray(self.ctx.handle, stream, self.handle, n, gray_ptr, stride, frame_stride, resize_ptr,
                                            i.resize_bytes, thumb_ptr, i.thumb_bytes, wm_ptr, i.wm_bytes))
 
+    def run_dev_paletted(self, n, index_ptr, stride, frame_stride, palettes_ptr, resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
+        """*image.Paletted frames resident in HBM: index bytes plus 256 x (R, G, B, A) per frame (ipx_plan_run_dev_paletted)"""
+        i = self.info
+        _check(lib().ipx_plan_run_dev_paletted(self.ctx.handle, stream, self.handle, n, index_ptr, stride, frame_stride, palettes_ptr,
+                                               resize_ptr, i.resize_bytes, thumb_ptr, i.thumb_bytes, wm_ptr, i.wm_bytes))
+
     def run_dev_ycbcr(self, n, y_ptr, cb_ptr, cr_ptr, ratio, ystride, cstride, y_frame_stride, c_frame_stride,
                       resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
         i = self.info

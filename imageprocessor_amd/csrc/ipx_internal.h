@@ -135,6 +135,8 @@ struct BandArgs {
 };
 hipError_t launch_band(const BandArgs &a, hipStream_t s);
 hipError_t launch_gray_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, int w, int h, int n, hipStream_t s);
+hipError_t launch_palette_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, const uint8_t *palettes, int w,
+                                 int h, int n, hipStream_t s);
 
 // the fused band kernel on *image.YCbCr planes (ipx_band_ycc.hip): BandArgs without `src`, plus the planes
 struct YccArgs {
@@ -149,6 +151,13 @@ struct YccArgs {
 };
 // *matched = false: shape / alignment the kernel is not built for, nothing was launched
 hipError_t launch_band_ycc(const YccArgs &a, hipStream_t s, bool *matched);
+// the fused band kernel on *image.NRGBA frames (ipx_band_nrgba.hip): b.src holds non-premultiplied pixels
+struct NrgbaArgs {
+    BandArgs b;
+    int mode[2];               // per b.sc entry: 0 = taps premultiplied to 16 bit (scale_RGBA_NRGBA_*),
+                               //                 1 = premultiplied RGBA8 first (the crop copy), then scale_RGBA_RGBA_*
+};
+hipError_t launch_band_nrgba(const NrgbaArgs &a, hipStream_t s, bool *matched);
 size_t band_lds_bytes(int band_rows, int blk_cols);
 bool band_pipe_shape(int band_rows, int blk_cols, int *rows, int *ch);  // tile shapes the pipelined kernel is built for
 

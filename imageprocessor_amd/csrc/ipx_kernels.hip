@@ -268,6 +268,41 @@ hipError_t launch_gray_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, i
     return hipGetLastError();
 }
 
+// *image.Paletted (GIF uploads, palette PNGs): no specialised routine upstream, the generic ones read Palette[i].RGBA() per tap / pixel.
+// For the entries the decoders produce (opaque color.RGBA, the zero colour, color.NRGBA) that is the premultiplication the NRGBA
+// routines apply to (R, G, B, A) itself, so the indices are expanded to NRGBA8 here and the frames take the NRGBA pass.
+__global__ __launch_bounds__(256) void palette_expand_kernel(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs,
+                                                             const uint32_t *palettes, int w, int h, int rows_per_block, int vec)
+{
+    __shared__ uint32_t pal[256];
+    pal[threadIdx.x] = palettes[(size_t)blockIdx.y * 256 + threadIdx.x];
+    __syncthreads();
+    dst += blockIdx.y * dst_fs; src += blockIdx.y * src_fs;
+    const int y0 = blockIdx.x * rows_per_block, y1 = min(h, y0 + rows_per_block);
+    for (int y = y0; y < y1; y++) {
+        const uint8_t *row = src + (size_t)y * sstride;
+        uint32_t *out = (uint32_t *)(dst + (size_t)y * w * 4);
+        if (vec) {           // four indices per load, sixteen bytes per store
+            for (int c = threadIdx.x; c < (w >> 2); c += 256) {
+                const uint32_t i4 = ((const uint32_t *)row)[c];
+                ((uint4 *)out)[c] = make_uint4(pal[i4 & 0xffu], pal[(i4 >> 8) & 0xffu], pal[(i4 >> 16) & 0xffu], pal[i4 >> 24]);
+            }
+        } else {
+            for (int x = threadIdx.x; x < w; x += 256) out[x] = pal[row[x]];
+        }
+    }
+}
+
+hipError_t launch_palette_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, const uint8_t *palettes, int w,
+                                 int h, int n, hipStream_t s)
+{
+    const int rows = 8;      // per workgroup: the 1 KiB palette load is shared by 8 rows
+    const int vec = !(w & 3) && !((((uintptr_t)src) | (uintptr_t)sstride | src_fs) & 3) && !((((uintptr_t)dst) | dst_fs) & 15);
+    hipLaunchKernelGGL(palette_expand_kernel, dim3((h + rows - 1) / rows, n), dim3(256), 0, s, dst, dst_fs, src, sstride, src_fs,
+                       (const uint32_t *)palettes, w, h, rows, vec);
+    return hipGetLastError();
+}
+
 hipError_t launch_draw_ycbcr(uint8_t *dst, int dstride, const uint8_t *y, int ystride, const uint8_t *cb,
                              const uint8_t *cr, int cstride, int ratio, int spx, int spy, int w, int h, hipStream_t s,
                              int nframes, size_t dst_fs, size_t y_fs, size_t c_fs)

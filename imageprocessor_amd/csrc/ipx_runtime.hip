@@ -224,6 +224,8 @@ int ipx_create(const ipx_config *cfg, ipx_ctx **out)
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&l.flag, sizeof(int));
     }
+    if (e == hipSuccess) e = hipMalloc((void **)&c->flat_chroma, ipx_ctx::kFlatChromaBytes);
+    if (e == hipSuccess) e = hipMemset(c->flat_chroma, 128, ipx_ctx::kFlatChromaBytes);
     if (e != hipSuccess) {
         set_error("context setup failed: %s", hipGetErrorString(e));
         ipx_destroy(c);
@@ -243,6 +245,7 @@ void ipx_destroy(ipx_ctx *c)
         if (l.flag) (void)hipFree(l.flag);
     }
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->flat_chroma) (void)hipFree(c->flat_chroma);
     for (auto &b : c->host_free_blocks) (void)hipHostFree(b.second);
     delete c;
 }
@@ -1039,6 +1042,47 @@ int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *sr
 //   watermark: draw.Draw converts to RGBA8 (DrawYCbCr), the glyphs go over that.
 // So: one conversion pass into the watermark frame (or scratch), the RGBA band kernel for the crop
 // thumbnail on the converted frames, the glyph composite in place, and a batched YCbCr scale.
+// BandArgs of the fused kernels that convert their source on the fly (ipx_band_ycc.hip, ipx_band_nrgba.hip): the plan's tiling, the
+// outputs that are wanted, and per scaled output the conversion rule -- mode 0 = 16-bit taps (resizeImage on the source image itself),
+// mode 1 = 8-bit RGBA first (the crop thumbnail scales the RGBA8 copy cropAndResize made, thumbnail.go:128-131)
+static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, uint8_t *res, size_t resize_frame_stride, uint8_t *th,
+                                      size_t thumb_frame_stride, uint8_t *wm, size_t wm_frame_stride, BandArgs &a, int mode[2])
+{
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    a.sw = sw; a.sh = sh;
+    a.band_rows = pl->band_rows; a.nbands = pl->nbands;
+    a.blk_cols = pl->blk_cols; a.ncolblk = pl->ncolblk;
+    a.nframes = n;
+    a.pipe_wgs = std::max(1, env_int("IPX_PIPE_WGS", 8));
+    a.pipe_nt = 512; a.pipe_order = 1;
+    a.cus = ctx->cus;
+    a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
+    uint8_t *outs[2] = {res, th};
+    const size_t ostr[2] = {resize_frame_stride, thumb_frame_stride};
+    for (int k = 0; k < 2; k++) {
+        const PlanScale &ps = pl->sc[k];
+        if (!outs[k] || ps.dw <= 0 || ps.dh <= 0) continue;
+        mode[a.nscale] = k == 1 && pl->p.crop_to_fit ? 1 : 0;
+        ScaleOut &o = a.sc[a.nscale++];
+        o.out = outs[k]; o.frame_stride = ostr[k]; o.ostride = ps.dw * 4;
+        o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
+        o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
+        o.dyadic_shift = ps.dyadic_shift;
+        // 16-bit taps in u32: x0*tap + x1*tap < 2^24 and the weights below 2^9 keep every product in 24 x 24 bits
+        if (mode[a.nscale - 1] == 0 && (ps.kx > 8 || ps.ky > 8)) o.dyadic_shift = -1;
+        a.nx_out[a.nscale - 1] = pl->nx_out[k];
+    }
+    if (a.nscale == 1) { a.sc[1] = a.sc[0]; mode[1] = mode[0]; }
+    const uint8_t *c = pl->p.glyphs ? pl->p.glyphs->col : nullptr;
+    a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
+    a.cr = c ? c[0] * 0x101u : 0; a.cg = c ? c[1] * 0x101u : 0; a.cb = c ? c[2] * 0x101u : 0; a.ca = c ? c[3] * 0x101u : 0;
+}
+
+// flat_chroma: cb == cr == one row of 128s read with stride 0 (a Gray frame seen as YCbCr); everything else as the public entry
+static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, bool flat_chroma,
+                         uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                         size_t wm_frame_stride);
+
 int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src,
                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                            size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride)
@@ -1051,7 +1095,14 @@ int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     }
     if (n == 0) return IPX_OK;
     if (n > 65535) { set_error("ipx_plan_run_dev_ycbcr: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    return run_dev_ycbcr(ctx, stream ? (hipStream_t)stream : ctx->stream, pl, n, src, false, resize_out, resize_frame_stride, thumb_out,
+                         thumb_frame_stride, wm_out, wm_frame_stride);
+}
+
+static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, bool flat_chroma,
+                         uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                         size_t wm_frame_stride)
+{
     const int sw = pl->p.sw, sh = pl->p.sh;
     uint8_t *res = pl->sc[0].on ? resize_out : nullptr;
     uint8_t *th = pl->sc[1].on ? thumb_out : nullptr;
@@ -1062,42 +1113,18 @@ int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     if (pl->fused && env_int("IPX_YCC_FUSED", 1) && pl->band_rows <= 8 && pl->most_rows <= 64) {
         YccArgs A{};
         BandArgs &a = A.b;
-        a.sw = sw; a.sh = sh;
-        a.band_rows = pl->band_rows; a.nbands = pl->nbands;
-        a.blk_cols = pl->blk_cols; a.ncolblk = pl->ncolblk;
-        a.nframes = n;
-        a.pipe_wgs = std::max(1, env_int("IPX_PIPE_WGS", 8));
-        a.pipe_nt = 512; a.pipe_order = 1;
-        a.cus = ctx->cus;
-        a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
-        uint8_t *outs[2] = {res, th};
-        const size_t ostr[2] = {resize_frame_stride, thumb_frame_stride};
-        for (int k = 0; k < 2; k++) {
-            const PlanScale &ps = pl->sc[k];
-            if (!outs[k] || ps.dw <= 0 || ps.dh <= 0) continue;
-            A.mode[a.nscale] = k == 1 && pl->p.crop_to_fit ? 1 : 0;
-            ScaleOut &o = a.sc[a.nscale++];
-            o.out = outs[k]; o.frame_stride = ostr[k]; o.ostride = ps.dw * 4;
-            o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
-            o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
-            o.dyadic_shift = ps.dyadic_shift;
-            // 16-bit taps in u32: x0*tap + x1*tap < 2^24 and the weights below 2^9 keep every product in 24 x 24 bits
-            if (A.mode[a.nscale - 1] == 0 && (ps.kx > 8 || ps.ky > 8)) o.dyadic_shift = -1;
-            a.nx_out[a.nscale - 1] = pl->nx_out[k];
-        }
-        if (a.nscale == 1) { a.sc[1] = a.sc[0]; A.mode[1] = A.mode[0]; }
-        const uint8_t *c = pl->p.glyphs ? pl->p.glyphs->col : nullptr;
-        a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
-        a.cr = c ? c[0] * 0x101u : 0; a.cg = c ? c[1] * 0x101u : 0; a.cb = c ? c[2] * 0x101u : 0; a.ca = c ? c[3] * 0x101u : 0;
+        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, a, A.mode);
         if (!wm && a.nscale == 0) return IPX_OK;
         A.y = src->y; A.cb = src->cb; A.cr = src->cr; A.ystride = src->ystride; A.cstride = src->cstride;
         A.y_fs = src->y_frame_stride; A.c_fs = src->c_frame_stride; A.ratio = src->ratio;
         A.cw = (src->ratio == IPX_YCBCR_422 || src->ratio == IPX_YCBCR_420) ? (sw + 1) / 2 : sw;
         A.ch = (src->ratio == IPX_YCBCR_420 || src->ratio == IPX_YCBCR_440) ? (sh + 1) / 2 : sh;
         bool matched = false;
-        if (src->cstride >= A.cw) IPX_HIP(launch_band_ycc(A, s, &matched));
+        if (src->cstride >= A.cw || flat_chroma) IPX_HIP(launch_band_ycc(A, s, &matched));
         if (matched) return IPX_OK;
     }
+
+    if (flat_chroma) return 1;   // Gray frames the fused kernel does not take: the caller expands them and uses the RGBA pass
 
     DevSrc ysrc;
     ysrc.kind = IPX_SRC_YCBCR; ysrc.pix = src->y; ysrc.stride = src->ystride; ysrc.cb = src->cb; ysrc.cr = src->cr;
@@ -1162,6 +1189,17 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     uint8_t *th = pl->sc[1].on ? thumb_out : nullptr;
     uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
     const bool crop_thumb = th && pl->p.crop_to_fit;
+    // one fused pass over the frames when the tile shape and alignments allow it (ipx_band_nrgba.hip)
+    if (pl->fused && env_int("IPX_NRGBA_FUSED", 1) && pl->band_rows <= 8 && pl->most_rows <= 64) {
+        NrgbaArgs A{};
+        BandArgs &a = A.b;
+        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, a, A.mode);
+        if (!wm && a.nscale == 0) return IPX_OK;
+        a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
+        bool matched = false;
+        IPX_HIP(launch_band_nrgba(A, s, &matched));
+        if (matched) return IPX_OK;
+    }
     // premultiplied RGBA8 of the whole batch (drawNRGBASrc == drawNRGBAOver onto a zeroed frame), into the watermark frames when wanted
     uint8_t *conv = wm;
     size_t conv_fs = wm_frame_stride;
@@ -1210,6 +1248,31 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     return rc;
 }
 
+int ipx_plan_run_dev_paletted(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *index, int stride, size_t frame_stride,
+                              const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
+                              size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !index || !palettes || stride < pl->p.sw || ((uintptr_t)palettes & 3)) {
+        set_error("ipx_plan_run_dev_paletted: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    if (n == 0) return IPX_OK;
+    if (n > 65535) { set_error("ipx_plan_run_dev_paletted: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    const size_t fs = align256((size_t)sw * sh * 4);
+    uint8_t *nrgba = nullptr;
+    IPX_HIP(hipMallocAsync((void **)&nrgba, fs * n, s));
+    hipError_t e = launch_palette_expand(nrgba, fs, index, stride, frame_stride, palettes, sw, sh, n, s);
+    int rc = IPX_OK;
+    if (e != hipSuccess) { set_error("palette expansion failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
+    if (!rc) rc = ipx_plan_run_dev_nrgba(ctx, s, pl, n, nrgba, sw * 4, fs, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride, wm_out,
+                                         wm_frame_stride);
+    (void)hipFreeAsync(nrgba, s);
+    return rc;
+}
+
 int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *gray, int stride, size_t frame_stride,
                           uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
                           size_t wm_frame_stride)
@@ -1220,6 +1283,17 @@ int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n,
     if (n > 65535) { set_error("ipx_plan_run_dev_gray: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const int sw = pl->p.sw, sh = pl->p.sh;
+    // A Gray pixel read as YCbCr with Cb = Cr = 128 converts to (y, y, y, 0xff) in both of the reference's conversions --
+    // color.YCbCrToRGB: (y*0x10101) >> 16 = y; color.YCbCr.RGBA: (y*0x10101) >> 8 = y*0x101 = color.Gray.RGBA -- so the batch takes the
+    // planar pass with a stride-0 row of 128s as both chroma planes: 1 byte per pixel is read and nothing is expanded in HBM.
+    if (env_int("IPX_GRAY_FLAT", 1) && (size_t)(sw + 1) / 2 + 8 <= ipx_ctx::kFlatChromaBytes) {
+        ipx_ycbcr_batch b;
+        b.y = gray; b.cb = b.cr = ctx->flat_chroma; b.ystride = stride; b.cstride = 0;
+        b.y_frame_stride = frame_stride; b.c_frame_stride = 0; b.ratio = IPX_YCBCR_420;
+        const int rc = run_dev_ycbcr(ctx, s, pl, n, &b, true, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride, wm_out,
+                                     wm_frame_stride);
+        if (rc <= 0) return rc;      // 1: not a shape the planar kernel takes
+    }
     const size_t fs = align256((size_t)sw * sh * 4);
     uint8_t *rgba = nullptr;
     IPX_HIP(hipMallocAsync((void **)&rgba, fs * n, s));

@@ -38,6 +38,9 @@ struct ipx_ctx {
     std::map<void *, size_t> host_size;            // every live block handed out by ipx_host_alloc
     std::multimap<size_t, void *> host_free_blocks;
     size_t host_cached = 0, host_cache_limit = (size_t)2 << 30;
+    // one row of 128s: the Cb / Cr "planes" (stride 0) that make a Gray frame a YCbCr frame with neutral chroma (ipx_plan_run_dev_gray)
+    uint8_t *flat_chroma = nullptr;
+    static constexpr size_t kFlatChromaBytes = (size_t)64 << 10;
 };
 
 struct GlyphHost {

@@ -234,6 +234,16 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int
 int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const uint8_t *gray, int stride,
                           size_t frame_stride, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                           size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
+/* A batch of *image.Paletted frames (what image.Decode returns for GIF uploads and palette PNGs, image_processor.go:47): one index
+ * byte per pixel plus, per frame, 256 palette entries of 4 bytes (R, G, B, A), non-premultiplied, unused entries zero; palettes of
+ * frame i at palettes + i*1024, in device memory, 4-byte aligned.  No routine of x/image or image/draw specialises on this type: the
+ * generic ones (scale_RGBA_Image_*, drawRGBA) read Palette[i].RGBA() per tap.  For every entry the GIF and PNG decoders produce --
+ * opaque color.RGBA, the zero colour for a GIF's transparent index, color.NRGBA for a PNG's tRNS -- that is exactly the
+ * premultiplication scale_RGBA_NRGBA_* / drawNRGBA* apply to (R, G, B, A), so the frames are expanded to NRGBA8 in HBM and take
+ * ipx_plan_run_dev_nrgba; outputs are bit for bit the generic routines' (tests/test_sources_gpu.py against an oracle of those). */
+int ipx_plan_run_dev_paletted(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const uint8_t *index, int stride,
+                              size_t frame_stride, const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride,
+                              uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
 int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *plan, int n, const ipx_ycbcr_batch *src,
                             uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                             size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);

@@ -229,6 +229,10 @@ def _decl_variants():
     L.ipxo_scale_bilinear_ycbcr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect, C.POINTER(YCbCrStruct), Rect]
     L.ipxo_draw_ycbcr.restype = None
     L.ipxo_draw_ycbcr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect, C.POINTER(YCbCrStruct), C.c_int, C.c_int]
+    L.ipxo_scale_bilinear_paletted.restype = C.c_int
+    L.ipxo_scale_bilinear_paletted.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, Rect, C.c_int]
+    L.ipxo_draw_paletted.restype = None
+    L.ipxo_draw_paletted.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
     L._variants = True
     return L
 
@@ -253,6 +257,47 @@ def draw_nrgba(dst, r, src, sp=(0, 0), op=OP_SRC):
     sh, sw = src.shape[:2]
     _decl_variants().ipxo_draw_nrgba8(dst.ctypes.data, dw, dh, dw * 4, _rect(r), src.ctypes.data, sw, sh, sw * 4,
                                       int(sp[0]), int(sp[1]), op)
+    return dst
+
+
+def palette16(entries, kind="nrgba"):
+    """Palette[i].RGBA() for 256 entries (missing ones: the zero colour).  kind "rgba": color.RGBA entries (the GIF decoder's, and a PNG
+    palette without tRNS) -> c | c<<8; kind "nrgba": color.NRGBA entries (a PNG palette with tRNS) -> color.NRGBA.RGBA: c |= c<<8;
+    c *= a; c /= 0xff; alpha a | a<<8."""
+    e = np.zeros((256, 4), np.uint32)
+    src = np.asarray(entries, np.uint32).reshape(-1, 4)
+    e[: len(src)] = src
+    out = np.zeros((256, 4), np.uint16)
+    if kind == "rgba":
+        out[:] = e * 0x101
+    else:
+        out[:, :3] = (e[:, :3] * 0x101) * e[:, 3:4] // 0xff
+        out[:, 3] = e[:, 3] * 0x101
+    return out
+
+
+def scale_bilinear_paletted(idx, pal16, dw, dh, sr=None, dr=None, op=OP_OVER, dst=None):
+    idx = np.ascontiguousarray(idx, np.uint8)
+    pal16 = np.ascontiguousarray(pal16, np.uint16)
+    sh, sw = idx.shape
+    if dst is None:
+        dst = np.zeros((dh, dw, 4), np.uint8)
+    dst = _u8(dst)
+    rc = _decl_variants().ipxo_scale_bilinear_paletted(dst.ctypes.data, dw, dh, dw * 4, _rect(dr if dr is not None else (0, 0, dw, dh)),
+                                                       idx.ctypes.data, sw, sh, sw, pal16.ctypes.data,
+                                                       _rect(sr if sr is not None else (0, 0, sw, sh)), op)
+    if rc:
+        raise ValueError("source rectangle leaves the source image")
+    return dst
+
+
+def draw_paletted(dst, r, idx, pal16, sp=(0, 0), op=OP_SRC):
+    idx = np.ascontiguousarray(idx, np.uint8)
+    pal16 = np.ascontiguousarray(pal16, np.uint16)
+    dh, dw = dst.shape[:2]
+    sh, sw = idx.shape
+    _decl_variants().ipxo_draw_paletted(dst.ctypes.data, dw, dh, dw * 4, _rect(r), idx.ctypes.data, sw, sh, sw, pal16.ctypes.data,
+                                        int(sp[0]), int(sp[1]), op)
     return dst
 
 

@@ -561,3 +561,76 @@ int ipxo_scale_bilinear_ycbcr(uint8_t *dst, int dw, int dh, int dstride, ipxo_re
     scale_core(dst, dstride, dr, adr, src, tap_ycbcr, sr, IPXO_OP_SRC); /* a YCbCr image is opaque */
     return 0;
 }
+
+/* ---- *image.Paletted (GIF uploads, palette PNGs) -----------------------------------------------------
+ * No specialised routine exists upstream for this source type, so the GENERIC ones run:
+ *   x/image@v0.33.0 draw/impl.go scale_RGBA_Image_{Src,Over}: every tap is src.At(x, y).RGBA(), i.e. the
+ *     palette entry's 16-bit premultiplied colour, then the same float64 lerps and the same stores;
+ *   Go 1.24 image/draw drawRGBA (the fallback of DrawMask for dst *image.RGBA): with a nil mask ma = m and
+ *     Src stores uint8(sr*ma/m >> 8), Over stores uint8((dr*a + sr*ma)/m >> 8) with a = (m - sa*ma/m)*0x101.
+ * pal16[i] = Palette[i].RGBA() is computed by the caller from the entry's concrete colour type (color.RGBA
+ * from the GIF decoder and from PNGs without tRNS: c*0x101; color.NRGBA from PNGs with tRNS:
+ * (c*0x101)*a/0xff, alpha a*0x101) -- oracle/__init__.py palette16. */
+typedef struct { const uint8_t *pix; int stride; const uint16_t (*pal)[4]; } pal_src;
+
+static void tap_paletted(const void *s, int x, int y, uint32_t out[4])
+{
+    const pal_src *p = (const pal_src *)s;
+    const uint16_t *c = p->pal[p->pix[(size_t)y * p->stride + x]];
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+void ipxo_draw_paletted(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r, const uint8_t *src, int sw, int sh,
+                        int sstride, const uint16_t pal16[256][4], int spx, int spy, int op)
+{
+    const uint32_t m = 0xffff, ma = 0xffff;
+    ipxo_rect db = {0, 0, dw, dh}, sb = {0, 0, sw, sh};
+    int ox = r.x0, oy = r.y0, x, y, c;
+    r = rect_intersect(r, db);
+    r = rect_intersect(r, rect_add(sb, ox - spx, oy - spy));
+    if (rect_empty(r)) return;
+    spx += r.x0 - ox;
+    spy += r.y0 - oy;
+    for (y = 0; y < r.y1 - r.y0; y++) {
+        uint8_t *d = dst + (size_t)(r.y0 + y) * dstride + (size_t)r.x0 * 4;
+        for (x = 0; x < r.x1 - r.x0; x++, d += 4) {
+            const uint16_t *s = pal16[src[(size_t)(spy + y) * sstride + spx + x]];
+            if (op == IPXO_OP_SRC) {
+                for (c = 0; c < 4; c++) d[c] = (uint8_t)((uint32_t)s[c] * ma / m >> 8);
+            } else {
+                uint32_t a = (m - ((uint32_t)s[3] * ma / m)) * 0x101;
+                for (c = 0; c < 4; c++) d[c] = (uint8_t)(((uint32_t)d[c] * a + (uint32_t)s[c] * ma) / m >> 8);
+            }
+        }
+    }
+}
+
+/* image.(*Paletted).Opaque: only the entries some pixel uses count */
+static int paletted_opaque(const uint8_t *src, int sw, int sh, int sstride, const uint16_t pal16[256][4])
+{
+    int present[256] = {0}, x, y, i;
+    for (y = 0; y < sh; y++)
+        for (x = 0; x < sw; x++) present[src[(size_t)y * sstride + x]] = 1;
+    for (i = 0; i < 256; i++)
+        if (present[i] && pal16[i][3] != 0xffff) return 0;
+    return 1;
+}
+
+int ipxo_scale_bilinear_paletted(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr, const uint8_t *src, int sw, int sh,
+                                 int sstride, const uint16_t pal16[256][4], ipxo_rect sr, int op)
+{
+    ipxo_rect db = {0, 0, dw, dh}, adr;
+    pal_src p;
+    if (dr.x1 - dr.x0 == sr.x1 - sr.x0 && dr.y1 - dr.y0 == sr.y1 - sr.y0) {
+        ipxo_draw_paletted(dst, dw, dh, dstride, dr, src, sw, sh, sstride, pal16, sr.x0, sr.y0, op);
+        return 0;
+    }
+    adr = rect_intersect(db, dr);
+    if (rect_empty(adr) || rect_empty(sr)) return 0;
+    adr = rect_add(adr, -dr.x0, -dr.y0);
+    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) return -1;
+    if (op == IPXO_OP_OVER && paletted_opaque(src, sw, sh, sstride, pal16)) op = IPXO_OP_SRC;
+    p.pix = src; p.stride = sstride; p.pal = pal16;
+    scale_core(dst, dstride, dr, adr, &p, tap_paletted, sr, op);
+    return 0;
+}

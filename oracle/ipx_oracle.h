@@ -96,6 +96,12 @@ int ipxo_scale_bilinear_nrgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_r
 void ipxo_draw_nrgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r,
                       const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op);
 
+/* *image.Paletted through the generic routines (scale_RGBA_Image_{Src,Over}, image/draw drawRGBA); pal16[i] = Palette[i].RGBA() */
+int ipxo_scale_bilinear_paletted(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr, const uint8_t *src, int sw, int sh,
+                                 int sstride, const uint16_t pal16[256][4], ipxo_rect sr, int op);
+void ipxo_draw_paletted(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r, const uint8_t *src, int sw, int sh,
+                        int sstride, const uint16_t pal16[256][4], int spx, int spy, int op);
+
 /* *image.YCbCr with Rect.Min = (0,0); ratio = image.YCbCrSubsampleRatio (444=0, 422=1, 420=2, 440=3) */
 typedef struct {
     const uint8_t *y, *cb, *cr;

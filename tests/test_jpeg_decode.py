@@ -283,10 +283,13 @@ def test_gray_close_to_libjpeg():
 
 
 @pytest.mark.gpu
-def test_gray_jpegs_on_the_gpu(ctx):
-    """One-component files: decoded on the GPU into an *image.Gray plane, expanded to (y, y, y, 0xff) -- what image/draw's drawGray and
-    x/image's scale_RGBA_Gray_Src read -- and run through the RGBA pass; against the oracle on the expanded frame."""
+@pytest.mark.parametrize("flat", ["1", "0"], ids=["planar-pass-flat-chroma", "expanded-rgba-pass"])
+def test_gray_jpegs_on_the_gpu(ctx, flat, monkeypatch):
+    """One-component files: decoded on the GPU into an *image.Gray plane and read as (y, y, y, 0xff) -- what image/draw's drawGray and
+    x/image's scale_RGBA_Gray_Src read -- either by the planar kernel with a stride-0 row of 128s as chroma (IPX_GRAY_FLAT=1, the default)
+    or expanded to RGBA8 and run through the RGBA pass; against the oracle on the expanded frame."""
     from helpers import DEFAULT_COL, text_glyphs
+    monkeypatch.setenv("IPX_GRAY_FLAT", flat)
     w, h = 320, 200
     files = [pil_jpeg(picture(w, h, seed=60 + i)[..., 0], quality=70 + 5 * i, **({"restart_marker_rows": 2} if i == 1 else {})) for i in range(5)]
     files.append(pil_jpeg(picture(w, h, seed=3)))                       # a colour file in a Gray batch: refused
@@ -296,16 +299,17 @@ def test_gray_jpegs_on_the_gpu(ctx):
         _check_batch(ctx, [pil_jpeg(picture(*big, seed=5)[..., 0], quality=85)] * 2)
     glyphs = text_glyphs(w, h, n=6, width_px=150, height_px=30)
     gs = ctx.glyphset(glyphs, DEFAULT_COL)
-    plan = ctx.plan(w, h, resize=(512, 384, True), thumbnail=(100, True), watermark=gs)
-    got, st = plan.run_jpeg_jpeg(files)
-    assert st == [0, 0, 0, 0, 0, -4]
-    for k in range(5):
-        y = oracle.jpeg_decode(files[k])["y"][:h, :w]
-        rgba = np.dstack([y, y, y, np.full_like(y, 255)])
-        want = oracle.process(rgba, resize=(512, 384, True), thumb=(100, True), glyphs=glyphs, col=DEFAULT_COL)
-        for key in ("resize", "thumbnail", "watermark"):
-            assert got[key][k] == oracle.jpeg_encode_rgba(want[key], 85), (key, k)
-    plan.close()
+    for resize, thumb in (((512, 384, True), (100, True)), ((500, 301, False), (90, False)), ((160, 100, False), (50, True))):
+        plan = ctx.plan(w, h, resize=resize, thumbnail=thumb, watermark=gs)
+        got, st = plan.run_jpeg_jpeg(files)
+        assert st == [0, 0, 0, 0, 0, -4]
+        for k in range(5):
+            y = oracle.jpeg_decode(files[k])["y"][:h, :w]
+            rgba = np.dstack([y, y, y, np.full_like(y, 255)])
+            want = oracle.process(rgba, resize=resize, thumb=thumb, glyphs=glyphs, col=DEFAULT_COL)
+            for key in ("resize", "thumbnail", "watermark"):
+                assert got[key][k] == oracle.jpeg_encode_rgba(want[key], 85), (key, k, resize, thumb)
+        plan.close()
     gs.close()
 
 

@@ -162,11 +162,15 @@ def test_ycbcr_batch_plan(ctx, case, fused, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [(640, 360, 3, (1024, 768, True), (200, True)), (333, 251, 2, (200, 100, False), (64, False)),
-                                  (200, 200, 2, (200, 200, False), (100, True))], ids=lambda c: "%dx%d" % (c[0], c[1]))
-def test_nrgba_batch_plan(ctx, case):
+                                  (200, 200, 2, (200, 200, False), (100, True)), (1920, 1080, 2, (1024, 768, False), (200, False)),
+                                  (1280, 720, 2, (500, 333, False), (200, True))], ids=lambda c: "%dx%d" % (c[0], c[1]))
+@pytest.mark.parametrize("fused", ["1", "0"], ids=["fused", "three-kernels"])
+def test_nrgba_batch_plan(ctx, case, fused, monkeypatch):
     """ipx_plan_run_dev_nrgba: a batch of *image.NRGBA frames (PNGs with alpha), per operator as the reference's helpers treat the
-    type: 16-bit premultiplied taps for resizeImage, drawNRGBA* first for the crop thumbnail and the watermark."""
+    type: 16-bit premultiplied taps for resizeImage, drawNRGBA* first for the crop thumbnail and the watermark.  Both the fused band
+    kernel (ipx_band_nrgba.hip; widths that are multiples of 4) and the three-kernel path."""
     from helpers import DEFAULT_COL, text_glyphs
+    monkeypatch.setenv("IPX_NRGBA_FUSED", fused)
     w, h, n, resize, thumb = case
     rng = np.random.default_rng(w)
     frames = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)          # non-premultiplied: colour may exceed alpha
@@ -195,4 +199,50 @@ def test_nrgba_batch_plan(ctx, case):
         want_w = oracle.draw_nrgba(np.zeros((h, w, 4), np.uint8), (0, 0, w, h), frames[k])
         np.testing.assert_array_equal(got["watermark"][k], oracle.composite_glyphs(want_w, glyphs, DEFAULT_COL), err_msg="watermark %d" % k)
     plan.close()
+    gs.close()
+
+
+@pytest.mark.parametrize("kind", ["gif", "png-trns"])
+def test_paletted_batch_plan(ctx, kind):
+    """ipx_plan_run_dev_paletted: *image.Paletted frames (GIF uploads, palette PNGs).  The oracle follows the GENERIC upstream routines
+    (scale_RGBA_Image_*, drawRGBA reading Palette[i].RGBA()); the product expands to NRGBA8 and takes the NRGBA pass -- the outputs
+    must be the same bytes.  "gif": opaque color.RGBA entries plus a transparent index (the zero colour); "png-trns": color.NRGBA."""
+    from helpers import DEFAULT_COL, text_glyphs
+    w, h, n, resize, thumb = (640, 360, 3, (320, 180, False), (64, True)) if kind == "gif" else (333, 251, 3, (200, 100, False), (64, True))
+    rng = np.random.default_rng(12)
+    idx = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    idx[:, 40:90, 30:200] = 7                                    # flat areas, as palette images have
+    pal = rng.integers(0, 256, (n, 256, 4), dtype=np.uint8)
+    if kind == "gif":
+        pal[..., 3] = 255
+        pal[:, 7] = 0                                            # the transparent index: color.RGBA{}
+        pal16 = [oracle.palette16(pal[k], "rgba") for k in range(n)]
+    else:
+        pal[:, :64, 3] = 255
+        pal16 = [oracle.palette16(pal[k], "nrgba") for k in range(n)]
+    glyphs = text_glyphs(w, h, n=6, width_px=150, height_px=30)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    for th in (thumb, (64, False)):
+        plan = ctx.plan(w, h, resize=resize, thumbnail=th, watermark=gs)
+        i = plan.info
+        d_idx, d_pal = ctx.alloc(idx.nbytes).upload(idx), ctx.alloc(pal.nbytes).upload(pal)
+        res, tho, wm = ctx.alloc(n * i.resize_bytes), ctx.alloc(n * i.thumb_bytes), ctx.alloc(n * i.wm_bytes)
+        plan.run_dev_paletted(n, d_idx.ptr, w, w * h, d_pal.ptr, res.ptr, tho.ptr, wm.ptr)
+        ctx.sync()
+        got = {"resize": res.download((n, i.resize_h, i.resize_w, 4)), "thumbnail": tho.download((n, i.thumb_h, i.thumb_w, 4)),
+               "watermark": wm.download((n, h, w, 4))}
+        for k in range(n):
+            nw, nh = oracle.resize_dims(w, h, *resize)
+            np.testing.assert_array_equal(got["resize"][k], oracle.scale_bilinear_paletted(idx[k], pal16[k], nw, nh), err_msg="resize %d" % k)
+            crop, tw, thh = oracle.thumb_geometry(w, h, *th)
+            if th[1]:
+                cs = crop[2] - crop[0]
+                cropped = oracle.scale_bilinear_paletted(idx[k], pal16[k], cs, cs, sr=crop)     # equal sizes: Copy -> drawRGBA, Over onto zeros
+                want_t = oracle.scale_bilinear(cropped, tw, thh)
+            else:
+                want_t = oracle.scale_bilinear_paletted(idx[k], pal16[k], tw, thh)
+            np.testing.assert_array_equal(got["thumbnail"][k], want_t, err_msg="thumbnail %d" % k)
+            want_w = oracle.draw_paletted(np.zeros((h, w, 4), np.uint8), (0, 0, w, h), idx[k], pal16[k])
+            np.testing.assert_array_equal(got["watermark"][k], oracle.composite_glyphs(want_w, glyphs, DEFAULT_COL), err_msg="watermark %d" % k)
+        plan.close()
     gs.close()

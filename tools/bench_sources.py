@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Throughput of the batch paths for the other source types image.Decode returns, frames resident in HBM, 1920x1080,
+resize 1024x768 + thumbnail 200 + watermark:
+  *image.NRGBA     ipx_plan_run_dev_nrgba     fused band_nrgba_kernel vs the three-kernel path (IPX_NRGBA_FUSED=0)
+  *image.Gray      ipx_plan_run_dev_gray      planar kernel with flat chroma vs expansion to RGBA8 (IPX_GRAY_FLAT=0)
+  *image.Paletted  ipx_plan_run_dev_paletted  palette expansion + the NRGBA pass
+usage: tools/bench_sources.py [frames]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import imageprocessor_amd as ipx  # noqa: E402
+from helpers import DEFAULT_COL, text_glyphs  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+w, h = 1920, 1080
+ctx = ipx.Context()
+gs = ctx.glyphset(text_glyphs(w, h), DEFAULT_COL)
+plan = ctx.plan(w, h, resize=(1024, 768, True), thumbnail=(200, True), watermark=gs)
+i = plan.info
+rng = np.random.default_rng(3)
+pool = 4
+res, th, wm = ctx.alloc(n * i.resize_bytes), ctx.alloc(n * i.thumb_bytes), ctx.alloc(n * i.wm_bytes)
+outs = i.resize_bytes + i.thumb_bytes + i.wm_bytes
+
+
+def timed(step, label, in_bytes):
+    for _ in range(2):
+        step()
+    ctx.device_sync()
+    ms = min(ctx.timed(step) for _ in range(6))
+    alg = n * (in_bytes + outs)
+    print("%-62s %4d frames in %7.3f ms = %7.0f images/s; algorithmic %6.1f GB/s (%.2f MB per frame)"
+          % (label, n, ms, n / ms * 1e3, alg / ms / 1e6, alg / n / 1e6), flush=True)
+
+
+nr = ctx.alloc(n * w * h * 4).upload(np.resize(rng.integers(0, 256, (pool, h, w, 4), dtype=np.uint8), (n, h, w, 4)))
+for fused in ("1", "0"):
+    os.environ["IPX_NRGBA_FUSED"] = fused
+    timed(lambda: plan.run_dev_nrgba(n, nr.ptr, res.ptr, th.ptr, wm.ptr),
+          "NRGBA, " + ("fused band_nrgba_kernel" if fused == "1" else "three kernels"), w * h * 4)
+os.environ["IPX_NRGBA_FUSED"] = "1"
+del nr
+gr = ctx.alloc(n * w * h).upload(np.resize(rng.integers(0, 256, (pool, h, w), dtype=np.uint8), (n, h, w)))
+for flat in ("1", "0"):
+    os.environ["IPX_GRAY_FLAT"] = flat
+    timed(lambda: plan.run_dev_gray(n, gr.ptr, w, w * h, res.ptr, th.ptr, wm.ptr),
+          "Gray, " + ("planar kernel with flat chroma" if flat == "1" else "expanded to RGBA8 + RGBA pass"), w * h)
+os.environ["IPX_GRAY_FLAT"] = "1"
+pal = rng.integers(0, 256, (n, 256, 4), dtype=np.uint8)
+pal[..., 3] = 255
+dp = ctx.alloc(pal.nbytes).upload(pal)
+timed(lambda: plan.run_dev_paletted(n, gr.ptr, w, w * h, dp.ptr, res.ptr, th.ptr, wm.ptr), "Paletted, palette expansion + fused NRGBA pass", w * h + 1024)
