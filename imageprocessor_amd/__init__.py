@@ -208,6 +208,47 @@ class Plan:
                                        p("watermark"), i.wm_bytes))
         return out
 
+    def _host_outs(self, n, want):
+        i = self.info
+        out = {}
+        if "resize" in want and i.resize_bytes:
+            out["resize"] = np.empty((n, i.resize_h, i.resize_w, 4), np.uint8)
+        if "thumbnail" in want and i.thumb_bytes:
+            out["thumbnail"] = np.empty((n, i.thumb_h, i.thumb_w, 4), np.uint8)
+        if "watermark" in want and i.wm_bytes:
+            out["watermark"] = np.empty((n, i.wm_h, i.wm_w, 4), np.uint8)
+        return out, lambda k: out[k].ctypes.data if k in out else None
+
+    def run_host_nrgba(self, frames, want=("resize", "thumbnail", "watermark")):
+        """frames: n x H x W x 4 uint8, non-premultiplied (*image.NRGBA, host) -> dict of output batches"""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, i = frames.shape[0], self.info
+        out, p = self._host_outs(n, want)
+        _check(lib().ipx_plan_run_host_nrgba(self.ctx.handle, self.handle, n, frames.ctypes.data, self._sw * 4, self._sw * self._sh * 4,
+                                             p("resize"), i.resize_bytes, p("thumbnail"), i.thumb_bytes, p("watermark"), i.wm_bytes))
+        return out
+
+    def run_host_gray(self, frames, want=("resize", "thumbnail", "watermark")):
+        """frames: n x H x W uint8 (*image.Gray, host) -> dict of output batches"""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, i = frames.shape[0], self.info
+        out, p = self._host_outs(n, want)
+        _check(lib().ipx_plan_run_host_gray(self.ctx.handle, self.handle, n, frames.ctypes.data, self._sw, self._sw * self._sh,
+                                            p("resize"), i.resize_bytes, p("thumbnail"), i.thumb_bytes, p("watermark"), i.wm_bytes))
+        return out
+
+    def run_host_paletted(self, index, palettes, want=("resize", "thumbnail", "watermark")):
+        """index: n x H x W uint8, palettes: n x 256 x 4 uint8 (R, G, B, A) non-premultiplied (*image.Paletted, host)"""
+        index = np.ascontiguousarray(index, dtype=np.uint8)
+        palettes = np.ascontiguousarray(palettes, dtype=np.uint8)
+        n, i = index.shape[0], self.info
+        assert palettes.shape == (n, 256, 4)
+        out, p = self._host_outs(n, want)
+        _check(lib().ipx_plan_run_host_paletted(self.ctx.handle, self.handle, n, index.ctypes.data, self._sw, self._sw * self._sh,
+                                                palettes.ctypes.data, p("resize"), i.resize_bytes, p("thumbnail"), i.thumb_bytes,
+                                                p("watermark"), i.wm_bytes))
+        return out
+
     def run_host_jpeg(self, frames, quality=85, want=("resize", "thumbnail", "watermark"), copy=True):
         """frames: n x H x W x 4 uint8 (host, ideally pinned) -> {operator: [jpeg bytes] * n}: operators and jpeg.Encode on
         the GPU, only the streams come back.  copy=False: lengths only (the streams are released unread; for timing)."""

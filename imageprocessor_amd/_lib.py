@@ -130,6 +130,9 @@ SIGNATURES = {
     "ipx_plan_run_dev_ycbcr": (_I, [_P, _P, _P, _I, C.POINTER(YCbCrBatch), _P, _Z, _P, _Z, _P, _Z]),
     "ipx_plan_run_dev_gray": (_I, [_P, _P, _P, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
     "ipx_plan_run_dev_paletted": (_I, [_P, _P, _P, _I, _P, _I, _Z, _P, _P, _Z, _P, _Z, _P, _Z]),
+    "ipx_plan_run_host_nrgba": (_I, [_P, _P, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
+    "ipx_plan_run_host_gray": (_I, [_P, _P, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
+    "ipx_plan_run_host_paletted": (_I, [_P, _P, _I, _P, _I, _Z, _P, _P, _Z, _P, _Z, _P, _Z]),
     "ipx_plan_run_dev_nrgba": (_I, [_P, _P, _P, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
     "ipx_plan_run_host_ycbcr": (_I, [_P, _P, _I, C.POINTER(YCbCrBatch), _P, _Z, _P, _Z, _P, _Z]),
     "ipx_event_create": (_P, [_P]),

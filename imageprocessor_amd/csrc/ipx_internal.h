@@ -225,11 +225,13 @@ struct JpegParArgs {
     uint32_t *stuffed;                     // [nimg][max_nsub] stuffed zeros before each 1 KiB chunk (after the scan)
     uint32_t *scan_end, *ulen;             // per image: first marker in the stuffed scan; bytes of the unstuffed scan
     unsigned long long *entry, *exit_a, *exit_b;
+    unsigned long long *ck_state; uint32_t *ck_ends;   // per sub-sequence, jpeg_par_checkpoints() each: state and block ends at the checkpoints
     uint32_t *ends, *total_ends;           // block ends per sub-sequence (after the scan: first block index); per image total
     uint32_t *changed;
     int16_t *coefs; int *status;
 };
 int jpeg_par_sub_bytes();
+int jpeg_par_checkpoints();
 hipError_t launch_par_count(const JpegParArgs &a, hipStream_t s);
 hipError_t launch_par_unstuff(const JpegParArgs &a, hipStream_t s);
 hipError_t launch_par_sync(const JpegParArgs &a, int round, hipStream_t s);

@@ -65,16 +65,6 @@ struct Reader {
     }
     __device__ __forceinline__ uint32_t upos() const { return widx * 32u - (uint32_t)cnt; }
     __device__ __forceinline__ bool exhausted() const { return upos() >= ubits; }
-    __device__ __forceinline__ uint32_t peek16()
-    {
-        refill();
-        return (uint32_t)(acc >> (cnt - 16)) & 0xffffu;      // cnt >= 33 after refill; past the end the buffer holds zeros
-    }
-    __device__ __forceinline__ bool skip(int n)      // false: the data ended inside this symbol
-    {
-        cnt -= n;
-        return upos() <= ubits;
-    }
     __device__ __forceinline__ void seek(uint32_t p)
     {
         widx = p >> 5;
@@ -84,27 +74,9 @@ struct Reader {
     }
 };
 
-// one Huffman symbol; 0..255, or -1 (no such code: a speculative decoder just moves on by one bit), or -2 (out of data)
-__device__ __forceinline__ int symbol(Reader &r, const Tables &T, int slot)
-{
-    const uint32_t bits = r.peek16();
-    const uint32_t e = T.lut[slot * 256 + (bits >> 8)];
-    if (e) return r.skip((int)(e >> 8)) ? (int)(e & 0xffu) : -2;
-    for (int len = 9; len <= 16; len++) {
-        const int code = (int)(bits >> (16 - len));
-        if (code <= T.maxcode[slot * 18 + len]) return r.skip(len) ? (int)T.vals[slot * 256 + ((T.valoff[slot * 18 + len] + code) & 255)] : -2;
-    }
-    return r.skip(1) ? -1 : -2;
-}
-__device__ __forceinline__ bool extend(Reader &r, int t, int &out)   // receiveExtend; false: out of data
-{
-    out = 0;
-    if (t == 0) return true;
-    const uint32_t v = r.peek16() >> (16 - t);
-    if (!r.skip(t)) return false;
-    out = (int)v < (1 << (t - 1)) ? (int)v + (int)(0xffffffffu << t) + 1 : (int)v;
-    return true;
-}
+constexpr int kCk = 3;                                   // checkpoints per sub-sequence
+constexpr unsigned long long kNoState = ~0ull;           // no packed state has its upper 16 bits set
+__device__ __forceinline__ uint32_t ck_bits(int k) { return k == 0 ? 512u : (k == 1 ? 1536u : 4096u); }
 
 struct NoSink {
     __device__ __forceinline__ void dc(int) {}
@@ -113,40 +85,59 @@ struct NoSink {
     __device__ __forceinline__ void bad() {}
 };
 
-// Decode from state (c, z) until the position reaches uend (or the data ends).  Returns the exit state; *ends counts blocks
-// that ended.  sink.end_block() returning false stops the lane (all blocks of the image are done).
+// Decode from state (c, z) until the position reaches uend <= ubits (or the data ends).  Returns the exit state; *ends counts
+// blocks that ended.  sink.end_block() returning false stops the lane (all blocks of the image are done).
+// One accumulator refill and one table lookup per symbol: the top 32 bits hold the code (<= 16 bits) AND the value bits that
+// follow it (<= 16), so receiveExtend needs no second look at the stream; the bounds test runs once per symbol on the sum.
 template <class Sink>
 __device__ __forceinline__ unsigned long long run(Reader &r, const Tables &T, const JpegParImage &im, int bpm, int ybl, int c, int z, uint32_t uend,
                                                   Sink &sink, uint32_t *ends)
 {
     uint32_t nend = 0;
     unsigned long long out;
+    const unsigned long long kOut = pack_state(kEnd, 0, 0);
     for (;;) {
         const uint32_t p = r.upos();
-        if (p >= r.ubits) { out = pack_state(kEnd, 0, 0); break; }
-        if (p >= uend) { out = pack_state(p, c, z); break; }
+        if (p >= uend) { out = p >= r.ubits ? kOut : pack_state(p, c, z); break; }
         const int comp = c < ybl ? 0 : c - ybl + 1;
+        const int slot = z == 0 ? (comp == 0 ? im.td[0] : (comp == 1 ? im.td[1] : im.td[2])) : (comp == 0 ? im.ta[0] : (comp == 1 ? im.ta[1] : im.ta[2]));
+        r.refill();
+        const uint32_t bits = (uint32_t)(r.acc >> (r.cnt - 32));        // cnt >= 33 after the refill; past the end the buffer holds zeros
+        const uint32_t e = T.lut[slot * 256 + (bits >> 24)];
+        int len = (int)(e >> 8), sym = (int)(e & 0xffu);
+        if (!e) {
+            sym = -1;
+            for (len = 9; len <= 16; len++) {
+                const int code = (int)(bits >> (32 - len));
+                if (code <= T.maxcode[slot * 18 + len]) { sym = (int)T.vals[slot * 256 + ((T.valoff[slot * 18 + len] + code) & 255)]; break; }
+            }
+            if (sym < 0) {                                               // no such code: a speculative decoder just moves on by one bit
+                r.cnt -= 1;
+                if (r.upos() > r.ubits) { out = kOut; break; }
+                sink.bad();
+                continue;
+            }
+        }
         bool block_done = false;
+        int nbits = 0;                                                   // value bits after the code (receiveExtend)
         if (z == 0) {
-            const int t = symbol(r, T, comp == 0 ? im.td[0] : (comp == 1 ? im.td[1] : im.td[2]));
-            if (t == -2) { out = pack_state(kEnd, 0, 0); break; }
-            if (t < 0 || t > 16) { sink.bad(); continue; }
-            int diff;
-            if (!extend(r, t, diff)) { out = pack_state(kEnd, 0, 0); break; }
-            sink.dc(diff);
+            if (sym <= 16) nbits = sym;
+        } else if ((sym & 15) && z + (sym >> 4) <= 63) nbits = sym & 15;   // Go: zig += val0; if zig > zigEnd { break } -- the value bits stay unread
+        r.cnt -= len + nbits;
+        if (r.upos() > r.ubits) { out = kOut; break; }                   // the data ended inside this symbol
+        const uint32_t v = nbits ? (bits << len) >> (32 - nbits) : 0u;
+        const int val = nbits ? ((int)v < (1 << (nbits - 1)) ? (int)v + (int)(0xffffffffu << nbits) + 1 : (int)v) : 0;
+        if (z == 0) {
+            if (sym > 16) { sink.bad(); continue; }
+            sink.dc(val);
             z = 1;
         } else {
-            const int v = symbol(r, T, comp == 0 ? im.ta[0] : (comp == 1 ? im.ta[1] : im.ta[2]));
-            if (v == -2) { out = pack_state(kEnd, 0, 0); break; }
-            if (v < 0) { sink.bad(); continue; }
-            const int run_ = v >> 4, sz = v & 15;
+            const int run_ = sym >> 4, sz = sym & 15;
             if (sz) {
                 z += run_;
-                if (z > 63) block_done = true;       // Go: zig += val0; if zig > zigEnd { break } -- the value bits stay unread
+                if (z > 63) block_done = true;
                 else {
-                    int ac;
-                    if (!extend(r, sz, ac)) { out = pack_state(kEnd, 0, 0); break; }
-                    sink.ac(z, ac);
+                    sink.ac(z, val);
                     z++;
                     if (z > 63) block_done = true;
                 }
@@ -161,7 +152,7 @@ __device__ __forceinline__ unsigned long long run(Reader &r, const Tables &T, co
             nend++;
             c = c + 1 == bpm ? 0 : c + 1;
             z = 0;
-            if (!sink.end_block()) { out = pack_state(kEnd, 0, 0); break; }
+            if (!sink.end_block()) { out = kOut; break; }
         }
     }
     *ends = nend;
@@ -302,14 +293,49 @@ __global__ __launch_bounds__(64) void par_sync_kernel(JpegParArgs a, int round)
     const uint32_t p = (uint32_t)entry;
     uint32_t ends = 0;
     unsigned long long out;
+    // Checkpoints: the decoder state at the first symbol boundary at or after ustart + ck_bits(k).  A re-decode (round >= 1) that
+    // arrives at a checkpoint in the state the previous decode of this sub-sequence had there decodes the rest exactly as before:
+    // it stops, keeps the old exit and adds the old block-end count of the remainder.  Streams re-synchronise within a few hundred
+    // bits as a rule, so round 1 costs a fraction of round 0.
+    unsigned long long *ck = a.ck_state + s * kCk;
+    uint32_t *cke = a.ck_ends + s * kCk;
+    int k = 0;
     if (p == kEnd || p >= uend) out = p >= r.ubits ? pack_state(kEnd, 0, 0) : entry;   // nothing of this sub-sequence is left to decode
     else {
+        const uint32_t old_total = a.ends[s];
         r.seek(p);
         NoSink sink;
-        out = run(r, T, im, a.bpm, a.ybl, (int)(entry >> 32) & 0xff, (int)(entry >> 40) & 0xff, uend, sink, &ends);
+        int c = (int)(entry >> 32) & 0xff, z = (int)(entry >> 40) & 0xff;
+        bool ended = false;
+        out = entry;
+        for (; k < kCk; k++) {
+            const uint32_t limit = ustart + ck_bits(k);
+            if (limit >= uend) break;                               // the remaining checkpoints lie beyond this sub-sequence
+            if (p >= limit) { ck[k] = kNoState; continue; }         // entered beyond it: not on this trajectory
+            uint32_t e1;
+            out = run(r, T, im, a.bpm, a.ybl, c, z, limit, sink, &e1);
+            ends += e1;
+            if ((uint32_t)out == kEnd) { ended = true; break; }
+            if (round > 0 && ck[k] == out) {
+                const uint32_t old_at = cke[k], shift = ends - old_at;
+                cke[k] = ends;
+                for (int j = k + 1; j < kCk; j++) cke[j] += shift;
+                exit_next[s] = exit_prev[s];
+                a.ends[s] = ends + (old_total - old_at);
+                return;
+            }
+            ck[k] = out; cke[k] = ends;
+            c = (int)(out >> 32) & 0xff; z = (int)(out >> 40) & 0xff;
+        }
+        if (!ended) {
+            uint32_t e1;
+            out = run(r, T, im, a.bpm, a.ybl, c, z, uend, sink, &e1);
+            ends += e1;
+        }
     }
+    for (int j = k; j < kCk; j++) ck[j] = kNoState;                 // checkpoints this decode did not reach
     exit_next[s] = out;
-    a.ends[(size_t)blockIdx.y * a.max_nsub + t] = ends;
+    a.ends[s] = ends;
 }
 
 struct CoefSink {
@@ -387,6 +413,7 @@ __global__ __launch_bounds__(256) void par_dc_kernel(JpegParArgs a)
 }  // namespace
 
 int jpeg_par_sub_bytes() { return kSub; }
+int jpeg_par_checkpoints() { return kCk; }
 
 hipError_t launch_par_count(const JpegParArgs &a, hipStream_t s)
 {

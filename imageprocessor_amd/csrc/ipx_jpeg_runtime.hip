@@ -540,6 +540,8 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         if (e == hipSuccess) e = mem.get(&P.exit_a, nsubs * 8);
         if (e == hipSuccess) e = mem.get(&P.exit_b, nsubs * 8);
         if (e == hipSuccess) e = mem.get(&P.ends, nsubs * 4);
+        if (e == hipSuccess) e = mem.get(&P.ck_state, nsubs * 8 * jpeg_par_checkpoints());
+        if (e == hipSuccess) e = mem.get(&P.ck_ends, nsubs * 4 * jpeg_par_checkpoints());
         if (e == hipSuccess) e = mem.get(&P.total_ends, par.size() * 4);
         if (e == hipSuccess) e = mem.get(&d_tot, par.size() * 4);
         if (e == hipSuccess) e = mem.get(&P.changed, 4);
@@ -548,6 +550,8 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         if (e == hipSuccess) e = hipMemsetAsync(P.stuffed, 0, nsubs * 4, s);
         if (e == hipSuccess) e = hipMemsetAsync(P.entry, 0xff, nsubs * 8, s);
         if (e == hipSuccess) e = hipMemsetAsync(P.ends, 0, nsubs * 4, s);
+        if (e == hipSuccess) e = hipMemsetAsync(P.ck_state, 0xff, nsubs * 8 * jpeg_par_checkpoints(), s);
+        if (e == hipSuccess) e = hipMemsetAsync(P.ck_ends, 0, nsubs * 4 * jpeg_par_checkpoints(), s);
         if (e == hipSuccess) e = mem.get(&P.ublob, blob_bytes + 64);
         if (e == hipSuccess) e = mem.get(&P.scan_end, par.size() * 4);
         if (e == hipSuccess) e = mem.get(&P.ulen, par.size() * 4);

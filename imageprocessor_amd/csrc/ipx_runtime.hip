@@ -948,26 +948,24 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
     return IPX_OK;
 }
 
-int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride,
-                      size_t src_frame_stride, uint8_t *resize_out, size_t resize_frame_stride,
-                      uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
-                      size_t wm_frame_stride)
+// Frames in host memory, any packed source type: chunks over the lanes so that H2D of one chunk, the kernel of another and D2H of
+// a third overlap.  kind: IPX_SRC_RGBA / IPX_SRC_NRGBA (4 bytes per pixel), IPX_GRAY (1), kPalettedKind (1 + 1 KiB palette per frame).
+constexpr int kPalettedKind = 100;
+static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, const uint8_t *src, int sstride, size_t src_frame_stride,
+                           const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
+                           size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride, const char *who)
 {
-    IPX_ENTER(ctx);
-    if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * 4) {
-        set_error("ipx_plan_run_host: bad argument");
-        return IPX_ERR_INVALID;
-    }
-    if (n == 0) return IPX_OK;
     const int sw = pl->p.sw, sh = pl->p.sh;
+    const int bpp = kind == IPX_SRC_RGBA || kind == IPX_SRC_NRGBA ? 4 : 1;
     // device-side frame strides: tight when that keeps rows 16-byte aligned (then a whole chunk moves
     // with one copy per direction and buffer), padded to 256 otherwise
     auto dstride = [](size_t bytes) { return (bytes & 15) == 0 ? bytes : align256(bytes); };
-    const size_t fsrc = dstride((size_t)sw * sh * 4);
+    const size_t fsrc = dstride((size_t)sw * sh * bpp);
+    const size_t fpal = kind == kPalettedKind ? 1024 : 0;
     const size_t fres = resize_out ? dstride(pl->info.resize_bytes) : 0;
     const size_t fth = thumb_out ? dstride(pl->info.thumb_bytes) : 0;
     const size_t fwm = wm_out ? dstride(pl->info.wm_bytes) : 0;
-    const size_t per_frame = fsrc + fres + fth + fwm;
+    const size_t per_frame = fsrc + fpal + fres + fth + fwm;
     // chunk the batch so that H2D of one chunk, the kernel of another and D2H of a third overlap on
     // different lanes (one stream each); several chunks per lane keep all three engines busy
     const int nl = (int)ctx->lanes.size();
@@ -988,7 +986,7 @@ int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *sr
         rc = lane_reserve(*l, per_frame * chunk + 256);
         if (rc) break;
     }
-    const bool src_tight = sstride == sw * 4 && src_frame_stride == fsrc;
+    const bool src_tight = sstride == sw * bpp && src_frame_stride == fsrc;
     auto d2h = [&](uint8_t *host, size_t host_stride, const uint8_t *dev, size_t dev_stride, size_t bytes, int i0, int m,
                    hipStream_t st) {
         if (!dev || !bytes) return hipSuccess;
@@ -1006,16 +1004,23 @@ int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *sr
         uint8_t *dres = fres ? dsrc + fsrc * chunk : nullptr;
         uint8_t *dth = fth ? dsrc + (fsrc + fres) * chunk : nullptr;
         uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * chunk : nullptr;
+        uint8_t *dpal = fpal ? dsrc + (fsrc + fres + fth + fwm) * chunk : nullptr;
         // the lane's stream serialises reuse of its scratch: chunk c waits for chunk c - lanes
         if (src_tight) {
             e = hipMemcpyAsync(dsrc, src + (size_t)i0 * src_frame_stride, fsrc * m, hipMemcpyHostToDevice, l.stream);
         } else {
             for (int i = 0; i < m && e == hipSuccess; i++)
-                e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * 4, src + (size_t)(i0 + i) * src_frame_stride, sstride,
-                                     (size_t)sw * 4, sh, hipMemcpyHostToDevice, l.stream);
+                e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * bpp, src + (size_t)(i0 + i) * src_frame_stride, sstride,
+                                     (size_t)sw * bpp, sh, hipMemcpyHostToDevice, l.stream);
         }
+        if (e == hipSuccess && dpal) e = hipMemcpyAsync(dpal, palettes + (size_t)i0 * 1024, (size_t)m * 1024, hipMemcpyHostToDevice, l.stream);
         if (e != hipSuccess) break;
-        rc = ipx_plan_run_dev(ctx, l.stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm);
+        switch (kind) {
+        case IPX_SRC_RGBA: rc = ipx_plan_run_dev(ctx, l.stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm); break;
+        case IPX_SRC_NRGBA: rc = ipx_plan_run_dev_nrgba(ctx, l.stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm); break;
+        case IPX_GRAY: rc = ipx_plan_run_dev_gray(ctx, l.stream, pl, m, dsrc, sw, fsrc, dres, fres, dth, fth, dwm, fwm); break;
+        default: rc = ipx_plan_run_dev_paletted(ctx, l.stream, pl, m, dsrc, sw, fsrc, dpal, dres, fres, dth, fth, dwm, fwm); break;
+        }
         if (rc) break;
         e = d2h(resize_out, resize_frame_stride, dres, fres, pl->info.resize_bytes, i0, m, l.stream);
         if (e == hipSuccess) e = d2h(thumb_out, thumb_frame_stride, dth, fth, pl->info.thumb_bytes, i0, m, l.stream);
@@ -1030,8 +1035,56 @@ int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *sr
         for (auto *l : lanes) l->busy = false;
     }
     ctx->cv.notify_all();
-    if (!rc && e != hipSuccess) { set_error("ipx_plan_run_host: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
+    if (!rc && e != hipSuccess) { set_error("%s: %s", who, hipGetErrorString(e)); rc = IPX_ERR_HIP; }
     return rc;
+}
+
+int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride,
+                      size_t src_frame_stride, uint8_t *resize_out, size_t resize_frame_stride,
+                      uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                      size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * 4) {
+        set_error("ipx_plan_run_host: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    if (n == 0) return IPX_OK;
+    return run_host_packed(ctx, pl, n, IPX_SRC_RGBA, src, sstride, src_frame_stride, nullptr, resize_out, resize_frame_stride, thumb_out,
+                           thumb_frame_stride, wm_out, wm_frame_stride, "ipx_plan_run_host");
+}
+
+int ipx_plan_run_host_nrgba(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
+                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                            size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * 4) { set_error("ipx_plan_run_host_nrgba: bad argument"); return IPX_ERR_INVALID; }
+    if (n == 0) return IPX_OK;
+    return run_host_packed(ctx, pl, n, IPX_SRC_NRGBA, src, sstride, src_frame_stride, nullptr, resize_out, resize_frame_stride, thumb_out,
+                           thumb_frame_stride, wm_out, wm_frame_stride, "ipx_plan_run_host_nrgba");
+}
+
+int ipx_plan_run_host_gray(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *gray, int stride, size_t frame_stride,
+                           uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                           size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !gray || stride < pl->p.sw) { set_error("ipx_plan_run_host_gray: bad argument"); return IPX_ERR_INVALID; }
+    if (n == 0) return IPX_OK;
+    return run_host_packed(ctx, pl, n, IPX_GRAY, gray, stride, frame_stride, nullptr, resize_out, resize_frame_stride, thumb_out,
+                           thumb_frame_stride, wm_out, wm_frame_stride, "ipx_plan_run_host_gray");
+}
+
+int ipx_plan_run_host_paletted(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *index, int stride, size_t frame_stride,
+                               const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
+                               size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride)
+{
+    IPX_ENTER(ctx);
+    if (!pl || n < 0 || !index || !palettes || stride < pl->p.sw) { set_error("ipx_plan_run_host_paletted: bad argument"); return IPX_ERR_INVALID; }
+    if (n == 0) return IPX_OK;
+    return run_host_packed(ctx, pl, n, kPalettedKind, index, stride, frame_stride, palettes, resize_out, resize_frame_stride, thumb_out,
+                           thumb_frame_stride, wm_out, wm_frame_stride, "ipx_plan_run_host_paletted");
 }
 
 

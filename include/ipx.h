@@ -244,6 +244,17 @@ int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int 
 int ipx_plan_run_dev_paletted(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const uint8_t *index, int stride,
                               size_t frame_stride, const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride,
                               uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
+/* The same three source types from host memory (frames Go's png / gif / jpeg decoders left there), chunked over the lanes like
+ * ipx_plan_run_host; `palettes` is host memory here. */
+int ipx_plan_run_host_nrgba(ipx_ctx *ctx, const ipx_plan *plan, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
+                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride,
+                            uint8_t *wm_out, size_t wm_frame_stride);
+int ipx_plan_run_host_gray(ipx_ctx *ctx, const ipx_plan *plan, int n, const uint8_t *gray, int stride, size_t frame_stride,
+                           uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride,
+                           uint8_t *wm_out, size_t wm_frame_stride);
+int ipx_plan_run_host_paletted(ipx_ctx *ctx, const ipx_plan *plan, int n, const uint8_t *index, int stride, size_t frame_stride,
+                               const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
+                               size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
 int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *plan, int n, const ipx_ycbcr_batch *src,
                             uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                             size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);

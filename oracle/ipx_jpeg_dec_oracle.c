@@ -191,6 +191,8 @@ int ipxo_jpeg_decode(const uint8_t *data, size_t len, ipxo_decoded *out, int16_t
             for (int c = 0; c < ncomp; c++) {
                 cid[c] = s[6 + 3 * c]; ch[c] = s[7 + 3 * c] >> 4; cv[c] = s[7 + 3 * c] & 15; ctq[c] = s[8 + 3 * c];
                 if (ctq[c] > 3 || ch[c] < 1 || ch[c] > 4 || cv[c] < 1 || cv[c] > 4) return -1;
+                for (int j = 0; j < c; j++)
+                    if (cid[j] == cid[c]) return -1;   /* processSOF: "repeated component identifier" (B.2.2) */
             }
             if (ncomp == 1) { ch[0] = cv[0] = 1; }        /* processSOF: "the component's (h, v) is effectively always (1, 1)" */
             else if (ch[1] != 1 || cv[1] != 1 || ch[2] != 1 || cv[2] != 1 || ch[0] > 2 || cv[0] > 2) return -2;

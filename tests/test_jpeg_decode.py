@@ -77,6 +77,12 @@ def test_unsupported_and_malformed():
     ok = pil_jpeg(img)
     with pytest.raises(ValueError, match="malformed"):
         oracle.jpeg_decode(ok[:len(ok) // 2])                                       # scan data runs out
+    dup = bytearray(ok)
+    sof = dup.index(b"\xff\xc0")
+    assert dup[sof + 10] == 1 and dup[sof + 13] == 2
+    dup[sof + 13] = 1                                                               # processSOF: "repeated component identifier"
+    with pytest.raises(ValueError, match="malformed"):
+        oracle.jpeg_decode(bytes(dup))
 
 
 # ---- GPU --------------------------------------------------------------------------------------------------

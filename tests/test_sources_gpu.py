@@ -246,3 +246,44 @@ def test_paletted_batch_plan(ctx, kind):
             np.testing.assert_array_equal(got["watermark"][k], oracle.composite_glyphs(want_w, glyphs, DEFAULT_COL), err_msg="watermark %d" % k)
         plan.close()
     gs.close()
+
+
+def test_host_variants_of_the_other_source_types(ctx, monkeypatch):
+    """ipx_plan_run_host_{nrgba,gray,paletted}: frames in host memory, chunked over the lanes (several chunks per lane, a ragged last one);
+    the same bytes as the oracle's routines for the type."""
+    from helpers import DEFAULT_COL, text_glyphs
+    monkeypatch.setenv("IPX_HOST_CHUNK", "2")
+    w, h, n, resize, thumb = 320, 200, 7, (200, 120, False), (64, True)
+    rng = np.random.default_rng(31)
+    glyphs = text_glyphs(w, h, n=6, width_px=150, height_px=30)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(w, h, resize=resize, thumbnail=thumb, watermark=gs)
+    crop, tw, th = oracle.thumb_geometry(w, h, *thumb)
+    cs = crop[2] - crop[0]
+    zeros = lambda: np.zeros((h, w, 4), np.uint8)   # noqa: E731
+
+    nrgba = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    got = plan.run_host_nrgba(nrgba)
+    for k in range(n):
+        np.testing.assert_array_equal(got["resize"][k], oracle.scale_bilinear_nrgba(nrgba[k], resize[0], resize[1]))
+        np.testing.assert_array_equal(got["thumbnail"][k], oracle.scale_bilinear(oracle.scale_bilinear_nrgba(nrgba[k], cs, cs, sr=crop), tw, th))
+        np.testing.assert_array_equal(got["watermark"][k], oracle.composite_glyphs(oracle.draw_nrgba(zeros(), (0, 0, w, h), nrgba[k]), glyphs, DEFAULT_COL))
+
+    gray = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    got = plan.run_host_gray(gray)
+    for k in range(n):
+        rgba = np.dstack([gray[k]] * 3 + [np.full_like(gray[k], 255)])
+        want = oracle.process(rgba, resize=resize, thumb=thumb, glyphs=glyphs, col=DEFAULT_COL)
+        for key in ("resize", "thumbnail", "watermark"):
+            np.testing.assert_array_equal(got[key][k], want[key], err_msg="gray %s %d" % (key, k))
+
+    pal = rng.integers(0, 256, (n, 256, 4), dtype=np.uint8)
+    pal[:, :128, 3] = 255
+    got = plan.run_host_paletted(gray, pal)
+    for k in range(n):
+        p16 = oracle.palette16(pal[k], "nrgba")
+        np.testing.assert_array_equal(got["resize"][k], oracle.scale_bilinear_paletted(gray[k], p16, resize[0], resize[1]))
+        np.testing.assert_array_equal(got["thumbnail"][k], oracle.scale_bilinear(oracle.scale_bilinear_paletted(gray[k], p16, cs, cs, sr=crop), tw, th))
+        np.testing.assert_array_equal(got["watermark"][k], oracle.composite_glyphs(oracle.draw_paletted(zeros(), (0, 0, w, h), gray[k], p16), glyphs, DEFAULT_COL))
+    plan.close()
+    gs.close()
