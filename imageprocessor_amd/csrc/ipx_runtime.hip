@@ -218,6 +218,7 @@ int ipx_create(const ipx_config *cfg, ipx_ctx **out)
     c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int lanes = cfg && cfg->lanes > 0 ? cfg->lanes : env_int("IPX_LANES", 3);
     c->lane_bytes = cfg && cfg->lane_bytes ? cfg->lane_bytes : (size_t)64 << 20;
+    c->host_cache_limit = (size_t)std::max(0, env_int("IPX_HOST_CACHE_MB", 8192)) << 20;
     c->lanes.resize(lanes);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (auto &l : c->lanes) {
@@ -264,6 +265,7 @@ void *ipx_host_alloc(ipx_ctx *ctx, size_t bytes)
             ctx->host_cached -= it->first;
             ctx->host_size[p] = it->first;
             ctx->host_free_blocks.erase(it);
+            ctx->host_lru.erase(std::find(ctx->host_lru.begin(), ctx->host_lru.end(), p));
             return p;
         }
     }
@@ -280,20 +282,35 @@ int ipx_host_free(ipx_ctx *ctx, void *p)
 {
     IPX_ENTER(ctx);
     if (!p) return IPX_OK;
+    std::vector<void *> victims;     // unpinned outside the lock
+    bool cached = false;
     {
         std::lock_guard<std::mutex> lk(ctx->host_mu);
         auto it = ctx->host_size.find(p);
         if (it != ctx->host_size.end()) {
             const size_t sz = it->second;
             ctx->host_size.erase(it);
-            if (ctx->host_cached + sz <= ctx->host_cache_limit) {
+            if (sz <= ctx->host_cache_limit) {
+                // keep the block; make room by dropping the blocks that have gone unused the longest (a cache full of sizes nobody
+                // asks for any more would otherwise make every later call pin fresh memory, ~0.2 ms per MB)
+                while (ctx->host_cached + sz > ctx->host_cache_limit && !ctx->host_lru.empty()) {
+                    void *old = ctx->host_lru.front();
+                    ctx->host_lru.pop_front();
+                    for (auto fb = ctx->host_free_blocks.begin(); fb != ctx->host_free_blocks.end(); ++fb)
+                        if (fb->second == old) { ctx->host_cached -= fb->first; ctx->host_free_blocks.erase(fb); break; }
+                    victims.push_back(old);
+                }
                 ctx->host_free_blocks.emplace(sz, p);
+                ctx->host_lru.push_back(p);
                 ctx->host_cached += sz;
-                return IPX_OK;
+                cached = true;
             }
         }
     }
-    IPX_HIP(hipHostFree(p));
+    hipError_t e = hipSuccess;
+    for (void *v : victims) { hipError_t e2 = hipHostFree(v); if (e == hipSuccess) e = e2; }
+    if (!cached) { hipError_t e2 = hipHostFree(p); if (e == hipSuccess) e = e2; }
+    IPX_HIP(e);
     return IPX_OK;
 }
 

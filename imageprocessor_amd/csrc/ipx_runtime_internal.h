@@ -6,6 +6,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -37,7 +38,8 @@ struct ipx_ctx {
     std::mutex host_mu;
     std::map<void *, size_t> host_size;            // every live block handed out by ipx_host_alloc
     std::multimap<size_t, void *> host_free_blocks;
-    size_t host_cached = 0, host_cache_limit = (size_t)2 << 30;
+    std::deque<void *> host_lru;                   // cached blocks, least recently freed first
+    size_t host_cached = 0, host_cache_limit = (size_t)8 << 30;   // IPX_HOST_CACHE_MB
     // one row of 128s: the Cb / Cr "planes" (stride 0) that make a Gray frame a YCbCr frame with neutral chroma (ipx_plan_run_dev_gray)
     uint8_t *flat_chroma = nullptr;
     static constexpr size_t kFlatChromaBytes = (size_t)64 << 10;
