@@ -202,6 +202,7 @@ struct JpegDecImage {
 struct JpegDecArgs {
     const uint8_t *blob; const JpegDecImage *img; const JpegDecTables *tab;
     int16_t *coefs; int *status;
+    int16_t *dcs;                    // [n][nblk] the DC coefficient of every block (coefs[...][0] stays zero)
     int n, mxx, myy, h0, v0, nblk;   // n = images
     int bpm, ybl;                    // blocks per MCU and how many of them are luma (Gray: 1, 1)
     int nitems;                      // pieces to decode (>= images)
@@ -229,6 +230,7 @@ struct JpegParArgs {
     uint32_t *ends, *total_ends;           // block ends per sub-sequence (after the scan: first block index); per image total
     uint32_t *changed;
     int16_t *coefs; int *status;
+    int16_t *dcs;                          // [image][nblk]: DC differences from the write pass, DC values after par_dc_kernel
 };
 int jpeg_par_sub_bytes();
 int jpeg_par_checkpoints();

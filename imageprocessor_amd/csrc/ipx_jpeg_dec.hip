@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
             const int dcv = (c == 0 ? dc0 : (c == 1 ? dc1 : dc2)) + diff;
             if (c == 0) dc0 = dcv; else if (c == 1) dc1 = dcv; else dc2 = dcv;
             if (dcv < -32768 || dcv > 32767) { br.err = true; break; }   // Go keeps int32; out of int16 = not a sane file
-            if (dcv) b[0] = (int16_t)dcv;
+            a.dcs[(size_t)img * a.nblk + (size_t)m * bpm + bi] = (int16_t)dcv;
             const uint16_t *aclut = lut + ta * 256;
             for (int zig = 1; zig < 64; zig++) {
                 const int v = decode_symbol(br, aclut, st, ta);
@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegDecArgs a, JpegPlane
         const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 8; i++) s[i] = (int)(int16_t)(wv[i >> 1] >> (16 * (i & 1))) * (int)q[i];   // b[unzig[zig]] *= qt[zig]
+        if (r == 0) s[0] = (int)a.dcs[(size_t)img * a.nblk + gb] * (int)q[0];                          // the DC values live in their own dense array
         idct_row(s);
 #pragma unroll
         for (int i = 0; i < 8; i++) ws[blk * 72 + r * 8 + i] = s[i];

@@ -339,14 +339,14 @@ __global__ __launch_bounds__(64) void par_sync_kernel(JpegParArgs a, int round)
 }
 
 struct CoefSink {
-    int16_t *coefs; const uint8_t *unz;
+    int16_t *coefs; int16_t *dcs; const uint8_t *unz;
     uint32_t g, nblk;
     int *status;
     __device__ __forceinline__ void dc(int d)
     {
         if (g >= nblk) return;
         if (d < -32768 || d > 32767) { atomicExch(status, IPX_ERR_INVALID); return; }
-        if (d) coefs[(size_t)g * 64] = (int16_t)d;
+        dcs[g] = (int16_t)d;
     }
     __device__ __forceinline__ void ac(int z, int v) { if (g < nblk) coefs[(size_t)g * 64 + unz[z]] = (int16_t)v; }
     __device__ __forceinline__ bool end_block() { g++; return g < nblk; }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64) void par_write_kernel(JpegParArgs a)
     const uint32_t p = (uint32_t)entry;
     const uint32_t uend = min(((uint32_t)t + 1) * kSub * 8u, r.ubits);
     if (p == kEnd || p >= uend) return;
-    CoefSink sink{a.coefs + (size_t)im.img * a.nblk * 64, T.unz, a.ends[(size_t)blockIdx.y * a.max_nsub + t], (uint32_t)a.nblk, a.status + im.img};
+    CoefSink sink{a.coefs + (size_t)im.img * a.nblk * 64, a.dcs + (size_t)im.img * a.nblk, T.unz, a.ends[(size_t)blockIdx.y * a.max_nsub + t], (uint32_t)a.nblk, a.status + im.img};
     if (sink.g >= sink.nblk) return;
     r.seek(p);
     uint32_t ends;
@@ -380,13 +380,13 @@ __global__ __launch_bounds__(256) void par_dc_kernel(JpegParArgs a)
 {
     __shared__ int part[256][3];
     const JpegParImage im = a.img[blockIdx.x];
-    int16_t *coefs = a.coefs + (size_t)im.img * a.nblk * 64;
+    int16_t *dcs = a.dcs + (size_t)im.img * a.nblk;
     const int t = threadIdx.x, nmcu = a.nblk / a.bpm;
     if (t == 0 && a.total_ends[blockIdx.x] < (uint32_t)a.nblk) atomicExch(a.status + im.img, IPX_ERR_INVALID);   // "short Huffman data"
     const int per = (nmcu + 255) / 256, m0 = min(nmcu, t * per), m1 = min(nmcu, m0 + per);
     int sum[3] = {0, 0, 0};
     for (int m = m0; m < m1; m++)
-        for (int bi = 0; bi < a.bpm; bi++) sum[bi < a.ybl ? 0 : bi - a.ybl + 1] += coefs[((size_t)m * a.bpm + bi) * 64];
+        for (int bi = 0; bi < a.bpm; bi++) sum[bi < a.ybl ? 0 : bi - a.ybl + 1] += dcs[(size_t)m * a.bpm + bi];
     for (int k = 0; k < 3; k++) part[t][k] = sum[k];
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void par_dc_kernel(JpegParArgs a)
     for (int m = m0; m < m1; m++)
         for (int bi = 0; bi < a.bpm; bi++) {
             const int k = bi < a.ybl ? 0 : bi - a.ybl + 1;
-            int16_t *b = coefs + ((size_t)m * a.bpm + bi) * 64;
+            int16_t *b = dcs + (size_t)m * a.bpm + bi;
             run_[k] += b[0];
             bad |= run_[k] < -32768 || run_[k] > 32767;
             b[0] = (int16_t)run_[k];

@@ -506,6 +506,8 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     if ((e = mem.get(&d_tab, sizeof(JpegDecTables) * n)) != hipSuccess) return fail(e, "scratch allocation");
     if ((e = mem.get(&d_coefs, (size_t)n * a.nblk * 128)) != hipSuccess) return fail(e, "scratch allocation");
     if ((e = mem.get(&d_status, sizeof(int) * n)) != hipSuccess) return fail(e, "scratch allocation");
+    int16_t *d_dcs;
+    if ((e = mem.get(&d_dcs, (size_t)n * a.nblk * 2 + 16)) != hipSuccess) return fail(e, "scratch allocation");
     uint8_t *hblob = (uint8_t *)ipx_host_alloc(ctx, blob_bytes + 16);
     if (!hblob) { ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
     parallel_for(n, [&](int i) { if (valid[i]) memcpy(hblob + blob_off[i], jpegs[i].data + info[i].scan_off, info[i].scan_len); });
@@ -517,7 +519,8 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tabs.data(), sizeof(JpegDecTables) * n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_coefs, 0, (size_t)n * a.nblk * 128, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int) * n, s);
-    a.blob = d_blob; a.img = d_img; a.tab = d_tab; a.coefs = d_coefs; a.status = d_status;
+    if (e == hipSuccess) e = hipMemsetAsync(d_dcs, 0, (size_t)n * a.nblk * 2, s);
+    a.blob = d_blob; a.img = d_img; a.tab = d_tab; a.coefs = d_coefs; a.status = d_status; a.dcs = d_dcs;
     a.first_valid = ref;
     a.shared_tables = env_int("IPX_JPEG_SHARED_TABLES", 1);
     for (int i = 0; i < n && a.shared_tables; i++)
@@ -528,7 +531,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     if (e == hipSuccess && !par.empty()) {
         JpegParArgs P{};
         P.blob = d_blob; P.tab = d_tab; P.nimg = (int)par.size(); P.bpm = a.bpm; P.ybl = a.ybl; P.nblk = a.nblk;
-        P.coefs = d_coefs; P.status = d_status;
+        P.coefs = d_coefs; P.status = d_status; P.dcs = d_dcs;
         P.stage_rows = env_int("IPX_JPEG_PAR_STAGE", 0);   // measured: 109 ms staged (2 waves per CU) against 49 ms through L1 / L2 (1024 x 1080p)
         for (auto &pi : par) P.max_nsub = std::max(P.max_nsub, (int)pi.nsub);
         for (size_t k = 0; k < par.size(); k++) par[k].sub_off = k * (size_t)P.max_nsub;
