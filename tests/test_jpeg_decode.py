@@ -421,3 +421,14 @@ def test_first_failing_restart_interval_decides(ctx):
         assert verdict(f) == first
         _, st = ctx.jpeg_decode_batch([f, clean])
         assert list(st) == [first, 0], (first, second, st)
+
+
+@pytest.mark.gpu
+def test_large_files(ctx):
+    """Thousands of sub-sequences per scan (several workgroups per image in the parallel decoder), 16-bit-wide block counts, high-entropy
+    scans: 4K 4:2:0, 8K 4:4:4, and a 1080p file at quality 100 over noise (a 4 MB scan); next to a small file in its own batch."""
+    for (w, h), kw, noise in (((3840, 2160), dict(quality=90, subsampling=2), 10.0), ((7680, 4320), dict(quality=50, subsampling=0), 4.0),
+                              ((1920, 1080), dict(quality=100, subsampling=2), 90.0), ((1920, 1080), dict(quality=97, subsampling=1, optimize=True), 30.0)):
+        f = pil_jpeg(picture(w, h, seed=w + h, noise=noise), **kw)
+        info, st = _check_batch(ctx, [f, f])
+        assert list(st) == [0, 0], (w, h, kw)
