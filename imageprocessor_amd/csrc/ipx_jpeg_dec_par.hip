@@ -410,10 +410,131 @@ __global__ __launch_bounds__(256) void par_dc_kernel(JpegParArgs a)
     if (bad) atomicExch(a.status + im.img, IPX_ERR_INVALID);
 }
 
+// ---- pieces with a known start state: restart intervals, and scans too short to be worth speculating on ------------------------
+// One lane per piece, as jpeg_huff_kernel (ipx_jpeg_dec.hip) has it, but through the reader above: the piece is first copied without its
+// stuffed zeros, so the decode loop refills with aligned words and never tests bytes (that test, divergent across the wave, is what made
+// the byte-wise kernel spend thousands of cycles per symbol step).
+__global__ __launch_bounds__(256) void piece_unstuff_kernel(JpegDecArgs a, uint8_t *ublob, uint32_t *ulen)
+{
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= a.nitems) return;
+    const JpegDecImage im = a.img[item];
+    if (!im.valid) { ulen[item] = 0; return; }
+    const uint8_t *src = a.blob + im.scan_off + im.pad;
+    const uint32_t n = im.scan_len - im.pad;
+    uint8_t *dst = ublob + im.uoff;
+    uint32_t o = 0, prev = 0, j = 0;
+    unsigned long long q = 0;
+    int nq = 0;
+    bool marker = false;
+    auto drain = [&](bool all) {
+        while (nq >= 4 || (all && nq > 0)) {
+            if (nq >= 4) { *(uint32_t *)(dst + o) = (uint32_t)q; q >>= 32; nq -= 4; o += 4; }   // o stays a multiple of 4 until the final bytes
+            else { dst[o++] = (uint8_t)q; q >>= 8; nq--; }
+        }
+    };
+    auto byte = [&](uint32_t c) {                         // false: a marker -- the entropy-coded data ended one byte earlier
+        if (prev == 0xff) {
+            if (c != 0x00) return false;
+            prev = 0x100;                                 // the stuffed zero is dropped and is nobody's predecessor
+            return true;
+        }
+        q |= (unsigned long long)c << (8 * nq); nq++;
+        prev = c;
+        return true;
+    };
+    for (; j < n && ((uintptr_t)(src + j) & 3); j++) { if (!byte(src[j])) { marker = true; break; } drain(false); }
+    if (!marker)
+        for (; j + 4 <= n; j += 4) {
+            const uint32_t wv = *(const uint32_t *)(src + j);
+            const uint32_t inv = ~wv;
+            if (prev != 0xff && ((inv - 0x01010101u) & ~inv & 0x80808080u) == 0) {   // no 0xff in sight: nothing to drop
+                q |= (unsigned long long)wv << (8 * nq);
+                nq += 4;
+                prev = wv >> 24;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (!marker && !byte((wv >> (8 * k)) & 0xffu)) marker = true;
+                if (marker) break;
+            }
+            drain(false);
+        }
+    if (!marker)
+        for (; j < n; j++) { if (!byte(src[j])) { marker = true; break; } drain(false); }
+    // the 0xff that opened the marker (or a lone 0xff at the very end) is not data
+    if (prev == 0xff && nq > 0) { nq--; q &= ~(0xffull << (8 * nq)); }
+    else if (prev == 0xff && o > 0) o--;                  // it had already gone out: step back over it (the reader is bounded by ulen)
+    drain(true);
+    ulen[item] = o;
+}
+
+struct PieceSink {
+    int16_t *coefs; int16_t *dcs; const uint8_t *unz;
+    uint32_t g, g_end;
+    int c, bpm, ybl;                 // block within the MCU, for the DC predictions
+    int dc0, dc1, dc2;
+    bool err;
+    __device__ __forceinline__ void dc(int d)
+    {
+        const int k = c < ybl ? 0 : c - ybl + 1;
+        const int v = (k == 0 ? dc0 : (k == 1 ? dc1 : dc2)) + d;
+        if (k == 0) dc0 = v; else if (k == 1) dc1 = v; else dc2 = v;
+        if (v < -32768 || v > 32767) { err = true; return; }   // Go keeps int32; out of int16 = not a sane file
+        dcs[g] = (int16_t)v;
+    }
+    __device__ __forceinline__ void ac(int z, int v) { coefs[(size_t)g * 64 + unz[z]] = (int16_t)v; }
+    __device__ __forceinline__ bool end_block() { g++; c = c + 1 == bpm ? 0 : c + 1; return g < g_end && !err; }
+    __device__ __forceinline__ void bad() { err = true; }   // "bad Huffman code" / "excessive DC component": nothing speculative here
+};
+
+__global__ __launch_bounds__(64) void piece_decode_kernel(JpegDecArgs a, const uint8_t *ublob, const uint32_t *ulen)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tb[4096];
+    const int lane = threadIdx.x, item = blockIdx.x * 64 + lane;
+    const JpegDecTables *tab = a.tab + a.first_valid;
+    for (int i = lane; i < 128; i += 64) ((uint4 *)tb)[i] = ((const uint4 *)&tab->lut[0][0])[i];
+    uint8_t *unz = tb + 2048;
+    unz[lane] = c_unzig_par[lane];
+    int32_t *mc = (int32_t *)(tb + 2048 + 64), *vo = mc + 72;
+    uint8_t *vl = (uint8_t *)(vo + 72);
+    for (int i = lane; i < 72; i += 64) { mc[i] = (&tab->maxcode[0][0])[i]; vo[i] = (&tab->valoff[0][0])[i]; }
+    for (int i = lane; i < 256; i += 64) ((uint32_t *)vl)[i] = ((const uint32_t *)&tab->vals[0][0])[i];
+    __syncthreads();
+    if (item >= a.nitems) return;
+    const JpegDecImage im = a.img[item];
+    if (!im.valid || im.n_mcu == 0) return;
+    const Tables T{(const uint16_t *)tb, mc, vo, vl, unz};
+    Reader r;
+    r.lds = nullptr; r.g = ublob + im.uoff; r.wg_base = 0; r.wg_bytes = 0; r.ubits = ulen[item] * 8u;
+    r.seek(0);
+    JpegParImage pim;
+    pim.td[0] = im.td[0]; pim.td[1] = im.td[1]; pim.td[2] = im.td[2]; pim.ta[0] = im.ta[0]; pim.ta[1] = im.ta[1]; pim.ta[2] = im.ta[2];
+    const uint32_t g0 = im.first_mcu * (uint32_t)a.bpm;
+    PieceSink sink{a.coefs + (size_t)im.img * a.nblk * 64, a.dcs + (size_t)im.img * a.nblk, unz, g0, g0 + im.n_mcu * (uint32_t)a.bpm,
+                   0, a.bpm, a.ybl, 0, 0, 0, false};
+    uint32_t ends;
+    (void)run(r, T, pim, a.bpm, a.ybl, 0, 0, r.ubits, sink, &ends);
+    int status = 0;
+    if (sink.err || sink.g < sink.g_end) status = IPX_ERR_INVALID;          // a bad code, or the data ran out before the last block
+    // An interval that does not end exactly at its marker (damaged data: too few or too many bits) is where Go's processSOS starts
+    // searching for the next RSTn (findRST); that heuristic is not restated here -- the file goes back to the CPU path.
+    else if (im.strict_end && r.ubits - r.upos() >= 8u) status = IPX_ERR_UNSUPPORTED;
+    if (status) atomicMin(&a.status[im.img], jpeg_status_key(im.first_mcu, status));
+}
+
 }  // namespace
 
 int jpeg_par_sub_bytes() { return kSub; }
 int jpeg_par_checkpoints() { return kCk; }
+
+hipError_t launch_jpeg_pieces(const JpegDecArgs &a, uint8_t *ublob, uint32_t *ulen, hipStream_t s)
+{
+    if (a.nitems <= 0) return hipSuccess;
+    hipLaunchKernelGGL(piece_unstuff_kernel, dim3((a.nitems + 255) / 256), dim3(256), 0, s, a, ublob, ulen);
+    hipLaunchKernelGGL(piece_decode_kernel, dim3((a.nitems + 63) / 64), dim3(64), 0, s, a, (const uint8_t *)ublob, (const uint32_t *)ulen);
+    return hipGetLastError();
+}
 
 hipError_t launch_par_count(const JpegParArgs &a, hipStream_t s)
 {

@@ -426,7 +426,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         if ((int)marks[i].size() != (nmcu + I.ri - 1) / I.ri - 1) status[i] = IPX_ERR_UNSUPPORTED;   // Go would try to resynchronise
     });
     int ref = -1;
-    size_t blob_bytes = 0;
+    size_t blob_bytes = 0, piece_ubytes = 0;
     std::vector<JpegParImage> par;
     const bool use_par = env_int("IPX_JPEG_PAR", 1) != 0;
     for (int i = 0; i < n; i++) {
@@ -448,6 +448,8 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
             memcpy(it.td, I.td, 3); memcpy(it.ta, I.ta, 3);
             it.valid = 1;
             it.pad = (uint8_t)(a0 & 15);           // bytes to skip: pieces start 16-byte aligned for the kernel's chunk loads
+            it.uoff = piece_ubytes;                // its unstuffed copy (launch_jpeg_pieces): a region of its own
+            piece_ubytes += ((a1 - a0) + 15 + 16) & ~(size_t)15;
             items.push_back(it);
         };
         size_t start = 0;
@@ -527,7 +529,16 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         if (valid[i] && (memcmp(tabs[i].lut, tabs[ref].lut, sizeof tabs[i].lut) || memcmp(tabs[i].maxcode, tabs[ref].maxcode, sizeof tabs[i].maxcode) ||
                               memcmp(tabs[i].valoff, tabs[ref].valoff, sizeof tabs[i].valoff) || memcmp(tabs[i].vals, tabs[ref].vals, sizeof tabs[i].vals)))
             a.shared_tables = 0;
-    if (e == hipSuccess && a.nitems > 0) e = launch_jpeg_huff(a, s);
+    if (e == hipSuccess && a.nitems > 0) {
+        if (a.shared_tables && env_int("IPX_JPEG_PIECE", 1)) {
+            uint8_t *d_upieces; uint32_t *d_ulen;
+            e = mem.get(&d_upieces, piece_ubytes + 64);
+            if (e == hipSuccess) e = mem.get(&d_ulen, sizeof(uint32_t) * items.size());
+            if (e == hipSuccess) e = launch_jpeg_pieces(a, d_upieces, d_ulen, s);
+        } else {
+            e = launch_jpeg_huff(a, s);     // byte-wise reader, per-lane tables when the files of the batch carry different ones
+        }
+    }
     if (e == hipSuccess && !par.empty()) {
         JpegParArgs P{};
         P.blob = d_blob; P.tab = d_tab; P.nimg = (int)par.size(); P.bpm = a.bpm; P.ybl = a.ybl; P.nblk = a.nblk;

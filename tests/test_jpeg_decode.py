@@ -113,11 +113,13 @@ def _check_batch(ctx, files, expect_status=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shared", ["1", "0"], ids=["shared-tables-kernel", "per-lane-tables-kernel"])
-def test_gpu_decode_same_tables_batch(ctx, shared, monkeypatch):
-    """A batch whose files all carry the Annex K tables takes the kernel with one shared table copy per workgroup (many waves
-    per CU); IPX_JPEG_SHARED_TABLES=0 forces the per-lane-table kernel on the same batch."""
+@pytest.mark.parametrize("shared,piece", [("1", "1"), ("1", "0"), ("0", "1")], ids=["piece-kernels", "bytewise-shared-tables-kernel", "bytewise-per-lane-tables-kernel"])
+def test_gpu_decode_same_tables_batch(ctx, shared, piece, monkeypatch):
+    """A batch whose files all carry the Annex K tables: restart intervals and short scans go through the piece kernels (unstuffed copy,
+    word-wise reader, one pass -- the default); IPX_JPEG_PIECE=0 keeps the byte-wise kernel with one shared table copy per workgroup,
+    IPX_JPEG_SHARED_TABLES=0 forces the byte-wise per-lane-table kernel on the same batch."""
     monkeypatch.setenv("IPX_JPEG_SHARED_TABLES", shared)
+    monkeypatch.setenv("IPX_JPEG_PIECE", piece)
     for (w, h, n) in ((320, 200, 300), (1920, 1080, 3), (17, 9, 5)):
         files = [pil_jpeg(picture(w, h, seed=i, noise=3.0 + 9 * (i % 5)), quality=[85, 60, 95][i % 3], **({"restart_marker_blocks": 7} if i % 4 == 0 else {}))
                  for i in range(n)]
