@@ -199,6 +199,7 @@ struct JpegDecImage {
     uint8_t td[3], ta[3], valid, pad;   // pad: bytes to skip at the start (pieces are read in aligned 16-byte chunks)
     uint8_t strict_end, rsv[3];         // a restart interval must end exactly at its RSTn marker (Go would resynchronise: not ours to guess)
     unsigned long long uoff;            // where the piece's unstuffed copy lives (launch_jpeg_pieces), 16-byte aligned, regions do not overlap
+    uint32_t tab_img, rsv2;             // the image whose Huffman tables this piece decodes with (the first of the batch with identical tables)
 };
 struct JpegDecArgs {
     const uint8_t *blob; const JpegDecImage *img; const JpegDecTables *tab;
@@ -243,7 +244,8 @@ hipError_t launch_par_dc(const JpegParArgs &a, hipStream_t s);
 int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *tab);
 hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s);
 // the same pieces through the word-wise reader of the parallel decoder: unstuff each piece into ublob (+ its length into ulen), then one
-// decode pass -- the state at the start of a piece is known, so nothing is speculative.  Shared tables only (a.shared_tables).
+// decode pass -- the state at the start of a piece is known, so nothing is speculative.  The 64 pieces of a workgroup share one set
+// of tables (img[64 * k].tab_img): the host groups the pieces by table set and pads each group to a multiple of 64.
 hipError_t launch_jpeg_pieces(const JpegDecArgs &a, uint8_t *ublob, uint32_t *ulen, hipStream_t s);
 hipError_t launch_jpeg_idct(const JpegDecArgs &a, const JpegPlanes &pl, hipStream_t s);
 

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(64) void piece_decode_kernel(JpegDecArgs a, const u
 {
     __shared__ __attribute__((aligned(16))) uint8_t tb[4096];
     const int lane = threadIdx.x, item = blockIdx.x * 64 + lane;
-    const JpegDecTables *tab = a.tab + a.first_valid;
+    const JpegDecTables *tab = a.tab + a.img[blockIdx.x * 64].tab_img;   // the host pads table groups to whole workgroups
     for (int i = lane; i < 128; i += 64) ((uint4 *)tb)[i] = ((const uint4 *)&tab->lut[0][0])[i];
     uint8_t *unz = tb + 2048;
     unz[lane] = c_unzig_par[lane];

@@ -427,6 +427,24 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     });
     int ref = -1;
     size_t blob_bytes = 0, piece_ubytes = 0;
+    // table classes: tab_of[i] = the first image of the batch whose Huffman tables equal image i's (most batches have one class, the
+    // Annex K tables every encoder defaults to); the piece kernels share one set per workgroup, so pieces are grouped by class
+    std::vector<int> tab_of(n, -1);
+    {
+        std::vector<int> reps;
+        auto same = [&](int x, int y) {
+            return !memcmp(tabs[x].lut, tabs[y].lut, sizeof tabs[x].lut) && !memcmp(tabs[x].maxcode, tabs[y].maxcode, sizeof tabs[x].maxcode) &&
+                   !memcmp(tabs[x].valoff, tabs[y].valoff, sizeof tabs[x].valoff) && !memcmp(tabs[x].vals, tabs[y].vals, sizeof tabs[x].vals);
+        };
+        for (int i = 0; i < n; i++) {
+            if (status[i] != IPX_OK) continue;
+            for (size_t k = reps.size(); k-- > 0 && tab_of[i] < 0;)     // newest first: neighbours tend to match
+                if (same(i, reps[k])) tab_of[i] = reps[k];
+            if (tab_of[i] < 0) { tab_of[i] = i; reps.push_back(i); }
+            if (reps.size() > 64) break;                                   // a batch of hand-optimised tables: not worth the quadratic search
+        }
+        for (int i = 0; i < n; i++) if (status[i] == IPX_OK && tab_of[i] < 0) tab_of[i] = i;
+    }
     std::vector<JpegParImage> par;
     const bool use_par = env_int("IPX_JPEG_PAR", 1) != 0;
     for (int i = 0; i < n; i++) {
@@ -449,6 +467,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
             it.valid = 1;
             it.pad = (uint8_t)(a0 & 15);           // bytes to skip: pieces start 16-byte aligned for the kernel's chunk loads
             it.uoff = piece_ubytes;                // its unstuffed copy (launch_jpeg_pieces): a region of its own
+            it.tab_img = (uint32_t)tab_of[i];
             piece_ubytes += ((a1 - a0) + 15 + 16) & ~(size_t)15;
             items.push_back(it);
         };
@@ -471,6 +490,23 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         blob_bytes += (I.scan_len + 15 + 16) & ~(size_t)15;
     }
     if (ref < 0) return IPX_OK;
+    {
+        // group the pieces by table class (stable: image order inside a class), each group padded to whole workgroups of 64
+        bool one_class = true;
+        for (auto &it : items) one_class = one_class && it.tab_img == items[0].tab_img;
+        if (!one_class) {
+            std::stable_sort(items.begin(), items.end(), [](const JpegDecImage &x, const JpegDecImage &y) { return x.tab_img < y.tab_img; });
+            std::vector<JpegDecImage> grouped;
+            JpegDecImage pad;
+            memset(&pad, 0, sizeof pad);
+            for (size_t k = 0; k < items.size(); k++) {
+                if (k && items[k].tab_img != items[k - 1].tab_img)
+                    while (grouped.size() & 63) { pad.tab_img = items[k - 1].tab_img; grouped.push_back(pad); }
+                grouped.push_back(items[k]);
+            }
+            items.swap(grouped);
+        }
+    }
     const JpegDecInfo &R = info[ref];
     *w = R.w; *h = R.h;
     JpegDecArgs a{};
@@ -530,13 +566,13 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
                               memcmp(tabs[i].valoff, tabs[ref].valoff, sizeof tabs[i].valoff) || memcmp(tabs[i].vals, tabs[ref].vals, sizeof tabs[i].vals)))
             a.shared_tables = 0;
     if (e == hipSuccess && a.nitems > 0) {
-        if (a.shared_tables && env_int("IPX_JPEG_PIECE", 1)) {
+        if (env_int("IPX_JPEG_PIECE", 1)) {
             uint8_t *d_upieces; uint32_t *d_ulen;
             e = mem.get(&d_upieces, piece_ubytes + 64);
             if (e == hipSuccess) e = mem.get(&d_ulen, sizeof(uint32_t) * items.size());
             if (e == hipSuccess) e = launch_jpeg_pieces(a, d_upieces, d_ulen, s);
         } else {
-            e = launch_jpeg_huff(a, s);     // byte-wise reader, per-lane tables when the files of the batch carry different ones
+            e = launch_jpeg_huff(a, s);     // the earlier kernel: byte-wise reader, per-lane tables when the files of the batch carry different ones
         }
     }
     if (e == hipSuccess && !par.empty()) {

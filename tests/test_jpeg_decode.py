@@ -113,7 +113,7 @@ def _check_batch(ctx, files, expect_status=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shared,piece", [("1", "1"), ("1", "0"), ("0", "1")], ids=["piece-kernels", "bytewise-shared-tables-kernel", "bytewise-per-lane-tables-kernel"])
+@pytest.mark.parametrize("shared,piece", [("1", "1"), ("1", "0"), ("0", "0")], ids=["piece-kernels", "bytewise-shared-tables-kernel", "bytewise-per-lane-tables-kernel"])
 def test_gpu_decode_same_tables_batch(ctx, shared, piece, monkeypatch):
     """A batch whose files all carry the Annex K tables: restart intervals and short scans go through the piece kernels (unstuffed copy,
     word-wise reader, one pass -- the default); IPX_JPEG_PIECE=0 keeps the byte-wise kernel with one shared table copy per workgroup,
@@ -434,3 +434,16 @@ def test_large_files(ctx):
         f = pil_jpeg(picture(w, h, seed=w + h, noise=noise), **kw)
         info, st = _check_batch(ctx, [f, f])
         assert list(st) == [0, 0], (w, h, kw)
+
+
+@pytest.mark.gpu
+def test_batch_with_many_table_sets(ctx):
+    """Files with their own (optimised) Huffman tables next to files with the Annex K ones, with and without restart intervals: the piece
+    kernels share one table set per workgroup, so the host groups the pieces by table set and pads the groups."""
+    files = []
+    for i in range(40):
+        kw = [{}, {"optimize": True}, {"restart_marker_rows": 1}, {"optimize": True, "restart_marker_blocks": 3}][i % 4]
+        files.append(pil_jpeg(picture(96, 80, seed=i, noise=2.0 + 5 * (i % 7)), quality=50 + i, **kw))
+    _check_batch(ctx, files)
+    big = [pil_jpeg(picture(640, 480, seed=i, noise=6.0), quality=80 + i, optimize=bool(i & 1), restart_marker_rows=1) for i in range(6)]
+    _check_batch(ctx, big)
