@@ -191,6 +191,7 @@ struct JpegDecTables {         // per image, as the kernels read them
     int32_t valoff[4][18];     // symbol index = valoff[len] + code
     uint8_t vals[4][256];
     uint16_t qnat[3][64];      // quantiser per component, natural order
+    uint32_t bound[4][8];      // for lengths 9..16: first 16-bit left-aligned value NOT covered by codes of at most that length
 };
 // one independently decodable piece of a scan: the whole scan, or one restart interval of it (DC predictions and the bit
 // reader start afresh after every RSTn, so intervals decode in parallel)

@@ -25,7 +25,7 @@ struct RawHuff { bool ok = false; uint8_t counts[16]; uint8_t vals[256]; int nva
 inline uint32_t be16(const uint8_t *p) { return (uint32_t)p[0] << 8 | p[1]; }
 
 // huffman.go's table, in the two forms the kernel uses
-bool build_huff(const RawHuff &r, uint16_t lut[256], int32_t maxcode[18], int32_t valoff[18], uint8_t vals[256])
+bool build_huff(const RawHuff &r, uint16_t lut[256], int32_t maxcode[18], int32_t valoff[18], uint8_t vals[256], uint32_t bound[8])
 {
     memset(lut, 0, 256 * sizeof(uint16_t));
     memcpy(vals, r.vals, 256);
@@ -33,7 +33,7 @@ bool build_huff(const RawHuff &r, uint16_t lut[256], int32_t maxcode[18], int32_
     for (int len = 1; len <= 16; len++) {
         code <<= 1;
         const int cnt = r.counts[len - 1];
-        if (cnt == 0) { maxcode[len] = -1; valoff[len] = 0; continue; }
+        if (cnt == 0) { maxcode[len] = -1; valoff[len] = 0; if (len >= 9) bound[len - 9] = (uint32_t)code << (16 - len); continue; }
         if (code + cnt > (1 << len)) return false;            // "bad Huffman table": more codes than the length can hold
         valoff[len] = idx - code;                              // symbol index = valoff + code
         if (len <= 8)
@@ -43,6 +43,7 @@ bool build_huff(const RawHuff &r, uint16_t lut[256], int32_t maxcode[18], int32_
             }
         code += cnt; idx += cnt;
         maxcode[len] = code - 1;
+        if (len >= 9) bound[len - 9] = (uint32_t)code << (16 - len);   // canonical codes: a 16-bit window below this has a code of at most len bits
     }
     maxcode[0] = -1; valoff[0] = 0; maxcode[17] = 0x7fffffff; valoff[17] = 0;
     return true;
@@ -157,9 +158,10 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
                         memset(tab->lut[slot], 0, sizeof tab->lut[slot]);
                         for (int l = 0; l < 18; l++) { tab->maxcode[slot][l] = -1; tab->valoff[slot][l] = 0; }
                         tab->maxcode[slot][17] = 0x7fffffff;
+                        memset(tab->bound[slot], 0, sizeof tab->bound[slot]);
                         continue;
                     }
-                    if (!build_huff(hf[tc][th], tab->lut[slot], tab->maxcode[slot], tab->valoff[slot], tab->vals[slot])) return IPX_ERR_INVALID;
+                    if (!build_huff(hf[tc][th], tab->lut[slot], tab->maxcode[slot], tab->valoff[slot], tab->vals[slot], tab->bound[slot])) return IPX_ERR_INVALID;
                 }
             for (int c = 0; c < 3; c++)
                 for (int zig = 0; zig < 64; zig++) tab->qnat[c][kUnzig[zig]] = c < ncomp ? quant[ctq[c]][zig] : 0;

@@ -41,6 +41,7 @@ __device__ __forceinline__ unsigned long long pack_state(uint32_t p, int c, int 
 
 struct Tables {          // LDS
     const uint16_t *lut; const int32_t *maxcode, *valoff; const uint8_t *vals, *unz;
+    const uint4 *bound;  // [slot][2]: the eight length bounds for codes of 9..16 bits
 };
 
 // Reads the UNSTUFFED scan of one image: bit position p <-> word p >> 5, most significant bit first within each byte.
@@ -59,9 +60,12 @@ struct Reader {
         const uint32_t wv = i < wg_bytes ? *(const uint32_t *)(lds + (i >> 10) * kRow + (i & (kSub - 1))) : *(const uint32_t *)(g + (size_t)wi * 4);
         return __builtin_bswap32(wv);
     }
+    // The word for the NEXT refill is loaded when the current one is consumed: its latency overlaps the ~5 symbols the current word lasts
+    // (what matters where few waves share a SIMD: one lane per restart interval gives about one wave per SIMD).
+    uint32_t nextw = 0;
     __device__ __forceinline__ void refill()
     {
-        if (cnt <= 32) { acc = (acc << 32) | word_at(widx); widx++; cnt += 32; }
+        if (cnt <= 32) { acc = (acc << 32) | nextw; widx++; cnt += 32; nextw = word_at(widx); }
     }
     __device__ __forceinline__ uint32_t upos() const { return widx * 32u - (uint32_t)cnt; }
     __device__ __forceinline__ bool exhausted() const { return upos() >= ubits; }
@@ -69,6 +73,7 @@ struct Reader {
     {
         widx = p >> 5;
         acc = 0; cnt = 0;
+        nextw = word_at(widx);
         refill();
         cnt -= (int)(p & 31u);
     }
@@ -89,8 +94,16 @@ struct NoSink {
 // blocks that ended.  sink.end_block() returning false stops the lane (all blocks of the image are done).
 // One accumulator refill and one table lookup per symbol: the top 32 bits hold the code (<= 16 bits) AND the value bits that
 // follow it (<= 16), so receiveExtend needs no second look at the stream; the bounds test runs once per symbol on the sum.
+// Huffman table slots of the three components as scalars (arrays indexed by the component would live in scratch memory: a global-memory
+// round trip per symbol -- measured on the first piece kernel: 12.5 ms instead of 3)
+struct Slots {
+    int td0, td1, td2, ta0, ta1, ta2;
+    template <class Im>
+    __device__ __forceinline__ static Slots of(const Im &im) { return Slots{im.td[0], im.td[1], im.td[2], im.ta[0], im.ta[1], im.ta[2]}; }
+};
+
 template <class Sink>
-__device__ __forceinline__ unsigned long long run(Reader &r, const Tables &T, const JpegParImage &im, int bpm, int ybl, int c, int z, uint32_t uend,
+__device__ __forceinline__ unsigned long long run(Reader &r, const Tables &T, const Slots im, int bpm, int ybl, int c, int z, uint32_t uend,
                                                   Sink &sink, uint32_t *ends)
 {
     uint32_t nend = 0;
@@ -100,17 +113,19 @@ __device__ __forceinline__ unsigned long long run(Reader &r, const Tables &T, co
         const uint32_t p = r.upos();
         if (p >= uend) { out = p >= r.ubits ? kOut : pack_state(p, c, z); break; }
         const int comp = c < ybl ? 0 : c - ybl + 1;
-        const int slot = z == 0 ? (comp == 0 ? im.td[0] : (comp == 1 ? im.td[1] : im.td[2])) : (comp == 0 ? im.ta[0] : (comp == 1 ? im.ta[1] : im.ta[2]));
+        const int slot = z == 0 ? (comp == 0 ? im.td0 : (comp == 1 ? im.td1 : im.td2)) : (comp == 0 ? im.ta0 : (comp == 1 ? im.ta1 : im.ta2));
         r.refill();
         const uint32_t bits = (uint32_t)(r.acc >> (r.cnt - 32));        // cnt >= 33 after the refill; past the end the buffer holds zeros
         const uint32_t e = T.lut[slot * 256 + (bits >> 24)];
         int len = (int)(e >> 8), sym = (int)(e & 0xffu);
         if (!e) {
+            // a code of 9..16 bits: canonical codes are ordered, so its length is 9 + the number of length bounds the 16-bit window has
+            // passed -- eight compares on two LDS reads instead of a loop of dependent table reads that every lane of the wave waits for
+            const uint32_t x = bits >> 16;
+            const uint4 b0 = T.bound[slot * 2], b1 = T.bound[slot * 2 + 1];
+            len = 9 + (int)(x >= b0.x) + (int)(x >= b0.y) + (int)(x >= b0.z) + (int)(x >= b0.w) + (int)(x >= b1.x) + (int)(x >= b1.y) + (int)(x >= b1.z);
             sym = -1;
-            for (len = 9; len <= 16; len++) {
-                const int code = (int)(bits >> (32 - len));
-                if (code <= T.maxcode[slot * 18 + len]) { sym = (int)T.vals[slot * 256 + ((T.valoff[slot * 18 + len] + code) & 255)]; break; }
-            }
+            if (x < b1.w) sym = (int)T.vals[slot * 256 + ((T.valoff[slot * 18 + len] + (int)(bits >> (32 - len))) & 255)];
             if (sym < 0) {                                               // no such code: a speculative decoder just moves on by one bit
                 r.cnt -= 1;
                 if (r.upos() > r.ubits) { out = kOut; break; }
@@ -171,6 +186,8 @@ __device__ __forceinline__ Tables stage(uint8_t *lds, const JpegParArgs &a, cons
     uint8_t *vl = (uint8_t *)(vo + 72);
     for (int i = lane; i < 72; i += 64) { mc[i] = (&tab->maxcode[0][0])[i]; vo[i] = (&tab->valoff[0][0])[i]; }
     for (int i = lane; i < 256; i += 64) ((uint32_t *)vl)[i] = ((const uint32_t *)&tab->vals[0][0])[i];
+    uint32_t *bd = (uint32_t *)(tb + 3712);                   // 2048 + 64 + 2 * 288 + 1024, 16-byte aligned
+    if (lane < 32) bd[lane] = (&tab->bound[0][0])[lane];
     uint8_t *rows = tb + 4096;
     const uint8_t *scan = a.ublob + im.scan_off;           // unstuffed copy: same offsets as the packed scans, zero padded
     const uint32_t base = (uint32_t)first_sub * kSub;
@@ -184,7 +201,7 @@ __device__ __forceinline__ Tables stage(uint8_t *lds, const JpegParArgs &a, cons
     }
     __syncthreads();
     r.lds = rows; r.g = scan; r.wg_base = base; r.wg_bytes = avail; r.ubits = a.ulen[py] * 8u;
-    return Tables{(const uint16_t *)tb, mc, vo, vl, unz};
+    return Tables{(const uint16_t *)tb, mc, vo, vl, unz, (const uint4 *)bd};
 }
 
 constexpr size_t kParLds = 4096 + (size_t)65 * kRow + 64;
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(64) void par_sync_kernel(JpegParArgs a, int round)
             if (limit >= uend) break;                               // the remaining checkpoints lie beyond this sub-sequence
             if (p >= limit) { ck[k] = kNoState; continue; }         // entered beyond it: not on this trajectory
             uint32_t e1;
-            out = run(r, T, im, a.bpm, a.ybl, c, z, limit, sink, &e1);
+            out = run(r, T, Slots::of(im), a.bpm, a.ybl, c, z, limit, sink, &e1);
             ends += e1;
             if ((uint32_t)out == kEnd) { ended = true; break; }
             if (round > 0 && ck[k] == out) {
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(64) void par_sync_kernel(JpegParArgs a, int round)
         }
         if (!ended) {
             uint32_t e1;
-            out = run(r, T, im, a.bpm, a.ybl, c, z, uend, sink, &e1);
+            out = run(r, T, Slots::of(im), a.bpm, a.ybl, c, z, uend, sink, &e1);
             ends += e1;
         }
     }
@@ -372,7 +389,7 @@ __global__ __launch_bounds__(64) void par_write_kernel(JpegParArgs a)
     if (sink.g >= sink.nblk) return;
     r.seek(p);
     uint32_t ends;
-    (void)run(r, T, im, a.bpm, a.ybl, (int)(entry >> 32) & 0xff, (int)(entry >> 40) & 0xff, uend, sink, &ends);
+    (void)run(r, T, Slots::of(im), a.bpm, a.ybl, (int)(entry >> 32) & 0xff, (int)(entry >> 40) & 0xff, uend, sink, &ends);
 }
 
 // step 4: DC differences -> DC values, per component in scan order; also the "scan ran out of data" verdict
@@ -477,9 +494,11 @@ struct PieceSink {
     bool err;
     __device__ __forceinline__ void dc(int d)
     {
+        // every prediction is updated arithmetically: written as v = (k == 0 ? dc0 : k == 1 ? dc1 : dc2) + d the compiler turns the
+        // three members into an indexed array in scratch memory (a round trip and a vmcnt(0) per block)
         const int k = c < ybl ? 0 : c - ybl + 1;
-        const int v = (k == 0 ? dc0 : (k == 1 ? dc1 : dc2)) + d;
-        if (k == 0) dc0 = v; else if (k == 1) dc1 = v; else dc2 = v;
+        dc0 += k == 0 ? d : 0; dc1 += k == 1 ? d : 0; dc2 += k == 2 ? d : 0;
+        const int v = (k == 0 ? dc0 : 0) + (k == 1 ? dc1 : 0) + (k == 2 ? dc2 : 0);
         if (v < -32768 || v > 32767) { err = true; return; }   // Go keeps int32; out of int16 = not a sane file
         dcs[g] = (int16_t)v;
     }
@@ -500,27 +519,31 @@ __global__ __launch_bounds__(64) void piece_decode_kernel(JpegDecArgs a, const u
     uint8_t *vl = (uint8_t *)(vo + 72);
     for (int i = lane; i < 72; i += 64) { mc[i] = (&tab->maxcode[0][0])[i]; vo[i] = (&tab->valoff[0][0])[i]; }
     for (int i = lane; i < 256; i += 64) ((uint32_t *)vl)[i] = ((const uint32_t *)&tab->vals[0][0])[i];
+    uint32_t *bd = (uint32_t *)(tb + 3712);
+    if (lane < 32) bd[lane] = (&tab->bound[0][0])[lane];
     __syncthreads();
     if (item >= a.nitems) return;
-    const JpegDecImage im = a.img[item];
-    if (!im.valid || im.n_mcu == 0) return;
-    const Tables T{(const uint16_t *)tb, mc, vo, vl, unz};
+    // field by field: a per-lane copy of the whole struct (byte arrays inside) ends up in scratch memory
+    const JpegDecImage *ip = a.img + item;
+    const uint32_t n_mcu = ip->n_mcu, first_mcu = ip->first_mcu, img = ip->img;
+    if (!ip->valid || n_mcu == 0) return;
+    const Slots slots{ip->td[0], ip->td[1], ip->td[2], ip->ta[0], ip->ta[1], ip->ta[2]};
+    const bool strict_end = ip->strict_end != 0;
+    const Tables T{(const uint16_t *)tb, mc, vo, vl, unz, (const uint4 *)bd};
     Reader r;
-    r.lds = nullptr; r.g = ublob + im.uoff; r.wg_base = 0; r.wg_bytes = 0; r.ubits = ulen[item] * 8u;
+    r.lds = nullptr; r.g = ublob + ip->uoff; r.wg_base = 0; r.wg_bytes = 0; r.ubits = ulen[item] * 8u;
     r.seek(0);
-    JpegParImage pim;
-    pim.td[0] = im.td[0]; pim.td[1] = im.td[1]; pim.td[2] = im.td[2]; pim.ta[0] = im.ta[0]; pim.ta[1] = im.ta[1]; pim.ta[2] = im.ta[2];
-    const uint32_t g0 = im.first_mcu * (uint32_t)a.bpm;
-    PieceSink sink{a.coefs + (size_t)im.img * a.nblk * 64, a.dcs + (size_t)im.img * a.nblk, unz, g0, g0 + im.n_mcu * (uint32_t)a.bpm,
+    const uint32_t g0 = first_mcu * (uint32_t)a.bpm;
+    PieceSink sink{a.coefs + (size_t)img * a.nblk * 64, a.dcs + (size_t)img * a.nblk, unz, g0, g0 + n_mcu * (uint32_t)a.bpm,
                    0, a.bpm, a.ybl, 0, 0, 0, false};
     uint32_t ends;
-    (void)run(r, T, pim, a.bpm, a.ybl, 0, 0, r.ubits, sink, &ends);
+    (void)run(r, T, slots, a.bpm, a.ybl, 0, 0, r.ubits, sink, &ends);
     int status = 0;
     if (sink.err || sink.g < sink.g_end) status = IPX_ERR_INVALID;          // a bad code, or the data ran out before the last block
     // An interval that does not end exactly at its marker (damaged data: too few or too many bits) is where Go's processSOS starts
     // searching for the next RSTn (findRST); that heuristic is not restated here -- the file goes back to the CPU path.
-    else if (im.strict_end && r.ubits - r.upos() >= 8u) status = IPX_ERR_UNSUPPORTED;
-    if (status) atomicMin(&a.status[im.img], jpeg_status_key(im.first_mcu, status));
+    else if (strict_end && r.ubits - r.upos() >= 8u) status = IPX_ERR_UNSUPPORTED;
+    if (status) atomicMin(&a.status[img], jpeg_status_key(first_mcu, status));
 }
 
 }  // namespace

@@ -225,6 +225,17 @@ int ipx_create(const ipx_config *cfg, ipx_ctx **out)
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&l.flag, sizeof(int));
     }
+    if (e == hipSuccess) {
+        // stream-ordered scratch (the codecs' coefficient arrays, gigabytes per batch) comes from the device's default pool; with the
+        // default release threshold of 0 every synchronisation hands the freed memory back to the driver and the next batch maps it
+        // again.  Keep up to IPX_POOL_KEEP_GB (64) in the pool.
+        hipMemPool_t pool = nullptr;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+            uint64_t keep = (uint64_t)std::max(0, env_int("IPX_POOL_KEEP_GB", 64)) << 30;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&c->flat_chroma, ipx_ctx::kFlatChromaBytes);
     if (e == hipSuccess) e = hipMemset(c->flat_chroma, 128, ipx_ctx::kFlatChromaBytes);
     if (e != hipSuccess) {
