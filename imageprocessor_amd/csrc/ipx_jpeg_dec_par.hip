@@ -22,6 +22,9 @@
 // A workgroup is one wave = 64 consecutive sub-sequences of ONE image, with that image's Huffman tables in LDS.  The scan
 // words are read through L1 / L2 (a lane walks its own KiB sequentially); staging the 64 KiB in LDS (IPX_JPEG_PAR_STAGE=1,
 // row stride 1028 bytes against bank aliasing) leaves two waves per CU and is 2.2x slower than the occupancy it costs.
+#include <algorithm>
+#include <cstdlib>
+
 #include "ipx_internal.h"
 
 namespace ipx {
@@ -583,7 +586,11 @@ hipError_t launch_par_sync(const JpegParArgs &a, int round, hipStream_t s)
 }
 hipError_t launch_par_write(const JpegParArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(par_write_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows ? kParLds : 4096, s, a);
+    // dynamic LDS beyond the 4 KiB of tables only limits how many waves share a CU: the lanes' scattered 2-byte coefficient stores keep one
+    // 128-byte line each in flight, and with 2048 lanes per CU those lines do not fit the XCD's 4 MiB L2 -- every line is then written
+    // back (and read for the merge) several times
+    static const int write_lds = [] { const char *e = getenv("IPX_JPEG_WRITE_LDS"); return e ? atoi(e) : 16384; }();   // measured per 1024 x 1080p files: 4 KiB 8.7 ms, 10 KiB 8.4, 16 KiB 7.9, 20 KiB 8.1, 40 KiB 11.7
+    hipLaunchKernelGGL(par_write_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows ? kParLds : (size_t)std::max(4096, write_lds), s, a);
     return hipGetLastError();
 }
 hipError_t launch_par_dc(const JpegParArgs &a, hipStream_t s)
