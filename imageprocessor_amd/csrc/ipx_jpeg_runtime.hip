@@ -2,6 +2,7 @@
 // chain them with the operators (host frames -> streams, planes -> streams, files -> streams).  Kernels: ipx_jpeg.hip,
 // ipx_jpeg_entropy.hip, ipx_jpeg_dec.hip, ipx_jpeg_dec_par.hip; host halves: ipx_jpeg_host.cpp, ipx_jpeg_dec_host.cpp.
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <memory>
 #include <string>
@@ -681,12 +682,32 @@ static int run_jpeg_jpeg_one(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_
         if (thumb_out) thumb_out[i] = ipx_bytes{nullptr, 0};
         if (wm_out) wm_out[i] = ipx_bytes{nullptr, 0};
     }
+    const bool dbg = getenv("IPX_DEBUG") != nullptr;
+    struct Slot {
+        ipx_ctx *c;
+        explicit Slot(ipx_ctx *ctx) : c(ctx)
+        {
+            const int cap = std::max(1, env_int("IPX_JPEG_JPEG_PARALLEL", 3));
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->jj_active < cap; });
+            c->jj_active++;
+        }
+        ~Slot()
+        {
+            { std::lock_guard<std::mutex> lk(c->mu); c->jj_active--; }
+            c->cv.notify_all();
+        }
+    } slot(ctx);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     LaneLease lane(ctx);
+    const double t_lane = ms_since(t0);
     hipStream_t s = lane->stream;
     int w = sw, h = sh;
     ipx_ycbcr_batch planes;
     ipx_jpeg_planes *owner = nullptr;
     int rc = ipx_jpeg_decode_batch(ctx, s, files, n, &w, &h, &planes, status, &owner);
+    const double t_dec = ms_since(t0);
     if (rc) return rc;
     if (!planes.y) return IPX_OK;                         // nothing decodable: every status says why
     struct Guard { ipx_ctx *c; ipx_jpeg_planes *o; ~Guard() { ipx_jpeg_planes_free(c, o); } } guard{ctx, owner};
@@ -701,6 +722,7 @@ static int run_jpeg_jpeg_one(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_
     const int chunk = std::max(1, std::min(n, env_int("IPX_JPEG_JPEG_CHUNK", 256)));
     rc = lane_reserve(lane.get(), per_frame * chunk + 256);
     if (rc) return rc;
+    const double t_res = ms_since(t0);
     std::unique_ptr<ipx_jpeg_result> res(new ipx_jpeg_result);
     std::vector<size_t> offs(chunk), lens(chunk);
     for (int i0 = 0; i0 < n && !rc; i0 += chunk) {
@@ -729,6 +751,7 @@ static int run_jpeg_jpeg_one(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_
         }
     }
     (void)hipStreamSynchronize(s);
+    if (dbg) fprintf(stderr, "[ipx] jpeg->jpeg part of %d files: lane after %.1f ms, decoded at %.1f, scratch at %.1f, done at %.1f\n", n, t_lane, t_dec, t_res, ms_since(t0));
     if (rc) { ipx_jpeg_result_free(ctx, res.release()); return rc; }
     *result = res.release();
     return IPX_OK;

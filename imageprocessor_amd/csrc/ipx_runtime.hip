@@ -282,6 +282,7 @@ void *ipx_host_alloc(ipx_ctx *ctx, size_t bytes)
     }
     (void)hipSetDevice(ctx->device);
     void *p = nullptr;
+    if (getenv("IPX_DEBUG")) fprintf(stderr, "[ipx] pinning %zu MiB (cache holds %zu MiB in %zu blocks)\n", want >> 20, ctx->host_cached >> 20, ctx->host_free_blocks.size());
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); return nullptr; }
     std::lock_guard<std::mutex> lk(ctx->host_mu);

@@ -41,6 +41,10 @@ struct ipx_ctx {
     std::deque<void *> host_lru;                   // cached blocks, least recently freed first
     size_t host_cached = 0, host_cache_limit = (size_t)8 << 30;   // IPX_HOST_CACHE_MB
     // one row of 128s: the Cb / Cr "planes" (stride 0) that make a Gray frame a YCbCr frame with neutral chroma (ipx_plan_run_dev_gray)
+    // compressed-in / compressed-out parts in flight (ipx_plan_run_jpeg_jpeg): capped at three per context.  Measured: two or three parts
+    // side by side overlap nicely (one decodes while another is in its host-paced encode read-backs), four take 0.9 s EACH in their
+    // decode step instead of 0.03 s -- whatever serialises there (allocation, synchronisation), a fourth part gains nothing
+    int jj_active = 0;
     uint8_t *flat_chroma = nullptr;
     static constexpr size_t kFlatChromaBytes = (size_t)64 << 10;
 };
@@ -126,7 +130,7 @@ public:
             std::lock_guard<std::mutex> lk(c_->mu);
             lane_->busy = false;
         }
-        c_->cv.notify_one();
+        c_->cv.notify_all();     // waiters differ (one lane / every lane): wake them all, the predicates sort it out
     }
     Lane *operator->() { return lane_; }
     Lane &get() { return *lane_; }

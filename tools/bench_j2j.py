@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Compressed in, compressed out alone (ipx_plan_run_jpeg_jpeg): n 1080p 4:2:0 q85 files -> decode + resize 1024x576 + thumbnail 200 + watermark
 + three jpeg.Encode on the GPU.  For rocprofv3: the kernel sums against the wall time say how much of a call is GPU work.
-usage: tools/bench_j2j.py [files] [reps]"""
+usage: tools/bench_j2j.py [files] [reps] [concurrent callers]"""
 import io
 import os
 import sys
@@ -39,3 +39,19 @@ for _ in range(reps):
     best = min(best, time.perf_counter() - t0)
 assert not any(st)
 print("JPEG files (%.0f KB) -> three JPEG streams: %d files in %.1f ms = %.0f images/s" % (len(files[0]) / 1e3, n, best * 1e3, n / best))
+callers = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if callers:
+    import threading
+
+    def call():
+        out, st = plan.run_jpeg_jpeg(batch, copy=False)
+        assert not any(st)
+    for rep in range(reps):
+        ths = [threading.Thread(target=call) for _ in range(callers)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        print("%d concurrent callers x %d files, repetition %d: %.1f ms = %.0f images/s" % (callers, n, rep, dt * 1e3, callers * n / dt), flush=True)
