@@ -398,13 +398,9 @@ __global__ __launch_bounds__(NT) void band_pipe_kernel(BandArgs a)
 template <int NX>
 hipError_t launch_nx(const BandArgs &a, unsigned total, size_t lds, hipStream_t s)
 {
-    static thread_local size_t lds_set = 0;
-    if (lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)band_kernel<NX>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_set = lds;
-    }
+    static KernelLaunchCache cache;
+    hipError_t e = cache.prepare((const void *)band_kernel<NX>, 256, lds, nullptr);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(band_kernel<NX>, dim3(total), dim3(256), lds, s, a);
     return hipGetLastError();
 }
@@ -414,22 +410,13 @@ hipError_t launch_pipe(const BandArgs &a, long long items, size_t lds, hipStream
 {
     // a persistent grid must be fully resident: size it from the occupancy the runtime reports for
     // this instantiation and LDS size, not from the LDS arithmetic alone (VGPRs may bind first)
-    static thread_local size_t lds_set = 0;
-    static thread_local int resident = 0;
+    static KernelLaunchCache cache;
+    int resident = 1;
     auto kern = band_pipe_kernel<NX0, FP0, NX1, FP1, ROWS, CH, NT>;
-    if (lds != lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        int n = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, NT, lds);
-        if (e != hipSuccess) return e;
-        resident = std::max(1, n);
-        lds_set = lds;
-    }
+    hipError_t e = cache.prepare((const void *)kern, NT, lds, &resident);
+    if (e != hipSuccess) return e;
     const long long grid = std::min<long long>(items, (long long)a.cus * std::min(a.pipe_wgs, resident));
-    static thread_local bool said = false;
-    if (!said && getenv("IPX_DEBUG")) {
-        said = true;
+    if (getenv("IPX_DEBUG") && cache.first_report()) {
         fprintf(stderr, "[ipx] band_pipe_kernel<%d,%d,%d,%d,%d,%d,%d>: tile %d rows x %d cols, lds %zu B, resident %d/CU, grid %lld, items %lld\n",
                 NX0, (int)FP0, NX1, (int)FP1, ROWS, CH, NT, a.band_rows, a.blk_cols, lds, resident, grid, items);
     }

@@ -321,22 +321,13 @@ __global__ __launch_bounds__(kNT) void band_nrgba_kernel(NrgbaArgs A)
 template <int NX0, bool FP0, int NX1, bool FP1>
 hipError_t launch_cfg(const NrgbaArgs &A, long long items, size_t lds, hipStream_t s)
 {
-    static thread_local size_t lds_set = 0;
-    static thread_local int resident = 0;
+    static KernelLaunchCache cache;
+    int resident = 1;
     auto kern = band_nrgba_kernel<NX0, FP0, NX1, FP1>;
-    if (lds != lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        int n = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, kNT, lds);
-        if (e != hipSuccess) return e;
-        resident = std::max(1, n);
-        lds_set = lds;
-    }
+    hipError_t e = cache.prepare((const void *)kern, kNT, lds, &resident);
+    if (e != hipSuccess) return e;
     const long long grid = std::min<long long>(items, (long long)A.b.cus * std::min(A.b.pipe_wgs, resident));
-    static thread_local bool said = false;
-    if (!said && getenv("IPX_DEBUG")) {
-        said = true;
+    if (getenv("IPX_DEBUG") && cache.first_report()) {
         fprintf(stderr, "[ipx] band_nrgba_kernel<%d,%d,%d,%d>: tile %d rows x %d cols, lds %zu B, resident %d/CU, grid %lld, items %lld\n", NX0,
                 (int)FP0, NX1, (int)FP1, A.b.band_rows, A.b.blk_cols, lds, resident, grid, items);
     }

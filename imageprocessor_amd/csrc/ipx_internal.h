@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
+#include <mutex>
 
 #include "../../include/ipx.h"
 
@@ -158,6 +160,36 @@ struct NrgbaArgs {
                                //                 1 = premultiplied RGBA8 first (the crop copy), then scale_RGBA_RGBA_*
 };
 hipError_t launch_band_nrgba(const NrgbaArgs &a, hipStream_t s, bool *matched);
+// Per kernel instantiation and process: the dynamic-LDS limit is raised once (it only has to be at least what a launch asks for) and the
+// occupancy is cached per LDS size.  These are properties of the loaded function, not of the calling thread; done per thread, every
+// short-lived worker thread repeated hipFuncSetAttribute / hipOccupancy... in the middle of other threads' launches.
+struct KernelLaunchCache {
+    std::mutex mu;
+    size_t lds_max = 0;
+    std::map<size_t, int> resident;
+    bool said = false;
+    hipError_t prepare(const void *fn, int threads, size_t lds, int *res)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (lds > lds_max) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            lds_max = lds;
+        }
+        if (res) {
+            auto it = resident.find(lds);
+            if (it == resident.end()) {
+                int n = 0;
+                hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, lds);
+                if (e != hipSuccess) return e;
+                it = resident.emplace(lds, n > 1 ? n : 1).first;
+            }
+            *res = it->second;
+        }
+        return hipSuccess;
+    }
+    bool first_report() { std::lock_guard<std::mutex> lk(mu); const bool f = !said; said = true; return f; }
+};
 size_t band_lds_bytes(int band_rows, int blk_cols);
 bool band_pipe_shape(int band_rows, int blk_cols, int *rows, int *ch);  // tile shapes the pipelined kernel is built for
 

@@ -335,12 +335,9 @@ hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s)
         return hipGetLastError();
     }
     const size_t lds = (size_t)64 * kLutStride + 64;
-    static thread_local bool set = false;
-    if (!set) {
-        hipError_t e = hipFuncSetAttribute((const void *)jpeg_huff_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        set = true;
-    }
+    static KernelLaunchCache cache;
+    hipError_t e = cache.prepare((const void *)jpeg_huff_kernel<false>, 64, lds, nullptr);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(jpeg_huff_kernel<false>, dim3((a.nitems + 63) / 64), dim3(64), lds, s, a);
     return hipGetLastError();
 }

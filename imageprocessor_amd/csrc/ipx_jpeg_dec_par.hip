@@ -595,13 +595,10 @@ hipError_t launch_par_unstuff(const JpegParArgs &a, hipStream_t s)
 }
 hipError_t launch_par_sync(const JpegParArgs &a, int round, hipStream_t s)
 {
-    static thread_local bool set = false;
-    if (!set) {
-        hipError_t e = hipFuncSetAttribute((const void *)par_sync_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kParLds);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)par_write_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kParLds);
-        if (e != hipSuccess) return e;
-        set = true;
-    }
+    static KernelLaunchCache sync_cache, write_cache;
+    hipError_t e = sync_cache.prepare((const void *)par_sync_kernel, 64, kParLds, nullptr);
+    if (e == hipSuccess) e = write_cache.prepare((const void *)par_write_kernel, 64, kParLds, nullptr);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(par_sync_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows ? kParLds : 4096, s, a, round);
     return hipGetLastError();
 }

@@ -363,7 +363,7 @@ int ipx_jpeg_encode_rgba8(ipx_ctx *ctx, const uint8_t *pix, int w, int h, int st
 
 
 // ---- image.Decode for JPEG batches -----------------------------------------------------------------------
-struct ipx_jpeg_planes { std::vector<void *> dev; };
+struct ipx_jpeg_planes { std::vector<void *> dev; hipStream_t stream = nullptr; };   // stream-ordered allocations of `stream`
 
 extern "C" {
 
@@ -371,9 +371,14 @@ void ipx_jpeg_planes_free(ipx_ctx *ctx, ipx_jpeg_planes *o)
 {
     if (!o) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    for (void *p : o->dev) (void)hipFree(p);
+    // stream-ordered, like the allocation: hipMalloc / hipFree wait for EVERY stream of the device, and with several decodes in flight on
+    // lanes of their own each such call waited for all the others' kernels (four concurrent parts: 0.9 s per decode instead of 0.03 s)
+    for (void *p : o->dev) (void)hipFreeAsync(p, o->stream);
     delete o;
 }
+
+static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_lane, const ipx_bytes *jpegs, int n, int *w, int *h,
+                        ipx_ycbcr_batch *planes, int *status, ipx_jpeg_planes **owner);
 
 int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, int n, int *w, int *h, ipx_ycbcr_batch *planes,
                           int *status, ipx_jpeg_planes **owner)
@@ -384,7 +389,17 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     memset(planes, 0, sizeof *planes);
     if (n == 0) return IPX_OK;
     if (n > 65535) { set_error("ipx_jpeg_decode_batch: at most 65535 files per call"); return IPX_ERR_UNSUPPORTED; }
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    // the scratch comes out of a lane's decode buffer for the duration of the call; the planes are the caller's (stream-ordered allocations)
+    LaneLease lane(ctx);
+    return decode_batch(ctx, stream ? (hipStream_t)stream : ctx->stream, env_int("IPX_JPEG_LANE_ARENA", 1) ? &lane.get() : nullptr, false, jpegs, n, w, h,
+                        planes, status, owner);
+}
+
+// lane != NULL: scratch is bumped out of the lane's decode buffer (no allocation in the steady state); planes_in_lane: the planes too --
+// the caller then holds the lane for as long as it uses them and *owner has nothing to free
+static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_lane, const ipx_bytes *jpegs, int n, int *w, int *h,
+                        ipx_ycbcr_batch *planes, int *status, ipx_jpeg_planes **owner)
+{
     std::vector<JpegDecInfo> info(n);
     std::vector<JpegDecTables> tabs(n);
     std::vector<JpegDecImage> items;
@@ -404,6 +419,9 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     // pieces of a scan: the whole scan, or one per restart interval.  Inside entropy-coded data 0xff is followed by 0x00 or by a
     // marker, so every 0xff 0xd0..0xd7 pair is an RSTn.
     std::vector<std::vector<uint32_t>> marks(n);
+    const auto td0 = std::chrono::steady_clock::now();
+    auto dms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count(); };
+    double t_parse = 0, t_alloc = 0, t_pin = 0, t_pack = 0, t_launch = 0;
     parallel_for(n, [&](int i) {
         status[i] = !jpegs[i].data ? IPX_ERR_INVALID : (jpegs[i].len >= ((size_t)1 << 30) ? IPX_ERR_UNSUPPORTED : jpeg_parse(jpegs[i].data, jpegs[i].len, &info[i], &tabs[i]));
         if (status[i] != IPX_OK) return;
@@ -426,6 +444,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         }
         if ((int)marks[i].size() != (nmcu + I.ri - 1) / I.ri - 1) status[i] = IPX_ERR_UNSUPPORTED;   // Go would try to resynchronise
     });
+    t_parse = dms();
     int ref = -1;
     size_t blob_bytes = 0, piece_ubytes = 0;
     // table classes: tab_of[i] = the first image of the batch whose Huffman tables equal image i's (most batches have one class, the
@@ -521,8 +540,23 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     pl.y_fs = align256((size_t)pl.ystride * 8 * R.v0 * a.myy); pl.c_fs = gray ? 0 : align256((size_t)pl.cstride * 8 * a.myy);
 
     std::unique_ptr<ipx_jpeg_planes> own(new ipx_jpeg_planes);
+    own->stream = s;
+    // scratch of this call: stream-ordered, or bumped out of the lane's decode buffer
+    AsyncFree mem{s, {}};
+    if (lane) {
+        size_t subs = 0;
+        for (auto &pi : par) subs = std::max(subs, (size_t)pi.nsub);
+        subs *= par.size();
+        const size_t est = (pl.y_fs + 2 * pl.c_fs) * n + (size_t)n * a.nblk * 130 + 3 * (blob_bytes + 1024) + piece_ubytes +
+                           items.size() * (sizeof(JpegDecImage) + 8) + (size_t)n * (sizeof(JpegDecTables) + 64) + par.size() * (sizeof(JpegParImage) + 64) +
+                           subs * 96 + ((size_t)4 << 20);
+        const int rr = lane_reserve_dec(*lane, est);
+        if (rr) return rr;
+        mem.arena = lane->dec; mem.cap = lane->dec_bytes;
+    }
     auto dalloc = [&](void **p, size_t bytes) {
-        hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+        if (lane && planes_in_lane) return mem.get((uint8_t **)p, bytes);   // first requests of the call and counted in est: they always fit
+        hipError_t e = hipMallocAsync(p, bytes ? bytes : 1, s);
         if (e == hipSuccess) own->dev.push_back(*p);
         return e;
     };
@@ -535,8 +569,6 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     if ((e = dalloc((void **)&pl.y, pl.y_fs * n)) != hipSuccess) return fail(e, "plane allocation");
     if (!gray && (e = dalloc((void **)&pl.cb, pl.c_fs * n)) != hipSuccess) return fail(e, "plane allocation");
     if (!gray && (e = dalloc((void **)&pl.cr, pl.c_fs * n)) != hipSuccess) return fail(e, "plane allocation");
-    // scratch of this call, stream-ordered
-    AsyncFree mem{s, {}};
     uint8_t *d_blob; JpegDecImage *d_img; JpegDecTables *d_tab; int16_t *d_coefs; int *d_status;
     if ((e = mem.get(&d_blob, blob_bytes + 16)) != hipSuccess) return fail(e, "scratch allocation");
     uint8_t *d_valid;
@@ -547,9 +579,12 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     if ((e = mem.get(&d_status, sizeof(int) * n)) != hipSuccess) return fail(e, "scratch allocation");
     int16_t *d_dcs;
     if ((e = mem.get(&d_dcs, (size_t)n * a.nblk * 2 + 16)) != hipSuccess) return fail(e, "scratch allocation");
+    t_alloc = dms();
     uint8_t *hblob = (uint8_t *)ipx_host_alloc(ctx, blob_bytes + 16);
+    t_pin = dms();
     if (!hblob) { ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
     parallel_for(n, [&](int i) { if (valid[i]) memcpy(hblob + blob_off[i], jpegs[i].data + info[i].scan_off, info[i].scan_len); });
+    t_pack = dms();
     e = hipMemcpyAsync(d_blob, hblob, blob_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_img, items.data(), sizeof(JpegDecImage) * items.size(), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_valid, valid.data(), (size_t)n, hipMemcpyHostToDevice, s);
@@ -649,9 +684,12 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
         }
     }
     if (e == hipSuccess) e = launch_jpeg_idct(a, pl, s);
+    t_launch = dms();
     std::vector<int> dev_status(n, 0);
     if (e == hipSuccess) e = hipMemcpyAsync(dev_status.data(), d_status, sizeof(int) * n, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);   // the host tables and the blob may go now
+    if (getenv("IPX_DEBUG") && dms() > 200.0)
+        fprintf(stderr, "[ipx] slow decode of %d files: parsed at %.1f ms, device scratch at %.1f, pinned block at %.1f, packed at %.1f, launched at %.1f, finished at %.1f\n", n, t_parse, t_alloc, t_pin, t_pack, t_launch, dms());
     (void)ipx_host_free(ctx, hblob);
     if (e != hipSuccess) return fail(e, "jpeg decode");
     for (int i = 0; i < n; i++)
@@ -706,7 +744,8 @@ static int run_jpeg_jpeg_one(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_
     int w = sw, h = sh;
     ipx_ycbcr_batch planes;
     ipx_jpeg_planes *owner = nullptr;
-    int rc = ipx_jpeg_decode_batch(ctx, s, files, n, &w, &h, &planes, status, &owner);
+    memset(&planes, 0, sizeof planes);
+    int rc = n > 65535 ? IPX_ERR_UNSUPPORTED : decode_batch(ctx, s, env_int("IPX_JPEG_LANE_ARENA", 1) ? &lane.get() : nullptr, true, files, n, &w, &h, &planes, status, &owner);
     const double t_dec = ms_since(t0);
     if (rc) return rc;
     if (!planes.y) return IPX_OK;                         // nothing decodable: every status says why

@@ -254,6 +254,7 @@ void ipx_destroy(ipx_ctx *c)
     for (auto &l : c->lanes) {
         if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
         if (l.dev) (void)hipFree(l.dev);
+        if (l.dec) (void)hipFree(l.dec);
         if (l.flag) (void)hipFree(l.flag);
     }
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }

@@ -22,6 +22,8 @@ struct Lane {
     uint8_t *dev = nullptr;   // device scratch
     size_t dev_bytes = 0;
     int *flag = nullptr;      // device int for the opaque() scan
+    uint8_t *dec = nullptr;   // second grow-only buffer: planes and scratch of a decode running on this lane (ipx_plan_run_jpeg_jpeg)
+    size_t dec_bytes = 0;
     bool busy = false;
 };
 
@@ -139,6 +141,21 @@ private:
     Lane *lane_ = nullptr;
 };
 
+inline int lane_reserve_dec(Lane &l, size_t bytes)
+{
+    if (bytes <= l.dec_bytes) return IPX_OK;
+    if (l.dec) { IPX_HIP(hipStreamSynchronize(l.stream)); IPX_HIP(hipFree(l.dec)); l.dec = nullptr; l.dec_bytes = 0; }
+    const size_t want = bytes + bytes / 8;        // a little headroom: batches of one size differ by a few files' worth of scan bytes
+    hipError_t e = hipMalloc((void **)&l.dec, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("device allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return IPX_ERR_NOMEM;
+    }
+    l.dec_bytes = want;
+    return IPX_OK;
+}
+
 inline int lane_reserve(Lane &l, size_t bytes)
 {
     if (bytes <= l.dev_bytes) return IPX_OK;
@@ -160,9 +177,16 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct AsyncFree {
     hipStream_t s;
     std::vector<void *> p;
+    // optional arena (a lane's grow-only buffer): requests are bumped out of it while they fit, so a call that holds a lane allocates
+    // nothing in the steady state.  Stream-ordered allocations of gigabytes per call turned out to stall for 0.5 - 5 s every few calls
+    // on some boxes (the time sat in hipMallocAsync or behind it).
+    uint8_t *arena = nullptr;
+    size_t cap = 0, off = 0;
     ~AsyncFree() { for (void *q : p) (void)hipFreeAsync(q, s); }
     template <class T> hipError_t get(T **out, size_t bytes)
     {
+        const size_t need = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+        if (arena && off + need <= cap) { *out = (T *)(arena + off); off += need; return hipSuccess; }
         void *q = nullptr;
         hipError_t e = hipMallocAsync(&q, bytes ? bytes : 1, s);
         if (e == hipSuccess) p.push_back(q);

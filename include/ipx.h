@@ -417,7 +417,8 @@ void ipx_jpeg_result_free(ipx_ctx *ctx, ipx_jpeg_result *result);
  * HBM, ready for ipx_plan_run_dev_ycbcr (ratio IPX_GRAY: only y is set; ipx_plan_run_dev_gray).  status[i]: IPX_OK, IPX_ERR_INVALID (malformed) or
  * IPX_ERR_UNSUPPORTED (progressive, CMYK / RGB, other samplings, several scans, a size or sampling
  * different from the batch's): the worker decodes those with Go as before.  planes->y == NULL when no
- * image was decodable.  Free the planes with ipx_jpeg_planes_free. */
+ * image was decodable.  Free the planes with ipx_jpeg_planes_free: they are stream-ordered allocations of `stream` (NULL: the
+ * context's default stream), which has to outlive them. */
 typedef struct ipx_jpeg_planes ipx_jpeg_planes;
 /* Compressed in, compressed out: the uploads as they arrive from the object store (image_processor.go:41-47), the
  * objects as they go back (:76).  image.Decode, every operator of the plan and jpeg.Encode run on the GPU; the

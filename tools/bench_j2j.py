@@ -37,6 +37,8 @@ for _ in range(reps):
     t0 = time.perf_counter()
     lens, st = plan.run_jpeg_jpeg(batch, copy=False)
     best = min(best, time.perf_counter() - t0)
+    if os.environ.get("IPX_BENCH_VERBOSE"):
+        print("  repetition: %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
 assert not any(st)
 print("JPEG files (%.0f KB) -> three JPEG streams: %d files in %.1f ms = %.0f images/s" % (len(files[0]) / 1e3, n, best * 1e3, n / best))
 callers = int(sys.argv[3]) if len(sys.argv) > 3 else 0
