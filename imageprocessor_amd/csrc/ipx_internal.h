@@ -249,6 +249,9 @@ struct JpegDecArgs {
 __host__ __device__
 #endif
 inline int jpeg_status_key(uint32_t first_mcu, int status) { return -(int)(((0x3ffffffu - (first_mcu & 0x3ffffffu)) << 3) | (uint32_t)(-status)); }
+// a DC value beyond int16: Go keeps int32 and decodes such a (damaged) file, this pipeline cannot represent it -> UNSUPPORTED, with the
+// lowest priority: any real decoding error elsewhere in the file, which Go fails on as well, wins
+constexpr uint32_t kJpegStatusLast = 0x3ffffffu;
 inline int jpeg_status_of(int key) { return key >= 0 ? 0 : -(int)((uint32_t)(-key) & 7u); }
 struct JpegPlanes { uint8_t *y, *cb, *cr; int ystride, cstride; size_t y_fs, c_fs; const uint8_t *valid; /* per image */ };
 // Huffman decoding parallel inside a scan (ipx_jpeg_dec_par.hip): per image and per 1 KiB sub-sequence of its scan

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
     const int td0 = im.td[0], td1 = im.td[1], td2 = im.td[2], ta0 = im.ta[0], ta1 = im.ta[1], ta2 = im.ta[2];
     int dc0 = 0, dc1 = 0, dc2 = 0;
     int status = 0;
+    bool wide = false;
     for (int m = (int)im.first_mcu; m < (int)(im.first_mcu + im.n_mcu); m++) {
         for (int bi = 0; bi < bpm; bi++) {
             const int c = bi < ybl ? 0 : bi - ybl + 1;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
             const int diff = br.receive_extend(t);
             const int dcv = (c == 0 ? dc0 : (c == 1 ? dc1 : dc2)) + diff;
             if (c == 0) dc0 = dcv; else if (c == 1) dc1 = dcv; else dc2 = dcv;
-            if (dcv < -32768 || dcv > 32767) { br.err = true; break; }   // Go keeps int32; out of int16 = not a sane file
+            if (dcv < -32768 || dcv > 32767) wide = true;   // Go keeps int32 and decodes on: not representable here (kJpegStatusLast)
             a.dcs[(size_t)img * a.nblk + (size_t)m * bpm + bi] = (int16_t)dcv;
             const uint16_t *aclut = lut + ta * 256;
             for (int zig = 1; zig < 64; zig++) {
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(64) void jpeg_huff_kernel(JpegDecArgs a)
     // Pieces of one image report into one word (zeroed by the host).  A sequential decoder stops at the FIRST interval that fails, so the
     // earliest piece's verdict is the image's: negative keys ordered by first_mcu, combined with atomicMin (jpeg_status_of unpacks).
     if (status) atomicMin(&a.status[img], jpeg_status_key(im.first_mcu, status));
+    else if (wide) atomicMin(&a.status[img], jpeg_status_key(kJpegStatusLast, IPX_ERR_UNSUPPORTED));
 }
 
 // ---- reconstruction -----------------------------------------------------------------------------------------

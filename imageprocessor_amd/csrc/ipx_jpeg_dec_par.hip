@@ -386,12 +386,12 @@ struct CoefSink {
     __device__ __forceinline__ void dc(int d)
     {
         if (g >= nblk) return;
-        if (d < -32768 || d > 32767) { atomicExch(status, IPX_ERR_INVALID); return; }
+        if (d < -32768 || d > 32767) { atomicMin(status, jpeg_status_key(kJpegStatusLast, IPX_ERR_UNSUPPORTED)); return; }   // see kJpegStatusLast
         dcs[g] = (int16_t)d;
     }
     __device__ __forceinline__ void ac(int z, int v) { if (g < nblk) coefs[(size_t)g * 64 + unz[z]] = (int16_t)v; }
     __device__ __forceinline__ bool end_block() { g++; return g < nblk; }
-    __device__ __forceinline__ void bad() { if (g < nblk) atomicExch(status, IPX_ERR_INVALID); }   // "bad Huffman code" in real data
+    __device__ __forceinline__ void bad() { if (g < nblk) atomicMin(status, jpeg_status_key(0, IPX_ERR_INVALID)); }   // "bad Huffman code" in real data
 };
 
 // step 3: a.ends holds the exclusive scan of the block ends = the block each lane starts in
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void par_dc_kernel(JpegParArgs a)
     const JpegParImage im = a.img[blockIdx.x];
     int16_t *dcs = a.dcs + (size_t)im.img * a.nblk;
     const int t = threadIdx.x, nmcu = a.nblk / a.bpm;
-    if (t == 0 && a.total_ends[blockIdx.x] < (uint32_t)a.nblk) atomicExch(a.status + im.img, IPX_ERR_INVALID);   // "short Huffman data"
+    if (t == 0 && a.total_ends[blockIdx.x] < (uint32_t)a.nblk) atomicMin(a.status + im.img, jpeg_status_key(0, IPX_ERR_INVALID));   // "short Huffman data"
     const int per = (nmcu + 255) / 256, m0 = min(nmcu, t * per), m1 = min(nmcu, m0 + per);
     int sum[3] = {0, 0, 0};
     for (int m = m0; m < m1; m++)
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void par_dc_kernel(JpegParArgs a)
             bad |= run_[k] < -32768 || run_[k] > 32767;
             b[0] = (int16_t)run_[k];
         }
-    if (bad) atomicExch(a.status + im.img, IPX_ERR_INVALID);
+    if (bad) atomicMin(a.status + im.img, jpeg_status_key(kJpegStatusLast, IPX_ERR_UNSUPPORTED));   // a DC value beyond int16: see kJpegStatusLast
 }
 
 // ---- pieces with a known start state: restart intervals, and scans too short to be worth speculating on ------------------------
@@ -515,7 +515,7 @@ struct PieceSink {
     uint32_t g, g_end;
     int c, bpm, ybl;                 // block within the MCU, for the DC predictions
     int dc0, dc1, dc2;
-    bool err;
+    bool err, wide;
     __device__ __forceinline__ void dc(int d)
     {
         // every prediction is updated arithmetically: written as v = (k == 0 ? dc0 : k == 1 ? dc1 : dc2) + d the compiler turns the
@@ -523,7 +523,7 @@ struct PieceSink {
         const int k = c < ybl ? 0 : c - ybl + 1;
         dc0 += k == 0 ? d : 0; dc1 += k == 1 ? d : 0; dc2 += k == 2 ? d : 0;
         const int v = (k == 0 ? dc0 : 0) + (k == 1 ? dc1 : 0) + (k == 2 ? dc2 : 0);
-        if (v < -32768 || v > 32767) { err = true; return; }   // Go keeps int32; out of int16 = not a sane file
+        if (v < -32768 || v > 32767) { wide = true; return; }  // Go keeps int32 and decodes on: not representable here (kJpegStatusLast)
         dcs[g] = (int16_t)v;
     }
     __device__ __forceinline__ void ac(int z, int v) { coefs[(size_t)g * 64 + unz[z]] = (int16_t)v; }
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64) void piece_decode_kernel(JpegDecArgs a, const u
     r.seek(0);
     const uint32_t g0 = first_mcu * (uint32_t)a.bpm;
     PieceSink sink{a.coefs + (size_t)img * a.nblk * 64, a.dcs + (size_t)img * a.nblk, unz, g0, g0 + n_mcu * (uint32_t)a.bpm,
-                   0, a.bpm, a.ybl, 0, 0, 0, false};
+                   0, a.bpm, a.ybl, 0, 0, 0, false, false};
     uint32_t ends;
     (void)run(r, T, slots, a.bpm, a.ybl, 0, 0, r.ubits, sink, &ends);
     int status = 0;
@@ -568,6 +568,7 @@ __global__ __launch_bounds__(64) void piece_decode_kernel(JpegDecArgs a, const u
     // searching for the next RSTn (findRST); that heuristic is not restated here -- the file goes back to the CPU path.
     else if (strict_end && r.ubits - r.upos() >= 8u) status = IPX_ERR_UNSUPPORTED;
     if (status) atomicMin(&a.status[img], jpeg_status_key(first_mcu, status));
+    else if (sink.wide) atomicMin(&a.status[img], jpeg_status_key(kJpegStatusLast, IPX_ERR_UNSUPPORTED));
 }
 
 }  // namespace

@@ -373,7 +373,7 @@ def jpeg_encode_gray(plane, quality=85):
 # ---- image/jpeg decoder, baseline (oracle/ipx_jpeg_dec_oracle.c) --------------------------------------------
 class Decoded(C.Structure):
     _fields_ = [("w", C.c_int), ("h", C.c_int), ("ratio", C.c_int), ("ystride", C.c_int), ("cstride", C.c_int),
-                ("yrows", C.c_int), ("crows", C.c_int), ("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p)]
+                ("yrows", C.c_int), ("crows", C.c_int), ("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p), ("dc_wide", C.c_int)]
 
 
 def jpeg_decode(data, want_coefs=False):
@@ -392,7 +392,7 @@ def jpeg_decode(data, want_coefs=False):
     def plane(p, rows, stride):
         return np.frombuffer(C.string_at(p, rows * stride), np.uint8).reshape(rows, stride).copy()
     out = {"w": d.w, "h": d.h, "ratio": d.ratio, "y": plane(d.y, d.yrows, d.ystride), "cb": plane(d.cb, d.crows, d.cstride),
-           "cr": plane(d.cr, d.crows, d.cstride)}
+           "cr": plane(d.cr, d.crows, d.cstride), "dc_wide": bool(d.dc_wide)}
     L.ipxo_decoded_free(C.byref(d))
     if want_coefs:
         out["coefs"] = coefs

@@ -24,6 +24,7 @@ typedef struct {
     int w, h, ratio;          /* ratio: 0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0, 3 = 4:4:0 (image.YCbCrSubsampleRatio); 4 = *image.Gray (y only) */
     int ystride, cstride, yrows, crows;
     uint8_t *y, *cb, *cr;
+    int dc_wide;              /* some DC value left the int16 range (Go keeps int32 and decodes on; the GPU pipeline reports such files unsupported) */
 } ipxo_decoded;
 
 static const uint8_t k_unzig[64] = {
@@ -277,6 +278,7 @@ int ipxo_jpeg_decode(const uint8_t *data, size_t len, ipxo_decoded *out, int16_t
                             int t = decode_huff(&br, &hf[0][td[c]]);
                             if (br.err || t > 16) { ipxo_decoded_free(out); return -1; }
                             dc[c] += receive_extend(&br, t);
+                            if (dc[c] < -32768 || dc[c] > 32767) out->dc_wide = 1;
                             b[0] = dc[c];
                             for (int zig = 1; zig < 64; zig++) {
                                 const int v = decode_huff(&br, &hf[1][ta[c]]);

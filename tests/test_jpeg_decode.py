@@ -105,6 +105,9 @@ def _check_batch(ctx, files, expect_status=None):
         if expect_status and expect_status[i]:
             assert st[i] == expect_status[i]
             continue
+        if want["dc_wide"]:       # a DC value beyond int16: Go (int32) decodes on, the GPU pipeline hands the file back
+            assert st[i] == -4, (i, st[i])
+            continue
         assert st[i] == 0, (i, st[i])
         assert (info["w"], info["h"], info["ratio"]) == (want["w"], want["h"], want["ratio"])
         for k in ("y", "cb", "cr") if want["ratio"] != 4 else ("y",):
@@ -378,6 +381,8 @@ def test_damaged_files_never_disagree(ctx):
         info, st = ctx.jpeg_decode_batch([f, clean[t % 4]])
         if want is not None and info is not None and (want["w"], want["h"], want["ratio"]) != (info["w"], info["h"], info["ratio"]):
             continue                      # the damage changed the size or kind: the one-size-per-batch rule decides, not the decoder
+        if want is not None and want["dc_wide"]:
+            exp = -4                      # decodable by Go's int32 arithmetic only
         assert st[0] == exp or (exp == -1 and st[0] == -4), (t, kind, exp, st)
         assert st[1] == 0
         if exp == 0:
@@ -447,3 +452,19 @@ def test_batch_with_many_table_sets(ctx):
     _check_batch(ctx, files)
     big = [pil_jpeg(picture(640, 480, seed=i, noise=6.0), quality=80 + i, optimize=bool(i & 1), restart_marker_rows=1) for i in range(6)]
     _check_batch(ctx, big)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"IPX_JPEG_PAR": "0"}, {"IPX_JPEG_PAR": "0", "IPX_JPEG_PIECE": "0"}], ids=["parallel", "pieces", "bytewise"])
+def test_dc_beyond_int16_goes_back_to_go(ctx, env, monkeypatch):
+    """tests/golden/damaged_gray_scan.jpg (found by tools/fuzz_corrupt.py, seed 101): bit flips push the running DC value of a Gray file
+    past 32767.  Go keeps DC predictions in int32 and decodes the file (the oracle does the same and says so in dc_wide); the GPU keeps
+    coefficients in int16, so every decoder path has to report IPX_ERR_UNSUPPORTED -- not "malformed", and never wrapped pixels."""
+    import os
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    f = open(os.path.join(os.path.dirname(__file__), "golden", "damaged_gray_scan.jpg"), "rb").read()
+    assert oracle.jpeg_decode(f)["dc_wide"]
+    ok = pil_jpeg(picture(500, 333, seed=1)[..., 0], quality=80)
+    _, st = ctx.jpeg_decode_batch([f, ok, f])
+    assert list(st) == [-4, 0, -4]
