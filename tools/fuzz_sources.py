@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Random geometries through the fused source-type kernels (NRGBA, Gray via flat chroma, Paletted, YCbCr) and their fallbacks, against the
+oracle's routines for the type: frame sizes (mostly multiples of 4: the fused kernels' domain), resize / thumbnail parameters, tile shapes.
+usage: tools/fuzz_sources.py [trials] [seed]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import imageprocessor_amd as ipx  # noqa: E402
+import oracle  # noqa: E402
+from helpers import DEFAULT_COL, text_glyphs  # noqa: E402
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+ctx = ipx.Context()
+bad = 0
+
+
+def expect(kind, src, resize, thumb, glyphs, w, h):
+    """(resize, thumbnail, watermark) as the reference's helpers treat a source of this type"""
+    if kind == "gray":
+        rgba = np.dstack([src] * 3 + [np.full_like(src, 255)])
+        o = oracle.process(rgba, resize=resize, thumb=thumb, glyphs=glyphs, col=DEFAULT_COL)
+        return o["resize"], o["thumbnail"], o["watermark"]
+    if kind == "nrgba":
+        scale = lambda dw, dh, sr=None: oracle.scale_bilinear_nrgba(src, dw, dh, sr=sr)          # noqa: E731
+        draw = lambda: oracle.draw_nrgba(np.zeros((h, w, 4), np.uint8), (0, 0, w, h), src)       # noqa: E731
+    else:
+        idx, p16 = src
+        scale = lambda dw, dh, sr=None: oracle.scale_bilinear_paletted(idx, p16, dw, dh, sr=sr)  # noqa: E731
+        draw = lambda: oracle.draw_paletted(np.zeros((h, w, 4), np.uint8), (0, 0, w, h), idx, p16)  # noqa: E731
+    nw, nh = oracle.resize_dims(w, h, *resize)
+    crop, tw, th = oracle.thumb_geometry(w, h, *thumb)
+    if thumb[1]:
+        cs_w, cs_h = crop[2] - crop[0], crop[3] - crop[1]
+        t = oracle.scale_bilinear(scale(cs_w, cs_h, sr=crop), tw, th)
+    else:
+        t = scale(tw, th)
+    return scale(nw, nh), t, oracle.composite_glyphs(draw(), glyphs, DEFAULT_COL)
+
+
+for trial in range(trials):
+    w = int(rng.choice([4 * rng.integers(1, 40), 4 * rng.integers(40, 520), rng.integers(1, 300)]))
+    h = int(rng.choice([rng.integers(1, 40), rng.integers(40, 600)]))
+    resize = (int(rng.integers(1, 1300)), int(rng.integers(1, 900)), bool(rng.integers(0, 2)))
+    thumb = (int(rng.integers(1, 300)), bool(rng.integers(0, 2)))
+    nw, nh = oracle.resize_dims(w, h, *resize)
+    _, tw0, th0 = oracle.thumb_geometry(w, h, *thumb)
+    if nw < 1 or nh < 1 or tw0 < 1 or th0 < 1:
+        continue
+    for k in ("IPX_BLK_COLS", "IPX_BAND_ROWS"):
+        os.environ.pop(k, None)
+    if rng.random() < 0.4:
+        os.environ["IPX_BLK_COLS"] = str(int(rng.choice([8, 64, 252, 1000, 2044])))
+    if rng.random() < 0.3:
+        os.environ["IPX_BAND_ROWS"] = str(int(rng.choice([2, 4, 8])))
+    kind = ["nrgba", "gray", "paletted"][trial % 3]
+    n = int(rng.integers(1, 4))
+    glyphs = text_glyphs(w, h, n=5, width_px=min(60, w), height_px=min(20, h))
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(w, h, resize=resize, thumbnail=thumb, watermark=gs)
+    if kind == "nrgba":
+        frames = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+        if rng.random() < 0.3:
+            frames[..., 3] = 255
+        got = plan.run_host_nrgba(frames)
+        srcs = [frames[i] for i in range(n)]
+    elif kind == "gray":
+        frames = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+        got = plan.run_host_gray(frames)
+        srcs = [frames[i] for i in range(n)]
+    else:
+        idx = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+        pal = rng.integers(0, 256, (n, 256, 4), dtype=np.uint8)
+        pal[:, : int(rng.integers(0, 257)), 3] = 255
+        got = plan.run_host_paletted(idx, pal)
+        srcs = [(idx[i], oracle.palette16(pal[i], "nrgba")) for i in range(n)]
+    for i in range(n):
+        want = expect(kind, srcs[i], resize, thumb, glyphs, w, h)
+        for key, wv in zip(("resize", "thumbnail", "watermark"), want):
+            if key in got and not np.array_equal(got[key][i], wv):
+                bad += 1
+                print("MISMATCH trial", trial, kind, key, "frame", i, "%dx%d" % (w, h), "resize", resize, "thumb", thumb,
+                      {e: os.environ.get(e) for e in ("IPX_BLK_COLS", "IPX_BAND_ROWS")}, flush=True)
+                break
+    plan.close()
+    gs.close()
+    if trial % 20 == 19:
+        print("...", trial + 1, "trials", bad, "mismatches", flush=True)
+print("done:", trials, "trials", bad, "mismatches")
