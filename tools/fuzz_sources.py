@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random geometries through the fused source-type kernels (NRGBA, Gray via flat chroma, Paletted, YCbCr) and their fallbacks, against the
+"""Random geometries through the fused source-type kernels (NRGBA, Gray via flat chroma, Paletted, YCbCr at every subsampling ratio) and their fallbacks, against the
 oracle's routines for the type: frame sizes (mostly multiples of 4: the fused kernels' domain), resize / thumbnail parameters, tile shapes.
 usage: tools/fuzz_sources.py [trials] [seed]"""
 import os
@@ -13,6 +13,7 @@ import numpy as np  # noqa: E402
 import imageprocessor_amd as ipx  # noqa: E402
 import oracle  # noqa: E402
 from helpers import DEFAULT_COL, text_glyphs  # noqa: E402
+from test_sources_gpu import _expect_ycbcr_ops  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
@@ -22,6 +23,9 @@ bad = 0
 
 def expect(kind, src, resize, thumb, glyphs, w, h):
     """(resize, thumbnail, watermark) as the reference's helpers treat a source of this type"""
+    if kind == "ycbcr":
+        o = _expect_ycbcr_ops(src[0], src[1], src[2], src[3], resize, thumb, glyphs, DEFAULT_COL)
+        return o["resize"], o["thumbnail"], o["watermark"]
     if kind == "gray":
         rgba = np.dstack([src] * 3 + [np.full_like(src, 255)])
         o = oracle.process(rgba, resize=resize, thumb=thumb, glyphs=glyphs, col=DEFAULT_COL)
@@ -58,7 +62,7 @@ for trial in range(trials):
         os.environ["IPX_BLK_COLS"] = str(int(rng.choice([8, 64, 252, 1000, 2044])))
     if rng.random() < 0.3:
         os.environ["IPX_BAND_ROWS"] = str(int(rng.choice([2, 4, 8])))
-    kind = ["nrgba", "gray", "paletted"][trial % 3]
+    kind = ["nrgba", "gray", "paletted", "ycbcr"][trial % 4]
     n = int(rng.integers(1, 4))
     glyphs = text_glyphs(w, h, n=5, width_px=min(60, w), height_px=min(20, h))
     gs = ctx.glyphset(glyphs, DEFAULT_COL)
@@ -73,6 +77,13 @@ for trial in range(trials):
         frames = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
         got = plan.run_host_gray(frames)
         srcs = [frames[i] for i in range(n)]
+    elif kind == "ycbcr":
+        ratio = int(rng.integers(0, 4))
+        chh, cww = oracle.chroma_shape(w, h, ratio)
+        yp = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+        cbp, crp = rng.integers(0, 256, (n, chh, cww), dtype=np.uint8), rng.integers(0, 256, (n, chh, cww), dtype=np.uint8)
+        got = plan.run_host_ycbcr(yp, cbp, crp, ratio)
+        srcs = [(yp[i], cbp[i], crp[i], ratio) for i in range(n)]
     else:
         idx = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
         pal = rng.integers(0, 256, (n, 256, 4), dtype=np.uint8)
