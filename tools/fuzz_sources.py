@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random geometries through the fused source-type kernels (NRGBA, Gray via flat chroma, Paletted, YCbCr at every subsampling ratio) and their fallbacks, against the
+"""Random geometries through the fused band kernels (RGBA, NRGBA, Gray via flat chroma, Paletted, YCbCr at every subsampling ratio) and their fallbacks, against the
 oracle's routines for the type: frame sizes (mostly multiples of 4: the fused kernels' domain), resize / thumbnail parameters, tile shapes.
 usage: tools/fuzz_sources.py [trials] [seed]"""
 import os
@@ -23,6 +23,9 @@ bad = 0
 
 def expect(kind, src, resize, thumb, glyphs, w, h):
     """(resize, thumbnail, watermark) as the reference's helpers treat a source of this type"""
+    if kind == "rgba":
+        o = oracle.process(src, resize=resize, thumb=thumb, glyphs=glyphs, col=DEFAULT_COL)
+        return o["resize"], o["thumbnail"], o["watermark"]
     if kind == "ycbcr":
         o = _expect_ycbcr_ops(src[0], src[1], src[2], src[3], resize, thumb, glyphs, DEFAULT_COL)
         return o["resize"], o["thumbnail"], o["watermark"]
@@ -62,7 +65,7 @@ for trial in range(trials):
         os.environ["IPX_BLK_COLS"] = str(int(rng.choice([8, 64, 252, 1000, 2044])))
     if rng.random() < 0.3:
         os.environ["IPX_BAND_ROWS"] = str(int(rng.choice([2, 4, 8])))
-    kind = ["nrgba", "gray", "paletted", "ycbcr"][trial % 4]
+    kind = ["nrgba", "gray", "paletted", "ycbcr", "rgba"][trial % 5]
     n = int(rng.integers(1, 4))
     glyphs = text_glyphs(w, h, n=5, width_px=min(60, w), height_px=min(20, h))
     gs = ctx.glyphset(glyphs, DEFAULT_COL)
@@ -76,6 +79,13 @@ for trial in range(trials):
     elif kind == "gray":
         frames = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
         got = plan.run_host_gray(frames)
+        srcs = [frames[i] for i in range(n)]
+    elif kind == "rgba":
+        frames = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+        frames[..., :3] = np.minimum(frames[..., :3], frames[..., 3:])      # premultiplied, as image.RGBA holds it
+        if rng.random() < 0.5:
+            frames[..., 3] = 255
+        got = plan.run_host(frames)
         srcs = [frames[i] for i in range(n)]
     elif kind == "ycbcr":
         ratio = int(rng.integers(0, 4))
