@@ -334,3 +334,53 @@ def test_concurrent_callers(ctx):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+def test_mixed_entries_from_many_threads(ctx):
+    """Goroutines of one worker use different entries of one context at once: compressed-in / compressed-out (one lane per part, decode
+    scratch bumped out of the lane's buffer), the batched host entries (every lane), decode alone (one lane), per-operation calls.
+    Every result must be the bytes the same call gives when it runs alone."""
+    import io
+    import threading
+    from PIL import Image
+    w, h, n = 320, 200, 20
+    frames = rgba_frames(n, w, h, seed=5)
+    files = []
+    for i in range(n):
+        buf = io.BytesIO()
+        Image.fromarray(frames[i][..., :3]).save(buf, "JPEG", quality=80 + i % 10, **({"restart_marker_rows": 2} if i % 3 == 0 else {}))
+        files.append(buf.getvalue())
+    glyphs = text_glyphs(w, h, n=5, width_px=120, height_px=24)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(w, h, resize=(256, 160, False), thumbnail=(64, True), watermark=gs)
+    nrgba = np.random.default_rng(1).integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+    jobs = {
+        "jpeg->jpeg": lambda: plan.run_jpeg_jpeg(files),
+        "host rgba": lambda: plan.run_host(frames),
+        "host nrgba": lambda: plan.run_host_nrgba(nrgba),
+        "host jpeg": lambda: plan.run_host_jpeg(frames, 85),
+        "decode": lambda: ctx.jpeg_decode_batch(files),
+        "scale": lambda: ctx.scale_bilinear(frames[0], 123, 77),
+    }
+
+    def flat(x):
+        if isinstance(x, dict):
+            return {k: flat(v) for k, v in x.items() if k != "free"}
+        if isinstance(x, (list, tuple)):
+            return [flat(v) for v in x]
+        return x.tobytes() if isinstance(x, np.ndarray) else x
+    alone = {k: flat(f()) for k, f in jobs.items()}
+    errs = []
+
+    def work(name):
+        try:
+            for _ in range(4):
+                assert flat(jobs[name]()) == alone[name], name
+        except Exception as e:  # noqa: BLE001
+            errs.append((name, repr(e)[:300]))
+    ts = [threading.Thread(target=work, args=(k,)) for k in list(jobs) * 2]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    plan.close()
+    gs.close()
+    assert not errs, errs
