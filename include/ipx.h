@@ -224,13 +224,15 @@ int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int
                            size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
 /* A batch of *image.NRGBA frames (PNGs with alpha): like the YCbCr batch, per operator as the reference's helpers treat the
  * type -- resize and the non-crop thumbnail interpolate 16-bit premultiplied taps (scale_RGBA_NRGBA_*), the crop thumbnail and
- * the watermark premultiply to RGBA8 first (drawNRGBAOver onto a zeroed frame / drawNRGBASrc).  Three kernels, not yet one. */
+ * the watermark premultiply to RGBA8 first (drawNRGBAOver onto a zeroed frame / drawNRGBASrc).  One fused pass (band_nrgba_kernel) for
+ * 16-byte aligned frames whose width is a multiple of 4, three kernels otherwise; the same bytes either way. */
 int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const uint8_t *src, int sstride,
                            size_t src_frame_stride, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                            size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
 /* A batch of *image.Gray frames (one-component JPEGs, grey PNGs): image/draw's drawGray and x/image's
- * scale_RGBA_Gray_Src both read a source pixel as (y, y, y, 0xff), so the frames are expanded to RGBA8 in HBM
- * and take the RGBA pass; the outputs are bit for bit the reference's. */
+ * scale_RGBA_Gray_Src both read a source pixel as (y, y, y, 0xff).  A YCbCr pixel with Cb = Cr = 128 converts to exactly that in both of
+ * the reference's conversions, so the batch takes the planar pass with a constant chroma row (1 byte per pixel read); shapes that kernel
+ * does not take are expanded to RGBA8 in HBM and take the RGBA pass.  The outputs are bit for bit the reference's either way. */
 int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const uint8_t *gray, int stride,
                           size_t frame_stride, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                           size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
