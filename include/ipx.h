@@ -414,11 +414,12 @@ void ipx_jpeg_result_free(ipx_ctx *ctx, ipx_jpeg_result *result);
 /* ---- image.Decode for JPEGs (decoder side) -------------------------------------------
  * image_processor.go:47 decodes every upload; for JPEG files that is Go's image/jpeg.  A batch of baseline,
  * files of one size and one kind (three components at 4:4:4 / 4:2:2 / 4:2:0 / 4:4:0, or one component) is decoded on the GPU:
- * the compressed bytes go up, Huffman decoding runs one lane per image, the integer IDCT of idct.go runs
+ * the compressed bytes go up, Huffman decoding runs in parallel inside each scan (or per restart interval), the integer IDCT of idct.go runs
  * block-parallel, and the *image.YCbCr planes (MCU-padded strides, as image.NewYCbCr lays them out) stay in
  * HBM, ready for ipx_plan_run_dev_ycbcr (ratio IPX_GRAY: only y is set; ipx_plan_run_dev_gray).  status[i]: IPX_OK, IPX_ERR_INVALID (malformed) or
  * IPX_ERR_UNSUPPORTED (progressive, CMYK / RGB, other samplings, several scans, a size or sampling
- * different from the batch's): the worker decodes those with Go as before.  planes->y == NULL when no
+ * different from the batch's, damaged restart intervals Go would resynchronise over, DC values beyond int16): the worker decodes those
+ * with Go as before.  planes->y == NULL when no
  * image was decodable.  Free the planes with ipx_jpeg_planes_free: they are stream-ordered allocations of `stream` (NULL: the
  * context's default stream), which has to outlive them. */
 typedef struct ipx_jpeg_planes ipx_jpeg_planes;
