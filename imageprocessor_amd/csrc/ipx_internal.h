@@ -205,6 +205,11 @@ struct JpegArgs {
     const uint8_t *src; size_t frame_stride; int stride, w, h;
     int aligned16;            // base, row stride and frame stride are multiples of 16
     int16_t *coefs; int mcus_per_frame;
+    // optional (all three or none): the AC part of every block's Huffman-coded length, and the quantised DC terms as a dense array --
+    // computed while the block sits in LDS, so that no separate pass has to read the coefficients back to size the scan
+    const uint32_t *huff;     // jpeg_huff_packed: four tables of 256 (len << 16 | code)
+    uint32_t *aclen;          // [frame][block] bits of the AC symbols (ZRL, EOB included)
+    int16_t *dcq;             // [frame][block]
     uint32_t recip[2][64];
     uint16_t div8[2][64];
 };
@@ -294,6 +299,8 @@ void jpeg_write_header(int w, int h, const JpegTables &t, std::vector<uint8_t> *
 void jpeg_huff_packed(uint32_t out[1024]);
 // the entropy coder on the GPU (ipx_jpeg_entropy.hip)
 hipError_t launch_jpeg_len(const int16_t *coefs, int nblk, int n, const uint32_t *tables, uint32_t *len, hipStream_t s);
+// len[b] += bits of block b's DC symbol (difference to the previous block of its component), from the dense DC array of the transform kernel
+hipError_t launch_jpeg_dclen(const int16_t *dcq, int nblk, int n, const uint32_t *tables, uint32_t *len, hipStream_t s);
 hipError_t launch_jpeg_bits(const int16_t *coefs, int nblk, int n, const uint32_t *tables, const uint32_t *off, const uint32_t *total_bits,
                             const unsigned long long *ubase, uint8_t *ustream, hipStream_t s);
 hipError_t launch_scan(uint32_t *v, int per_frame, int n, uint32_t *total, hipStream_t s);

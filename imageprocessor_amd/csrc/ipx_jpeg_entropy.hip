@@ -119,6 +119,23 @@ __global__ __launch_bounds__(256) void jpeg_len_kernel(const int16_t *coefs, int
     len[(size_t)f * nblk + b] = s.bits;
 }
 
+// pass A': the AC part of len[] comes from the transform kernel (ipx_jpeg.hip, step 2b); this adds the DC symbol
+__global__ __launch_bounds__(256) void jpeg_dclen_kernel(const int16_t *dcq, int nblk, const uint32_t *tables, uint32_t *len)
+{
+    const int f = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblk) return;
+    const int16_t *fd = dcq + (size_t)f * nblk;
+    const int m = b / 6, j = b - m * 6;
+    int p;                                                   // the previous block of the same component (prev_dc_of)
+    if (j == 0) p = m > 0 ? (m - 1) * 6 + 3 : -1;
+    else if (j < 4) p = b - 1;
+    else p = m > 0 ? b - 6 : -1;
+    const int diff = (int)fd[b] - (p < 0 ? 0 : (int)fd[p]);
+    const int a = diff < 0 ? -diff : diff;
+    const int nb = a ? 32 - __clz(a) : 0;
+    len[(size_t)f * nblk + b] += (tables[(j < 4 ? 0 : 2) * 256 + nb] >> 16) + (uint32_t)nb;
+}
+
 struct BitSink {
     uint32_t *out;          // big-endian words of the frame's unstuffed stream
     unsigned long long acc = 0;
@@ -241,6 +258,12 @@ __global__ __launch_bounds__(256) void jpeg_stuff_kernel(const uint8_t *ustream,
 }
 
 }  // namespace
+
+hipError_t launch_jpeg_dclen(const int16_t *dcq, int nblk, int n, const uint32_t *tables, uint32_t *len, hipStream_t s)
+{
+    hipLaunchKernelGGL(jpeg_dclen_kernel, dim3((nblk + 255) / 256, n), dim3(256), 0, s, dcq, nblk, tables, len);
+    return hipGetLastError();
+}
 
 hipError_t launch_jpeg_len(const int16_t *coefs, int nblk, int n, const uint32_t *tables, uint32_t *len, hipStream_t s)
 {

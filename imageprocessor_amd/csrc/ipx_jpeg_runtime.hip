@@ -14,10 +14,23 @@
 
 extern "C" {
 
+static int fdct_rgba8(ipx_ctx *ctx, hipStream_t s, const uint8_t *src, int w, int h, int stride, size_t frame_stride, int n, int quality,
+                      int16_t *coefs, const uint32_t *huff, uint32_t *aclen, int16_t *dcq);
+
 int ipx_dev_jpeg_fdct_rgba8(ipx_ctx *ctx, void *stream, const uint8_t *src, int w, int h, int stride, size_t frame_stride,
                             int n, int quality, int16_t *coefs)
 {
     IPX_ENTER(ctx);
+    return fdct_rgba8(ctx, stream ? (hipStream_t)stream : ctx->stream, src, w, h, stride, frame_stride, n, quality, coefs, nullptr, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+// huff / aclen / dcq: all or none -- the transform kernel then also sizes every block's AC symbols and leaves the DC terms in a dense array
+static int fdct_rgba8(ipx_ctx *ctx, hipStream_t s, const uint8_t *src, int w, int h, int stride, size_t frame_stride, int n, int quality,
+                      int16_t *coefs, const uint32_t *huff, uint32_t *aclen, int16_t *dcq)
+{
+    (void)ctx;
     if (!src || !coefs || n < 0 || w <= 0 || h <= 0 || (long long)stride < (long long)w * 4) {
         set_error("ipx_dev_jpeg_fdct_rgba8: bad argument");
         return IPX_ERR_INVALID;
@@ -31,13 +44,12 @@ int ipx_dev_jpeg_fdct_rgba8(ipx_ctx *ctx, void *stream, const uint8_t *src, int 
     a.src = src; a.frame_stride = frame_stride; a.stride = stride; a.w = w; a.h = h;
     a.aligned16 = ((((uintptr_t)src) | (uintptr_t)stride | frame_stride) & 15) == 0;
     a.coefs = coefs; a.mcus_per_frame = ((w + 15) / 16) * ((h + 15) / 16);
+    a.huff = huff; a.aclen = aclen; a.dcq = dcq;
     memcpy(a.recip, t.recip, sizeof a.recip);
     memcpy(a.div8, t.div8, sizeof a.div8);
-    IPX_HIP(launch_jpeg_fdct(a, n, stream ? (hipStream_t)stream : ctx->stream));
+    IPX_HIP(launch_jpeg_fdct(a, n, s));
     return IPX_OK;
 }
-
-}  // extern "C"
 
 // host entropy coding of a downloaded coefficient batch (IPX_JPEG_HOST_ENTROPY=1, and the reference point of tools/bench_jpeg.py)
 static int jpeg_batch_host_entropy(ipx_ctx *ctx, Lane &lane, const int16_t *dcoefs, int w, int h, int n, int quality,
@@ -110,8 +122,6 @@ static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const 
                             int n, int quality, uint8_t **blob, size_t *offs, size_t *lens)
 {
     const size_t per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
-    int rc = ipx_dev_jpeg_fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, dcoefs);
-    if (rc) return rc;
 
     // ---- entropy coding on the GPU: size, scan, place, stuff (ipx_jpeg_entropy.hip); two small read-backs ----
     const int nblk = (int)(per / 128);
@@ -135,7 +145,18 @@ static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const 
     IPX_HIP(mem.get(&d_hdr, hdr.size()));
     IPX_HIP(hipMemcpyAsync(d_tab, packed, sizeof packed, hipMemcpyHostToDevice, s));
     IPX_HIP(hipMemcpyAsync(d_hdr, hdr.data(), hdr.size(), hipMemcpyHostToDevice, s));
-    IPX_HIP(launch_jpeg_len(dcoefs, nblk, n, d_tab, d_len, s));
+    if (env_int("IPX_JPEG_FUSED_LEN", 1)) {
+        // the transform kernel sizes the AC symbols of every block while it has the block in LDS; a small kernel adds the DC symbols
+        int16_t *d_dcq;
+        IPX_HIP(mem.get(&d_dcq, (size_t)n * nblk * 2));
+        int rc = fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, dcoefs, d_tab, d_len, d_dcq);
+        if (rc) return rc;
+        IPX_HIP(launch_jpeg_dclen(d_dcq, nblk, n, d_tab, d_len, s));
+    } else {
+        int rc = fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, dcoefs, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        IPX_HIP(launch_jpeg_len(dcoefs, nblk, n, d_tab, d_len, s));     // the earlier separate pass over the coefficients
+    }
     IPX_HIP(launch_scan(d_len, nblk, n, d_tot, s));
     std::vector<uint32_t> tot(n), ubytes(n), ff(n);
     IPX_HIP(hipMemcpyAsync(tot.data(), d_tot, (size_t)n * 4, hipMemcpyDeviceToHost, s));

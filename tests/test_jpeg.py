@@ -196,13 +196,15 @@ def test_gpu_batch_encode_from_hbm(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("host_entropy", ["0", "1"], ids=["gpu-entropy", "host-entropy"])
-def test_gpu_batch_entropy_paths(ctx, host_entropy, monkeypatch):
-    """Both entropy coders behind ipx_jpeg_encode_batch_dev: sizing + scan + placement + stuffing on the GPU (default) and the
-    host loop over downloaded coefficients.  Frames of one batch differ wildly in stream length; q=100 on black / white
-    noise gives the longest codes and the most 0xff bytes; 1x1 and 17x9 frames are a single (partial) MCU."""
+@pytest.mark.parametrize("host_entropy,fused_len", [("0", "1"), ("0", "0"), ("1", "1")], ids=["gpu-entropy", "gpu-entropy-separate-sizing-pass", "host-entropy"])
+def test_gpu_batch_entropy_paths(ctx, host_entropy, fused_len, monkeypatch):
+    """The entropy coders behind ipx_jpeg_encode_batch_dev: sizing (inside the transform kernel by default, or as the earlier separate pass
+    over the coefficients) + scan + placement + stuffing on the GPU, and the host loop over downloaded coefficients.  Frames of one batch
+    differ wildly in stream length; q=100 on black / white noise gives the longest codes and the most 0xff bytes; 1x1 and 17x9 frames
+    are a single (partial) MCU."""
     from helpers import rgba_frames
     monkeypatch.setenv("IPX_JPEG_HOST_ENTROPY", host_entropy)
+    monkeypatch.setenv("IPX_JPEG_FUSED_LEN", fused_len)
     rng = np.random.default_rng(21)
     for (w, h), q in (((320, 200), 85), ((64, 64), 100), ((17, 9), 85), ((1, 1), 50), ((640, 360), 20), ((1024, 64), 95)):
         frames = rgba_frames(4, w, h, seed=w + q)
