@@ -8,7 +8,11 @@ collective (weak scaling) and torch.distributed (gloo, CPU tensors) only carries
 the max-over-ranks of the timed region.
 
 A "step" is one pass of the hot path over the whole batch (one fused launch).  Prints ONE JSON
-line on rank 0.
+line on rank 0: `value` is the HBM-resident rate; `roofline` comes from HIP events on the stream
+the kernel runs on; `cpu_baseline` is the CPU oracle on a time-bounded sample; `e2e` holds the
+PCIe-inclusive legs (pinned host memory in and out, JPEG in and out) -- reported, never `value`.
+
+--mixed N runs BASELINE config 5 instead (mixed 480p-8K sizes, pull scheduling).
 """
 import argparse
 import json
@@ -34,7 +38,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pool", type=int, default=32, help="distinct seeded frames tiled over the batch")
-    ap.add_argument("--cpu-sample", type=int, default=384, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="seconds per row of the CPU baseline (0 = skip)")
+    ap.add_argument("--e2e-frames", type=int, default=256, help="frames per call of the PCIe-inclusive legs (0 = skip; N = 1 only)")
+    ap.add_argument("--e2e-reps", type=int, default=4)
     ap.add_argument("--check", action="store_true", help="compare frame 0 with the oracle after the run")
     ap.add_argument("--mixed", type=int, default=0, metavar="N",
                     help="BASELINE config 5 instead: N frames per GPU of mixed sizes (480p-8K, seed 0x51), full "
@@ -42,69 +48,151 @@ def parse():
     return ap.parse_args()
 
 
-MIXED_SIZES = [(854, 480), (1280, 720), (1920, 1080), (2560, 1440), (3840, 2160), (7680, 4320)]
+def host_info():
+    """What the CPU rows ran on: model string, logical CPUs of the node, CPUs this process may use."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0))
+    try:   # a cgroup CPU quota bounds what the threads can really get
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                usable = max(1, min(usable, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "usable_cpus": usable}
+
+
+def timed_pool(fn, threads, seconds, limit=None):
+    """threads workers call fn(i) for i = 0, 1, 2, ... until `seconds` have passed (or `limit` calls were started); every started call
+    is finished and counted.  -> (calls, wall seconds)"""
+    import itertools
+    import threading
+    counter = itertools.count()
+    lock = threading.Lock()
+    done = [0]
+    t0 = time.perf_counter()
+    deadline = t0 + seconds
+
+    def work():
+        while time.perf_counter() < deadline:
+            with lock:
+                i = next(counter)
+            if limit is not None and i >= limit:
+                return
+            fn(i)
+            with lock:
+                done[0] += 1
+    ts = [threading.Thread(target=work) for _ in range(threads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    return done[0], time.perf_counter() - t0
+
+
+def cpu_rows(one, seconds, what):
+    """The CPU oracle (scalar C restatement of the reference's loops; one frame per thread, as Go's loops are single-threaded per
+    image) on a time-bounded sample of the same workload: once on every usable CPU, once at the reference's deployed concurrency of 3
+    goroutines (.env.example:38, worker.go:90)."""
+    hi = host_info()
+    threads = max(1, min(hi["usable_cpus"], 64))
+    one(0)  # warm: page in the library
+    n_all, dt_all = timed_pool(one, threads, seconds)
+    n3, dt3 = timed_pool(one, 3, seconds)
+    return {"value": round(n_all / dt_all, 2), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d frames of %s through oracle/ipx_oracle.c (C restatement of the Go loops, gcc -O2, no FMA) in %.1f s on %d "
+                      "threads, one frame per thread; then %d frames in %.1f s on 3 threads" % (n_all, what, dt_all, threads, n3, dt3),
+            "threads": threads, "nproc": hi["nproc"], "usable_cpus": hi["usable_cpus"], "cpu_model": hi["cpu_model"],
+            "at_reference_concurrency_3": round(n3 / dt3, 2), "seconds_per_row": [round(dt_all, 2), round(dt3, 2)]}
+
+
+def cpu_baseline(pool, glyphs, col, resize, thumb, want, seconds):
+    import oracle
+
+    def one(i):
+        oracle.process(pool[i % len(pool)], resize=resize or (1, 1, False), thumb=thumb or (1, False),
+                       glyphs=glyphs, col=col, want=want)
+    return cpu_rows(one, seconds, "the same workload (seeded %dx%d frames)" % (pool.shape[2], pool.shape[1]))
 
 
 def run_mixed(args, ipx, shard, rank, local_rank, world):
-    """Config 5: frames of six sizes drawn uniformly (seed 0x51); every rank holds a small seeded pool per
-    size in HBM; work items are chunks of equal-size frames (~256 MB of source each), ordered largest
-    first, claimed with an atomic counter in the rendezvous store."""
+    """Config 5: args.mixed frames per GPU, sizes drawn uniformly from six (854x480 ... 7680x4320, seed 0x51), full pipeline with the
+    product-default keep_aspect=true.  Every rank holds one plan, one pool of source frames and two sets of outputs per size in HBM
+    (shard.MixedBatch); work items are chunks of equal-size frames (~256 MB of source), ordered largest first and claimed with an
+    atomic counter in the rendezvous store, so a rank that finishes early claims more (work stealing).  A rank keeps two chunks in
+    flight on two streams: the next chunk is claimed and launched while the previous one runs.  A step = one pass over the batch."""
+    import ctypes
     import numpy as np
     import torch.distributed as dist
     from helpers import DEFAULT_COL, rgba_frames, text_glyphs
+    sizes = shard.MIXED_SIZES
     rng = np.random.default_rng(0x51)
     total = args.mixed * world
-    draw = rng.integers(0, len(MIXED_SIZES), total)
+    draw = [int(v) for v in rng.integers(0, len(sizes), total)]
     ctx = ipx.Context(device=local_rank % max(1, ipx.device_count()))
-    plans, bufs, chunk_of = {}, {}, {}
-    for si, (w, h) in enumerate(MIXED_SIZES):
-        fb = w * h * 4
-        chunk_of[si] = max(1, min(64, (256 << 20) // fb))
-        gs = ctx.glyphset(text_glyphs(w, h), DEFAULT_COL)
-        pl = ctx.plan(w, h, resize=(1024, 768, True), thumbnail=(200, True), watermark=gs)
-        n = chunk_of[si]
-        src = ctx.alloc(n * fb)
-        one = rgba_frames(1, w, h, seed=0x1F00D + si)
-        for i in range(n):
-            src.upload(one, offset=i * fb)
-        i_ = pl.info
-        bufs[si] = (src, ctx.alloc(n * i_.resize_bytes), ctx.alloc(n * i_.thumb_bytes), ctx.alloc(n * i_.wm_bytes))
-        plans[si] = pl
-    # items: (size index, frame count), largest total bytes first
-    items = []
-    for si in range(len(MIXED_SIZES)):
-        cnt = int((draw == si).sum())
-        while cnt > 0:
-            m = min(cnt, chunk_of[si])
-            items.append((si, m))
-            cnt -= m
-    order = shard.lpt_order([shard.frame_cost(*MIXED_SIZES[si]) * m for si, m in items])
-    q = shard.WorkQueue(len(order), chunk=1, key="ipx_mixed", store=shard.default_store())
+    L = ipx.lib()
 
-    def run_item(si, m):
-        src, res, th, wm = bufs[si]
-        plans[si].run_dev(m, src.ptr, res.ptr, th.ptr, wm.ptr)
-        ctx.sync()     # pull scheduling: claim again only when this chunk is done
+    def make_frames(si, w, h, k):
+        return rgba_frames(k, w, h, seed=0x1F00D + si)
+    mb = shard.MixedBatch(ctx, make_frames, text_glyphs, DEFAULT_COL, resize=(1024, 768, True), thumbnail=(200, True))
+    items = mb.items_for(draw)
+    store = shard.default_store()
 
-    for si in range(len(MIXED_SIZES)):   # warm every plan once
-        run_item(si, 1)
+    def ev():
+        return L.ipx_event_create(ctx.handle)
+
+    def elapsed(e0, e1):
+        ms = ctypes.c_float()
+        L.ipx_event_elapsed_ms(ctx.handle, e0, e1, ctypes.byref(ms))
+        return ms.value
+
+    # every plan once on every stream (first-launch costs), then each size alone: full chunks back to back on one stream give the
+    # uniform rate of that size, from which the byte-weighted expectation for this mix follows
+    for si in range(len(sizes)):
+        for k in range(len(mb.streams)):
+            mb.launch(si, 1, k)
+    ctx.device_sync()
+    uniform_ms = []
+    for si in range(len(sizes)):
+        reps = 3
+        e0, e1 = ev(), ev()
+        mb.launch(si, mb.chunk_of[si], 0)
+        L.ipx_event_record(ctx.handle, e0, mb.streams[0])
+        for _ in range(reps):
+            mb.launch(si, mb.chunk_of[si], 0)
+        L.ipx_event_record(ctx.handle, e1, mb.streams[0])
+        uniform_ms.append(elapsed(e0, e1) / reps / mb.chunk_of[si])        # ms per frame of this size, uniform batch
+        L.ipx_event_destroy(ctx.handle, e0)
+        L.ipx_event_destroy(ctx.handle, e1)
+    for w_ in range(args.warmup):
+        mb.run(items, shard.WorkQueue(len(items), chunk=1, key="ipx_mixed_w%d" % w_, store=store))
     ctx.device_sync()
     if world > 1:
         dist.barrier()
+    K = args.steps
+    e_start = ev()
+    e_end = [ev() for _ in mb.streams]
     t0 = time.perf_counter()
-    mine = 0
-    while True:
-        c = q.claim()
-        if c is None:
-            break
-        for pos in c:
-            si, m = items[order[pos]]
-            run_item(si, m)
-            mine += m
+    L.ipx_event_record(ctx.handle, e_start, mb.streams[0])
+    mine = alg = 0
+    for k in range(K):
+        f_, a_ = mb.run(items, shard.WorkQueue(len(items), chunk=1, key="ipx_mixed_%d" % k, store=store))
+        mine += f_
+        alg += a_
+    for st, e in zip(mb.streams, e_end):
+        L.ipx_event_record(ctx.handle, e, st)
     ctx.device_sync()
     if world > 1:
         dist.barrier()
-    frames_done, elapsed = shard.aggregate(mine, time.perf_counter() - t0)
+    wall = time.perf_counter() - t0
+    dev_ms = max(elapsed(e_start, e) for e in e_end)      # device timeline of this rank: first launch -> last completion
+    frames_done, wall_max = shard.aggregate(mine, wall)
     counts = [mine]
     if world > 1:
         import torch
@@ -113,19 +201,42 @@ def run_mixed(args, ipx, shard, rank, local_rank, world):
         dist.all_reduce(t)
         counts = t.tolist()
     if rank == 0:
-        print(json.dumps({
+        achieved = alg / (dev_ms * 1e-3) / 1e9
+        expect_ms = sum(uniform_ms[si] for si in draw) * K / world      # the same frames as uniform batches, one size after the other
+        out = {
             "metric": "images/sec (resize+thumb+watermark) on mixed-size batch (480p-8K), work stealing",
-            "value": round(frames_done / elapsed, 1), "unit": "images/sec", "n_gpus": world, "steps": 1, "warmup": 1,
-            "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(frames_done / wall_max, 1), "unit": "images/sec", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(wall_max / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic: one seeded frame per size tiled per chunk, resident in HBM",
-            "config": {"workload": "%d frames of sizes %s drawn uniformly (seed 0x51), full pipeline keep_aspect=true"
-                                   % (int(frames_done), MIXED_SIZES), "items": len(items),
-                       "frames_per_rank": counts, "sharding": "pull scheduling, largest first, atomic counter in the store"},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "data": "synthetic: one seeded opaque RGBA8 frame per size tiled over each chunk, resident in HBM",
+            "config": {"workload": "%d frames per step of sizes %s drawn uniformly (seed 0x51), full pipeline keep_aspect=true (BASELINE config 5)"
+                                   % (total, sizes), "items_per_step": len(items), "frames_per_rank": counts,
+                       "sharding": "pull scheduling, largest first, atomic counter in the store; two chunks in flight per rank"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "band_pipe_kernel (band_kernel for 854x480, whose rows are not 16-byte aligned)",
+                         "algorithmic_bytes": alg,
+                         "basis": "sum of algorithmic bytes of the frames rank 0 processed / rank 0's device timeline from the first launch "
+                                  "to the last completion (HIP events on the two streams the kernels run on): %.3f ms" % dev_ms,
+                         "uniform_ms_per_frame": {"%dx%d" % sizes[si]: round(uniform_ms[si], 5) for si in range(len(sizes))},
+                         "vs_byte_weighted_uniform": round(expect_ms / (wall_max * 1e3), 4)},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            import oracle
+            pools = [mb.pool[si][0] for si in range(len(sizes))]
+            glyphs = mb.glyphs
+
+            def one(i):
+                si = draw[i % len(draw)]
+                oracle.process(pools[si], resize=(1024, 768, True), thumb=(200, True), glyphs=glyphs[si], col=DEFAULT_COL)
+            out["cpu_baseline"] = cpu_rows(one, args.cpu_seconds, "the same mix (sizes in the order of the seeded draw)")
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    mb.close()
     ctx.close()
 
 
@@ -138,32 +249,74 @@ def self_launch(args):
     sys.exit(subprocess.call(cmd))
 
 
-def cpu_baseline(pool, glyphs, col, resize, thumb, want, nsample):
-    """The CPU oracle (scalar C restatement of the reference's loops, one frame per thread, as Go's
-    loops are single-threaded per image) on a bounded sample of the same workload."""
-    import concurrent.futures as cf
-    import oracle
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+def photo_like(n, sw, sh):
+    """n x sh x sw x 4 opaque frames with photograph-like content (smooth gradients + mild texture): noise frames would make the JPEG
+    streams of the codec legs unrealistically large"""
+    import numpy as np
+    yy, xx = np.mgrid[0:sh, 0:sw]
+    out = np.empty((n, sh, sw, 4), np.uint8)
+    for k in range(n):
+        base = np.stack([np.sin(xx / (40.0 + 7 * k)) * 90 + 128, np.cos(yy / (31.0 + 5 * k)) * 90 + 128, ((xx + 2 * yy) / 6.0 + 40 * k) % 256], -1)
+        out[k, ..., :3] = (base + np.random.default_rng(k).normal(0, 6, (sh, sw, 3))).clip(0, 255)
+        out[k, ..., 3] = 255
+    return out
 
-    def one(i):
-        oracle.process(pool[i % len(pool)], resize=resize or (1, 1, False), thumb=thumb or (1, False),
-                       glyphs=glyphs, col=col, want=want)
 
-    one(0)  # warm: page in the library
-    t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(cores) as ex:
-        list(ex.map(one, range(nsample)))
-    dt = time.perf_counter() - t0
-    # the reference deploys WORKER_CONCURRENCY=3 goroutines (.env.example:38)
-    n3 = max(3, min(nsample, 24))
-    t0 = time.perf_counter()
-    with cf.ThreadPoolExecutor(3) as ex:
-        list(ex.map(one, range(n3)))
-    dt3 = time.perf_counter() - t0
-    return {"value": round(nsample / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d frames of the same workload through oracle/ipx_oracle.c (C restatement of the "
-                      "Go loops, -O2, no FMA), %d threads, one frame per thread; %.1f s wall" % (nsample, cores, dt),
-            "at_reference_concurrency_3": round(n3 / dt3, 2)}
+def e2e_legs(ipx, device, n, sw, sh, resize, reps, lanes=4):
+    """The PCIe-inclusive legs of the north star's pipeline (decode -> H2D -> kernel -> D2H -> encode) on the same workload, through the
+    synchronous host entries of the ABI: n frames in pinned host memory per call, chunks pipelined over `lanes` streams.  Never
+    `value`: these are bound by the link, not by HBM.  Every repetition is reported, not the best."""
+    from helpers import DEFAULT_COL, text_glyphs
+    ctx = ipx.Context(device=device, lanes=lanes, lane_bytes=1 << 30)
+    gs = ctx.glyphset(text_glyphs(sw, sh), DEFAULT_COL)
+    plan = ctx.plan(sw, sh, resize=resize, thumbnail=(200, True), watermark=gs)
+    i = plan.info
+    pool = photo_like(4, sw, sh)
+    src = ctx.host_alloc((n, sh, sw, 4))
+    for k in range(n):
+        src[k] = pool[k % 4]
+    outs = {"resize": ctx.host_alloc((n, i.resize_h, i.resize_w, 4)), "thumbnail": ctx.host_alloc((n, i.thumb_h, i.thumb_w, 4)),
+            "watermark": ctx.host_alloc((n, i.wm_h, i.wm_w, 4))}
+    up = sw * sh * 4
+    down = i.resize_bytes + i.thumb_bytes + i.wm_bytes
+    legs = {}
+
+    def leg(name, call, up_b, down_b, note):
+        call()     # warm: lane buffers, pinned blocks
+        ms = []
+        res = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = call()
+            ms.append((time.perf_counter() - t0) * 1e3)
+        mean = sum(ms) / len(ms)
+        d = down_b(res) if callable(down_b) else down_b
+        legs[name] = {"images_per_s": round(n / (mean * 1e-3), 1), "ms_per_call": [round(v, 2) for v in ms], "frames_per_call": n,
+                      "h2d_GBps": round(n * up_b / (mean * 1e-3) / 1e9, 2), "d2h_GBps": round(n * d / (mean * 1e-3) / 1e9, 2),
+                      "bytes_up_per_image": int(up_b), "bytes_down_per_image": int(d), "what": note}
+        return res
+
+    leg("pixels_to_pixels", lambda: plan.run_host(src, out=outs), up, down,
+        "ipx_plan_run_host: RGBA8 frames in, the three RGBA8 outputs back")
+    leg("pixels_to_jpeg", lambda: plan.run_host_jpeg(src, 85, copy=False), up,
+        lambda r: sum(sum(v) for v in r.values()) / n,
+        "ipx_plan_run_host_jpeg: RGBA8 frames in, operators + jpeg.Encode(q85) on the GPU, three streams back")
+    files = [ctx.jpeg_encode(pool[k], 85) for k in range(4)]       # Go-layout baseline 4:2:0 streams, made by the GPU encoder
+    batch = [files[k % 4] for k in range(n)]
+
+    def j2j():
+        r, st = plan.run_jpeg_jpeg(batch, 85, copy=False)
+        assert not any(st), st
+        return r
+    leg("jpeg_to_jpeg", j2j, sum(len(f) for f in files) / 4.0, lambda r: sum(sum(v) for v in r.values()) / n,
+        "ipx_plan_run_jpeg_jpeg: JPEG files in, image.Decode + operators + jpeg.Encode on the GPU, three streams back")
+    ctx.host_free(src)
+    for a in outs.values():
+        ctx.host_free(a)
+    plan.close()
+    gs.close()
+    ctx.close()
+    return {"workload": "%d x %dx%d per call, photograph-like frames, %d lanes, pinned host memory" % (n, sw, sh, lanes), "legs": legs}
 
 
 def main():
@@ -260,7 +413,9 @@ def main():
         avg_ms = sum(launch_ms) / len(launch_ms)
         alg = info.algorithmic_bytes * F  # source read once + each output written once
         achieved = alg / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come from the separate
+        # rocprofv3 --pmc passes whose summaries are committed under profiles/ (another session, possibly another box)
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -268,6 +423,9 @@ def main():
                     tj = json.load(f)
                 key = "%s_%dx%d_%d" % (args.workload, sw, sh, F)
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_src = "profiles/pmc_traffic.json[%s]: rocprofv3 --pmc passes of %s, not measured in this run" % (
+                        key, tj.get(key, {}).get("session", "an earlier session"))
             except Exception:
                 traffic = None
         out = {
@@ -294,14 +452,21 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "band_pipe_kernel", "algorithmic_bytes_per_launch": alg,
-                         "avg_launch_ms": round(avg_ms, 4)},
+                         "avg_launch_ms": round(avg_ms, 4), "traffic_source": traffic_src},
         }
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pool, glyphs, DEFAULT_COL, resize, thumb,
                                                [k for k, b in (("resize", res), ("thumbnail", th), ("watermark", wm)) if b],
-                                               args.cpu_sample)
+                                               args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and args.e2e_frames > 0 and args.workload in ("full", "full-keepaspect"):
+            for b in (src, res, th, wm):
+                if b:
+                    b.free()
+            out["e2e"] = e2e_legs(ipx, local_rank % max(1, ipx.device_count()), args.e2e_frames, sw, sh, resize, args.e2e_reps)
+        else:
+            out["e2e"] = None
         print(json.dumps(out), flush=True)
 
     if dist:

@@ -406,6 +406,16 @@ class Context:
         if p:
             lib().ipx_host_free(self.handle, p)
 
+    def stream(self):
+        """A stream of the caller's own for the asynchronous device-pointer entries (free with stream_destroy)."""
+        st = lib().ipx_stream_create(self.handle)
+        if not st:
+            raise IpxError(-3, lib().ipx_last_error().decode())
+        return st
+
+    def stream_destroy(self, st):
+        _check(lib().ipx_stream_destroy(self.handle, st))
+
     def sync(self, stream=None):
         _check(lib().ipx_stream_sync(self.handle, stream))
 

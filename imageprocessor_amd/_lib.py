@@ -96,6 +96,7 @@ SIGNATURES = {
     "ipx_last_error": (C.c_char_p, []),
     "ipx_abi_version": (_I, []),
     "ipx_device_count": (_I, []),
+    "ipx_frame_supported": (_I, [_I, _I, C.c_longlong, _I]),
     "ipx_resize_dims": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I), C.POINTER(_I)]),
     "ipx_thumb_geometry": (_I, [_I, _I, _I, _I, C.POINTER(Rect), C.POINTER(_I), C.POINTER(_I)]),
     "ipx_text_height_px": (_I, [C.c_double]),
@@ -110,6 +111,8 @@ SIGNATURES = {
     "ipx_memcpy_d2d": (_I, [_P, _P, _P, _Z]),
     "ipx_device_sync": (_I, [_P]),
     "ipx_stream_sync": (_I, [_P, _P]),
+    "ipx_stream_create": (_P, [_P]),
+    "ipx_stream_destroy": (_I, [_P, _P]),
     "ipx_scale_bilinear_rgba8": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, Rect, _I]),
     "ipx_draw_rgba8": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, _I, _I, _I]),
     "ipx_composite_glyphs_rgba8": (_I, [_P, _P, _I, _I, _I, C.POINTER(Glyph), _I, _P]),

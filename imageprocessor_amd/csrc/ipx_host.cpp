@@ -7,7 +7,9 @@
 // those of the reference's GOAMD64=v1 build.
 #include <cmath>
 #include <cstring>
+#include <new>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "ipx_internal.h"
@@ -24,6 +26,15 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 void clear_error() { g_err[0] = 0; }
+
+int status_of_exception() noexcept
+{
+    try { throw; }
+    catch (const std::bad_alloc &) { set_error("out of memory"); return IPX_ERR_NOMEM; }
+    catch (const std::system_error &e) { set_error("system resource unavailable: %s", e.what()); return IPX_ERR_NOMEM; }
+    catch (const std::exception &e) { set_error("internal error: %s", e.what()); return IPX_ERR_INVALID; }
+    catch (...) { set_error("internal error"); return IPX_ERR_INVALID; }
+}
 
 Rect Rect::intersect(const Rect &s) const
 {
@@ -101,6 +112,18 @@ extern "C" {
 
 const char *ipx_last_error(void) { return g_err; }
 int ipx_abi_version(void) { return IPX_ABI_VERSION; }
+
+int ipx_frame_supported(int w, int h, long long stride, int bytes_per_pixel)
+{
+    clear_error();
+    if (w < 0 || h < 0 || bytes_per_pixel <= 0 || stride < (long long)w * bytes_per_pixel) {
+        set_error("ipx_frame_supported: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    if (frame_span_ok(w, h, stride, bytes_per_pixel)) return IPX_OK;
+    set_error("a %dx%d frame (stride %lld) is beyond the 2 GiB / 65535-pixel span the kernels address", w, h, stride);
+    return IPX_ERR_UNSUPPORTED;
+}
 
 int ipx_resize_dims(int ow, int oh, int w, int h, int keep_aspect, int *nw, int *nh)
 {

@@ -16,6 +16,11 @@ namespace ipx {
 // ---- error plumbing: every ABI entry returns a status, text goes to a thread-local buffer ----
 void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void clear_error();
+// Nothing may unwind through the C ABI (a cgo or ctypes caller would be terminated): every extern "C" entry that can allocate is a
+// function-try-block closed by IPX_CATCH_STATUS, which maps std::bad_alloc / std::system_error to IPX_ERR_NOMEM and anything else to
+// IPX_ERR_INVALID, with the text in ipx_last_error().  Call status_of_exception() only inside a catch block.
+int status_of_exception() noexcept;
+#define IPX_CATCH_STATUS catch (...) { return ipx::status_of_exception(); }
 
 #define IPX_HIP(call)                                                                        \
     do {                                                                                     \
@@ -26,6 +31,19 @@ void clear_error();
             return IPX_ERR_HIP;                                                              \
         }                                                                                    \
     } while (0)
+
+// ---- frame geometry the kernels can address --------------------------------------------------------------------------
+// Frames are addressed through buffer descriptors (32-bit num_records) and int byte offsets; an idle lane's offset is kOOB =
+// 0x7fffffff, which has to lie beyond every frame.  So a frame's span (h-1)*stride + w*bpp must stay below 2 GiB, and a side
+// below 65536 (grid dimensions; also jpeg.Encode's own limit).  A 32 MiB PNG upload (domain/task.go:55) can decode past that:
+// such frames get IPX_ERR_UNSUPPORTED and stay on the reference's CPU path -- never wrapped offsets.
+constexpr long long kMaxFrameSpan = 0x7fff0000LL;
+constexpr int kMaxFrameSide = 65535;
+inline bool frame_span_ok(long long w, long long h, long long stride, int bpp)
+{
+    if (w > kMaxFrameSide || h > kMaxFrameSide) return false;
+    return w <= 0 || h <= 0 || (h - 1) * stride + w * bpp <= kMaxFrameSpan;
+}
 
 // ---- image.Rectangle arithmetic (image/geom.go semantics) ------------------------------------
 struct Rect {

@@ -209,7 +209,7 @@ size_t ipx_jpeg_coef_count(int w, int h)
     return (size_t)((w + 15) / 16) * (size_t)((h + 15) / 16) * 384;
 }
 
-int ipx_jpeg_quant_tables(int quality, uint8_t out[128])
+int ipx_jpeg_quant_tables(int quality, uint8_t out[128]) try
 {
     if (!out) { ipx::set_error("ipx_jpeg_quant_tables: null argument"); return IPX_ERR_INVALID; }
     ipx::JpegTables t;
@@ -217,8 +217,9 @@ int ipx_jpeg_quant_tables(int quality, uint8_t out[128])
     memcpy(out, t.quant, 128);
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
-int ipx_jpeg_entropy_encode(const int16_t *coefs, int w, int h, int quality, uint8_t **out, size_t *len)
+int ipx_jpeg_entropy_encode(const int16_t *coefs, int w, int h, int quality, uint8_t **out, size_t *len) try
 {
     if (!coefs || !out || !len) { ipx::set_error("ipx_jpeg_entropy_encode: null argument"); return IPX_ERR_INVALID; }
     if (w <= 0 || h <= 0 || w >= 1 << 16 || h >= 1 << 16) { ipx::set_error("jpeg: image is too large to encode"); return IPX_ERR_INVALID; }
@@ -232,6 +233,7 @@ int ipx_jpeg_entropy_encode(const int16_t *coefs, int w, int h, int quality, uin
     *out = p; *len = v.size();
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 void ipx_buffer_free(void *p) { free(p); }
 

@@ -18,11 +18,12 @@ static int fdct_rgba8(ipx_ctx *ctx, hipStream_t s, const uint8_t *src, int w, in
                       int16_t *coefs, const uint32_t *huff, uint32_t *aclen, int16_t *dcq);
 
 int ipx_dev_jpeg_fdct_rgba8(ipx_ctx *ctx, void *stream, const uint8_t *src, int w, int h, int stride, size_t frame_stride,
-                            int n, int quality, int16_t *coefs)
+                            int n, int quality, int16_t *coefs) try
 {
     IPX_ENTER(ctx);
     return fdct_rgba8(ctx, stream ? (hipStream_t)stream : ctx->stream, src, w, h, stride, frame_stride, n, quality, coefs, nullptr, nullptr, nullptr);
 }
+IPX_CATCH_STATUS
 
 }  // extern "C"
 
@@ -71,11 +72,14 @@ static int jpeg_batch_host_entropy(ipx_ctx *ctx, Lane &lane, const int16_t *dcoe
         for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1))
             jpeg_write_stream(host + (per / sizeof(int16_t)) * (size_t)i, w, h, t, &streams[i]);
     };
+    std::atomic<int> failed{IPX_OK};
+    auto guarded = [&] { const int rc = guarded_status(work, nullptr); if (rc) failed = rc; };
     std::vector<std::thread> pool;
-    for (int i = 1; i < nt; i++) pool.emplace_back(work);
-    work();
+    for (int i = 1; i < nt; i++) pool.emplace_back(guarded);
+    guarded();
     for (auto &th : pool) th.join();
     (void)hipHostFree(host);
+    if (failed) { set_error("entropy coding on the host failed (out of memory)"); return failed; }
     size_t total = 0;
     for (int i = 0; i < n; i++) { offs[i] = total; lens[i] = streams[i].size(); total += (lens[i] + 15) & ~(size_t)15; }
     uint8_t *b = (uint8_t *)ipx_host_alloc(ctx, total ? total : 1);
@@ -97,7 +101,7 @@ static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const 
 extern "C" {
 
 int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, int stride, size_t frame_stride, int n,
-                              int quality, uint8_t **blob, size_t *offs, size_t *lens)
+                              int quality, uint8_t **blob, size_t *offs, size_t *lens) try
 {
     IPX_ENTER(ctx);
     if (!blob || !offs || !lens || n < 0) { set_error("ipx_jpeg_encode_batch_dev: bad argument"); return IPX_ERR_INVALID; }
@@ -115,6 +119,7 @@ int ipx_jpeg_encode_batch_dev(ipx_ctx *ctx, const uint8_t *src, int w, int h, in
     }
     return jpeg_encode_core(ctx, lane->stream, dcoefs, src, w, h, stride, frame_stride, n, quality, blob, offs, lens);
 }
+IPX_CATCH_STATUS
 
 }  // extern "C"
 
@@ -313,9 +318,17 @@ static int run_host_jpeg_impl(ipx_ctx *ctx, const ipx_plan *pl, int n, const uin
         }
         (void)hipStreamSynchronize(l->stream);
     };
+    auto guarded = [&](Lane *l) {
+        std::string text;
+        const int rc = guarded_status([&] { worker(l); }, &text);
+        if (!rc) return;
+        (void)hipStreamSynchronize(l->stream);   // whatever the worker queued may still be reading the lane's scratch
+        std::lock_guard<std::mutex> lk(res_mu);
+        if (status == IPX_OK) { status = rc; err_text = text; }
+    };
     std::vector<std::thread> pool;
-    for (int i = 1; i < nl; i++) pool.emplace_back(worker, lanes[i]);
-    worker(lanes[0]);
+    for (int i = 1; i < nl; i++) pool.emplace_back(guarded, lanes[i]);
+    guarded(lanes[0]);
     for (auto &t : pool) t.join();
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
@@ -334,7 +347,7 @@ static int run_host_jpeg_impl(ipx_ctx *ctx, const ipx_plan *pl, int n, const uin
 extern "C" {
 
 int ipx_plan_run_host_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
-                           int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, ipx_jpeg_result **result)
+                           int quality, ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, ipx_jpeg_result **result) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !src || !result || (long long)sstride < (long long)pl->p.sw * 4) {
@@ -343,9 +356,10 @@ int ipx_plan_run_host_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_
     }
     return run_host_jpeg_impl(ctx, pl, n, src, sstride, src_frame_stride, nullptr, quality, resize_out, thumb_out, wm_out, result);
 }
+IPX_CATCH_STATUS
 
 int ipx_plan_run_host_ycbcr_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, int quality,
-                                 ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, ipx_jpeg_result **result)
+                                 ipx_bytes *resize_out, ipx_bytes *thumb_out, ipx_bytes *wm_out, ipx_jpeg_result **result) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !result || !src || !src->y || !src->cb || !src->cr || src->ratio < 0 || src->ratio > IPX_YCBCR_440 ||
@@ -355,8 +369,9 @@ int ipx_plan_run_host_ycbcr_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const 
     }
     return run_host_jpeg_impl(ctx, pl, n, nullptr, 0, 0, src, quality, resize_out, thumb_out, wm_out, result);
 }
+IPX_CATCH_STATUS
 
-int ipx_jpeg_encode_rgba8(ipx_ctx *ctx, const uint8_t *pix, int w, int h, int stride, int quality, uint8_t **out, size_t *len)
+int ipx_jpeg_encode_rgba8(ipx_ctx *ctx, const uint8_t *pix, int w, int h, int stride, int quality, uint8_t **out, size_t *len) try
 {
     IPX_ENTER(ctx);
     if (!pix || !out || !len || w <= 0 || h <= 0 || (long long)stride < (long long)w * 4) {
@@ -379,6 +394,7 @@ int ipx_jpeg_encode_rgba8(ipx_ctx *ctx, const uint8_t *pix, int w, int h, int st
     }
     return ipx_jpeg_entropy_encode(host.data(), w, h, quality, out, len);
 }
+IPX_CATCH_STATUS
 
 }  // extern "C"
 
@@ -402,7 +418,7 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
                         ipx_ycbcr_batch *planes, int *status, ipx_jpeg_planes **owner);
 
 int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, int n, int *w, int *h, ipx_ycbcr_batch *planes,
-                          int *status, ipx_jpeg_planes **owner)
+                          int *status, ipx_jpeg_planes **owner) try
 {
     IPX_ENTER(ctx);
     if (!jpegs || n < 0 || !w || !h || !planes || !status || !owner) { set_error("ipx_jpeg_decode_batch: bad argument"); return IPX_ERR_INVALID; }
@@ -415,6 +431,7 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
     return decode_batch(ctx, stream ? (hipStream_t)stream : ctx->stream, env_int("IPX_JPEG_LANE_ARENA", 1) ? &lane.get() : nullptr, false, jpegs, n, w, h,
                         planes, status, owner);
 }
+IPX_CATCH_STATUS
 
 // lane != NULL: scratch is bumped out of the lane's decode buffer (no allocation in the steady state); planes_in_lane: the planes too --
 // the caller then holds the lane for as long as it uses them and *owner has nothing to free
@@ -428,10 +445,14 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     std::vector<size_t> blob_off(n, 0);
     // host preparation runs on a few threads: parsing is trivial, but finding the RSTn markers and packing the scans walk
     // every compressed byte (0.3 GB for a thousand 1080p files)
+    std::atomic<int> prep_failed{IPX_OK};     // an exception inside a preparation thread (allocation): checked after each parallel_for
     auto parallel_for = [&](int count, const std::function<void(int)> &fn) {
         const int nt = std::max(1, std::min({count / 8, (int)std::thread::hardware_concurrency(), 16}));
         std::atomic<int> next{0};
-        auto work = [&] { for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); };
+        auto work = [&] {
+            const int rc = guarded_status([&] { for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); }, nullptr);
+            if (rc) prep_failed = rc;
+        };
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; t++) pool.emplace_back(work);
         work();
@@ -466,6 +487,7 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
         if ((int)marks[i].size() != (nmcu + I.ri - 1) / I.ri - 1) status[i] = IPX_ERR_UNSUPPORTED;   // Go would try to resynchronise
     });
     t_parse = dms();
+    if (prep_failed) { set_error("jpeg decode: host preparation failed"); return prep_failed; }
     int ref = -1;
     size_t blob_bytes = 0, piece_ubytes = 0;
     // table classes: tab_of[i] = the first image of the batch whose Huffman tables equal image i's (most batches have one class, the
@@ -605,6 +627,7 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     t_pin = dms();
     if (!hblob) { ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
     parallel_for(n, [&](int i) { if (valid[i]) memcpy(hblob + blob_off[i], jpegs[i].data + info[i].scan_off, info[i].scan_len); });
+    if (prep_failed) { (void)ipx_host_free(ctx, hblob); ipx_jpeg_planes_free(ctx, own.release()); set_error("jpeg decode: host preparation failed"); return prep_failed; }
     t_pack = dms();
     e = hipMemcpyAsync(d_blob, hblob, blob_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_img, items.data(), sizeof(JpegDecImage) * items.size(), hipMemcpyHostToDevice, s);
@@ -708,7 +731,9 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     t_launch = dms();
     std::vector<int> dev_status(n, 0);
     if (e == hipSuccess) e = hipMemcpyAsync(dev_status.data(), d_status, sizeof(int) * n, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);   // the host tables and the blob may go now
+    // unconditionally: after a failed enqueue the copies and kernels queued before it may still be reading the pinned blob, the host
+    // tables and the lane's arena, all of which are handed back below
+    { const hipError_t e2 = hipStreamSynchronize(s); if (e == hipSuccess) e = e2; }
     if (getenv("IPX_DEBUG") && dms() > 200.0)
         fprintf(stderr, "[ipx] slow decode of %d files: parsed at %.1f ms, device scratch at %.1f, pinned block at %.1f, packed at %.1f, launched at %.1f, finished at %.1f\n", n, t_parse, t_alloc, t_pin, t_pack, t_launch, dms());
     (void)ipx_host_free(ctx, hblob);
@@ -819,7 +844,7 @@ static int run_jpeg_jpeg_one(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_
 
 
 int ipx_plan_run_jpeg_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_bytes *files, int quality, ipx_bytes *resize_out,
-                           ipx_bytes *thumb_out, ipx_bytes *wm_out, int *status, ipx_jpeg_result **result)
+                           ipx_bytes *thumb_out, ipx_bytes *wm_out, int *status, ipx_jpeg_result **result) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !files || !status || !result) { set_error("ipx_plan_run_jpeg_jpeg: bad argument"); return IPX_ERR_INVALID; }
@@ -837,9 +862,10 @@ int ipx_plan_run_jpeg_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_by
                                    wm_out ? wm_out + i0 : nullptr, status + i0, &res[k]);
         if (rcs[k]) errs[k] = ipx_last_error();
     };
+    auto guarded = [&](int k) { const int rc = guarded_status([&] { work(k); }, &errs[k]); if (rc) rcs[k] = rc; };
     std::vector<std::thread> pool;
-    for (int k = 1; k < parts; k++) pool.emplace_back(work, k);
-    work(0);
+    for (int k = 1; k < parts; k++) pool.emplace_back(guarded, k);
+    guarded(0);
     for (auto &t : pool) t.join();
     std::unique_ptr<ipx_jpeg_result> all(new ipx_jpeg_result);
     int rc = IPX_OK;
@@ -851,5 +877,6 @@ int ipx_plan_run_jpeg_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_by
     *result = all.release();
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 }  // extern "C"

@@ -15,7 +15,11 @@
 
 #include "../../include/ipx.h"
 
-namespace ipx { void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2))); }
+namespace ipx {
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+int status_of_exception() noexcept;   // inside a catch block: the ipx_status an exception maps to (nothing unwinds through the ABI)
+}
+#define IPX_CATCH_STATUS catch (...) { return ipx::status_of_exception(); }
 
 namespace {
 
@@ -72,7 +76,7 @@ bool parse_resize(const ipx_param *p, int n, ResizeReq *r, std::string *err)
     if (!number(find(p, n, "width"), &w)) { *err = "width parameter is required and must be a number"; return false; }
     if (!number(find(p, n, "height"), &h)) { *err = "height parameter is required and must be a number"; return false; }
     if (w <= 0 || h <= 0) { *err = "width and height must be positive numbers"; return false; }
-    if (w > 0x3fffffff || h > 0x3fffffff) { *err = "width and height are too large"; return false; }
+    if (w > 0x3fffffff || h > 0x3fffffff) { *err = "width and height are too large"; return false; }   // beyond 65535 the plan reports IPX_ERR_UNSUPPORTED
     r->w = (int)w; r->h = (int)h; r->keep = boolean(find(p, n, "keep_aspect"));
     return true;
 }
@@ -104,6 +108,7 @@ void parse_wm(const ipx_param *p, int n, WmReq *r)  // watermark.go:41-60: no pa
 
 bool alloc_image(ipx_image *im, int w, int h)
 {
+    if (w > 0x1fffffff) return false;               // the stride is an int32 in ipx_image (plans cap sides at 65535 anyway)
     im->w = w; im->h = h; im->stride = w * 4;
     im->pix = (uint8_t *)malloc((size_t)(w > 0 && h > 0 ? (size_t)w * h * 4 : 1));
     return im->pix != nullptr;
@@ -204,7 +209,7 @@ void ipx_image_free(ipx_image *img)
 }
 
 int ipx_resizer_process(ipx_ctx *ctx, const ipx_image *img, const char *format, const ipx_param *params,
-                        int nparams, ipx_image *out, char out_format[8])
+                        int nparams, ipx_image *out, char out_format[8]) try
 {
     if (!ctx || !out || !out_format) { ipx::set_error("ipx_resizer_process: bad argument"); return IPX_ERR_INVALID; }
     memset(out, 0, sizeof *out);
@@ -217,9 +222,10 @@ int ipx_resizer_process(ipx_ctx *ctx, const ipx_image *img, const char *format, 
     snprintf(out_format, 8, "%s", f == "gif" ? "gif" : static_format(f));  // resize.go:55-58,78-91
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 int ipx_thumbnailer_process(ipx_ctx *ctx, const ipx_image *img, const char *format, const ipx_param *params,
-                            int nparams, ipx_image *out, char out_format[8])
+                            int nparams, ipx_image *out, char out_format[8]) try
 {
     if (!ctx || !out || !out_format) { ipx::set_error("ipx_thumbnailer_process: bad argument"); return IPX_ERR_INVALID; }
     memset(out, 0, sizeof *out);
@@ -232,9 +238,10 @@ int ipx_thumbnailer_process(ipx_ctx *ctx, const ipx_image *img, const char *form
     snprintf(out_format, 8, "%s", f == "gif" ? "gif" : static_format(f));  // thumbnail.go:42-46,68-81
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 int ipx_watermarker_process(ipx_ctx *ctx, const ipx_image *img, const char *format, const ipx_param *params,
-                            int nparams, const ipx_text_rasterizer *font, ipx_image *out, char out_format[8])
+                            int nparams, const ipx_text_rasterizer *font, ipx_image *out, char out_format[8]) try
 {
     if (!ctx || !out || !out_format) { ipx::set_error("ipx_watermarker_process: bad argument"); return IPX_ERR_INVALID; }
     memset(out, 0, sizeof *out);
@@ -251,9 +258,10 @@ int ipx_watermarker_process(ipx_ctx *ctx, const ipx_image *img, const char *form
     snprintf(out_format, 8, "%s", f == "png" ? "png" : "jpeg");  // watermark.go:66-79: gif and others -> jpeg
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 int ipx_processor_process(ipx_ctx *ctx, const ipx_task *task, const ipx_image *decoded, const char *decoded_format,
-                          const ipx_text_rasterizer *font, ipx_processed *out, int *n_out)
+                          const ipx_text_rasterizer *font, ipx_processed *out, int *n_out) try
 {
     if (!ctx || !task || !out || !n_out || (task->nops && !task->ops)) {
         ipx::set_error("ipx_processor_process: bad argument");
@@ -313,7 +321,17 @@ int ipx_processor_process(ipx_ctx *ctx, const ipx_task *task, const ipx_image *d
         }
         rc = run_ops(ctx, decoded, rz, th, wm, font, o[0], o[1], o[2], &err);
         if (!rc) done = ops.size();
-    } else {
+        else {
+            // the fused pass failed as a whole (e.g. the rasteriser): go operator by operator, so that the operators before the
+            // failing one still deliver their results and the error names the one that failed, as the sequential loop of
+            // image_processor.go:64-92 would
+            for (auto &im : imgs) { ipx_image_free(&im); memset(&im, 0, sizeof im); }
+            fusable = false;
+            rc = IPX_OK;
+            err.clear();
+        }
+    }
+    if (!fusable) {
         for (size_t i = 0; i < ops.size() && !rc; i++) {
             const Parsed &p = ops[i];
             rc = run_ops(ctx, decoded, p.kind == 0 ? &p.r : nullptr, p.kind == 1 ? &p.t : nullptr,
@@ -363,5 +381,6 @@ int ipx_processor_process(ipx_ctx *ctx, const ipx_task *task, const ipx_image *d
     if (fail_status) { ipx::set_error("%s", fail_text.c_str()); return fail_status; }
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 }  // extern "C"

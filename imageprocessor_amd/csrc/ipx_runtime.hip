@@ -22,12 +22,6 @@
 
 namespace {
 
-
-bool frame_args_ok(const void *p, int w, int h, int stride)
-{
-    return p && w >= 0 && h >= 0 && (long long)stride >= (long long)w * 4;
-}
-
 // Scale's argument checks and dispatch decisions, shared by host- and device-pointer entries
 struct ScalePrep {
     bool copy;      // equal sizes: Copy -> DrawMask
@@ -182,7 +176,7 @@ int dev_composite(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, size
 // =============================================================================================
 extern "C" {
 
-int ipx_device_count(void)
+int ipx_device_count(void) try
 {
     clear_error();
     int n = 0;
@@ -190,8 +184,9 @@ int ipx_device_count(void)
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return IPX_ERR_NODEVICE; }
     return n;
 }
+IPX_CATCH_STATUS
 
-int ipx_create(const ipx_config *cfg, ipx_ctx **out)
+int ipx_create(const ipx_config *cfg, ipx_ctx **out) try
 {
     clear_error();
     if (!out) { set_error("ipx_create: null out"); return IPX_ERR_INVALID; }
@@ -246,6 +241,7 @@ int ipx_create(const ipx_config *cfg, ipx_ctx **out)
     *out = c;
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 void ipx_destroy(ipx_ctx *c)
 {
@@ -291,7 +287,7 @@ void *ipx_host_alloc(ipx_ctx *ctx, size_t bytes)
     return p;
 }
 
-int ipx_host_free(ipx_ctx *ctx, void *p)
+int ipx_host_free(ipx_ctx *ctx, void *p) try
 {
     IPX_ENTER(ctx);
     if (!p) return IPX_OK;
@@ -326,6 +322,7 @@ int ipx_host_free(ipx_ctx *ctx, void *p)
     IPX_HIP(e);
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 void *ipx_dev_alloc(ipx_ctx *ctx, size_t bytes)
 {
@@ -338,47 +335,73 @@ void *ipx_dev_alloc(ipx_ctx *ctx, size_t bytes)
     return p;
 }
 
-int ipx_dev_free(ipx_ctx *ctx, void *p)
+int ipx_dev_free(ipx_ctx *ctx, void *p) try
 {
     IPX_ENTER(ctx);
     if (p) IPX_HIP(hipFree(p));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
-int ipx_memcpy_h2d(ipx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+int ipx_memcpy_h2d(ipx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) try
 {
     IPX_ENTER(ctx);
     if (bytes) IPX_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
-int ipx_memcpy_d2h(ipx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+int ipx_memcpy_d2h(ipx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) try
 {
     IPX_ENTER(ctx);
     if (bytes) IPX_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
-int ipx_memcpy_d2d(ipx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes)
+int ipx_memcpy_d2d(ipx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes) try
 {
     IPX_ENTER(ctx);
     if (bytes) IPX_HIP(hipMemcpy(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
-int ipx_device_sync(ipx_ctx *ctx)
+int ipx_device_sync(ipx_ctx *ctx) try
 {
     IPX_ENTER(ctx);
     IPX_HIP(hipDeviceSynchronize());
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
-int ipx_stream_sync(ipx_ctx *ctx, void *stream)
+int ipx_stream_sync(ipx_ctx *ctx, void *stream) try
 {
     IPX_ENTER(ctx);
     IPX_HIP(hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
+
+void *ipx_stream_create(ipx_ctx *ctx)
+{
+    clear_error();
+    if (!ctx) return nullptr;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); set_error("hipStreamCreate failed"); return nullptr; }
+    return st;
+}
+
+int ipx_stream_destroy(ipx_ctx *ctx, void *stream) try
+{
+    IPX_ENTER(ctx);
+    if (!stream) return IPX_OK;
+    IPX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    IPX_HIP(hipStreamDestroy((hipStream_t)stream));
+    return IPX_OK;
+}
+IPX_CATCH_STATUS
 
 void *ipx_event_create(ipx_ctx *ctx)
 {
@@ -390,15 +413,16 @@ void *ipx_event_create(ipx_ctx *ctx)
     return ev;
 }
 
-int ipx_event_record(ipx_ctx *ctx, void *event, void *stream)
+int ipx_event_record(ipx_ctx *ctx, void *event, void *stream) try
 {
     IPX_ENTER(ctx);
     if (!event) { set_error("ipx_event_record: null event"); return IPX_ERR_INVALID; }
     IPX_HIP(hipEventRecord((hipEvent_t)event, stream ? (hipStream_t)stream : ctx->stream));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
-int ipx_event_elapsed_ms(ipx_ctx *ctx, void *start, void *stop, float *ms)
+int ipx_event_elapsed_ms(ipx_ctx *ctx, void *start, void *stop, float *ms) try
 {
     IPX_ENTER(ctx);
     if (!start || !stop || !ms) { set_error("ipx_event_elapsed_ms: bad argument"); return IPX_ERR_INVALID; }
@@ -406,6 +430,7 @@ int ipx_event_elapsed_ms(ipx_ctx *ctx, void *start, void *stop, float *ms)
     IPX_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 void ipx_event_destroy(ipx_ctx *ctx, void *event)
 {
@@ -417,13 +442,11 @@ void ipx_event_destroy(ipx_ctx *ctx, void *event)
 // ---- device-pointer operations ---------------------------------------------------------------------
 int ipx_dev_scale_bilinear_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int dw, int dh,
                                  int dstride, ipx_rect dr, const uint8_t *src, int sw, int sh,
-                                 int sstride, ipx_rect sr, int op)
+                                 int sstride, ipx_rect sr, int op) try
 {
     IPX_ENTER(ctx);
-    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
-        set_error("ipx_dev_scale_bilinear_rgba8: bad frame arguments");
-        return IPX_ERR_INVALID;
-    }
+    IPX_FRAME("ipx_dev_scale_bilinear_rgba8", "destination", dst, dw, dh, dstride);
+    IPX_FRAME("ipx_dev_scale_bilinear_rgba8", "source", src, sw, sh, sstride);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     int *flag = nullptr;
     if (op == IPX_OP_OVER) {
@@ -434,22 +457,22 @@ int ipx_dev_scale_bilinear_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int d
     if (flag) (void)hipFreeAsync(flag, s);
     return rc;
 }
+IPX_CATCH_STATUS
 
 int ipx_dev_draw_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int dw, int dh, int dstride,
                        ipx_rect r, const uint8_t *src, int sw, int sh, int sstride, int spx, int spy,
-                       int op)
+                       int op) try
 {
     IPX_ENTER(ctx);
-    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
-        set_error("ipx_dev_draw_rgba8: bad frame arguments");
-        return IPX_ERR_INVALID;
-    }
+    IPX_FRAME("ipx_dev_draw_rgba8", "destination", dst, dw, dh, dstride);
+    IPX_FRAME("ipx_dev_draw_rgba8", "source", src, sw, sh, sstride);
     return dev_draw(stream ? (hipStream_t)stream : ctx->stream, dst, dw, dh, dstride, to_rect(r), src,
                     sw, sh, sstride, spx, spy, op);
 }
+IPX_CATCH_STATUS
 
 int ipx_glyphset_create(ipx_ctx *ctx, const ipx_glyph *glyphs, int n, const uint8_t col[4],
-                        ipx_glyphset **out)
+                        ipx_glyphset **out) try
 {
     IPX_ENTER(ctx);
     if (!out || n < 0 || (n && !glyphs) || !col) { set_error("ipx_glyphset_create: bad argument"); return IPX_ERR_INVALID; }
@@ -486,6 +509,7 @@ int ipx_glyphset_create(ipx_ctx *ctx, const ipx_glyph *glyphs, int n, const uint
     *out = gs;
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 void ipx_glyphset_destroy(ipx_ctx *ctx, ipx_glyphset *gs)
 {
@@ -497,22 +521,22 @@ void ipx_glyphset_destroy(ipx_ctx *ctx, ipx_glyphset *gs)
 }
 
 int ipx_dev_composite_glyphs_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int dw, int dh,
-                                   int dstride, const ipx_glyphset *gs)
+                                   int dstride, const ipx_glyphset *gs) try
 {
     IPX_ENTER(ctx);
-    if (!frame_args_ok(dst, dw, dh, dstride) || !gs) { set_error("ipx_dev_composite_glyphs_rgba8: bad argument"); return IPX_ERR_INVALID; }
+    if (!gs) { set_error("ipx_dev_composite_glyphs_rgba8: bad argument"); return IPX_ERR_INVALID; }
+    IPX_FRAME("ipx_dev_composite_glyphs_rgba8", "destination", dst, dw, dh, dstride);
     return dev_composite(stream ? (hipStream_t)stream : ctx->stream, dst, dw, dh, dstride, 0, 1, gs);
 }
+IPX_CATCH_STATUS
 
 // ---- host-pointer operations: stage through a lane ------------------------------------------------
 int ipx_scale_bilinear_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
-                             const uint8_t *src, int sw, int sh, int sstride, ipx_rect sr, int op)
+                             const uint8_t *src, int sw, int sh, int sstride, ipx_rect sr, int op) try
 {
     IPX_ENTER(ctx);
-    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
-        set_error("ipx_scale_bilinear_rgba8: bad frame arguments");
-        return IPX_ERR_INVALID;
-    }
+    IPX_FRAME("ipx_scale_bilinear_rgba8", "destination", dst, dw, dh, dstride);
+    IPX_FRAME("ipx_scale_bilinear_rgba8", "source", src, sw, sh, sstride);
     ScalePrep pr;
     int rc = scale_prepare(dw, dh, to_rect(dr), sw, sh, to_rect(sr), op, &pr);
     if (rc) return rc;
@@ -532,15 +556,14 @@ int ipx_scale_bilinear_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dst
     IPX_HIP(hipStreamSynchronize(s));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 int ipx_draw_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r,
-                   const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op)
+                   const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op) try
 {
     IPX_ENTER(ctx);
-    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
-        set_error("ipx_draw_rgba8: bad frame arguments");
-        return IPX_ERR_INVALID;
-    }
+    IPX_FRAME("ipx_draw_rgba8", "destination", dst, dw, dh, dstride);
+    IPX_FRAME("ipx_draw_rgba8", "source", src, sw, sh, sstride);
     if (op != IPX_OP_OVER && op != IPX_OP_SRC) { set_error("draw: unknown op %d", op); return IPX_ERR_INVALID; }
     if (!dw || !dh || !sw || !sh) return IPX_OK;
     LaneLease lane(ctx);
@@ -557,15 +580,14 @@ int ipx_draw_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_
     IPX_HIP(hipStreamSynchronize(s));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 int ipx_composite_glyphs_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride,
-                               const ipx_glyph *glyphs, int n, const uint8_t col[4])
+                               const ipx_glyph *glyphs, int n, const uint8_t col[4]) try
 {
     IPX_ENTER(ctx);
-    if (!frame_args_ok(dst, dw, dh, dstride) || n < 0 || (n && !glyphs) || !col) {
-        set_error("ipx_composite_glyphs_rgba8: bad argument");
-        return IPX_ERR_INVALID;
-    }
+    if (n < 0 || (n && !glyphs) || !col) { set_error("ipx_composite_glyphs_rgba8: bad argument"); return IPX_ERR_INVALID; }
+    IPX_FRAME("ipx_composite_glyphs_rgba8", "destination", dst, dw, dh, dstride);
     if (!n || !dw || !dh) return IPX_OK;
     ipx_glyphset *gs = nullptr;
     int rc = ipx_glyphset_create(ctx, glyphs, n, col, &gs);
@@ -588,6 +610,7 @@ int ipx_composite_glyphs_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int d
     ipx_glyphset_destroy(ctx, gs);
     return rc;
 }
+IPX_CATCH_STATUS
 
 }  // extern "C"
 
@@ -637,44 +660,41 @@ int upload_ycbcr(hipStream_t s, const ipx_ycbcr *y, int cw, int ch, uint8_t *dsr
 extern "C" {
 
 int ipx_scale_bilinear_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
-                              const uint8_t *src, int sw, int sh, int sstride, ipx_rect sr, int op)
+                              const uint8_t *src, int sw, int sh, int sstride, ipx_rect sr, int op) try
 {
     IPX_ENTER(ctx);
-    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
-        set_error("ipx_scale_bilinear_nrgba8: bad frame arguments");
-        return IPX_ERR_INVALID;
-    }
+    IPX_FRAME("ipx_scale_bilinear_nrgba8", "destination", dst, dw, dh, dstride);
+    IPX_FRAME("ipx_scale_bilinear_nrgba8", "source", src, sw, sh, sstride);
     if (!dw || !dh || !sw || !sh) return IPX_OK;
     return stage_and_run(ctx, dst, dw, dh, dstride, align256((size_t)sw * sh * 4), [&](hipStream_t s, int *flag, uint8_t *ddst, uint8_t *dsrc) -> int {
         IPX_HIP(hipMemcpy2DAsync(dsrc, (size_t)sw * 4, src, sstride, (size_t)sw * 4, sh, hipMemcpyHostToDevice, s));
         return dev_scale_src(s, flag, ddst, dw, dh, dw * 4, to_rect(dr), rgba_src(dsrc, sw, sh, sw * 4, IPX_SRC_NRGBA), to_rect(sr), op);
     });
 }
+IPX_CATCH_STATUS
 
 int ipx_draw_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r, const uint8_t *src,
-                    int sw, int sh, int sstride, int spx, int spy, int op)
+                    int sw, int sh, int sstride, int spx, int spy, int op) try
 {
     IPX_ENTER(ctx);
-    if (!frame_args_ok(dst, dw, dh, dstride) || !frame_args_ok(src, sw, sh, sstride)) {
-        set_error("ipx_draw_nrgba8: bad frame arguments");
-        return IPX_ERR_INVALID;
-    }
+    IPX_FRAME("ipx_draw_nrgba8", "destination", dst, dw, dh, dstride);
+    IPX_FRAME("ipx_draw_nrgba8", "source", src, sw, sh, sstride);
     if (!dw || !dh || !sw || !sh) return IPX_OK;
     return stage_and_run(ctx, dst, dw, dh, dstride, align256((size_t)sw * sh * 4), [&](hipStream_t s, int *, uint8_t *ddst, uint8_t *dsrc) -> int {
         IPX_HIP(hipMemcpy2DAsync(dsrc, (size_t)sw * 4, src, sstride, (size_t)sw * 4, sh, hipMemcpyHostToDevice, s));
         return dev_draw_src(s, ddst, dw, dh, dw * 4, to_rect(r), rgba_src(dsrc, sw, sh, sw * 4, IPX_SRC_NRGBA), spx, spy, op);
     });
 }
+IPX_CATCH_STATUS
 
 int ipx_scale_bilinear_ycbcr(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
-                             const ipx_ycbcr *src, ipx_rect sr)
+                             const ipx_ycbcr *src, ipx_rect sr) try
 {
     IPX_ENTER(ctx);
     int cw = 0, ch = 0;
-    if (!frame_args_ok(dst, dw, dh, dstride) || !ycbcr_ok(src, &cw, &ch)) {
-        set_error("ipx_scale_bilinear_ycbcr: bad arguments");
-        return IPX_ERR_INVALID;
-    }
+    IPX_FRAME("ipx_scale_bilinear_ycbcr", "destination", dst, dw, dh, dstride);
+    if (!ycbcr_ok(src, &cw, &ch)) { set_error("ipx_scale_bilinear_ycbcr: bad arguments"); return IPX_ERR_INVALID; }
+    if (!frame_span_ok(src->w, src->h, src->ystride, 1)) { set_error("ipx_scale_bilinear_ycbcr: source planes beyond the addressable span"); return IPX_ERR_UNSUPPORTED; }
     if (!dw || !dh) return IPX_OK;
     const size_t bytes = align256((size_t)src->w * src->h) + 2 * align256((size_t)cw * ch);
     return stage_and_run(ctx, dst, dw, dh, dstride, bytes, [&](hipStream_t s, int *flag, uint8_t *ddst, uint8_t *dsrc) -> int {
@@ -684,16 +704,16 @@ int ipx_scale_bilinear_ycbcr(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dst
         return dev_scale_src(s, flag, ddst, dw, dh, dw * 4, to_rect(dr), d, to_rect(sr), IPX_OP_SRC);
     });
 }
+IPX_CATCH_STATUS
 
 int ipx_draw_ycbcr(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r, const ipx_ycbcr *src,
-                   int spx, int spy)
+                   int spx, int spy) try
 {
     IPX_ENTER(ctx);
     int cw = 0, ch = 0;
-    if (!frame_args_ok(dst, dw, dh, dstride) || !ycbcr_ok(src, &cw, &ch)) {
-        set_error("ipx_draw_ycbcr: bad arguments");
-        return IPX_ERR_INVALID;
-    }
+    IPX_FRAME("ipx_draw_ycbcr", "destination", dst, dw, dh, dstride);
+    if (!ycbcr_ok(src, &cw, &ch)) { set_error("ipx_draw_ycbcr: bad arguments"); return IPX_ERR_INVALID; }
+    if (!frame_span_ok(src->w, src->h, src->ystride, 1)) { set_error("ipx_draw_ycbcr: source planes beyond the addressable span"); return IPX_ERR_UNSUPPORTED; }
     if (!dw || !dh) return IPX_OK;
     const size_t bytes = align256((size_t)src->w * src->h) + 2 * align256((size_t)cw * ch);
     return stage_and_run(ctx, dst, dw, dh, dstride, bytes, [&](hipStream_t s, int *, uint8_t *ddst, uint8_t *dsrc) -> int {
@@ -703,18 +723,23 @@ int ipx_draw_ycbcr(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_
         return dev_draw_src(s, ddst, dw, dh, dw * 4, to_rect(r), d, spx, spy, IPX_OP_SRC);
     });
 }
+IPX_CATCH_STATUS
 
 }  // extern "C"
 
 extern "C" {
 
 // ---- plans -------------------------------------------------------------------------------------------
-int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
+int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
 {
     IPX_ENTER(ctx);
     if (!p || !out) { set_error("ipx_plan_create: bad argument"); return IPX_ERR_INVALID; }
     *out = nullptr;
     if (p->sw <= 0 || p->sh <= 0) { set_error("ipx_plan_create: frame size %dx%d", p->sw, p->sh); return IPX_ERR_INVALID; }
+    if (!frame_span_ok(p->sw, p->sh, (long long)p->sw * 4, 4)) {
+        set_error("ipx_plan_create: a %dx%d frame is beyond the 2 GiB / 65535-pixel span the kernels address", p->sw, p->sh);
+        return IPX_ERR_UNSUPPORTED;
+    }
     ipx_plan *pl = new (std::nothrow) ipx_plan;
     if (!pl) { set_error("out of memory"); return IPX_ERR_NOMEM; }
     pl->p = *p;
@@ -724,6 +749,11 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
         int nw, nh;
         rc = ipx_resize_dims(sw, sh, p->resize_w, p->resize_h, p->keep_aspect, &nw, &nh);
         if (rc) { delete pl; return rc; }
+        if (!frame_span_ok(nw, nh, (long long)nw * 4, 4)) {
+            set_error("ipx_plan_create: a %dx%d resize output is beyond the 2 GiB / 65535-pixel span the kernels address", nw, nh);
+            delete pl;
+            return IPX_ERR_UNSUPPORTED;
+        }
         pl->sc[0].on = true; pl->sc[0].dw = nw; pl->sc[0].dh = nh; pl->sc[0].sr = Rect{0, 0, sw, sh};
         pl->info.resize_w = nw; pl->info.resize_h = nh;
         pl->info.resize_bytes = (size_t)nw * nh * 4;
@@ -733,6 +763,11 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
         ipx_rect crop;
         rc = ipx_thumb_geometry(sw, sh, p->thumb_size, p->crop_to_fit, &crop, &nw, &nh);
         if (rc) { delete pl; return rc; }
+        if (!frame_span_ok(nw, nh, (long long)nw * 4, 4)) {
+            set_error("ipx_plan_create: a %dx%d thumbnail is beyond the 2 GiB / 65535-pixel span the kernels address", nw, nh);
+            delete pl;
+            return IPX_ERR_UNSUPPORTED;
+        }
         pl->sc[1].on = true; pl->sc[1].dw = nw; pl->sc[1].dh = nh; pl->sc[1].sr = to_rect(crop);
         pl->info.thumb_w = nw; pl->info.thumb_h = nh; pl->info.thumb_crop = crop;
         pl->info.thumb_bytes = (size_t)nw * nh * 4;
@@ -852,6 +887,7 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out)
     *out = pl;
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 void ipx_plan_destroy(ipx_ctx *ctx, ipx_plan *plan)
 {
@@ -862,24 +898,35 @@ void ipx_plan_destroy(ipx_ctx *ctx, ipx_plan *plan)
     delete plan;
 }
 
-int ipx_plan_query(const ipx_plan *plan, ipx_plan_info *info)
+int ipx_plan_query(const ipx_plan *plan, ipx_plan_info *info) try
 {
     clear_error();
     if (!plan || !info) { set_error("ipx_plan_query: bad argument"); return IPX_ERR_INVALID; }
     *info = plan->info;
     return IPX_OK;
 }
+IPX_CATCH_STATUS
+
+// the source rows of a batch entry: stride given by the caller, size by the plan
+static int plan_src_status(const char *who, const ipx_plan *pl, long long stride, int bpp)
+{
+    if (frame_span_ok(pl->p.sw, pl->p.sh, stride, bpp)) return IPX_OK;
+    set_error("%s: %dx%d frames with a row stride of %lld bytes are beyond the 2 GiB span the kernels address", who, pl->p.sw, pl->p.sh, stride);
+    return IPX_ERR_UNSUPPORTED;
+}
+#define IPX_PLAN_SRC(who, pl, stride, bpp) do { const int rc_ = plan_src_status(who, pl, stride, bpp); if (rc_) return rc_; } while (0)
 
 int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *src,
                      int sstride, size_t src_frame_stride, uint8_t *resize_out,
                      size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride,
-                     uint8_t *wm_out, size_t wm_frame_stride)
+                     uint8_t *wm_out, size_t wm_frame_stride) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * 4) {
         set_error("ipx_plan_run_dev: bad argument");
         return IPX_ERR_INVALID;
     }
+    IPX_PLAN_SRC("ipx_plan_run_dev", pl, sstride, 4);
     if (n == 0) return IPX_OK;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const int sw = pl->p.sw, sh = pl->p.sh;
@@ -977,6 +1024,7 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
                                  col[0], col[1], col[2], col[3], s));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 // Frames in host memory, any packed source type: chunks over the lanes so that H2D of one chunk, the kernel of another and D2H of
 // a third overlap.  kind: IPX_SRC_RGBA / IPX_SRC_NRGBA (4 bytes per pixel), IPX_GRAY (1), kPalettedKind (1 + 1 KiB palette per frame).
@@ -1072,50 +1120,58 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
 int ipx_plan_run_host(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride,
                       size_t src_frame_stride, uint8_t *resize_out, size_t resize_frame_stride,
                       uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
-                      size_t wm_frame_stride)
+                      size_t wm_frame_stride) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * 4) {
         set_error("ipx_plan_run_host: bad argument");
         return IPX_ERR_INVALID;
     }
+    IPX_PLAN_SRC("ipx_plan_run_host", pl, sstride, 4);
     if (n == 0) return IPX_OK;
     return run_host_packed(ctx, pl, n, IPX_SRC_RGBA, src, sstride, src_frame_stride, nullptr, resize_out, resize_frame_stride, thumb_out,
                            thumb_frame_stride, wm_out, wm_frame_stride, "ipx_plan_run_host");
 }
+IPX_CATCH_STATUS
 
 int ipx_plan_run_host_nrgba(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
                             uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
-                            size_t wm_frame_stride)
+                            size_t wm_frame_stride) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * 4) { set_error("ipx_plan_run_host_nrgba: bad argument"); return IPX_ERR_INVALID; }
+    IPX_PLAN_SRC("ipx_plan_run_host_nrgba", pl, sstride, 4);
     if (n == 0) return IPX_OK;
     return run_host_packed(ctx, pl, n, IPX_SRC_NRGBA, src, sstride, src_frame_stride, nullptr, resize_out, resize_frame_stride, thumb_out,
                            thumb_frame_stride, wm_out, wm_frame_stride, "ipx_plan_run_host_nrgba");
 }
+IPX_CATCH_STATUS
 
 int ipx_plan_run_host_gray(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *gray, int stride, size_t frame_stride,
                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
-                           size_t wm_frame_stride)
+                           size_t wm_frame_stride) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !gray || stride < pl->p.sw) { set_error("ipx_plan_run_host_gray: bad argument"); return IPX_ERR_INVALID; }
+    IPX_PLAN_SRC("ipx_plan_run_host_gray", pl, stride, 1);
     if (n == 0) return IPX_OK;
     return run_host_packed(ctx, pl, n, IPX_GRAY, gray, stride, frame_stride, nullptr, resize_out, resize_frame_stride, thumb_out,
                            thumb_frame_stride, wm_out, wm_frame_stride, "ipx_plan_run_host_gray");
 }
+IPX_CATCH_STATUS
 
 int ipx_plan_run_host_paletted(ipx_ctx *ctx, const ipx_plan *pl, int n, const uint8_t *index, int stride, size_t frame_stride,
                                const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
-                               size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride)
+                               size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !index || !palettes || stride < pl->p.sw) { set_error("ipx_plan_run_host_paletted: bad argument"); return IPX_ERR_INVALID; }
+    IPX_PLAN_SRC("ipx_plan_run_host_paletted", pl, stride, 1);
     if (n == 0) return IPX_OK;
     return run_host_packed(ctx, pl, n, kPalettedKind, index, stride, frame_stride, palettes, resize_out, resize_frame_stride, thumb_out,
                            thumb_frame_stride, wm_out, wm_frame_stride, "ipx_plan_run_host_paletted");
 }
+IPX_CATCH_STATUS
 
 
 // ---- decoded JPEG batches ---------------------------------------------------------------------------
@@ -1168,7 +1224,7 @@ static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n,
 
 int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src,
                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
-                           size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride)
+                           size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !src || !src->y || !src->cb || !src->cr || src->ratio < 0 || src->ratio > IPX_YCBCR_440 ||
@@ -1176,11 +1232,14 @@ int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
         set_error("ipx_plan_run_dev_ycbcr: bad argument");
         return IPX_ERR_INVALID;
     }
+    IPX_PLAN_SRC("ipx_plan_run_dev_ycbcr", pl, src->ystride, 1);
+    if (!frame_span_ok(pl->p.sw, pl->p.sh, src->cstride, 1)) { set_error("ipx_plan_run_dev_ycbcr: chroma planes beyond the addressable span"); return IPX_ERR_UNSUPPORTED; }
     if (n == 0) return IPX_OK;
     if (n > 65535) { set_error("ipx_plan_run_dev_ycbcr: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
     return run_dev_ycbcr(ctx, stream ? (hipStream_t)stream : ctx->stream, pl, n, src, false, resize_out, resize_frame_stride, thumb_out,
                          thumb_frame_stride, wm_out, wm_frame_stride);
 }
+IPX_CATCH_STATUS
 
 static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, bool flat_chroma,
                          uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
@@ -1260,10 +1319,11 @@ static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n,
 
 int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
-                           size_t wm_frame_stride)
+                           size_t wm_frame_stride) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * 4) { set_error("ipx_plan_run_dev_nrgba: bad argument"); return IPX_ERR_INVALID; }
+    IPX_PLAN_SRC("ipx_plan_run_dev_nrgba", pl, sstride, 4);
     if (n == 0) return IPX_OK;
     if (n > 65535) { set_error("ipx_plan_run_dev_nrgba: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -1330,16 +1390,18 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     if (scratch) (void)hipFreeAsync(scratch, s);
     return rc;
 }
+IPX_CATCH_STATUS
 
 int ipx_plan_run_dev_paletted(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *index, int stride, size_t frame_stride,
                               const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
-                              size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride)
+                              size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !index || !palettes || stride < pl->p.sw || ((uintptr_t)palettes & 3)) {
         set_error("ipx_plan_run_dev_paletted: bad argument");
         return IPX_ERR_INVALID;
     }
+    IPX_PLAN_SRC("ipx_plan_run_dev_paletted", pl, stride, 1);
     if (n == 0) return IPX_OK;
     if (n > 65535) { set_error("ipx_plan_run_dev_paletted: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -1355,13 +1417,15 @@ int ipx_plan_run_dev_paletted(ipx_ctx *ctx, void *stream, const ipx_plan *pl, in
     (void)hipFreeAsync(nrgba, s);
     return rc;
 }
+IPX_CATCH_STATUS
 
 int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *gray, int stride, size_t frame_stride,
                           uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
-                          size_t wm_frame_stride)
+                          size_t wm_frame_stride) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !gray || stride < pl->p.sw) { set_error("ipx_plan_run_dev_gray: bad argument"); return IPX_ERR_INVALID; }
+    IPX_PLAN_SRC("ipx_plan_run_dev_gray", pl, stride, 1);
     if (n == 0) return IPX_OK;
     if (n > 65535) { set_error("ipx_plan_run_dev_gray: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
@@ -1387,16 +1451,19 @@ int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n,
     (void)hipFreeAsync(rgba, s);
     return rc;
 }
+IPX_CATCH_STATUS
 
 int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, uint8_t *resize_out,
                             size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride,
-                            uint8_t *wm_out, size_t wm_frame_stride)
+                            uint8_t *wm_out, size_t wm_frame_stride) try
 {
     IPX_ENTER(ctx);
     if (!pl || n < 0 || !src || !src->y || !src->cb || !src->cr || src->ratio < 0 || src->ratio > IPX_YCBCR_440) {
         set_error("ipx_plan_run_host_ycbcr: bad argument");
         return IPX_ERR_INVALID;
     }
+    IPX_PLAN_SRC("ipx_plan_run_host_ycbcr", pl, src->ystride, 1);
+    if (!frame_span_ok(pl->p.sw, pl->p.sh, src->cstride, 1)) { set_error("ipx_plan_run_host_ycbcr: chroma planes beyond the addressable span"); return IPX_ERR_UNSUPPORTED; }
     if (n == 0) return IPX_OK;
     const int sw = pl->p.sw, sh = pl->p.sh;
     const int cw = (src->ratio == IPX_YCBCR_422 || src->ratio == IPX_YCBCR_420) ? (sw + 1) / 2 : sw;
@@ -1432,5 +1499,6 @@ int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_y
     IPX_HIP(hipStreamSynchronize(s));
     return IPX_OK;
 }
+IPX_CATCH_STATUS
 
 }  // extern "C"

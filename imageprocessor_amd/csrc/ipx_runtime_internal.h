@@ -9,6 +9,7 @@
 #include <deque>
 #include <map>
 #include <mutex>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -169,6 +170,30 @@ inline int lane_reserve(Lane &l, size_t bytes)
     }
     l.dev_bytes = want;
     return IPX_OK;
+}
+
+// status of a frame argument: IPX_ERR_INVALID for a malformed one, IPX_ERR_UNSUPPORTED for one beyond the addressable span
+inline int frame_status(const char *who, const char *what, const void *p, int w, int h, long long stride, int bpp = 4)
+{
+    if (!p || w < 0 || h < 0 || stride < (long long)w * bpp) { set_error("%s: bad %s frame arguments", who, what); return IPX_ERR_INVALID; }
+    if (!frame_span_ok(w, h, stride, bpp)) {
+        set_error("%s: %s frame %dx%d (stride %lld) is beyond the 2 GiB / 65535-pixel span the kernels address", who, what, w, h, stride);
+        return IPX_ERR_UNSUPPORTED;
+    }
+    return IPX_OK;
+}
+#define IPX_FRAME(who, what, p, w, h, stride) do { const int rc_ = frame_status(who, what, p, w, h, stride); if (rc_) return rc_; } while (0)
+
+// The body of a worker thread: an exception must not leave the thread (std::terminate would take the Go / Python worker down);
+// it becomes the status and text the spawning call reports.
+template <class F> inline int guarded_status(F &&fn, std::string *text) noexcept
+{
+    try { fn(); return IPX_OK; }
+    catch (...) {
+        const int rc = status_of_exception();
+        if (text) { try { *text = ipx_last_error(); } catch (...) { } }
+        return rc;
+    }
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }

@@ -72,6 +72,12 @@ int ipx_abi_version(void);
 /* Number of gfx950 devices visible; a negative ipx_status on failure. */
 int ipx_device_count(void);
 
+/* Whether a frame of w x h pixels with this row stride can go to the GPU path at all: the kernels address a frame through 32-bit
+ * buffer descriptors, so (h-1)*stride + w*bytes_per_pixel must stay below 2 GiB and each side below 65536.  IPX_OK, or
+ * IPX_ERR_UNSUPPORTED -- the answer every plan / per-operation entry gives for such a frame; the worker keeps its CPU path for it
+ * (a 32 MiB PNG upload, domain/task.go:55, can decode past 23170 x 23170).  Host only. */
+int ipx_frame_supported(int w, int h, long long stride, int bytes_per_pixel);
+
 /* ---- geometry and parameter rules (host only, no GPU needed) ------------------------------- */
 
 /* resize.go:61-75: aspect-fit in float64 with truncation, or (w,h) as given. */
@@ -103,6 +109,12 @@ int ipx_memcpy_d2d(ipx_ctx *ctx, void *dst_dev, const void *src_dev, size_t byte
 int ipx_device_sync(ipx_ctx *ctx);
 /* Blocks until everything queued on `stream` (a hipStream_t, NULL = the context's stream) is done. */
 int ipx_stream_sync(ipx_ctx *ctx, void *stream);
+
+/* A stream of the caller's own on the context's device (a hipStream_t, non-blocking) for the asynchronous device-pointer entries:
+ * two of them let a worker queue the next batch while the previous one runs (bench.py --mixed does exactly that).  Destroying a
+ * stream waits for what is queued on it. */
+void *ipx_stream_create(ipx_ctx *ctx);
+int ipx_stream_destroy(ipx_ctx *ctx, void *stream);
 
 /* ---- per-operation seam, host pointers, synchronous ------------------------------------------
  * Each call stages through a pinned lane, runs the HIP kernel and copies the result back. */

@@ -106,3 +106,25 @@ def test_host_rules_agree_with_oracle_on_a_sweep(ipx):
     for s in ("255,255,255", " 1, 2,3 ,4", "a,b,c", "1,2,3,", "-1,999,5", "+7,8,9", "1,,3", "1,2,3,4,5", "0x10,1,1"):
         for op in (0.0, 0.3, 0.5, 1.0):
             assert ipx.parse_color(s, op) == oracle.parse_color(s, op), (s, op)
+
+
+def test_frame_geometry_guard(ipx):
+    """Frames the 32-bit buffer descriptors cannot address are refused with IPX_ERR_UNSUPPORTED (the worker keeps its CPU path,
+    domain/task.go:55: a 32 MiB PNG can decode past 23170 x 23170), never processed with wrapped offsets."""
+    L = ipx.lib()
+    ok = [(1920, 1080, 7680, 4), (7680, 4320, 30720, 4), (23168, 23168, 92672, 4), (32764, 16380, 131056, 4), (65535, 8000, 65535, 1),
+          (0, 0, 0, 4), (65535, 1, 262140, 4)]
+    for w, h, stride, bpp in ok:
+        assert L.ipx_frame_supported(w, h, stride, bpp) == 0, (w, h, stride)
+    unsupported = [(23171, 23171, 92684, 4),      # 2^31 bytes and a bit
+                   (32768, 16384, 131072, 4),    # exactly 2 GiB
+                   (65536, 16, 262144, 4), (16, 65536, 64, 4),   # a side beyond 65535
+                   (1920, 1080, 2 << 20, 4)]     # a small frame inside an enormous pitch
+    for w, h, stride, bpp in unsupported:
+        assert L.ipx_frame_supported(w, h, stride, bpp) == -4, (w, h, stride)
+        assert b"span" in L.ipx_last_error()
+    for w, h, stride, bpp in [(-1, 5, 100, 4), (10, 10, 39, 4), (10, 10, 40, 0)]:
+        assert L.ipx_frame_supported(w, h, stride, bpp) == -1
+    # the largest tight RGBA8 frame whose last byte a 31-bit offset reaches
+    assert L.ipx_frame_supported(23169, 23169, 23169 * 4, 4) == 0
+    assert 23169 * 23169 * 4 < 0x7fff0000 <= 23170 * 23170 * 4 + 0x10000
