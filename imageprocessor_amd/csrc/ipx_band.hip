@@ -134,10 +134,8 @@ __global__ __launch_bounds__(256) void band_kernel(BandArgs a)
     const Tile t = make_tile(a, b, cb);
 
     // taps first: the oldest loads of the wave, so nothing later waits behind a store
-    AxisTap *ytap = (AxisTap *)(lds + (a.band_rows + 1) * t.pitch);  // [2][kYChunk]
     int dyA[2] = {0, 0}, dyB[2] = {0, 0};
     OutCols<NX, true> o0, o1;
-    v4u ty_stage[2][2];  // an AxisTap as two 16-byte words
     if (a.nscale > 0) {
         load_xtaps<NX, true>(a, 0, cb, tid, o0);
         load_xtaps<NX, true>(a, 1, cb, tid, o1);
@@ -146,8 +144,6 @@ __global__ __launch_bounds__(256) void band_kernel(BandArgs a)
             const ScaleOut &S = a.sc[k];
             dyA[k] = S.row_begin[b];
             dyB[k] = k < a.nscale ? S.row_begin[b + 1] : dyA[k];
-            const v4u *yp = (const v4u *)&S.yt[min(dyA[k] + tid, S.dh - 1)];
-            ty_stage[k][0] = yp[0]; ty_stage[k][1] = yp[1];
         }
     }
 
@@ -162,20 +158,12 @@ __global__ __launch_bounds__(256) void band_kernel(BandArgs a)
 
     const bool glyph_tile = any_glyph && tile_meets_textbox(a, t);
     if (a.nscale == 0 && !glyph_tile) return;
-    if (a.nscale > 0) {
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-            if (tid < min(dyB[k] - dyA[k], kYChunk)) {
-                v4u *yl = (v4u *)&ytap[k * kYChunk + tid];
-                yl[0] = ty_stage[k][0]; yl[1] = ty_stage[k][1];
-            }
-    }
     __syncthreads();
     // the composite goes first so that its few loads are not queued behind the pixel stores
     if (glyph_tile) glyph_phase(a, t, wframe, lds, tid);
     if (a.nscale > 0) {
-        scale_out<NX, true, true>(a, 0, t, f, lds, ytap, tid, o0, dyA[0], dyB[0]);
-        scale_out<NX, true, true>(a, 1, t, f, lds, ytap + kYChunk, tid, o1, dyA[1], dyB[1]);
+        scale_out<NX, true>(a, 0, t, f, lds, tid, o0, dyA[0], dyB[0]);
+        scale_out<NX, true>(a, 1, t, f, lds, tid, o1, dyA[1], dyB[1]);
     }
 }
 
@@ -212,8 +200,7 @@ __device__ __forceinline__ void item_setup(const BandArgs &a, Item &it, bool val
 }
 
 template <int ROWS, int CH, int NT>
-__device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, int tid, v4u (&stage)[ROWS * CH],
-                                           v4u (&ty_stage)[2][2])
+__device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, int tid, v4u (&stage)[ROWS * CH])
 {
     const int frame_bytes = (a.sh - 1) * a.sstride + a.sw * 4;
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
@@ -237,18 +224,11 @@ __device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, in
         for (int h = 0; h < CH; h++)   // r < rows is wave-uniform
             stage[r * CH + h] = __builtin_amdgcn_raw_buffer_load_b128(srs, in_tile[h] && r < rows ? voff[h] + r * a.sstride : kOOB, 0, 0);
     }
-    if (a.nscale > 0) {
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const v4u *yp = (const v4u *)&a.sc[k].yt[min(it.dyA[k] + tid, a.sc[k].dh - 1)];
-            ty_stage[k][0] = yp[0]; ty_stage[k][1] = yp[1];
-        }
-    }
 }
 
 template <int ROWS, int CH, int NT>
 __device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, int tid, const v4u (&stage)[ROWS * CH],
-                                           const v4u (&ty_stage)[2][2], uint8_t *lds, AxisTap *ytap, bool any_glyph)
+                                           uint8_t *lds, bool any_glyph)
 {
     uint8_t *wframe = a.wm ? a.wm + (size_t)it.f * a.wm_frame_stride : nullptr;
     const int wm_bytes = wframe ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0;
@@ -275,18 +255,10 @@ __device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, in
             __builtin_amdgcn_raw_buffer_store_b128(stage[r * CH + h], wrs, off, 0, 0);
         }
     }
-    if (a.nscale > 0) {
-#pragma unroll
-        for (int k = 0; k < 2; k++)
-            if (tid < min(it.dyB[k] - it.dyA[k], kYChunk)) {
-                v4u *yl = (v4u *)&ytap[k * kYChunk + tid];
-                yl[0] = ty_stage[k][0]; yl[1] = ty_stage[k][1];
-            }
-    }
 }
 
 template <int NX0, bool FP0, int NX1, bool FP1, int ROWS, int CH, int NT>
-__global__ __launch_bounds__(NT) void band_pipe_kernel(BandArgs a)
+__global__ __launch_bounds__(NT, NT / 128) void band_pipe_kernel(BandArgs a)   // two workgroups per CU (LDS-bound): 128 VGPRs at 512 threads
 {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = (uint8_t *)lds_raw;
@@ -313,7 +285,6 @@ __global__ __launch_bounds__(NT) void band_pipe_kernel(BandArgs a)
     }
     if (idx >= idx_end) return;
 
-    AxisTap *ytap = (AxisTap *)(lds + (a.band_rows + 1) * ((a.blk_cols + 4) * 4));  // [2][kYChunk]
     const bool any_glyph = a.nglyphs > 0 && a.wm;
 
     Item cur;
@@ -327,8 +298,7 @@ __global__ __launch_bounds__(NT) void band_pipe_kernel(BandArgs a)
     if (a.nscale > 0) { load_xtaps<NX0, FP0, NT>(a, 0, cur.cb, tid, o0); load_xtaps<NX1, FP1, NT>(a, 1, cur.cb, tid, o1); }
 
     v4u stage[ROWS * CH];
-    v4u ty_stage[2][2];
-    issue_tile<ROWS, CH, NT>(a, cur, tid, stage, ty_stage);
+    issue_tile<ROWS, CH, NT>(a, cur, tid, stage);
 
     // In-kernel phase stamps exist only in the diagnostic build (-DIPX_DIAG=1, tools/build_diag.sh);
     // the shipped kernel executes none.
@@ -341,7 +311,7 @@ __global__ __launch_bounds__(NT) void band_pipe_kernel(BandArgs a)
 #endif
     for (;;) {
         // A: staged tile -> LDS (+ watermark copy)
-        drain_tile<ROWS, CH, NT>(a, cur, tid, stage, ty_stage, lds, ytap, any_glyph);
+        drain_tile<ROWS, CH, NT>(a, cur, tid, stage, lds, any_glyph);
         IPX_STAMP(0);
         __syncthreads();
         IPX_STAMP(1);
@@ -362,7 +332,7 @@ __global__ __launch_bounds__(NT) void band_pipe_kernel(BandArgs a)
             nxt.b = ni - nxt.cb * per_cb - nxt.f * a.nbands;
         }
         item_setup(a, nxt, has_next);
-        issue_tile<ROWS, CH, NT>(a, nxt, tid, stage, ty_stage);
+        issue_tile<ROWS, CH, NT>(a, nxt, tid, stage);
         IPX_STAMP(2);
 
         // C: the current item from LDS
@@ -373,8 +343,8 @@ __global__ __launch_bounds__(NT) void band_pipe_kernel(BandArgs a)
 #else
         if (a.nscale > 0) {
 #endif
-            scale_out<NX0, FP0, false, NT>(a, 0, cur.t, cur.f, lds, ytap, tid, o0, cur.dyA[0], cur.dyB[0]);
-            scale_out<NX1, FP1, false, NT>(a, 1, cur.t, cur.f, lds, ytap + kYChunk, tid, o1, cur.dyA[1], cur.dyB[1]);
+            scale_out<NX0, FP0, NT>(a, 0, cur.t, cur.f, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
+            scale_out<NX1, FP1, NT>(a, 1, cur.t, cur.f, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
         }
         IPX_STAMP(3);
         __syncthreads();

@@ -100,11 +100,13 @@ struct XTapT<true> {
     double w0, w1;
     float f0, f1;
     int base;
+    uint32_t iw;
 };
 template <>
 struct XTapT<false> {
     float f0, f1;
     int base;
+    uint32_t iw;
 };
 
 template <int NX, bool FP>
@@ -125,81 +127,210 @@ __device__ __forceinline__ void load_xtaps(const BandArgs &a, int k, int cb, int
     for (int i = 0; i < NX; i++) {
         const AxisTap *p = &S.xt[min(o.dxA + tid + NT * i, S.dw - 1)];
         if constexpr (FP) { o.tx[i].w0 = p->w0; o.tx[i].w1 = p->w1; }
-        o.tx[i].f0 = p->f0; o.tx[i].f1 = p->f1; o.tx[i].base = p->base;
+        o.tx[i].f0 = p->f0; o.tx[i].f1 = p->f1; o.tx[i].base = p->base; o.tx[i].iw = p->iw;
+    }
+}
+
+// ---- the packed-integer lerp (dyadic axes, RGBA8 taps) -------------------------------------------------
+// Same exact value as lerp_dyadic -- sum = y0*(x0*t00 + x1*t10) + y1*(x0*t01 + x1*t11), byte = (257*sum) >> (kx+ky+8) -- in
+// integer arithmetic shaped for few instructions:
+//   H   one tile row lerped horizontally for a thread's column, two channels per register (16-bit lanes: 8 + kx <= 16 bits):
+//       h_rb = x0*(p0 & 0x00ff00ff) + x1*(p1 & 0x00ff00ff), h_ga likewise on (p >> 8).  A thread's columns are fixed, so an H row
+//       is computed once and serves the output row above and the one below it (vertical scale < 2: 1.4 H rows per output row
+//       at 1080 -> 768 instead of 2);
+//   V   per channel one v_dot2_u32_u16 on the pair [H_top.c | H_bot.c << 16] and the packed weights [y0 | y1 << 16];
+//   out byte = mul_hi_u24(sum', 257 << (24 - k')): the y weights are pre-scaled so that k' = kx + ky' >= 9, which puts the byte
+//       (257*sum) >> (k + 8) into bits 32..39 of a 24 x 24 bit product.
+// Straight-line: every lane computes, dead lanes store to an out-of-range buffer offset.  Rows are walked in order; their tap
+// rows never decrease, so two H rows (top, bottom) with a scalar tag are all the state there is.
+struct HRow { uint32_t rb, ga; };
+
+__device__ __forceinline__ HRow h_row(const uint8_t *lds, int off, uint32_t x0, uint32_t x1)
+{
+    const uint32_t p0 = lds_u32(lds, off), p1 = lds_u32(lds, off + 4);
+    HRow h;
+    h.rb = __umul24(p0 & 0x00ff00ffu, x0) + __umul24(p1 & 0x00ff00ffu, x1);
+    // v_perm_b32: bytes {p.1, 0, p.3, 0} = (p >> 8) & 0x00ff00ff in one instruction
+    h.ga = __umul24(__builtin_amdgcn_perm(0u, p0, 0x0c030c01u), x0) + __umul24(__builtin_amdgcn_perm(0u, p1, 0x0c030c01u), x1);
+    return h;
+}
+
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, b), 0u, false);
+}
+// out[i] = byte r | byte g << 8 | byte b << 16 | byte a << 24 with byte c = mul_hi_u24(sum[i][c], m) (<= 255): four instructions per pixel,
+// the multiply writing its low byte straight into byte c of the result (SDWA dst_sel, the other bytes preserved).  gfx940+ need one
+// wait state between a dst_sel write and a VALU read of that register (LLVM's DstSelForwardingHazard; the compiler cannot see into
+// inline asm): the NX pixels of a thread are interleaved inside ONE asm statement per channel, so a register's next use is at least
+// NX >= 2 instructions away, and a lone pixel gets an s_nop.
+template <int NX>
+__device__ __forceinline__ void finish_bytes(const uint32_t (&sum)[NX][4], uint32_t m, uint32_t (&out)[NX])
+{
+    static_assert(NX == 1 || NX == 2 || NX == 4, "column counts the band kernels are built for");
+#define IPX_SDWA(B) "v_mul_hi_u32_u24_sdwa %0, %1, %2 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n"
+    if constexpr (NX == 1) {
+        asm("v_mul_hi_u32_u24_e32 %0, %1, %2" : "=v"(out[0]) : "v"(m), "v"(sum[0][0]));
+        asm(IPX_SDWA(1) "s_nop 0" : "+v"(out[0]) : "v"(m), "v"(sum[0][1]));
+        asm(IPX_SDWA(2) "s_nop 0" : "+v"(out[0]) : "v"(m), "v"(sum[0][2]));
+        asm(IPX_SDWA(3) "s_nop 0" : "+v"(out[0]) : "v"(m), "v"(sum[0][3]));
+    } else if constexpr (NX == 2) {
+#define IPX_SDWA2(B) "v_mul_hi_u32_u24_sdwa %0, %2, %3 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n" \
+                     "v_mul_hi_u32_u24_sdwa %1, %2, %4 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        asm("v_mul_hi_u32_u24_e32 %0, %2, %3\nv_mul_hi_u32_u24_e32 %1, %2, %4" : "=&v"(out[0]), "=&v"(out[1]) : "v"(m), "v"(sum[0][0]), "v"(sum[1][0]));
+        asm(IPX_SDWA2(1) : "+v"(out[0]), "+v"(out[1]) : "v"(m), "v"(sum[0][1]), "v"(sum[1][1]));
+        asm(IPX_SDWA2(2) : "+v"(out[0]), "+v"(out[1]) : "v"(m), "v"(sum[0][2]), "v"(sum[1][2]));
+        asm(IPX_SDWA2(3) : "+v"(out[0]), "+v"(out[1]) : "v"(m), "v"(sum[0][3]), "v"(sum[1][3]));
+#undef IPX_SDWA2
+    } else {
+#define IPX_SDWA4(B) "v_mul_hi_u32_u24_sdwa %0, %4, %5 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n" \
+                     "v_mul_hi_u32_u24_sdwa %1, %4, %6 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n" \
+                     "v_mul_hi_u32_u24_sdwa %2, %4, %7 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n" \
+                     "v_mul_hi_u32_u24_sdwa %3, %4, %8 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        asm("v_mul_hi_u32_u24_e32 %0, %4, %5\nv_mul_hi_u32_u24_e32 %1, %4, %6\nv_mul_hi_u32_u24_e32 %2, %4, %7\nv_mul_hi_u32_u24_e32 %3, %4, %8"
+            : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]) : "v"(m), "v"(sum[0][0]), "v"(sum[1][0]), "v"(sum[2][0]), "v"(sum[3][0]));
+        asm(IPX_SDWA4(1) : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]) : "v"(m), "v"(sum[0][1]), "v"(sum[1][1]), "v"(sum[2][1]), "v"(sum[3][1]));
+        asm(IPX_SDWA4(2) : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]) : "v"(m), "v"(sum[0][2]), "v"(sum[1][2]), "v"(sum[2][2]), "v"(sum[3][2]));
+        asm(IPX_SDWA4(3) : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]) : "v"(m), "v"(sum[0][3]), "v"(sum[1][3]), "v"(sum[2][3]), "v"(sum[3][3]));
+#undef IPX_SDWA4
+    }
+#undef IPX_SDWA
+}
+
+typedef const __attribute__((address_space(4))) AxisTap *ConstTapsFwd;
+template <int NX, bool FP, int NT>
+__device__ __forceinline__ void scale_rows_int(const ScaleOut &S, const Tile &t, const uint8_t *lds, ConstTapsFwd yt, int tid,
+                                               const OutCols<NX, FP> &o, __amdgpu_buffer_rsrc_t ors, int dyA, int dyB)
+{
+    const int ybias = S.sr_y0 - t.r0, xbias = S.sr_x0 - t.c0;
+    const uint32_t m3 = S.imul;
+    const int ysh = S.iyshift;
+    uint32_t x0[NX], x1[NX];
+    int lx[NX], voff[NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+        const int dx = o.dxA + tid + NT * i;
+        lx[i] = (xbias + o.tx[i].base) * 4;
+        x0[i] = o.tx[i].iw & 0xffffu; x1[i] = o.tx[i].iw >> 16;
+        voff[i] = dx < o.dxB ? dx * 4 : kOOB;
+    }
+    HRow top[NX], bot[NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) top[i] = bot[i] = HRow{0u, 0u};
+    int have = -4;                                   // the tile row `bot` holds; `top` holds row have - 1
+    int nb = yt[dyA].base;                           // scalar loads: the table is read through the constant address space
+    uint32_t niw = yt[dyA].iw;
+    int soff = dyA * S.ostride;
+    for (int dy = dyA; dy < dyB; dy++) {
+        const int b = ybias + nb;                    // tile row of the upper tap; the lower one is b + 1 (the halo at most)
+        const uint32_t yw = niw << ysh;
+        const int dn = min(dy + 1, dyB - 1);         // the next row's tap, fetched before this row's arithmetic
+        nb = yt[dn].base;
+        niw = yt[dn].iw;
+        if (b != have - 1) {                         // (b == have - 1: the same pair again, an upscaled axis)
+            if (b != have) {                         // a gap: the row that becomes the top row is not at hand
+#pragma unroll
+                for (int i = 0; i < NX; i++) bot[i] = h_row(lds, b * t.pitch + lx[i], x0[i], x1[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NX; i++) { top[i] = bot[i]; bot[i] = h_row(lds, (b + 1) * t.pitch + lx[i], x0[i], x1[i]); }
+        }
+        have = b + 1;
+        uint32_t sum[NX][4], v[NX];
+#pragma unroll
+        for (int i = 0; i < NX; i++) {               // [top.c | bot.c << 16] per channel, then y0 * top.c + y1 * bot.c
+            sum[i][0] = dot2_u16(__builtin_amdgcn_perm(bot[i].rb, top[i].rb, 0x05040100u), yw);
+            sum[i][1] = dot2_u16(__builtin_amdgcn_perm(bot[i].ga, top[i].ga, 0x05040100u), yw);
+            sum[i][2] = dot2_u16(__builtin_amdgcn_perm(bot[i].rb, top[i].rb, 0x07060302u), yw);
+            sum[i][3] = dot2_u16(__builtin_amdgcn_perm(bot[i].ga, top[i].ga, 0x07060302u), yw);
+        }
+        finish_bytes<NX>(sum, m3, v);
+#pragma unroll
+        for (int i = 0; i < NX; i++) __builtin_amdgcn_raw_buffer_store_b32(v[i], ors, voff[i], soff, 0);
+        soff += S.ostride;
     }
 }
 
 // Step 2 for one scaled output: its destination rows [dyA, dyB) x this thread's columns, from the
 // LDS tile.  Global memory is touched with stores only: on gfx9 loads and stores share vmcnt in issue
-// order, and a load in here would wait for every pixel store before it.  The y taps of the rows sit
-// in LDS (wave-uniform reads).  Rows outermost, the NX columns innermost and unrolled: a row's y tap
-// is fetched once for NX pixels and the NX x 4 tap reads are issued together, so their LDS latency
-// overlaps.  All reads are unconditional (clamped taps keep the addresses inside the tile); only the
-// store is predicated.
-template <int NX, bool FP, bool REFILL, int NT = 256>
+// order, and a vector load in here would wait for every pixel store before it.  The y taps are wave-uniform: they are
+// read from the plan's table through the constant address space, i.e. with scalar loads into SGPRs (lgkmcnt, not vmcnt; no
+// registers or LDS spent on staging them), the next row's tap while the current row computes.  Rows outermost, the NX columns
+// innermost and unrolled, so the NX x 4 tap reads are issued together and their LDS latency overlaps.  Straight-line: every lane
+// reads (clamped taps keep the addresses inside the tile) and computes; a lane without a column stores to an out-of-range buffer
+// offset, which the hardware drops -- no exec-mask branch around the arithmetic.
+typedef const __attribute__((address_space(4))) AxisTap *ConstTaps;
+__device__ __forceinline__ ConstTaps const_taps(const AxisTap *p) { return (ConstTaps)(uintptr_t)p; }
+struct YTapF32 { int base; float f0, f1; };
+struct YTapF64 { int base; double w0, w1; };
+
+template <int NX, bool FP, int NT = 256>
 __device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &t, int f, const uint8_t *lds,
-                                          AxisTap *ytap_k, int tid, const OutCols<NX, FP> &o, int dyA, int dyB)
+                                          int tid, const OutCols<NX, FP> &o, int dyA, int dyB)
 {
     if (k >= a.nscale || dyA >= dyB) return;
     const ScaleOut &S = a.sc[k];
     uint8_t *oframe = S.out + (size_t)f * S.frame_stride;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, S.dh * S.ostride, 0x00020000);
+    const ConstTaps yt = const_taps(S.yt);
+    if (S.imul) {   // dyadic axes within the packed-integer limits: the common case (1080p, 4K, 8K, 720p, 1440p to 1024 wide)
+        scale_rows_int<NX, FP, NT>(S, t, lds, yt, tid, o, ors, dyA, dyB);
+        return;
+    }
     const int ybias = S.sr_y0 - t.r0, xbias = S.sr_x0 - t.c0;
-    for (int chunk = dyA; chunk < dyB; chunk += kYChunk) {
-        const int rows = min(kYChunk, dyB - chunk);
-        if (REFILL && chunk != dyA) {  // more destination rows than one chunk: refill the y taps
-            __syncthreads();
-            ytap_k[tid & (kYChunk - 1)] = S.yt[min(chunk + (tid & (kYChunk - 1)), S.dh - 1)];
-            __syncthreads();
-        }
-        bool live[NX];
-        int lx[NX];
-        uint32_t *op[NX];
+    int lx[NX], voff[NX];
 #pragma unroll
-        for (int i = 0; i < NX; i++) {
-            const int dx = o.dxA + tid + NT * i;
-            live[i] = dx < o.dxB;
-            lx[i] = (xbias + o.tx[i].base) * 4;
-            op[i] = (uint32_t *)(oframe + (size_t)chunk * S.ostride + (size_t)dx * 4);
-        }
-        if (!FP || S.dyadic_shift >= 0) {
-            // both axes dyadic: every product and sum is exact in fp32 (8 + kx + ky <= 24 bits) and
-            // 257 * sum / 2^(kx+ky) is the reference's float64 value
-            const int sh = S.dyadic_shift + 8;
-            for (int r = 0; r < rows; r++) {
-                const int rowoff = (ybias + __builtin_amdgcn_readfirstlane(ytap_k[r].base)) * t.pitch;
-                const float yf0 = ytap_k[r].f0, yf1 = ytap_k[r].f1;
-                uint32_t p[NX][4];
+    for (int i = 0; i < NX; i++) {
+        const int dx = o.dxA + tid + NT * i;
+        lx[i] = (xbias + o.tx[i].base) * 4;
+        voff[i] = dx < o.dxB ? dx * 4 : kOOB;
+    }
+    int soff = dyA * S.ostride;
+    if (!FP || S.dyadic_shift >= 0) {
+        // both axes dyadic but beyond the integer path's lanes: every product and sum is exact in fp32 (8 + kx + ky <= 24 bits)
+        // and 257 * sum / 2^(kx+ky) is the reference's float64 value
+        const int sh = S.dyadic_shift + 8;
+        YTapF32 nx = {yt[dyA].base, yt[dyA].f0, yt[dyA].f1};
+        for (int dy = dyA; dy < dyB; dy++) {
+            const YTapF32 y = nx;
+            const int dn = min(dy + 1, dyB - 1);
+            nx = YTapF32{yt[dn].base, yt[dn].f0, yt[dn].f1};
+            const int rowoff = (ybias + y.base) * t.pitch;
+            uint32_t p[NX][4];
 #pragma unroll
-                for (int i = 0; i < NX; i++) {
-                    const int off = rowoff + lx[i];
-                    p[i][0] = lds_u32(lds, off); p[i][1] = lds_u32(lds, off + 4);
-                    p[i][2] = lds_u32(lds, off + t.pitch); p[i][3] = lds_u32(lds, off + t.pitch + 4);
-                }
-#pragma unroll
-                for (int i = 0; i < NX; i++) {
-                    const uint32_t v = lerp_dyadic(p[i][0], p[i][1], p[i][2], p[i][3], o.tx[i].f0, o.tx[i].f1, yf0, yf1, sh);
-                    if (live[i]) *op[i] = v;
-                    op[i] = (uint32_t *)((uint8_t *)op[i] + S.ostride);
-                }
+            for (int i = 0; i < NX; i++) {
+                const int off = rowoff + lx[i];
+                p[i][0] = lds_u32(lds, off); p[i][1] = lds_u32(lds, off + 4);
+                p[i][2] = lds_u32(lds, off + t.pitch); p[i][3] = lds_u32(lds, off + t.pitch + 4);
             }
-        } else if constexpr (FP) {
-            for (int r = 0; r < rows; r++) {
-                const int rowoff = (ybias + __builtin_amdgcn_readfirstlane(ytap_k[r].base)) * t.pitch;
-                const double yw0 = ytap_k[r].w0, yw1 = ytap_k[r].w1;
 #pragma unroll
-                for (int i = 0; i < NX; i++) {
-                    const int off = rowoff + lx[i];
-                    const uint32_t p00 = lds_u32(lds, off), p10 = lds_u32(lds, off + 4);
-                    const uint32_t p01 = lds_u32(lds, off + t.pitch), p11 = lds_u32(lds, off + t.pitch + 4);
-                    const double xw0 = o.tx[i].w0, xw1 = o.tx[i].w1;
-                    const uint32_t pr = lerp_channel<0>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
-                    const uint32_t pg = lerp_channel<1>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
-                    const uint32_t pb = lerp_channel<2>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
-                    const uint32_t pa = lerp_channel<3>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
-                    if (live[i]) *op[i] = pack_src(pr, pg, pb, pa);
-                    op[i] = (uint32_t *)((uint8_t *)op[i] + S.ostride);
-                }
+            for (int i = 0; i < NX; i++) {
+                const uint32_t v = lerp_dyadic(p[i][0], p[i][1], p[i][2], p[i][3], o.tx[i].f0, o.tx[i].f1, y.f0, y.f1, sh);
+                __builtin_amdgcn_raw_buffer_store_b32(v, ors, voff[i], soff, 0);
             }
+            soff += S.ostride;
+        }
+    } else if constexpr (FP) {
+        YTapF64 nx = {yt[dyA].base, yt[dyA].w0, yt[dyA].w1};
+        for (int dy = dyA; dy < dyB; dy++) {
+            const YTapF64 y = nx;
+            const int dn = min(dy + 1, dyB - 1);
+            nx = YTapF64{yt[dn].base, yt[dn].w0, yt[dn].w1};
+            const int rowoff = (ybias + y.base) * t.pitch;
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                const int off = rowoff + lx[i];
+                const uint32_t p00 = lds_u32(lds, off), p10 = lds_u32(lds, off + 4);
+                const uint32_t p01 = lds_u32(lds, off + t.pitch), p11 = lds_u32(lds, off + t.pitch + 4);
+                const double xw0 = o.tx[i].w0, xw1 = o.tx[i].w1;
+                const uint32_t pr = lerp_channel<0>(p00, p10, p01, p11, xw0, xw1, y.w0, y.w1);
+                const uint32_t pg = lerp_channel<1>(p00, p10, p01, p11, xw0, xw1, y.w0, y.w1);
+                const uint32_t pb = lerp_channel<2>(p00, p10, p01, p11, xw0, xw1, y.w0, y.w1);
+                const uint32_t pa = lerp_channel<3>(p00, p10, p01, p11, xw0, xw1, y.w0, y.w1);
+                __builtin_amdgcn_raw_buffer_store_b32(pack_src(pr, pg, pb, pa), ors, voff[i], soff, 0);
+            }
+            soff += S.ostride;
         }
     }
 }

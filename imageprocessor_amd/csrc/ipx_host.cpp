@@ -73,7 +73,7 @@ void build_axis_taps(int src_extent, int dst_extent, int d_begin, int d_end, Axi
         double f0 = s - (double)s0;
         double f1 = 1 - f0;
         AxisTap t;
-        t.pad = 0; t.f0 = 0; t.f1 = 0;
+        t.iw = 0; t.f0 = 0; t.f1 = 0;
         if (s < 0) {                 // both taps index 0, weights (1, 0)
             t.base = 0; t.w0 = 1; t.w1 = 0;
         } else if (s0 + 1 > last) {  // both taps index last, weights (0, 1)
@@ -85,9 +85,9 @@ void build_axis_taps(int src_extent, int dst_extent, int d_begin, int d_end, Axi
     }
 }
 
-int axis_dyadic_bits(AxisTap *taps, int n, int max_k)
+int axis_dyadic_bits(AxisTap *taps, int n, int max_k, int min_k)
 {
-    for (int k = 0; k <= max_k; k++) {
+    for (int k = min_k; k <= max_k; k++) {
         const double unit = (double)(1 << k);
         bool ok = true;
         for (int i = 0; i < n && ok; i++) {
@@ -98,6 +98,7 @@ int axis_dyadic_bits(AxisTap *taps, int n, int max_k)
         for (int i = 0; i < n; i++) {
             taps[i].f0 = (float)(taps[i].w0 * unit);
             taps[i].f1 = (float)(taps[i].w1 * unit);
+            taps[i].iw = (uint32_t)(taps[i].w0 * unit) | (uint32_t)(taps[i].w1 * unit) << 16;
         }
         return k;
     }

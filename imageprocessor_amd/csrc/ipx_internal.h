@@ -72,15 +72,16 @@ struct AxisTap {
     double w1;    // weight of src[base + 1] (xFrac0 / yFrac0 upstream)
     int32_t base;
     float f0, f1; // w0 * 2^k, w1 * 2^k as exact small integers when the axis is dyadic (see below)
-    int32_t pad;
+    uint32_t iw;  // the same two integers packed: (w0 * 2^k) | (w1 * 2^k) << 16; 0 when the axis is not dyadic
 };
 static_assert(sizeof(AxisTap) == 32, "AxisTap is loaded as two 16-byte words");
 void build_axis_taps(int src_extent, int dst_extent, int d_begin, int d_end, AxisTap *out);
 // Smallest k <= max_k such that every weight of the axis is an exact multiple of 2^-k and each
 // pair sums to exactly 1; -1 if there is none.  On such an axis every float64 product and sum of
 // the reference's lerp is exact (weights k bits, taps 16 bits), so the result equals the rational
-// value and can be computed in narrower exact arithmetic.  Fills f0 / f1 for that k.
-int axis_dyadic_bits(AxisTap *taps, int n, int max_k);
+// value and can be computed in narrower exact arithmetic.  Fills f0 / f1 / iw for that k.  min_k: the smallest k to report
+// (an axis that is exact at k = 0 is also exact at k = 1 with doubled weights).
+int axis_dyadic_bits(AxisTap *taps, int n, int max_k, int min_k = 0);
 
 // ---- kernel launchers (ipx_kernels.hip) --------------------------------------------------------
 struct ScaleArgs {
@@ -130,6 +131,8 @@ struct ScaleOut {
     int sr_x0, sr_y0;          // source rectangle origin
     const AxisTap *xt, *yt;    // dw / dh entries, device
     int dyadic_shift;          // kx + ky when both axes are dyadic, else -1 (float64 lerp)
+    uint32_t imul;             // packed-integer lerp (kx <= 8, ky <= 12, 1 <= kx + ky <= 16): 257 << (24 - k'), k' = max(kx + ky, 9); else 0
+    int iyshift;               // k' - (kx + ky): the y weights are scaled by 2^iyshift so that the output byte is mul_hi_u24(sum, imul)
     const int *row_begin;      // nbands+1 entries: first output row owned by each band
     const int *col_begin;      // ncolblk+1 entries
 };

@@ -800,7 +800,7 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
         build_axis_taps(s.sr.dx(), s.dw, 0, s.dw, xt[k].data());
         build_axis_taps(s.sr.dy(), s.dh, 0, s.dh, yt[k].data());
         if (!env_int("IPX_NO_DYADIC", 0)) {
-            const int kx = axis_dyadic_bits(xt[k].data(), s.dw, 12);
+            const int kx = axis_dyadic_bits(xt[k].data(), s.dw, 12, 1);   // kx >= 1 keeps kx + ky >= 1 for the packed-integer lerp
             const int ky = axis_dyadic_bits(yt[k].data(), s.dh, 12);
             if (kx >= 0 && ky >= 0 && kx + ky <= 16) { s.dyadic_shift = kx + ky; s.kx = kx; s.ky = ky; }  // 8 + kx + ky <= 24 bits
         }
@@ -907,6 +907,17 @@ int ipx_plan_query(const ipx_plan *plan, ipx_plan_info *info) try
 }
 IPX_CATCH_STATUS
 
+// multiplier of the packed-integer lerp (ScaleOut::imul), or 0 when the output's axes do not qualify
+static void plan_scale_imul(const PlanScale &ps, ScaleOut &o)
+{
+    o.imul = 0; o.iyshift = 0;
+    if (ps.dyadic_shift < 1 || ps.kx < 0 || ps.ky < 0 || ps.kx > 8 || ps.ky > 12 || ps.kx + ps.ky > 16) return;
+    if (env_int("IPX_NO_INTLERP", 0)) return;
+    const int k = ps.dyadic_shift, k2 = std::max(k, 9);
+    o.iyshift = k2 - k;                 // ky + iyshift <= 15: the scaled weights stay 16-bit lanes (ky <= 12, and iyshift > 0 only for k < 9)
+    o.imul = 257u << (24 - k2);
+}
+
 // the source rows of a batch entry: stride given by the caller, size by the plan
 static int plan_src_status(const char *who, const ipx_plan *pl, long long stride, int bpp)
 {
@@ -979,6 +990,7 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
             o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
             o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
             o.dyadic_shift = ps.dyadic_shift;
+            plan_scale_imul(ps, o);
             a.nx_out[a.nscale - 1] = pl->nx_out[k];
         }
         if (a.nscale == 1) a.sc[1] = a.sc[0];  // keeps the kernel's unconditional tap loads legal
@@ -1207,6 +1219,7 @@ static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, u
         o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
         o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
         o.dyadic_shift = ps.dyadic_shift;
+        if (mode[a.nscale - 1] == 1) plan_scale_imul(ps, o);   // RGBA8 taps only
         // 16-bit taps in u32: x0*tap + x1*tap < 2^24 and the weights below 2^9 keep every product in 24 x 24 bits
         if (mode[a.nscale - 1] == 0 && (ps.kx > 8 || ps.ky > 8)) o.dyadic_shift = -1;
         a.nx_out[a.nscale - 1] = pl->nx_out[k];

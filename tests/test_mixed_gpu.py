@@ -87,11 +87,11 @@ def test_mixed_queue_is_drained_once_by_two_pullers(ipx):
                                     chunk_bytes=32 << 20, max_chunk=4) for _ in range(2)]
         items = pullers[0].items_for(draw)
         q = SharedQueue(len(items), chunk=1)
-        done, errs = [0, 0], []
+        done, errs, ran = [0, 0], [], [set(), set()]
 
         def work(r):
             try:
-                done[r], _ = pullers[r].run(items, q)
+                done[r], _ = pullers[r].run(items, q, lambda si, m, s: ran[r].add((si, s)))
             except Exception as e:  # noqa: BLE001
                 errs.append(repr(e))
         ts = [threading.Thread(target=work, args=(r,)) for r in range(2)]
@@ -99,14 +99,13 @@ def test_mixed_queue_is_drained_once_by_two_pullers(ipx):
         [t.join() for t in ts]
         assert not errs, errs
         assert sum(done) == len(draw) and min(done) > 0
-        # the last chunk either puller ran is still the oracle's
-        for p in pullers:
-            si = 0
-            got = p.download(si, 0, 0)
-            want = oracle.process(p.pool[si][0], resize=RESIZE, thumb=THUMB, glyphs=p.glyphs[si], col=DEFAULT_COL)
-            # stream 0 of size 0 may not have run in this puller: compare only if its output buffer was written
-            if got["thumbnail"].any():
-                np.testing.assert_array_equal(got["thumbnail"], want["thumbnail"])
+        # whatever chunk ran last on a (size, stream) of either puller is still the oracle's
+        for r, p in enumerate(pullers):
+            for si, s_ in sorted(ran[r])[:3]:
+                got = p.download(si, s_, 0)
+                want = oracle.process(p.pool[si][0], resize=RESIZE, thumb=THUMB, glyphs=p.glyphs[si], col=DEFAULT_COL)
+                for k in ("resize", "thumbnail", "watermark"):
+                    np.testing.assert_array_equal(got[k], want[k])
             p.close()
 
 

@@ -3,8 +3,8 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 "$@" > $out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 "$@" > $out/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-frames 0 "$@" > $out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-frames 0 "$@" > $out/pmc_write.log 2>&1
 python3 - $out <<'PY'
 import csv,glob,sys,collections
 out=sys.argv[1]
