@@ -169,90 +169,149 @@ __global__ __launch_bounds__(256) void band_kernel(BandArgs a)
 
 // ---------------------------------------------------------------------------------------------
 // band_pipe_kernel: persistent, software-pipelined.  Items are ordered (column block, frame, band)
-// and each workgroup walks a contiguous run of them, so consecutive items are consecutive bands of
-// one frame (the halo row of one is the first row of the next: an L2 hit) and the x taps rarely
-// change.  Per item:
+// and each workgroup walks ONE contiguous run of them, so consecutive items are consecutive bands of
+// one frame and the x taps rarely change.  Per item:
 //     A  the staged tile (registers, loaded during the previous item's compute) -> LDS, and the
 //        owned chunks -> watermark frame;                                   barrier
 //     B  issue the NEXT item's tile loads into the same registers (ROWS*CH x 16 B per thread)
 //     C  composite + scale the current item from LDS, pixel stores;         barrier
 // The tile is laid over the workgroup as ROWS x CH slots per thread: slot (r, h) is tile row r,
-// chunk tid + 256*h, so every address is base + r*stride + constant: no per-slot division.
-// Template parameters: NXk = destination columns per thread of output k (256*NXk per column block),
+// chunk tid + NT*h, so every address is base + r*stride + constant: no per-slot division.
+//
+// Every source row is read from HBM ONCE: the halo row of a band is the first row of the next band,
+// which the same workgroup processes next, and the thread that loaded a chunk of it still holds that
+// chunk in its last staging slot -- it moves to slot 0 and only ROWS-1 rows are loaded (8 of 9: 11 % fewer
+// read requests, and no reliance on the halo row surviving in an L2 that 64 workgroups stream through).
+//
+// Clipping is the buffer descriptor's job: the source descriptor of an item starts at the tile's first
+// row and ends with its last one, the watermark descriptor covers the owned rows, so row slots beyond
+// either fall out of range by themselves (loads return 0, stores are dropped) and the per-slot
+// offset is one add; a thread whose chunk lies outside the tile (or, for stores, in the halo column)
+// carries an out-of-range base offset.  What depends only on the column block (those base offsets, the
+// LDS offsets, the x taps) is recomputed when the column block changes, i.e. almost never.
+// Template parameters: NXk = destination columns per thread of output k (NT*NXk per column block),
 // FPk = output k may be non-dyadic (float64 lerp, float64 x weights in registers).
 // ---------------------------------------------------------------------------------------------
 struct Item {
     int f, b, cb;
-    bool valid;
-    Tile t;
+    int r0, own_rows, rows_ld;
     int dyA[2], dyB[2];
 };
 
-__device__ __forceinline__ void item_setup(const BandArgs &a, Item &it, bool valid)
+typedef const __attribute__((address_space(4))) int *ConstInts;
+
+__device__ __forceinline__ void item_rows(const BandArgs &a, Item &it, bool valid)
 {
-    it.valid = valid;
-    it.t = make_tile(a, it.b, it.cb);
+    it.r0 = it.b * a.band_rows;
+    it.own_rows = min(a.band_rows, a.sh - it.r0);
+    it.rows_ld = min(it.own_rows + 1, a.sh - it.r0);
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        it.dyA[k] = a.nscale > 0 ? a.sc[k].row_begin[it.b] : 0;
-        it.dyB[k] = valid && k < a.nscale ? a.sc[k].row_begin[it.b + 1] : it.dyA[k];
+    for (int k = 0; k < 2; k++) {   // scalar loads (the tables are read through the constant address space)
+        const ConstInts rb = (ConstInts)(uintptr_t)a.sc[k].row_begin;
+        it.dyA[k] = a.nscale > 0 ? rb[it.b] : 0;
+        it.dyB[k] = valid && k < a.nscale ? rb[it.b + 1] : it.dyA[k];
     }
 }
 
-template <int ROWS, int CH, int NT>
-__device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, int tid, v4u (&stage)[ROWS * CH])
-{
-    const int frame_bytes = (a.sh - 1) * a.sstride + a.sw * 4;
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.src + (size_t)it.f * a.src_frame_stride), 0, frame_bytes, 0x00020000);
-#if IPX_DIAG
-    const int rows = it.valid && !(a.dbg & 2) ? it.t.rows_ld : 0;
-#else
-    const int rows = it.valid ? it.t.rows_ld : 0;   // no item: every offset out of range
-#endif
-    int voff[CH];
+// what a thread keeps per column block
+template <int CH>
+struct ColState {
+    int c0, c1, cols_ld, nchunk, own_cols;
+    int ld_voff[CH];    // byte offset of chunk h from the start of a frame row; kOOB: the chunk is outside the tile
+    int st_voff[CH];    // the same for the watermark store; kOOB: not owned (the halo column)
+    int loff[CH];       // LDS offset within a tile row
     bool in_tile[CH];
+    bool in_box[CH];    // the chunk's columns meet the text box
+};
+
+template <int CH, int NT>
+__device__ __forceinline__ void col_setup(const BandArgs &a, int cb, int tid, ColState<CH> &cs)
+{
+    cs.c0 = cb * a.blk_cols;
+    cs.c1 = min(cs.c0 + a.blk_cols, a.sw);
+    cs.cols_ld = min(cs.c1 + 1, a.sw) - cs.c0;
+    cs.nchunk = (cs.cols_ld + 3) >> 2;
+    cs.own_cols = cs.c1 - cs.c0;
 #pragma unroll
     for (int h = 0; h < CH; h++) {
-        const int ch = tid + NT * h;
-        in_tile[h] = ch < it.t.nchunk;
-        voff[h] = it.t.r0 * a.sstride + it.t.c0 * 4 + ch * 16;
-    }
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-#pragma unroll
-        for (int h = 0; h < CH; h++)   // r < rows is wave-uniform
-            stage[r * CH + h] = __builtin_amdgcn_raw_buffer_load_b128(srs, in_tile[h] && r < rows ? voff[h] + r * a.sstride : kOOB, 0, 0);
+        const int ch = tid + NT * h, x = cs.c0 + ch * 4;
+        cs.in_tile[h] = ch < cs.nchunk;
+        cs.loff[h] = ch * 16;
+        cs.ld_voff[h] = cs.in_tile[h] ? x * 4 : kOOB;
+        cs.st_voff[h] = ch * 4 < cs.own_cols ? x * 4 : kOOB;
+        cs.in_box[h] = x + 4 > a.gbox.x0 && x < a.gbox.x1;
     }
 }
 
+template <int CH>
+__device__ __forceinline__ Tile tile_of(const BandArgs &a, const Item &it, const ColState<CH> &cs)
+{
+    Tile t;
+    t.r0 = it.r0; t.r1 = it.r0 + it.own_rows; t.c0 = cs.c0; t.c1 = cs.c1;
+    t.rows_ld = it.rows_ld; t.cols_ld = cs.cols_ld;
+    t.pitch = (a.blk_cols + 4) * 4; t.nchunk = cs.nchunk;
+    t.own_rows = it.own_rows; t.own_cols = cs.own_cols;
+    return t;
+}
+
+// B: the tile loads of item `it`.  carry: slot 0 takes the chunk this thread holds in its last slot (the previous band's halo
+// row is this band's first row) and only rows 1 .. ROWS-1 are loaded.  valid = false: an empty descriptor, every load out of range.
 template <int ROWS, int CH, int NT>
-__device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, int tid, const v4u (&stage)[ROWS * CH],
+__device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, const ColState<CH> &cs, bool valid, bool carry,
+                                           v4u (&stage)[ROWS * CH])
+{
+    const int records = valid ? (it.rows_ld - 1) * a.sstride + a.sw * 4 : 0;
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.src + (size_t)it.f * a.src_frame_stride + (size_t)it.r0 * a.sstride), 0, records, 0x00020000);
+    if (carry) {
+#pragma unroll
+        for (int h = 0; h < CH; h++) stage[h] = stage[(ROWS - 1) * CH + h];
+#pragma unroll
+        for (int r = 1; r < ROWS; r++) {
+#pragma unroll
+            for (int h = 0; h < CH; h++) stage[r * CH + h] = __builtin_amdgcn_raw_buffer_load_b128(srs, cs.ld_voff[h] + r * a.sstride, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+            for (int h = 0; h < CH; h++) stage[r * CH + h] = __builtin_amdgcn_raw_buffer_load_b128(srs, cs.ld_voff[h] + r * a.sstride, 0, 0);
+        }
+    }
+}
+
+// A: registers -> LDS tile (ROWS rows are allocated; rows past the frame's end hold the zeros their loads returned and are never
+// read) and the owned chunks -> watermark frame.  Chunks that meet the text box are written by the composite step instead.
+template <int ROWS, int CH, int NT>
+__device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, const ColState<CH> &cs, const v4u (&stage)[ROWS * CH],
                                            uint8_t *lds, bool any_glyph)
 {
-    uint8_t *wframe = a.wm ? a.wm + (size_t)it.f * a.wm_frame_stride : nullptr;
-    const int wm_bytes = wframe ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wframe, 0, wm_bytes, 0x00020000);
-    const bool gl_rows = any_glyph && it.t.r0 < a.gbox.y1 && it.t.r1 > a.gbox.y0;   // wave-uniform
-    int woff[CH], loff[CH];
-    bool in_tile[CH], owned[CH];
+    const int pitch = (a.blk_cols + 4) * 4;
 #pragma unroll
     for (int h = 0; h < CH; h++) {
-        const int ch = tid + NT * h;
-        in_tile[h] = ch < it.t.nchunk;
-        loff[h] = ch * 16;
-        owned[h] = wframe && ch * 4 < it.t.own_cols;
-        woff[h] = it.t.r0 * a.wm_stride + it.t.c0 * 4 + ch * 16;
+        if (cs.in_tile[h]) {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) *(v4u *)(lds + r * pitch + cs.loff[h]) = stage[r * CH + h];
+        }
     }
+    if (!a.wm) return;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.wm + (size_t)it.f * a.wm_frame_stride + (size_t)it.r0 * a.wm_stride), 0, (it.own_rows - 1) * a.wm_stride + a.sw * 4,
+        0x00020000);
+    const bool gl_rows = any_glyph && it.r0 < a.gbox.y1 && it.r0 + it.own_rows > a.gbox.y0;   // wave-uniform
+    if (!gl_rows) {
 #pragma unroll
-    for (int r = 0; r < ROWS; r++) {
+        for (int r = 0; r < ROWS; r++) {
 #pragma unroll
-        for (int h = 0; h < CH; h++) {
-            if (r < it.t.rows_ld && in_tile[h]) *(v4u *)(lds + r * it.t.pitch + loff[h]) = stage[r * CH + h];
-            int off = r < it.t.own_rows && owned[h] ? woff[h] + r * a.wm_stride : kOOB;
-            // chunks that meet the text box are written by the composite step
-            if (gl_rows && chunk_in_textbox(a, it.t.c0 + (tid + NT * h) * 4, it.t.r0 + r)) off = kOOB;
-            __builtin_amdgcn_raw_buffer_store_b128(stage[r * CH + h], wrs, off, 0, 0);
+            for (int h = 0; h < CH; h++) __builtin_amdgcn_raw_buffer_store_b128(stage[r * CH + h], wrs, cs.st_voff[h] + r * a.wm_stride, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const bool row_in = it.r0 + r >= a.gbox.y0 && it.r0 + r < a.gbox.y1;
+#pragma unroll
+            for (int h = 0; h < CH; h++)
+                __builtin_amdgcn_raw_buffer_store_b128(stage[r * CH + h], wrs, row_in && cs.in_box[h] ? kOOB : cs.st_voff[h] + r * a.wm_stride, 0, 0);
         }
     }
 }
@@ -266,39 +325,39 @@ __global__ __launch_bounds__(NT, NT / 128) void band_pipe_kernel(BandArgs a)   /
 
     const int per_cb = a.nframes * a.nbands;
     const int items = per_cb * a.ncolblk;
-    // pipe_order 0: a workgroup walks a contiguous run of items (its own stream through HBM);
-    // pipe_order 1: the grid sweeps the items together, workgroup `slot` takes items slot, slot + G, ...;
-    //   slots are XCD-contiguous (blockIdx % 8 = XCD), so neighbouring bands (shared halo row) meet in one L2
-    //   and the whole chip reads / writes one moving window of ~G tiles.
     const int G = (int)gridDim.x;
-    int idx, idx_end, step;
-    if (a.pipe_order == 0) {
-        const int per = (items + G - 1) / G;
-        idx = blockIdx.x * per;
-        idx_end = min(items, idx + per);
-        step = 1;
-    } else {
-        const int bid = blockIdx.x;
-        idx = (G & 7) == 0 ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
-        idx_end = items;
-        step = G;
-    }
-    if (idx >= idx_end) return;
+    const int per = (items + G - 1) / G;
+    const int idx0 = blockIdx.x * per, idx_end = min(items, idx0 + per);
+    if (idx0 >= idx_end) return;
+    // pipe_order 1: a workgroup enters its run at an offset of its own and wraps around at the end.  Runs are whole frames more often
+    // than not (1024 frames x 135 bands over 512 workgroups = 2 frames each), and with every workgroup at the same band of "its"
+    // frame at the same time the chip's 512 streams sit at addresses a multiple of the frame size apart -- how well that spreads
+    // over the HBM channels depended on where the allocations happened to land (3.5 or 4.0 ms per launch, per process).
+    int idx = idx0 + (a.pipe_order ? (int)((blockIdx.x * 67u) % (unsigned)(idx_end - idx0)) : 0);
+    int left = idx_end - idx0;
 
     const bool any_glyph = a.nglyphs > 0 && a.wm;
+    const bool can_carry = a.band_rows + 1 == ROWS;    // the halo row sits in the last staging slot
 
     Item cur;
     cur.cb = idx / per_cb;
     cur.f = (idx - cur.cb * per_cb) / a.nbands;
     cur.b = idx - cur.cb * per_cb - cur.f * a.nbands;
-    item_setup(a, cur, true);
+    item_rows(a, cur, true);
+    ColState<CH> cs;
+    col_setup<CH, NT>(a, cur.cb, tid, cs);
 
     OutCols<NX0, FP0> o0;
     OutCols<NX1, FP1> o1;
     if (a.nscale > 0) { load_xtaps<NX0, FP0, NT>(a, 0, cur.cb, tid, o0); load_xtaps<NX1, FP1, NT>(a, 1, cur.cb, tid, o1); }
 
     v4u stage[ROWS * CH];
-    issue_tile<ROWS, CH, NT>(a, cur, tid, stage);
+#if IPX_DIAG
+    const bool do_loads = !(a.dbg & 2);
+#else
+    const bool do_loads = true;
+#endif
+    issue_tile<ROWS, CH, NT>(a, cur, cs, do_loads, false, stage);
 
     // In-kernel phase stamps exist only in the diagnostic build (-DIPX_DIAG=1, tools/build_diag.sh);
     // the shipped kernel executes none.
@@ -311,40 +370,50 @@ __global__ __launch_bounds__(NT, NT / 128) void band_pipe_kernel(BandArgs a)   /
 #endif
     for (;;) {
         // A: staged tile -> LDS (+ watermark copy)
-        drain_tile<ROWS, CH, NT>(a, cur, tid, stage, lds, any_glyph);
+        drain_tile<ROWS, CH, NT>(a, cur, cs, stage, lds, any_glyph);
         IPX_STAMP(0);
         __syncthreads();
         IPX_STAMP(1);
 
-        // B: the next item's loads go out now and land while C computes.  Past the end of the run
-        // the "item" is not valid: the same loads are issued with out-of-range offsets, which keeps
-        // this block free of branches around memory operations.
+        // B: the next item's loads go out now and land while C computes.  Past the end of the run there is no item: the same
+        // loads are issued against an empty descriptor, which keeps this block free of branches around memory operations.
         Item nxt;
-        const bool has_next = idx + step < idx_end;
-        if (!has_next) { nxt.b = cur.b; nxt.f = cur.f; nxt.cb = cur.cb; }
-        else if (step == 1) {
-            nxt.b = cur.b + 1; nxt.f = cur.f; nxt.cb = cur.cb;
-            if (nxt.b == a.nbands) { nxt.b = 0; if (++nxt.f == a.nframes) { nxt.f = 0; ++nxt.cb; } }
-        } else {
-            const int ni = idx + step;
-            nxt.cb = ni / per_cb;
-            nxt.f = (ni - nxt.cb * per_cb) / a.nbands;
-            nxt.b = ni - nxt.cb * per_cb - nxt.f * a.nbands;
+        const bool has_next = left > 1;
+        nxt.b = cur.b; nxt.f = cur.f; nxt.cb = cur.cb;
+        if (has_next) {
+            if (idx + 1 == idx_end) {                    // wrap to the start of the run (once per launch)
+                idx = idx0 - 1;
+                nxt.cb = idx0 / per_cb;
+                nxt.f = (idx0 - nxt.cb * per_cb) / a.nbands;
+                nxt.b = idx0 - nxt.cb * per_cb - nxt.f * a.nbands;
+            } else {
+                nxt.b = cur.b + 1;
+                if (nxt.b == a.nbands) { nxt.b = 0; if (++nxt.f == a.nframes) { nxt.f = 0; ++nxt.cb; } }
+            }
         }
-        item_setup(a, nxt, has_next);
-        issue_tile<ROWS, CH, NT>(a, nxt, tid, stage);
+        item_rows(a, nxt, has_next);
+        const Tile t = tile_of<CH>(a, cur, cs);          // before the column state may move on
+        if (nxt.cb != cur.cb) {                          // (the staged tile of `cur` is in LDS by now; cs serves the loads below)
+            // the current item still needs its own x taps in C: they stay in o0 / o1 until the end of the iteration
+            ColState<CH> ncs;
+            col_setup<CH, NT>(a, nxt.cb, tid, ncs);
+            issue_tile<ROWS, CH, NT>(a, nxt, ncs, has_next && do_loads, false, stage);
+            cs = ncs;
+        } else {
+            issue_tile<ROWS, CH, NT>(a, nxt, cs, has_next && do_loads, can_carry && has_next && nxt.b == cur.b + 1 && nxt.f == cur.f, stage);
+        }
         IPX_STAMP(2);
 
         // C: the current item from LDS
-        if (any_glyph && tile_meets_textbox(a, cur.t))
-            glyph_phase<NT>(a, cur.t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
+        if (any_glyph && tile_meets_textbox(a, t))
+            glyph_phase<NT>(a, t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
 #if IPX_DIAG
         if (a.nscale > 0 && !(a.dbg & 1)) {
 #else
         if (a.nscale > 0) {
 #endif
-            scale_out<NX0, FP0, NT>(a, 0, cur.t, cur.f, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
-            scale_out<NX1, FP1, NT>(a, 1, cur.t, cur.f, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
+            scale_out<NX0, FP0, NT>(a, 0, t, cur.f, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
+            scale_out<NX1, FP1, NT>(a, 1, t, cur.f, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
         }
         IPX_STAMP(3);
         __syncthreads();
@@ -356,7 +425,8 @@ __global__ __launch_bounds__(NT, NT / 128) void band_pipe_kernel(BandArgs a)   /
             load_xtaps<NX1, FP1, NT>(a, 1, nxt.cb, tid, o1);
         }
         cur = nxt;
-        idx += step;
+        idx++;
+        left--;
     }
 #if IPX_DIAG
     if (a.stamps && (tid & 63) == 0 && tid < 256)
@@ -383,6 +453,7 @@ hipError_t launch_pipe(const BandArgs &a, long long items, size_t lds, hipStream
     static KernelLaunchCache cache;
     int resident = 1;
     auto kern = band_pipe_kernel<NX0, FP0, NX1, FP1, ROWS, CH, NT>;
+    lds = (size_t)ROWS * (size_t)(a.blk_cols + 4) * 4;     // the tile alone: ROWS rows (y taps come through scalar loads)
     hipError_t e = cache.prepare((const void *)kern, NT, lds, &resident);
     if (e != hipSuccess) return e;
     const long long grid = std::min<long long>(items, (long long)a.cus * std::min(a.pipe_wgs, resident));

@@ -198,14 +198,14 @@ __device__ __forceinline__ void finish_bytes(const uint32_t (&sum)[NX][4], uint3
 #undef IPX_SDWA
 }
 
-typedef const __attribute__((address_space(4))) AxisTap *ConstTapsFwd;
+struct IntRow { uint32_t ctl, yw; };
+typedef const __attribute__((address_space(4))) IntRow *ConstRows;
 template <int NX, bool FP, int NT>
-__device__ __forceinline__ void scale_rows_int(const ScaleOut &S, const Tile &t, const uint8_t *lds, ConstTapsFwd yt, int tid,
+__device__ __forceinline__ void scale_rows_int(const ScaleOut &S, const Tile &t, const uint8_t *lds, int tid,
                                                const OutCols<NX, FP> &o, __amdgpu_buffer_rsrc_t ors, int dyA, int dyB)
 {
-    const int ybias = S.sr_y0 - t.r0, xbias = S.sr_x0 - t.c0;
+    const int xbias = S.sr_x0 - t.c0;
     const uint32_t m3 = S.imul;
-    const int ysh = S.iyshift;
     uint32_t x0[NX], x1[NX];
     int lx[NX], voff[NX];
 #pragma unroll
@@ -218,32 +218,30 @@ __device__ __forceinline__ void scale_rows_int(const ScaleOut &S, const Tile &t,
     HRow top[NX], bot[NX];
 #pragma unroll
     for (int i = 0; i < NX; i++) top[i] = bot[i] = HRow{0u, 0u};
-    int have = -4;                                   // the tile row `bot` holds; `top` holds row have - 1
-    int nb = yt[dyA].base;                           // scalar loads: the table is read through the constant address space
-    uint32_t niw = yt[dyA].iw;
+    // the row table is read through the constant address space: scalar loads, one row ahead of the arithmetic
+    ConstRows yr = (ConstRows)(uintptr_t)S.yrow + dyA;
+    IntRow nx = {yr[0].ctl, yr[0].yw};
     int soff = dyA * S.ostride;
-    for (int dy = dyA; dy < dyB; dy++) {
-        const int b = ybias + nb;                    // tile row of the upper tap; the lower one is b + 1 (the halo at most)
-        const uint32_t yw = niw << ysh;
-        const int dn = min(dy + 1, dyB - 1);         // the next row's tap, fetched before this row's arithmetic
-        nb = yt[dn].base;
-        niw = yt[dn].iw;
-        if (b != have - 1) {                         // (b == have - 1: the same pair again, an upscaled axis)
-            if (b != have) {                         // a gap: the row that becomes the top row is not at hand
+    for (int n = dyB - dyA; n > 0; n--) {
+        const IntRow row = nx;
+        ++yr;
+        nx = IntRow{yr[0].ctl, yr[0].yw};            // (the table carries one entry past the last row)
+        const int off = (int)(row.ctl & 0x0fffffffu);
+        if (row.ctl >> 28) {                         // 0: the same pair of tile rows as the row before (an upscaled axis)
+            if (row.ctl >> 29) {                     // 2: a gap -- the row that becomes the upper one is not at hand
 #pragma unroll
-                for (int i = 0; i < NX; i++) bot[i] = h_row(lds, b * t.pitch + lx[i], x0[i], x1[i]);
+                for (int i = 0; i < NX; i++) bot[i] = h_row(lds, off + lx[i], x0[i], x1[i]);
             }
 #pragma unroll
-            for (int i = 0; i < NX; i++) { top[i] = bot[i]; bot[i] = h_row(lds, (b + 1) * t.pitch + lx[i], x0[i], x1[i]); }
+            for (int i = 0; i < NX; i++) { top[i] = bot[i]; bot[i] = h_row(lds, off + t.pitch + lx[i], x0[i], x1[i]); }
         }
-        have = b + 1;
         uint32_t sum[NX][4], v[NX];
 #pragma unroll
         for (int i = 0; i < NX; i++) {               // [top.c | bot.c << 16] per channel, then y0 * top.c + y1 * bot.c
-            sum[i][0] = dot2_u16(__builtin_amdgcn_perm(bot[i].rb, top[i].rb, 0x05040100u), yw);
-            sum[i][1] = dot2_u16(__builtin_amdgcn_perm(bot[i].ga, top[i].ga, 0x05040100u), yw);
-            sum[i][2] = dot2_u16(__builtin_amdgcn_perm(bot[i].rb, top[i].rb, 0x07060302u), yw);
-            sum[i][3] = dot2_u16(__builtin_amdgcn_perm(bot[i].ga, top[i].ga, 0x07060302u), yw);
+            sum[i][0] = dot2_u16(__builtin_amdgcn_perm(bot[i].rb, top[i].rb, 0x05040100u), row.yw);
+            sum[i][1] = dot2_u16(__builtin_amdgcn_perm(bot[i].ga, top[i].ga, 0x05040100u), row.yw);
+            sum[i][2] = dot2_u16(__builtin_amdgcn_perm(bot[i].rb, top[i].rb, 0x07060302u), row.yw);
+            sum[i][3] = dot2_u16(__builtin_amdgcn_perm(bot[i].ga, top[i].ga, 0x07060302u), row.yw);
         }
         finish_bytes<NX>(sum, m3, v);
 #pragma unroll
@@ -275,7 +273,7 @@ __device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, S.dh * S.ostride, 0x00020000);
     const ConstTaps yt = const_taps(S.yt);
     if (S.imul) {   // dyadic axes within the packed-integer limits: the common case (1080p, 4K, 8K, 720p, 1440p to 1024 wide)
-        scale_rows_int<NX, FP, NT>(S, t, lds, yt, tid, o, ors, dyA, dyB);
+        scale_rows_int<NX, FP, NT>(S, t, lds, tid, o, ors, dyA, dyB);
         return;
     }
     const int ybias = S.sr_y0 - t.r0, xbias = S.sr_x0 - t.c0;

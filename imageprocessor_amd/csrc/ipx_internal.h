@@ -132,7 +132,10 @@ struct ScaleOut {
     const AxisTap *xt, *yt;    // dw / dh entries, device
     int dyadic_shift;          // kx + ky when both axes are dyadic, else -1 (float64 lerp)
     uint32_t imul;             // packed-integer lerp (kx <= 8, ky <= 12, 1 <= kx + ky <= 16): 257 << (24 - k'), k' = max(kx + ky, 9); else 0
-    int iyshift;               // k' - (kx + ky): the y weights are scaled by 2^iyshift so that the output byte is mul_hi_u24(sum, imul)
+    const uint32_t *yrow;      // with imul: per destination row {ctl, yw}, dh + 1 entries.  yw = the packed y weights scaled by
+                               // 2^(k' - kx - ky), so that the output byte is mul_hi_u24(sum, imul).  ctl = LDS byte offset of the upper
+                               // tap's tile row | code << 28: what the row needs of the two horizontally lerped tile rows a thread keeps --
+                               // 0 both at hand (same pair as the row before), 1 the previous lower row becomes the upper one, 2 both new
     const int *row_begin;      // nbands+1 entries: first output row owned by each band
     const int *col_begin;      // ncolblk+1 entries
 };

@@ -859,13 +859,31 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
         memcpy(blob.data() + off, src, bytes);
         return off;
     };
-    size_t off_xt[2] = {0, 0}, off_yt[2] = {0, 0}, off_rb[2] = {0, 0}, off_cb[2] = {0, 0};
+    size_t off_xt[2] = {0, 0}, off_yt[2] = {0, 0}, off_rb[2] = {0, 0}, off_cb[2] = {0, 0}, off_yr[2] = {0, 0};
     for (int k = 0; k < 2; k++) {
         if (xt[k].empty()) continue;
         off_xt[k] = put(xt[k].data(), xt[k].size() * sizeof(AxisTap));
         off_yt[k] = put(yt[k].data(), yt[k].size() * sizeof(AxisTap));
         off_rb[k] = put(rb[k].data(), rb[k].size() * sizeof(int));
         off_cb[k] = put(cbv[k].data(), cbv[k].size() * sizeof(int));
+        // the packed-integer lerp's row table (ScaleOut::yrow): RGBA8 taps, kx <= 8 (16-bit lanes hold 8 + kx bits), ky <= 12
+        PlanScale &s = pl->sc[k];
+        if (s.dyadic_shift < 1 || s.kx > 8 || s.ky > 12 || env_int("IPX_NO_INTLERP", 0)) continue;
+        const int kk = std::max(s.dyadic_shift, 9), ysh = kk - s.dyadic_shift;   // ky + ysh <= 15: the scaled weights stay 16-bit lanes
+        const uint32_t pitch = (uint32_t)(bc + 4) * 4;
+        std::vector<uint32_t> yr((size_t)(s.dh + 1) * 2, 0);
+        for (int d = 0; d < s.dh; d++) {
+            const int row = s.sr.y0 + yt[k][d].base, band = row / br;
+            uint32_t code = 2;                                   // the first row of a band finds nothing at hand
+            if (d > rb[k][band]) {
+                const int step = yt[k][d].base - yt[k][d - 1].base;
+                code = step == 0 ? 0 : step == 1 ? 1 : 2;
+            }
+            yr[2 * d] = (uint32_t)(row - band * br) * pitch | code << 28;
+            yr[2 * d + 1] = yt[k][d].iw << ysh;
+        }
+        s.imul = 257u << (24 - kk);
+        off_yr[k] = put(yr.data(), yr.size() * sizeof(uint32_t));
     }
     if (!blob.empty()) {
         hipError_t e = hipMalloc((void **)&pl->blob, blob.size());
@@ -882,6 +900,7 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
             s.yt = (AxisTap *)(pl->blob + off_yt[k]);
             s.row_begin = (int *)(pl->blob + off_rb[k]);
             s.col_begin = (int *)(pl->blob + off_cb[k]);
+            if (s.imul) s.yrow = (uint32_t *)(pl->blob + off_yr[k]);
         }
     }
     *out = pl;
@@ -906,17 +925,6 @@ int ipx_plan_query(const ipx_plan *plan, ipx_plan_info *info) try
     return IPX_OK;
 }
 IPX_CATCH_STATUS
-
-// multiplier of the packed-integer lerp (ScaleOut::imul), or 0 when the output's axes do not qualify
-static void plan_scale_imul(const PlanScale &ps, ScaleOut &o)
-{
-    o.imul = 0; o.iyshift = 0;
-    if (ps.dyadic_shift < 1 || ps.kx < 0 || ps.ky < 0 || ps.kx > 8 || ps.ky > 12 || ps.kx + ps.ky > 16) return;
-    if (env_int("IPX_NO_INTLERP", 0)) return;
-    const int k = ps.dyadic_shift, k2 = std::max(k, 9);
-    o.iyshift = k2 - k;                 // ky + iyshift <= 15: the scaled weights stay 16-bit lanes (ky <= 12, and iyshift > 0 only for k < 9)
-    o.imul = 257u << (24 - k2);
-}
 
 // the source rows of a batch entry: stride given by the caller, size by the plan
 static int plan_src_status(const char *who, const ipx_plan *pl, long long stride, int bpp)
@@ -990,17 +998,16 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
             o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
             o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
             o.dyadic_shift = ps.dyadic_shift;
-            plan_scale_imul(ps, o);
+            o.imul = ps.imul; o.yrow = ps.yrow;
             a.nx_out[a.nscale - 1] = pl->nx_out[k];
         }
         if (a.nscale == 1) a.sc[1] = a.sc[0];  // keeps the kernel's unconditional tap loads legal
         a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
         a.cr = col[0]; a.cg = col[1]; a.cb = col[2]; a.ca = col[3];
         if (!wm && a.nscale == 0) return IPX_OK;
-        // item order of the persistent kernel: the grid-interleaved sweep is steadier when outputs are scaled
-        // (run-to-run 3.63-3.74 ms against 3.65-4.13 ms on one box, profiles/r01_item_order.txt); a plain
-        // watermark copy is ~2 % faster with one contiguous run per workgroup
-        if (a.pipe_order < 0) a.pipe_order = env_int("IPX_PIPE_ORDER", a.nscale > 0 ? 1 : 0) ? 1 : 0;
+        // every workgroup of the persistent kernel walks one contiguous run of items; 1 = it enters the run at an offset of its own
+        // (IPX_PIPE_ORDER=0: every run from its first item -- bimodal from process to process, see band_pipe_kernel)
+        if (a.pipe_order < 0) a.pipe_order = env_int("IPX_PIPE_ORDER", 1) ? 1 : 0;
         IPX_HIP(launch_band(a, s));
         if (a.stamps) {
             unsigned long long h[8];
@@ -1219,7 +1226,7 @@ static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, u
         o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
         o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
         o.dyadic_shift = ps.dyadic_shift;
-        if (mode[a.nscale - 1] == 1) plan_scale_imul(ps, o);   // RGBA8 taps only
+        if (mode[a.nscale - 1] == 1) { o.imul = ps.imul; o.yrow = ps.yrow; }   // RGBA8 taps only
         // 16-bit taps in u32: x0*tap + x1*tap < 2^24 and the weights below 2^9 keep every product in 24 x 24 bits
         if (mode[a.nscale - 1] == 0 && (ps.kx > 8 || ps.ky > 8)) o.dyadic_shift = -1;
         a.nx_out[a.nscale - 1] = pl->nx_out[k];

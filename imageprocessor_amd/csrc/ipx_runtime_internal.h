@@ -83,6 +83,9 @@ struct PlanScale {
     int *row_begin = nullptr, *col_begin = nullptr;
     int dyadic_shift = -1;
     int kx = -1, ky = -1;   // dyadic bits per axis (dyadic_shift = kx + ky), -1 = not dyadic
+    // the packed-integer lerp (ScaleOut::imul / yrow): set when the axes qualify, see plan_int_rows()
+    uint32_t imul = 0;
+    uint32_t *yrow = nullptr;   // device: dh + 1 entries of {ctl, yw}
 };
 
 struct ipx_plan {
