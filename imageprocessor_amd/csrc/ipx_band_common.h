@@ -145,9 +145,12 @@ __device__ __forceinline__ void load_xtaps(const BandArgs &a, int k, int cb, int
 // rows never decrease, so two H rows (top, bottom) with a scalar tag are all the state there is.
 struct HRow { uint32_t rb, ga; };
 
+struct TapAsIs { static __device__ __forceinline__ uint32_t rgba8(uint32_t p) { return p; } };   // the tile holds RGBA8 pixels
+
+template <class Conv = TapAsIs>
 __device__ __forceinline__ HRow h_row(const uint8_t *lds, int off, uint32_t x0, uint32_t x1)
 {
-    const uint32_t p0 = lds_u32(lds, off), p1 = lds_u32(lds, off + 4);
+    const uint32_t p0 = Conv::rgba8(lds_u32(lds, off)), p1 = Conv::rgba8(lds_u32(lds, off + 4));
     HRow h;
     h.rb = __umul24(p0 & 0x00ff00ffu, x0) + __umul24(p1 & 0x00ff00ffu, x1);
     // v_perm_b32: bytes {p.1, 0, p.3, 0} = (p >> 8) & 0x00ff00ff in one instruction
@@ -200,7 +203,7 @@ __device__ __forceinline__ void finish_bytes(const uint32_t (&sum)[NX][4], uint3
 
 struct IntRow { uint32_t ctl, yw; };
 typedef const __attribute__((address_space(4))) IntRow *ConstRows;
-template <int NX, bool FP, int NT>
+template <int NX, bool FP, int NT, class Conv = TapAsIs>
 __device__ __forceinline__ void scale_rows_int(const ScaleOut &S, const Tile &t, const uint8_t *lds, int tid,
                                                const OutCols<NX, FP> &o, __amdgpu_buffer_rsrc_t ors, int dyA, int dyB)
 {
@@ -230,10 +233,10 @@ __device__ __forceinline__ void scale_rows_int(const ScaleOut &S, const Tile &t,
         if (row.ctl >> 28) {                         // 0: the same pair of tile rows as the row before (an upscaled axis)
             if (row.ctl >> 29) {                     // 2: a gap -- the row that becomes the upper one is not at hand
 #pragma unroll
-                for (int i = 0; i < NX; i++) bot[i] = h_row(lds, off + lx[i], x0[i], x1[i]);
+                for (int i = 0; i < NX; i++) bot[i] = h_row<Conv>(lds, off + lx[i], x0[i], x1[i]);
             }
 #pragma unroll
-            for (int i = 0; i < NX; i++) { top[i] = bot[i]; bot[i] = h_row(lds, off + t.pitch + lx[i], x0[i], x1[i]); }
+            for (int i = 0; i < NX; i++) { top[i] = bot[i]; bot[i] = h_row<Conv>(lds, off + t.pitch + lx[i], x0[i], x1[i]); }
         }
         uint32_t sum[NX][4], v[NX];
 #pragma unroll
@@ -327,6 +330,157 @@ __device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &
                 const uint32_t pb = lerp_channel<2>(p00, p10, p01, p11, xw0, xw1, y.w0, y.w1);
                 const uint32_t pa = lerp_channel<3>(p00, p10, p01, p11, xw0, xw1, y.w0, y.w1);
                 __builtin_amdgcn_raw_buffer_store_b32(pack_src(pr, pg, pb, pa), ors, voff[i], soff, 0);
+            }
+            soff += S.ostride;
+        }
+    }
+}
+
+// ---- scaled outputs of the kernels whose tile holds a source type that is converted per tap (ipx_band_ycc.hip, ipx_band_nrgba.hip) ----
+// Conv::NC        3: the converted alpha is constant 0xffff (YCbCr), 4: it is a channel like the others (NRGBA)
+// Conv::tap16     a tile dword -> the 16-bit channels the reference's scale_RGBA_<type>_* interpolates (mode 0)
+// Conv::rgba8     a tile dword -> the RGBA8 pixel of the reference's copy / draw routine for the type (mode 1: the crop thumbnail scales
+//                 the RGBA8 copy cropAndResize made, thumbnail.go:128-131)
+// Mode 0 on dyadic axes (kx, ky <= 8) is exact in u32: h.c = x0*t0.c + x1*t1.c (< 2^24), sum.c = y0'*h_top.c + y1'*h_bot.c with the y
+// weights scaled by 2^(16-kx-ky), so that the output byte is the TOP byte of the 32-bit sum; the H rows are reused between output
+// rows exactly as in the packed-integer lerp above (two converted taps per H row instead of four per pixel).
+struct IntRow16 { uint32_t ctl, y0, y1, pad; };
+typedef const __attribute__((address_space(4))) IntRow16 *ConstRows16;
+
+template <int NX, bool FP, int NT, class Conv>
+__device__ __forceinline__ void scale_rows_int16(const ScaleOut &S, const Tile &t, const uint8_t *lds, int tid,
+                                                 const OutCols<NX, FP> &o, __amdgpu_buffer_rsrc_t ors, int dyA, int dyB)
+{
+    constexpr int NC = Conv::NC;
+    const int xbias = S.sr_x0 - t.c0;
+    uint32_t x0[NX], x1[NX];
+    int lx[NX], voff[NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+        const int dx = o.dxA + tid + NT * i;
+        lx[i] = (xbias + o.tx[i].base) * 4;
+        x0[i] = o.tx[i].iw & 0xffffu; x1[i] = o.tx[i].iw >> 16;
+        voff[i] = dx < o.dxB ? dx * 4 : kOOB;
+    }
+    uint32_t top[NX][NC], bot[NX][NC];
+#pragma unroll
+    for (int i = 0; i < NX; i++)
+#pragma unroll
+        for (int j = 0; j < NC; j++) top[i][j] = bot[i][j] = 0;
+    auto h16 = [&](int off, int i, uint32_t (&h)[NC]) {
+        uint32_t t0[NC], t1[NC];
+        Conv::tap16(lds_u32(lds, off), t0);
+        Conv::tap16(lds_u32(lds, off + 4), t1);
+#pragma unroll
+        for (int j = 0; j < NC; j++) h[j] = __umul24(x0[i], t0[j]) + __umul24(x1[i], t1[j]);
+    };
+    ConstRows16 yr = (ConstRows16)(uintptr_t)S.yrow16 + dyA;
+    IntRow16 nx = {yr[0].ctl, yr[0].y0, yr[0].y1, 0};
+    int soff = dyA * S.ostride;
+    for (int n = dyB - dyA; n > 0; n--) {
+        const IntRow16 row = nx;
+        ++yr;
+        nx = IntRow16{yr[0].ctl, yr[0].y0, yr[0].y1, 0};     // (the table carries one entry past the last row)
+        const int off = (int)(row.ctl & 0x0fffffffu);
+        if (row.ctl >> 28) {
+            if (row.ctl >> 29) {
+#pragma unroll
+                for (int i = 0; i < NX; i++) h16(off + lx[i], i, bot[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+#pragma unroll
+                for (int j = 0; j < NC; j++) top[i][j] = bot[i][j];
+                h16(off + t.pitch + lx[i], i, bot[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            uint32_t sum[NC];
+#pragma unroll
+            for (int j = 0; j < NC; j++) sum[j] = __umul24(row.y0, top[i][j]) + __umul24(row.y1, bot[i][j]);
+            const uint32_t rg = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0703u);               // {r, g, 0, 0}: the top bytes
+            uint32_t v;
+            if constexpr (NC == 3) v = __builtin_amdgcn_perm(sum[2], rg, 0x0d070100u);            // {r, g, b, 0xff}
+            else v = rg | __builtin_amdgcn_perm(sum[3], sum[2], 0x07030c0cu);
+            __builtin_amdgcn_raw_buffer_store_b32(v, ors, voff[i], soff, 0);
+        }
+        soff += S.ostride;
+    }
+}
+
+template <class Conv>
+struct ConvRgba8 { static __device__ __forceinline__ uint32_t rgba8(uint32_t p) { return Conv::rgba8(p); } };
+
+__device__ __forceinline__ uint32_t lerp16_f64(uint32_t s00, uint32_t s10, uint32_t s01, uint32_t s11, double xw0, double xw1, double yw0,
+                                               double yw1)
+{
+    const double top = xw0 * (double)s00 + xw1 * (double)s10;
+    const double bot = xw0 * (double)s01 + xw1 * (double)s11;
+    return (uint32_t)(yw0 * top + yw1 * bot);
+}
+
+template <int NX, bool FP, int NT, class Conv>
+__device__ __forceinline__ void scale_out_conv(const BandArgs &a, int k, int mode, const Tile &t, int f, const uint8_t *lds, int tid,
+                                               const OutCols<NX, FP> &o, int dyA, int dyB)
+{
+    if (k >= a.nscale || dyA >= dyB) return;
+    const ScaleOut &S = a.sc[k];
+    uint8_t *oframe = S.out + (size_t)f * S.frame_stride;
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, S.dh * S.ostride, 0x00020000);
+    if (mode == 0 && S.yrow16) { scale_rows_int16<NX, FP, NT, Conv>(S, t, lds, tid, o, ors, dyA, dyB); return; }
+    if (mode == 1 && S.imul) { scale_rows_int<NX, FP, NT, ConvRgba8<Conv>>(S, t, lds, tid, o, ors, dyA, dyB); return; }
+    const ConstTaps yt = const_taps(S.yt);
+    const int ybias = S.sr_y0 - t.r0, xbias = S.sr_x0 - t.c0;
+    int lx[NX], voff[NX];
+#pragma unroll
+    for (int i = 0; i < NX; i++) {
+        const int dx = o.dxA + tid + NT * i;
+        lx[i] = (xbias + o.tx[i].base) * 4;
+        voff[i] = dx < o.dxB ? dx * 4 : kOOB;
+    }
+    int soff = dyA * S.ostride;
+    if (mode == 1 && (!FP || S.dyadic_shift >= 0)) {       // dyadic beyond the integer path's lanes: exact fp32 on the converted RGBA8 taps
+        const int sh = S.dyadic_shift + 8;
+        for (int dy = dyA; dy < dyB; dy++) {
+            const int rowoff = (ybias + yt[dy].base) * t.pitch;
+            const float yf0 = yt[dy].f0, yf1 = yt[dy].f1;
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                const int off = rowoff + lx[i];
+                const uint32_t p00 = Conv::rgba8(lds_u32(lds, off)), p10 = Conv::rgba8(lds_u32(lds, off + 4));
+                const uint32_t p01 = Conv::rgba8(lds_u32(lds, off + t.pitch)), p11 = Conv::rgba8(lds_u32(lds, off + t.pitch + 4));
+                __builtin_amdgcn_raw_buffer_store_b32(lerp_dyadic(p00, p10, p01, p11, o.tx[i].f0, o.tx[i].f1, yf0, yf1, sh), ors, voff[i], soff, 0);
+            }
+            soff += S.ostride;
+        }
+    } else if constexpr (FP) {                              // the reference's float64 lerp (a host-side rule turns mode 0 on dyadic axes beyond 8 bits into this as well)
+        for (int dy = dyA; dy < dyB; dy++) {
+            const int rowoff = (ybias + yt[dy].base) * t.pitch;
+            const double yw0 = yt[dy].w0, yw1 = yt[dy].w1;
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                const int off = rowoff + lx[i];
+                const uint32_t q00 = lds_u32(lds, off), q10 = lds_u32(lds, off + 4);
+                const uint32_t q01 = lds_u32(lds, off + t.pitch), q11 = lds_u32(lds, off + t.pitch + 4);
+                const double xw0 = o.tx[i].w0, xw1 = o.tx[i].w1;
+                uint32_t v;
+                if (mode == 0) {
+                    uint32_t t00[Conv::NC], t10[Conv::NC], t01[Conv::NC], t11[Conv::NC], pc[4];
+                    Conv::tap16(q00, t00); Conv::tap16(q10, t10); Conv::tap16(q01, t01); Conv::tap16(q11, t11);
+#pragma unroll
+                    for (int j = 0; j < Conv::NC; j++) pc[j] = lerp16_f64(t00[j], t10[j], t01[j], t11[j], xw0, xw1, yw0, yw1);
+                    if constexpr (Conv::NC == 3) pc[3] = 0xffffu;
+                    v = pack_src(pc[0], pc[1], pc[2], pc[3]);
+                } else {
+                    const uint32_t p00 = Conv::rgba8(q00), p10 = Conv::rgba8(q10), p01 = Conv::rgba8(q01), p11 = Conv::rgba8(q11);
+                    const uint32_t pr = lerp_channel<0>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
+                    const uint32_t pg = lerp_channel<1>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
+                    const uint32_t pb = lerp_channel<2>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
+                    const uint32_t pa = lerp_channel<3>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
+                    v = pack_src(pr, pg, pb, pa);
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(v, ors, voff[i], soff, 0);
             }
             soff += S.ostride;
         }

@@ -41,68 +41,68 @@ __device__ __forceinline__ uint32_t nrgba_rgba8(uint32_t p)
     const uint32_t r = ((p & 0xffu) * sa / 0xffu) >> 8, g = (((p >> 8) & 0xffu) * sa / 0xffu) >> 8, b = (((p >> 16) & 0xffu) * sa / 0xffu) >> 8;
     return r | (g << 8) | (b << 16) | (p & 0xff000000u);
 }
-// a tap as scale_RGBA_NRGBA_* reads it
-struct Rgba16 { uint32_t r, g, b, a; };
-__device__ __forceinline__ Rgba16 nrgba_tap16(uint32_t p)
-{
-    Rgba16 t;
-    t.a = (p >> 24) * 0x101u;
-    t.r = (p & 0xffu) * t.a / 0xffu;
-    t.g = ((p >> 8) & 0xffu) * t.a / 0xffu;
-    t.b = ((p >> 16) & 0xffu) * t.a / 0xffu;
-    return t;
-}
-__device__ __forceinline__ uint32_t lerp16_f64(uint32_t s00, uint32_t s10, uint32_t s01, uint32_t s11, double xw0, double xw1, double yw0,
-                                               double yw1)
-{
-    const double top = xw0 * (double)s00 + xw1 * (double)s10;
-    const double bot = xw0 * (double)s01 + xw1 * (double)s11;
-    return (uint32_t)(yw0 * top + yw1 * bot);
-}
-// dyadic axes, integer weights x0 + x1 = 2^kx <= 256, y0 + y1 = 2^ky <= 256: exact in u32, operands < 2^24
-__device__ __forceinline__ uint32_t lerp16_int(uint32_t s00, uint32_t s10, uint32_t s01, uint32_t s11, uint32_t x0, uint32_t x1, uint32_t y0,
-                                               uint32_t y1, int sh)
-{
-    const uint32_t top = __umul24(x0, s00) + __umul24(x1, s10);
-    const uint32_t bot = __umul24(x0, s01) + __umul24(x1, s11);
-    return (__umul24(y0, top) + __umul24(y1, bot)) >> sh;
-}
+// how the shared scale paths (ipx_band_common.h, scale_out_conv) read a tile dword (a non-premultiplied pixel)
+struct NrgbaConv {
+    static constexpr int NC = 4;
+    // a tap as scale_RGBA_NRGBA_* reads it: a16 = a * 0x101, c * a16 / 0xff
+    static __device__ __forceinline__ void tap16(uint32_t p, uint32_t (&c)[4])
+    {
+        c[3] = (p >> 24) * 0x101u;
+        c[0] = (p & 0xffu) * c[3] / 0xffu;
+        c[1] = ((p >> 8) & 0xffu) * c[3] / 0xffu;
+        c[2] = ((p >> 16) & 0xffu) * c[3] / 0xffu;
+    }
+    static __device__ __forceinline__ uint32_t rgba8(uint32_t p) { return nrgba_rgba8(p); }
+};
+
+typedef const __attribute__((address_space(4))) int *ConstIntsN;
 
 struct Stage { v4u px[kRows]; };
 
-__device__ __forceinline__ void issue_tile(const BandArgs &a, const Tile &t, int f, bool valid, int tid, Stage &st)
+// The tile loads of one item; clipping by the descriptor (it spans the tile's rows), an out-of-range base offset for a thread without
+// a chunk.  carry: slot 0 takes the chunk the thread holds in its last slot (the previous band's halo row is this band's first row)
+// and only rows 1 .. kRows-1 are loaded, so every source row is read from HBM once.
+__device__ __forceinline__ void issue_tile(const BandArgs &a, const Tile &t, int f, bool valid, bool carry, int tid, Stage &st)
 {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.src + (size_t)f * a.src_frame_stride), 0,
-                                                                        (a.sh - 1) * a.sstride + a.sw * 4, 0x00020000);
-    const int rows = valid ? t.rows_ld : 0;
-    const bool in_tile = tid < t.nchunk;
-    const int off = t.r0 * a.sstride + t.c0 * 4 + tid * 16;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.src + (size_t)f * a.src_frame_stride + (size_t)t.r0 * a.sstride), 0, valid ? (t.rows_ld - 1) * a.sstride + a.sw * 4 : 0, 0x00020000);
+    const int off = tid < t.nchunk ? t.c0 * 4 + tid * 16 : kOOB;
+    if (carry) {
+        st.px[0] = st.px[kRows - 1];
 #pragma unroll
-    for (int r = 0; r < kRows; r++)   // r < rows is wave-uniform
-        st.px[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, in_tile && r < rows ? off + r * a.sstride : kOOB, 0, 0);
+        for (int r = 1; r < kRows; r++) st.px[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + r * a.sstride, 0, 0);
+    } else {
+#pragma unroll
+        for (int r = 0; r < kRows; r++) st.px[r] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + r * a.sstride, 0, 0);
+    }
 }
 
-// staged pixels -> LDS tile as they are, and the owned pixels premultiplied -> watermark frame
+// staged pixels -> LDS tile as they are (kRows rows are allocated), and the owned pixels premultiplied -> watermark frame.  The last
+// tile row is never an owned one (band_rows + 1 <= kRows): neither premultiplied nor stored.
 __device__ __forceinline__ void drain_tile(const BandArgs &a, const Tile &t, int f, int tid, const Stage &st, uint8_t *lds, bool any_glyph)
 {
-    uint8_t *wframe = a.wm ? a.wm + (size_t)f * a.wm_frame_stride : nullptr;
-    const int wm_bytes = wframe ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0;
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)wframe, 0, wm_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.wm ? a.wm + (size_t)f * a.wm_frame_stride + (size_t)t.r0 * a.wm_stride : nullptr), 0,
+        a.wm ? (t.own_rows - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);
     const bool gl_rows = any_glyph && t.r0 < a.gbox.y1 && t.r1 > a.gbox.y0;   // wave-uniform
     const bool in_tile = tid < t.nchunk;
-    const bool owned = wframe && tid * 4 < t.own_cols;
-    const int woff = t.r0 * a.wm_stride + t.c0 * 4 + tid * 16;
+    const int x = t.c0 + tid * 4;
+    const int woff = tid * 4 < t.own_cols ? x * 4 : kOOB;
+    const bool in_box = gl_rows && x + 4 > a.gbox.x0 && x < a.gbox.x1;
     const int loff = tid * 16;
+    if (in_tile) {
 #pragma unroll
-    for (int r = 0; r < kRows; r++) {
+        for (int r = 0; r < kRows; r++) *(v4u *)(lds + r * t.pitch + loff) = st.px[r];
+    }
+    if (!a.wm) return;
+#pragma unroll
+    for (int r = 0; r < kRows - 1; r++) {
         const v4u p = st.px[r];
-        if (r < t.rows_ld && in_tile) *(v4u *)(lds + r * t.pitch + loff) = p;
         v4u rgba;
 #pragma unroll
         for (int i = 0; i < 4; i++) rgba[i] = nrgba_rgba8(p[i]);
-        int off = r < t.own_rows && owned ? woff + r * a.wm_stride : kOOB;
-        if (gl_rows && chunk_in_textbox(a, t.c0 + tid * 4, t.r0 + r)) off = kOOB;   // chunks that meet the text box are written by the composite step
-        __builtin_amdgcn_raw_buffer_store_b128(rgba, wrs, off, 0, 0);
+        const bool skip = in_box && t.r0 + r >= a.gbox.y0 && t.r0 + r < a.gbox.y1;   // chunks that meet the text box are written by the composite step
+        __builtin_amdgcn_raw_buffer_store_b128(rgba, wrs, skip ? kOOB : woff + r * a.wm_stride, 0, 0);
     }
 }
 
@@ -119,102 +119,6 @@ __device__ __forceinline__ void glyph_phase_nrgba(const BandArgs &a, const Tile 
     }
 }
 
-// One scaled output from the tile.  mode 0: taps -> 16-bit premultiplied, then interpolate (scale_RGBA_NRGBA_*);
-// mode 1: taps -> premultiplied RGBA8 first (the crop copy), then scale_RGBA_RGBA_*.
-template <int NX, bool FP>
-__device__ __forceinline__ void scale_out_nrgba(const BandArgs &a, int k, int mode, const Tile &t, int f, const uint8_t *lds,
-                                                const AxisTap *ytap_k, int tid, const OutCols<NX, FP> &o, int dyA, int dyB)
-{
-    if (k >= a.nscale || dyA >= dyB) return;
-    const ScaleOut &S = a.sc[k];
-    uint8_t *oframe = S.out + (size_t)f * S.frame_stride;
-    const int ybias = S.sr_y0 - t.r0, xbias = S.sr_x0 - t.c0;
-    const int rows = min(kYChunk, dyB - dyA);
-    bool live[NX];
-    int lx[NX];
-    uint32_t *op[NX];
-#pragma unroll
-    for (int i = 0; i < NX; i++) {
-        const int dx = o.dxA + tid + kNT * i;
-        live[i] = dx < o.dxB;
-        lx[i] = (xbias + o.tx[i].base) * 4;
-        op[i] = (uint32_t *)(oframe + (size_t)dyA * S.ostride + (size_t)dx * 4);
-    }
-    const bool dyadic = !FP || S.dyadic_shift >= 0;
-    if (dyadic && mode == 0) {
-        const int sh = S.dyadic_shift + 8;
-        uint32_t x0[NX], x1[NX];
-#pragma unroll
-        for (int i = 0; i < NX; i++) { x0[i] = (uint32_t)o.tx[i].f0; x1[i] = (uint32_t)o.tx[i].f1; }
-        for (int r = 0; r < rows; r++) {
-            const int rowoff = (ybias + __builtin_amdgcn_readfirstlane(ytap_k[r].base)) * t.pitch;
-            const uint32_t y0 = (uint32_t)ytap_k[r].f0, y1 = (uint32_t)ytap_k[r].f1;
-            uint32_t p[NX][4];
-#pragma unroll
-            for (int i = 0; i < NX; i++) {
-                const int off = rowoff + lx[i];
-                p[i][0] = lds_u32(lds, off); p[i][1] = lds_u32(lds, off + 4);
-                p[i][2] = lds_u32(lds, off + t.pitch); p[i][3] = lds_u32(lds, off + t.pitch + 4);
-            }
-#pragma unroll
-            for (int i = 0; i < NX; i++) {
-                const Rgba16 t00 = nrgba_tap16(p[i][0]), t10 = nrgba_tap16(p[i][1]), t01 = nrgba_tap16(p[i][2]), t11 = nrgba_tap16(p[i][3]);
-                const uint32_t pr = lerp16_int(t00.r, t10.r, t01.r, t11.r, x0[i], x1[i], y0, y1, sh);
-                const uint32_t pg = lerp16_int(t00.g, t10.g, t01.g, t11.g, x0[i], x1[i], y0, y1, sh);
-                const uint32_t pb = lerp16_int(t00.b, t10.b, t01.b, t11.b, x0[i], x1[i], y0, y1, sh);
-                const uint32_t pa = lerp16_int(t00.a, t10.a, t01.a, t11.a, x0[i], x1[i], y0, y1, sh);
-                if (live[i]) *op[i] = pr | (pg << 8) | (pb << 16) | (pa << 24);
-                op[i] = (uint32_t *)((uint8_t *)op[i] + S.ostride);
-            }
-        }
-    } else if (dyadic) {
-        const int sh = S.dyadic_shift + 8;
-        for (int r = 0; r < rows; r++) {
-            const int rowoff = (ybias + __builtin_amdgcn_readfirstlane(ytap_k[r].base)) * t.pitch;
-            const float yf0 = ytap_k[r].f0, yf1 = ytap_k[r].f1;
-#pragma unroll
-            for (int i = 0; i < NX; i++) {
-                const int off = rowoff + lx[i];
-                const uint32_t p00 = nrgba_rgba8(lds_u32(lds, off)), p10 = nrgba_rgba8(lds_u32(lds, off + 4));
-                const uint32_t p01 = nrgba_rgba8(lds_u32(lds, off + t.pitch)), p11 = nrgba_rgba8(lds_u32(lds, off + t.pitch + 4));
-                const uint32_t v = lerp_dyadic(p00, p10, p01, p11, o.tx[i].f0, o.tx[i].f1, yf0, yf1, sh);
-                if (live[i]) *op[i] = v;
-                op[i] = (uint32_t *)((uint8_t *)op[i] + S.ostride);
-            }
-        }
-    } else if constexpr (FP) {
-        for (int r = 0; r < rows; r++) {
-            const int rowoff = (ybias + __builtin_amdgcn_readfirstlane(ytap_k[r].base)) * t.pitch;
-            const double yw0 = ytap_k[r].w0, yw1 = ytap_k[r].w1;
-#pragma unroll
-            for (int i = 0; i < NX; i++) {
-                const int off = rowoff + lx[i];
-                const uint32_t q00 = lds_u32(lds, off), q10 = lds_u32(lds, off + 4);
-                const uint32_t q01 = lds_u32(lds, off + t.pitch), q11 = lds_u32(lds, off + t.pitch + 4);
-                const double xw0 = o.tx[i].w0, xw1 = o.tx[i].w1;
-                uint32_t v;
-                if (mode == 0) {
-                    const Rgba16 t00 = nrgba_tap16(q00), t10 = nrgba_tap16(q10), t01 = nrgba_tap16(q01), t11 = nrgba_tap16(q11);
-                    const uint32_t pr = lerp16_f64(t00.r, t10.r, t01.r, t11.r, xw0, xw1, yw0, yw1);
-                    const uint32_t pg = lerp16_f64(t00.g, t10.g, t01.g, t11.g, xw0, xw1, yw0, yw1);
-                    const uint32_t pb = lerp16_f64(t00.b, t10.b, t01.b, t11.b, xw0, xw1, yw0, yw1);
-                    const uint32_t pa = lerp16_f64(t00.a, t10.a, t01.a, t11.a, xw0, xw1, yw0, yw1);
-                    v = pack_src(pr, pg, pb, pa);
-                } else {
-                    const uint32_t p00 = nrgba_rgba8(q00), p10 = nrgba_rgba8(q10), p01 = nrgba_rgba8(q01), p11 = nrgba_rgba8(q11);
-                    const uint32_t pr = lerp_channel<0>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
-                    const uint32_t pg = lerp_channel<1>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
-                    const uint32_t pb = lerp_channel<2>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
-                    const uint32_t pa = lerp_channel<3>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
-                    v = pack_src(pr, pg, pb, pa);
-                }
-                if (live[i]) *op[i] = v;
-                op[i] = (uint32_t *)((uint8_t *)op[i] + S.ostride);
-            }
-        }
-    }
-}
-
 struct ItemN {
     int f, b, cb;
     Tile t;
@@ -225,30 +129,33 @@ __device__ __forceinline__ void item_setup(const BandArgs &a, ItemN &it, bool va
 {
     it.t = make_tile(a, it.b, it.cb);
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        it.dyA[k] = a.nscale > 0 ? a.sc[k].row_begin[it.b] : 0;
-        it.dyB[k] = valid && k < a.nscale ? a.sc[k].row_begin[it.b + 1] : it.dyA[k];
+    for (int k = 0; k < 2; k++) {   // scalar loads: the tables are read through the constant address space
+        const ConstIntsN rb = (ConstIntsN)(uintptr_t)a.sc[k].row_begin;
+        it.dyA[k] = a.nscale > 0 ? rb[it.b] : 0;
+        it.dyB[k] = valid && k < a.nscale ? rb[it.b + 1] : it.dyA[k];
     }
 }
 
 template <int NX0, bool FP0, int NX1, bool FP1>
-__global__ __launch_bounds__(kNT) void band_nrgba_kernel(NrgbaArgs A)
+__global__ __launch_bounds__(kNT, kNT / 128) void band_nrgba_kernel(NrgbaArgs A)
 {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = (uint8_t *)lds_raw;
     const BandArgs &a = A.b;
     const int tid = threadIdx.x;
 
+    // one contiguous run of (column block, frame, band) items per workgroup, entered at an offset of its own (band_pipe_kernel has the why)
     const int per_cb = a.nframes * a.nbands;
     const int items = per_cb * a.ncolblk;
     const int G = (int)gridDim.x;
-    // grid-interleaved, XCD-contiguous slots (band_pipe_kernel's pipe_order 1)
-    const int bid = blockIdx.x;
-    int idx = (G & 7) == 0 ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
-    if (idx >= items) return;
+    const int per = (items + G - 1) / G;
+    const int idx0 = blockIdx.x * per, idx_end = min(items, idx0 + per);
+    if (idx0 >= idx_end) return;
+    int idx = idx0 + (int)((blockIdx.x * 67u) % (unsigned)(idx_end - idx0));
+    int left = idx_end - idx0;
 
-    AxisTap *ytap = (AxisTap *)(lds + (a.band_rows + 1) * ((a.blk_cols + 4) * 4));  // [2][kYChunk]
     const bool any_glyph = a.nglyphs > 0 && a.wm;
+    const bool can_carry = a.band_rows + 1 == kRows;
 
     auto decode = [&](int i, ItemN &it) {
         it.cb = i / per_cb;
@@ -264,47 +171,33 @@ __global__ __launch_bounds__(kNT) void band_nrgba_kernel(NrgbaArgs A)
     if (a.nscale > 0) { load_xtaps<NX0, FP0, kNT>(a, 0, cur.cb, tid, o0); load_xtaps<NX1, FP1, kNT>(a, 1, cur.cb, tid, o1); }
 
     Stage st;
-    v4u ty_stage[2][2];
-    auto issue_ytaps = [&](const ItemN &it) {
-        if (a.nscale > 0) {
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const v4u *yp = (const v4u *)&a.sc[k].yt[min(it.dyA[k] + tid, a.sc[k].dh - 1)];
-                ty_stage[k][0] = yp[0]; ty_stage[k][1] = yp[1];
-            }
-        }
-    };
-    issue_tile(a, cur.t, cur.f, true, tid, st);
-    issue_ytaps(cur);
+    issue_tile(a, cur.t, cur.f, true, false, tid, st);
 
     for (;;) {
-        // A: staged pixels -> LDS tile + premultiplied watermark pixels; y taps -> LDS
+        // A: staged pixels -> LDS tile + premultiplied watermark pixels
         drain_tile(a, cur.t, cur.f, tid, st, lds, any_glyph);
-        if (a.nscale > 0) {
-#pragma unroll
-            for (int k = 0; k < 2; k++)
-                if (tid < min(cur.dyB[k] - cur.dyA[k], kYChunk)) {
-                    v4u *yl = (v4u *)&ytap[k * kYChunk + tid];
-                    yl[0] = ty_stage[k][0]; yl[1] = ty_stage[k][1];
-                }
-        }
         __syncthreads();
 
         // B: the next item's loads
         ItemN nxt;
-        const bool has_next = idx + G < items;
-        if (has_next) decode(idx + G, nxt);
-        else { nxt.b = cur.b; nxt.f = cur.f; nxt.cb = cur.cb; }
+        const bool has_next = left > 1;
+        nxt.b = cur.b; nxt.f = cur.f; nxt.cb = cur.cb;
+        if (has_next) {
+            if (idx + 1 == idx_end) { idx = idx0 - 1; decode(idx0, nxt); }     // wrap to the start of the run (once per launch)
+            else {
+                nxt.b = cur.b + 1;
+                if (nxt.b == a.nbands) { nxt.b = 0; if (++nxt.f == a.nframes) { nxt.f = 0; ++nxt.cb; } }
+            }
+        }
         item_setup(a, nxt, has_next);
-        issue_tile(a, nxt.t, nxt.f, has_next, tid, st);
-        issue_ytaps(nxt);
+        issue_tile(a, nxt.t, nxt.f, has_next, can_carry && has_next && nxt.b == cur.b + 1 && nxt.f == cur.f && nxt.cb == cur.cb, tid, st);
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, cur.t))
             glyph_phase_nrgba(a, cur.t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
         if (a.nscale > 0) {
-            scale_out_nrgba<NX0, FP0>(a, 0, A.mode[0], cur.t, cur.f, lds, ytap, tid, o0, cur.dyA[0], cur.dyB[0]);
-            scale_out_nrgba<NX1, FP1>(a, 1, A.mode[1], cur.t, cur.f, lds, ytap + kYChunk, tid, o1, cur.dyA[1], cur.dyB[1]);
+            scale_out_conv<NX0, FP0, kNT, NrgbaConv>(a, 0, A.mode[0], cur.t, cur.f, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
+            scale_out_conv<NX1, FP1, kNT, NrgbaConv>(a, 1, A.mode[1], cur.t, cur.f, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
         }
         __syncthreads();
 
@@ -314,7 +207,8 @@ __global__ __launch_bounds__(kNT) void band_nrgba_kernel(NrgbaArgs A)
             load_xtaps<NX1, FP1, kNT>(a, 1, nxt.cb, tid, o1);
         }
         cur = nxt;
-        idx += G;
+        idx++;
+        left--;
     }
 }
 
@@ -354,7 +248,7 @@ hipError_t launch_band_nrgba(const NrgbaArgs &A, hipStream_t s, bool *matched)
     const long long total = (long long)a.nbands * a.ncolblk * a.nframes;
     if (total <= 0) { *matched = true; return hipSuccess; }
     if (total > 0x7fffffffLL || !band_nrgba_supported(A)) return hipSuccess;
-    const size_t lds = band_lds_bytes(a.band_rows, a.blk_cols);
+    const size_t lds = (size_t)kRows * (size_t)(a.blk_cols + 4) * 4;     // the tile alone (y taps come through scalar loads)
     // a.nx_out counts blocks of 256 destination columns per column block; a 512-thread workgroup serves two each
     const int need0 = a.nscale > 0 ? (a.nx_out[0] + 1) / 2 : 0, need1 = a.nscale > 1 ? (a.nx_out[1] + 1) / 2 : 0;
     const bool fp0 = a.nscale > 0 && a.sc[0].dyadic_shift < 0;

@@ -136,6 +136,8 @@ struct ScaleOut {
                                // 2^(k' - kx - ky), so that the output byte is mul_hi_u24(sum, imul).  ctl = LDS byte offset of the upper
                                // tap's tile row | code << 28: what the row needs of the two horizontally lerped tile rows a thread keeps --
                                // 0 both at hand (same pair as the row before), 1 the previous lower row becomes the upper one, 2 both new
+    const uint32_t *yrow16;    // for 16-bit converted taps (YCbCr / NRGBA sources, kx and ky <= 8): {ctl, y0', y1', 0} per row, dh + 1
+                               // entries; the y weights scaled by 2^(16 - kx - ky): the output byte is the top byte of the u32 sum
     const int *row_begin;      // nbands+1 entries: first output row owned by each band
     const int *col_begin;      // ncolblk+1 entries
 };

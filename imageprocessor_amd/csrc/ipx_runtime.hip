@@ -859,7 +859,8 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
         memcpy(blob.data() + off, src, bytes);
         return off;
     };
-    size_t off_xt[2] = {0, 0}, off_yt[2] = {0, 0}, off_rb[2] = {0, 0}, off_cb[2] = {0, 0}, off_yr[2] = {0, 0};
+    size_t off_xt[2] = {0, 0}, off_yt[2] = {0, 0}, off_rb[2] = {0, 0}, off_cb[2] = {0, 0}, off_yr[2] = {0, 0}, off_y16[2] = {0, 0};
+    bool has_y16[2] = {false, false};
     for (int k = 0; k < 2; k++) {
         if (xt[k].empty()) continue;
         off_xt[k] = put(xt[k].data(), xt[k].size() * sizeof(AxisTap));
@@ -884,6 +885,16 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
         }
         s.imul = 257u << (24 - kk);
         off_yr[k] = put(yr.data(), yr.size() * sizeof(uint32_t));
+        if (s.kx <= 8 && s.ky <= 8) {   // the same walk for 16-bit converted taps (ScaleOut::yrow16)
+            std::vector<uint32_t> y16((size_t)(s.dh + 1) * 4, 0);
+            for (int d = 0; d < s.dh; d++) {
+                y16[4 * d] = yr[2 * d];
+                y16[4 * d + 1] = (yt[k][d].iw & 0xffffu) << (16 - s.dyadic_shift);
+                y16[4 * d + 2] = (yt[k][d].iw >> 16) << (16 - s.dyadic_shift);
+            }
+            off_y16[k] = put(y16.data(), y16.size() * sizeof(uint32_t));
+            has_y16[k] = true;
+        }
     }
     if (!blob.empty()) {
         hipError_t e = hipMalloc((void **)&pl->blob, blob.size());
@@ -901,6 +912,7 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
             s.row_begin = (int *)(pl->blob + off_rb[k]);
             s.col_begin = (int *)(pl->blob + off_cb[k]);
             if (s.imul) s.yrow = (uint32_t *)(pl->blob + off_yr[k]);
+            if (has_y16[k]) s.yrow16 = (uint32_t *)(pl->blob + off_y16[k]);
         }
     }
     *out = pl;
@@ -1227,6 +1239,7 @@ static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, u
         o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
         o.dyadic_shift = ps.dyadic_shift;
         if (mode[a.nscale - 1] == 1) { o.imul = ps.imul; o.yrow = ps.yrow; }   // RGBA8 taps only
+        else o.yrow16 = ps.yrow16;
         // 16-bit taps in u32: x0*tap + x1*tap < 2^24 and the weights below 2^9 keep every product in 24 x 24 bits
         if (mode[a.nscale - 1] == 0 && (ps.kx > 8 || ps.ky > 8)) o.dyadic_shift = -1;
         a.nx_out[a.nscale - 1] = pl->nx_out[k];

@@ -86,6 +86,7 @@ struct PlanScale {
     // the packed-integer lerp (ScaleOut::imul / yrow): set when the axes qualify, see plan_int_rows()
     uint32_t imul = 0;
     uint32_t *yrow = nullptr;   // device: dh + 1 entries of {ctl, yw}
+    uint32_t *yrow16 = nullptr; // device: dh + 1 entries of {ctl, y0', y1', 0} (ScaleOut::yrow16), when kx and ky <= 8
 };
 
 struct ipx_plan {

@@ -3,7 +3,9 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/pmci_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $out -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --e2e-frames 0 "$@" > $out/log.txt 2>&1
+# IPX_PMC_CMD="python3 tools/bench_ycbcr.py 1024": profile that instead of bench.py
+if [ -n "$IPX_PMC_CMD" ]; then cmd="$IPX_PMC_CMD"; else cmd="python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --e2e-frames 0 $*"; fi
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $out -- $cmd > $out/log.txt 2>&1
 python3 - "$out" "$tag" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)
