@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void band_kernel(BandArgs a)
     // the composite goes first so that its few loads are not queued behind the pixel stores
     if (glyph_tile) glyph_phase(a, t, wframe, lds, tid);
     if (a.nscale > 0) {
-        scale_out<NX, true>(a, 0, t, f, lds, tid, o0, dyA[0], dyB[0]);
-        scale_out<NX, true>(a, 1, t, f, lds, tid, o1, dyA[1], dyB[1]);
+        scale_out<NX, true>(a, 0, t, a.sc[0].out + (size_t)f * a.sc[0].frame_stride, lds, tid, o0, dyA[0], dyB[0]);
+        scale_out<NX, true>(a, 1, t, a.sc[1].out + (size_t)f * a.sc[1].frame_stride, lds, tid, o1, dyA[1], dyB[1]);
     }
 }
 
@@ -257,12 +257,11 @@ __device__ __forceinline__ Tile tile_of(const BandArgs &a, const Item &it, const
 // B: the tile loads of item `it`.  carry: slot 0 takes the chunk this thread holds in its last slot (the previous band's halo
 // row is this band's first row) and only rows 1 .. ROWS-1 are loaded.  valid = false: an empty descriptor, every load out of range.
 template <int ROWS, int CH, int NT>
-__device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, const ColState<CH> &cs, bool valid, bool carry,
-                                           v4u (&stage)[ROWS * CH])
+__device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, const uint8_t *sframe, const ColState<CH> &cs, bool valid,
+                                           bool carry, v4u (&stage)[ROWS * CH])
 {
     const int records = valid ? (it.rows_ld - 1) * a.sstride + a.sw * 4 : 0;
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.src + (size_t)it.f * a.src_frame_stride + (size_t)it.r0 * a.sstride), 0, records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)(sframe + (size_t)it.r0 * a.sstride), 0, records, 0x00020000);
     if (carry) {
 #pragma unroll
         for (int h = 0; h < CH; h++) stage[h] = stage[(ROWS - 1) * CH + h];
@@ -283,8 +282,8 @@ __device__ __forceinline__ void issue_tile(const BandArgs &a, const Item &it, co
 // A: registers -> LDS tile (ROWS rows are allocated; rows past the frame's end hold the zeros their loads returned and are never
 // read) and the owned chunks -> watermark frame.  Chunks that meet the text box are written by the composite step instead.
 template <int ROWS, int CH, int NT>
-__device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, const ColState<CH> &cs, const v4u (&stage)[ROWS * CH],
-                                           uint8_t *lds, bool any_glyph)
+__device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, uint8_t *wframe, const ColState<CH> &cs,
+                                           const v4u (&stage)[ROWS * CH], uint8_t *lds, bool any_glyph)
 {
     const int pitch = (a.blk_cols + 4) * 4;
 #pragma unroll
@@ -296,8 +295,7 @@ __device__ __forceinline__ void drain_tile(const BandArgs &a, const Item &it, co
     }
     if (!a.wm) return;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.wm + (size_t)it.f * a.wm_frame_stride + (size_t)it.r0 * a.wm_stride), 0, (it.own_rows - 1) * a.wm_stride + a.sw * 4,
-        0x00020000);
+        (void *)(wframe + (size_t)it.r0 * a.wm_stride), 0, (it.own_rows - 1) * a.wm_stride + a.sw * 4, 0x00020000);
     const bool gl_rows = any_glyph && it.r0 < a.gbox.y1 && it.r0 + it.own_rows > a.gbox.y0;   // wave-uniform
     if (!gl_rows) {
 #pragma unroll
@@ -357,7 +355,9 @@ __global__ __launch_bounds__(NT, NT / 128) void band_pipe_kernel(BandArgs a)   /
 #else
     const bool do_loads = true;
 #endif
-    issue_tile<ROWS, CH, NT>(a, cur, cs, do_loads, false, stage);
+    const uint8_t *sframe = a.src + (size_t)cur.f * a.src_frame_stride;     // of the item whose loads go out next
+    OutBases ob = out_bases(a, cur.f);                                      // of the item being drained / computed
+    issue_tile<ROWS, CH, NT>(a, cur, sframe, cs, do_loads, false, stage);
 
     // In-kernel phase stamps exist only in the diagnostic build (-DIPX_DIAG=1, tools/build_diag.sh);
     // the shipped kernel executes none.
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(NT, NT / 128) void band_pipe_kernel(BandArgs a)   /
 #endif
     for (;;) {
         // A: staged tile -> LDS (+ watermark copy)
-        drain_tile<ROWS, CH, NT>(a, cur, cs, stage, lds, any_glyph);
+        drain_tile<ROWS, CH, NT>(a, cur, ob.wm, cs, stage, lds, any_glyph);
         IPX_STAMP(0);
         __syncthreads();
         IPX_STAMP(1);
@@ -392,28 +392,29 @@ __global__ __launch_bounds__(NT, NT / 128) void band_pipe_kernel(BandArgs a)   /
             }
         }
         item_rows(a, nxt, has_next);
+        if (nxt.f != cur.f) sframe = a.src + (size_t)nxt.f * a.src_frame_stride;
         const Tile t = tile_of<CH>(a, cur, cs);          // before the column state may move on
         if (nxt.cb != cur.cb) {                          // (the staged tile of `cur` is in LDS by now; cs serves the loads below)
             // the current item still needs its own x taps in C: they stay in o0 / o1 until the end of the iteration
             ColState<CH> ncs;
             col_setup<CH, NT>(a, nxt.cb, tid, ncs);
-            issue_tile<ROWS, CH, NT>(a, nxt, ncs, has_next && do_loads, false, stage);
+            issue_tile<ROWS, CH, NT>(a, nxt, sframe, ncs, has_next && do_loads, false, stage);
             cs = ncs;
         } else {
-            issue_tile<ROWS, CH, NT>(a, nxt, cs, has_next && do_loads, can_carry && has_next && nxt.b == cur.b + 1 && nxt.f == cur.f, stage);
+            issue_tile<ROWS, CH, NT>(a, nxt, sframe, cs, has_next && do_loads, can_carry && has_next && nxt.b == cur.b + 1 && nxt.f == cur.f, stage);
         }
         IPX_STAMP(2);
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, t))
-            glyph_phase<NT>(a, t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
+            glyph_phase<NT>(a, t, ob.wm, lds, tid);
 #if IPX_DIAG
         if (a.nscale > 0 && !(a.dbg & 1)) {
 #else
         if (a.nscale > 0) {
 #endif
-            scale_out<NX0, FP0, NT>(a, 0, t, cur.f, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
-            scale_out<NX1, FP1, NT>(a, 1, t, cur.f, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
+            scale_out<NX0, FP0, NT>(a, 0, t, ob.o0, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
+            scale_out<NX1, FP1, NT>(a, 1, t, ob.o1, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
         }
         IPX_STAMP(3);
         __syncthreads();
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(NT, NT / 128) void band_pipe_kernel(BandArgs a)   /
             load_xtaps<NX0, FP0, NT>(a, 0, nxt.cb, tid, o0);
             load_xtaps<NX1, FP1, NT>(a, 1, nxt.cb, tid, o1);
         }
+        if (nxt.f != cur.f) ob = out_bases(a, nxt.f);
         cur = nxt;
         idx++;
         left--;

@@ -88,6 +88,18 @@ __device__ __forceinline__ void glyph_phase(const BandArgs &a, const Tile &t, ui
     }
 }
 
+// Where the frames of one batch index start: 64-bit products of the frame index, recomputed only when the index changes (a
+// workgroup walks the bands of a frame one after the other), not per item.
+struct OutBases { uint8_t *wm, *o0, *o1; };
+__device__ __forceinline__ OutBases out_bases(const BandArgs &a, int f)
+{
+    OutBases b;
+    b.wm = a.wm ? a.wm + (size_t)f * a.wm_frame_stride : nullptr;
+    b.o0 = a.sc[0].out + (size_t)f * a.sc[0].frame_stride;
+    b.o1 = a.sc[1].out + (size_t)f * a.sc[1].frame_stride;
+    return b;
+}
+
 // ---- per-output state a thread keeps in registers -------------------------------------------------
 // A thread serves destination columns dxA + tid + NT*i, i < NX, of one scaled output (NT = threads of
 // the workgroup).  FP = the
@@ -267,12 +279,11 @@ struct YTapF32 { int base; float f0, f1; };
 struct YTapF64 { int base; double w0, w1; };
 
 template <int NX, bool FP, int NT = 256>
-__device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &t, int f, const uint8_t *lds,
+__device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &t, uint8_t *oframe, const uint8_t *lds,
                                           int tid, const OutCols<NX, FP> &o, int dyA, int dyB)
 {
     if (k >= a.nscale || dyA >= dyB) return;
     const ScaleOut &S = a.sc[k];
-    uint8_t *oframe = S.out + (size_t)f * S.frame_stride;
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, S.dh * S.ostride, 0x00020000);
     const ConstTaps yt = const_taps(S.yt);
     if (S.imul) {   // dyadic axes within the packed-integer limits: the common case (1080p, 4K, 8K, 720p, 1440p to 1024 wide)
@@ -421,12 +432,11 @@ __device__ __forceinline__ uint32_t lerp16_f64(uint32_t s00, uint32_t s10, uint3
 }
 
 template <int NX, bool FP, int NT, class Conv>
-__device__ __forceinline__ void scale_out_conv(const BandArgs &a, int k, int mode, const Tile &t, int f, const uint8_t *lds, int tid,
+__device__ __forceinline__ void scale_out_conv(const BandArgs &a, int k, int mode, const Tile &t, uint8_t *oframe, const uint8_t *lds, int tid,
                                                const OutCols<NX, FP> &o, int dyA, int dyB)
 {
     if (k >= a.nscale || dyA >= dyB) return;
     const ScaleOut &S = a.sc[k];
-    uint8_t *oframe = S.out + (size_t)f * S.frame_stride;
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, S.dh * S.ostride, 0x00020000);
     if (mode == 0 && S.yrow16) { scale_rows_int16<NX, FP, NT, Conv>(S, t, lds, tid, o, ors, dyA, dyB); return; }
     if (mode == 1 && S.imul) { scale_rows_int<NX, FP, NT, ConvRgba8<Conv>>(S, t, lds, tid, o, ors, dyA, dyB); return; }

@@ -62,10 +62,10 @@ struct Stage { v4u px[kRows]; };
 // The tile loads of one item; clipping by the descriptor (it spans the tile's rows), an out-of-range base offset for a thread without
 // a chunk.  carry: slot 0 takes the chunk the thread holds in its last slot (the previous band's halo row is this band's first row)
 // and only rows 1 .. kRows-1 are loaded, so every source row is read from HBM once.
-__device__ __forceinline__ void issue_tile(const BandArgs &a, const Tile &t, int f, bool valid, bool carry, int tid, Stage &st)
+__device__ __forceinline__ void issue_tile(const BandArgs &a, const Tile &t, const uint8_t *sframe, bool valid, bool carry, int tid, Stage &st)
 {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.src + (size_t)f * a.src_frame_stride + (size_t)t.r0 * a.sstride), 0, valid ? (t.rows_ld - 1) * a.sstride + a.sw * 4 : 0, 0x00020000);
+        (void *)(sframe + (size_t)t.r0 * a.sstride), 0, valid ? (t.rows_ld - 1) * a.sstride + a.sw * 4 : 0, 0x00020000);
     const int off = tid < t.nchunk ? t.c0 * 4 + tid * 16 : kOOB;
     if (carry) {
         st.px[0] = st.px[kRows - 1];
@@ -79,10 +79,10 @@ __device__ __forceinline__ void issue_tile(const BandArgs &a, const Tile &t, int
 
 // staged pixels -> LDS tile as they are (kRows rows are allocated), and the owned pixels premultiplied -> watermark frame.  The last
 // tile row is never an owned one (band_rows + 1 <= kRows): neither premultiplied nor stored.
-__device__ __forceinline__ void drain_tile(const BandArgs &a, const Tile &t, int f, int tid, const Stage &st, uint8_t *lds, bool any_glyph)
+__device__ __forceinline__ void drain_tile(const BandArgs &a, const Tile &t, uint8_t *wframe, int tid, const Stage &st, uint8_t *lds, bool any_glyph)
 {
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.wm ? a.wm + (size_t)f * a.wm_frame_stride + (size_t)t.r0 * a.wm_stride : nullptr), 0,
+        (void *)(a.wm ? wframe + (size_t)t.r0 * a.wm_stride : nullptr), 0,
         a.wm ? (t.own_rows - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);
     const bool gl_rows = any_glyph && t.r0 < a.gbox.y1 && t.r1 > a.gbox.y0;   // wave-uniform
     const bool in_tile = tid < t.nchunk;
@@ -171,11 +171,13 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_nrgba_kernel(NrgbaArgs A)
     if (a.nscale > 0) { load_xtaps<NX0, FP0, kNT>(a, 0, cur.cb, tid, o0); load_xtaps<NX1, FP1, kNT>(a, 1, cur.cb, tid, o1); }
 
     Stage st;
-    issue_tile(a, cur.t, cur.f, true, false, tid, st);
+    const uint8_t *sframe = a.src + (size_t)cur.f * a.src_frame_stride;     // of the item whose loads go out next
+    OutBases ob = out_bases(a, cur.f);                                      // of the item being drained / computed
+    issue_tile(a, cur.t, sframe, true, false, tid, st);
 
     for (;;) {
         // A: staged pixels -> LDS tile + premultiplied watermark pixels
-        drain_tile(a, cur.t, cur.f, tid, st, lds, any_glyph);
+        drain_tile(a, cur.t, ob.wm, tid, st, lds, any_glyph);
         __syncthreads();
 
         // B: the next item's loads
@@ -190,14 +192,15 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_nrgba_kernel(NrgbaArgs A)
             }
         }
         item_setup(a, nxt, has_next);
-        issue_tile(a, nxt.t, nxt.f, has_next, can_carry && has_next && nxt.b == cur.b + 1 && nxt.f == cur.f && nxt.cb == cur.cb, tid, st);
+        if (nxt.f != cur.f) sframe = a.src + (size_t)nxt.f * a.src_frame_stride;
+        issue_tile(a, nxt.t, sframe, has_next, can_carry && has_next && nxt.b == cur.b + 1 && nxt.f == cur.f && nxt.cb == cur.cb, tid, st);
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, cur.t))
-            glyph_phase_nrgba(a, cur.t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
+            glyph_phase_nrgba(a, cur.t, ob.wm, lds, tid);
         if (a.nscale > 0) {
-            scale_out_conv<NX0, FP0, kNT, NrgbaConv>(a, 0, A.mode[0], cur.t, cur.f, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
-            scale_out_conv<NX1, FP1, kNT, NrgbaConv>(a, 1, A.mode[1], cur.t, cur.f, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
+            scale_out_conv<NX0, FP0, kNT, NrgbaConv>(a, 0, A.mode[0], cur.t, ob.o0, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
+            scale_out_conv<NX1, FP1, kNT, NrgbaConv>(a, 1, A.mode[1], cur.t, ob.o1, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
         }
         __syncthreads();
 
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_nrgba_kernel(NrgbaArgs A)
             load_xtaps<NX0, FP0, kNT>(a, 0, nxt.cb, tid, o0);
             load_xtaps<NX1, FP1, kNT>(a, 1, nxt.cb, tid, o1);
         }
+        if (nxt.f != cur.f) ob = out_bases(a, nxt.f);
         cur = nxt;
         idx++;
         left--;

@@ -43,18 +43,21 @@ __device__ __forceinline__ Chroma8 chroma_products(int cb, int cr)
     const int cb1 = cb - 128, cr1 = cr - 128;
     return Chroma8{91881 * cr1, -22554 * cb1 - 46802 * cr1, 116130 * cb1};
 }
+// v_ashr_pk_u8_i32 (new on gfx950): the low half of the result is {sat_u8(a >> 16), sat_u8(b >> 16)} -- shift, clamp and pack of two
+// channels in one instruction; the upper half is left as it was, so consumers read the low half only.  (hipcc's own pattern for
+// `r | g << 8 | b << 16` uses this instruction and assumes a zeroed upper half: green bits leaked into blue.  The builtin of the same
+// name masks its result with an extra v_and; inline asm plus a v_perm_b32 that picks the two low bytes needs neither.)
+__device__ __forceinline__ uint32_t ashr16_pk_u8(int a, int b)
+{
+    uint32_t d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ uint32_t rgba8_of(int y, const Chroma8 &c)
 {
     const int yy1 = y * 0x10101;
-    const uint32_t r = (uint32_t)min(max((yy1 + c.r) >> 16, 0), 255);
-    const uint32_t g = (uint32_t)min(max((yy1 + c.g) >> 16, 0), 255);
-    const uint32_t b = (uint32_t)min(max((yy1 + c.b) >> 16, 0), 255);
-    // Packed with v_perm_b32 on purpose.  Written as r | g << 8 | b << 16, hipcc (ROCm 7.2) selects
-    // v_ashr_pk_u8_i32 for the clamp-and-pack of r and g and then ORs b << 16 into the same register assuming its
-    // upper half is zero; on gfx950 the instruction leaves the destination's upper 16 bits as they were (the
-    // raw green value), which showed up as green bits leaking into blue.
-    const uint32_t rg = __builtin_amdgcn_perm(g, r, 0x0c0c0400u);            // {r, g, 0, 0}
-    return __builtin_amdgcn_perm(b | 0xff00u, rg, 0x05040100u);              // {r, g, b, 0xff}
+    const uint32_t rg = ashr16_pk_u8(yy1 + c.r, yy1 + c.g), ba = ashr16_pk_u8(yy1 + c.b, 255 << 16);
+    return __builtin_amdgcn_perm(ba, rg, 0x05040100u);   // {r, g, b, 0xff}
 }
 // a packed (Y, Cb, Cr, 0) tap -> RGBA8
 __device__ __forceinline__ uint32_t ycc_rgba8(uint32_t p)
@@ -86,16 +89,22 @@ struct Stage {
 // The tile loads of one item.  Clipping is the descriptors' job: each plane's descriptor starts at the tile's first row and ends with
 // its last one, so row slots past the tile (or the frame) fall out of range by themselves and return 0; a thread whose chunk lies
 // outside the tile carries an out-of-range base offset.  valid = false: empty descriptors.
+struct PlaneBases { const uint8_t *y, *cb, *cr; };    // the three planes of one frame of the batch
+__device__ __forceinline__ PlaneBases plane_bases(const YccArgs &A, int f)
+{
+    return PlaneBases{A.y + (size_t)f * A.y_fs, A.cb + (size_t)f * A.c_fs, A.cr + (size_t)f * A.c_fs};
+}
+
 template <int HS, int VS>
-__device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, int f, bool valid, int tid, Stage &st)
+__device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, const PlaneBases &pb, bool valid, int tid, Stage &st)
 {
     const BandArgs &a = A.b;
     const int crow0 = t.r0 >> VS, crows = valid ? ((t.rows_ld - 1) >> VS) + 1 : 0;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(A.y + (size_t)f * A.y_fs + (size_t)t.r0 * A.ystride), 0, valid ? (t.rows_ld - 1) * A.ystride + a.sw : 0, 0x00020000);
+        (void *)(pb.y + (size_t)t.r0 * A.ystride), 0, valid ? (t.rows_ld - 1) * A.ystride + a.sw : 0, 0x00020000);
     const int cbytes = crows > 0 ? (crows - 1) * A.cstride + A.cw : 0;
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)(A.cb + (size_t)f * A.c_fs + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(A.cr + (size_t)f * A.c_fs + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cb + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cr + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
     const bool in_tile = tid < t.nchunk;
     const int yoff = in_tile ? t.c0 + tid * 4 : kOOB;
 #pragma unroll
@@ -119,12 +128,12 @@ __device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, 
 // read), and the owned pixels converted to RGBA8 -> watermark frame.  The last tile row is never an owned one (band_rows + 1 <=
 // kRows), so it is neither converted nor stored.
 template <int HS, int VS>
-__device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, int f, int tid, const Stage &st,
+__device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, uint8_t *wframe, int tid, const Stage &st,
                                                uint8_t *lds, bool any_glyph)
 {
     const BandArgs &a = A.b;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.wm ? a.wm + (size_t)f * a.wm_frame_stride + (size_t)t.r0 * a.wm_stride : nullptr), 0,
+        (void *)(a.wm ? wframe + (size_t)t.r0 * a.wm_stride : nullptr), 0,
         a.wm ? (t.own_rows - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);
     const bool gl_rows = any_glyph && t.r0 < a.gbox.y1 && t.r1 > a.gbox.y0;   // wave-uniform
     const bool in_tile = tid < t.nchunk;
@@ -136,28 +145,29 @@ __device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, 
 #pragma unroll
     for (int j = 0; j < NCR; j++) {
         const uint32_t cbw = st.cb[j], crw = st.cr[j];
-        uint32_t cbs[4], crs[4];   // per pixel of the chunk
-        if (HS) {
-            cbs[0] = cbs[1] = cbw & 0xffu; cbs[2] = cbs[3] = (cbw >> 8) & 0xffu;
-            crs[0] = crs[1] = crw & 0xffu; crs[2] = crs[3] = (crw >> 8) & 0xffu;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) { cbs[i] = (cbw >> (8 * i)) & 0xffu; crs[i] = (crw >> (8 * i)) & 0xffu; }
-        }
+        // per pixel of the chunk: the chroma pair as (cb | cr << 8) for the packed tile dword, and the chroma products for the
+        // watermark pixel (shared by the pixels that share a sample)
+        uint32_t c2[4];
         Chroma8 cp[4];
-        if (HS) { cp[0] = cp[1] = chroma_products((int)cbs[0], (int)crs[0]); cp[2] = cp[3] = chroma_products((int)cbs[2], (int)crs[2]); }
-        else {
+        if (HS) {
+            c2[0] = c2[1] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0400u);
+            c2[2] = c2[3] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0501u);
+            cp[0] = cp[1] = chroma_products((int)(cbw & 0xffu), (int)(crw & 0xffu));
+            cp[2] = cp[3] = chroma_products((int)((cbw >> 8) & 0xffu), (int)((crw >> 8) & 0xffu));
+        } else {
+            c2[0] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0400u); c2[1] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0501u);
+            c2[2] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0602u); c2[3] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0703u);
 #pragma unroll
-            for (int i = 0; i < 4; i++) cp[i] = chroma_products((int)cbs[i], (int)crs[i]);
+            for (int i = 0; i < 4; i++) cp[i] = chroma_products((int)((cbw >> (8 * i)) & 0xffu), (int)((crw >> (8 * i)) & 0xffu));
         }
 #pragma unroll
         for (int rr = 0; rr < (VS ? 2 : 1); rr++) {
             const int r = VS ? 2 * j + rr : j;
             if (r >= kRows) continue;
             const uint32_t yw = st.y[r];
-            v4u packed;
-#pragma unroll
-            for (int i = 0; i < 4; i++) packed[i] = ((yw >> (8 * i)) & 0xffu) | (cbs[i] << 8) | (crs[i] << 16);
+            v4u packed;     // (Y, Cb, Cr, 0): one v_perm_b32 per pixel
+            packed[0] = __builtin_amdgcn_perm(c2[0], yw, 0x0c050400u); packed[1] = __builtin_amdgcn_perm(c2[1], yw, 0x0c050401u);
+            packed[2] = __builtin_amdgcn_perm(c2[2], yw, 0x0c050402u); packed[3] = __builtin_amdgcn_perm(c2[3], yw, 0x0c050403u);
             if (in_tile) *(v4u *)(lds + r * t.pitch + loff) = packed;
             if (r == kRows - 1 || !a.wm) continue;
             v4u rgba;
@@ -234,11 +244,13 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
     if (a.nscale > 0) { load_xtaps<NX0, FP0, kNT>(a, 0, cur.cb, tid, o0); load_xtaps<NX1, FP1, kNT>(a, 1, cur.cb, tid, o1); }
 
     Stage st;
-    issue_tile_ycc<HS, VS>(A, cur.t, cur.f, true, tid, st);
+    PlaneBases pb = plane_bases(A, cur.f);        // of the item whose loads go out next
+    OutBases ob = out_bases(a, cur.f);            // of the item being drained / computed
+    issue_tile_ycc<HS, VS>(A, cur.t, pb, true, tid, st);
 
     for (;;) {
         // A: staged planes -> packed LDS tile + converted watermark pixels
-        drain_tile_ycc<HS, VS>(A, cur.t, cur.f, tid, st, lds, any_glyph);
+        drain_tile_ycc<HS, VS>(A, cur.t, ob.wm, tid, st, lds, any_glyph);
         __syncthreads();
 
         // B: the next item's loads
@@ -253,14 +265,15 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
             }
         }
         item_setup_ycc(a, nxt, has_next);
-        issue_tile_ycc<HS, VS>(A, nxt.t, nxt.f, has_next, tid, st);
+        if (nxt.f != cur.f) pb = plane_bases(A, nxt.f);
+        issue_tile_ycc<HS, VS>(A, nxt.t, pb, has_next, tid, st);
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, cur.t))
-            glyph_phase_ycc(a, cur.t, a.wm + (size_t)cur.f * a.wm_frame_stride, lds, tid);
+            glyph_phase_ycc(a, cur.t, ob.wm, lds, tid);
         if (a.nscale > 0) {
-            scale_out_conv<NX0, FP0, kNT, YccConv>(a, 0, A.mode[0], cur.t, cur.f, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
-            scale_out_conv<NX1, FP1, kNT, YccConv>(a, 1, A.mode[1], cur.t, cur.f, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
+            scale_out_conv<NX0, FP0, kNT, YccConv>(a, 0, A.mode[0], cur.t, ob.o0, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
+            scale_out_conv<NX1, FP1, kNT, YccConv>(a, 1, A.mode[1], cur.t, ob.o1, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
         }
         __syncthreads();
 
@@ -269,6 +282,7 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
             load_xtaps<NX0, FP0, kNT>(a, 0, nxt.cb, tid, o0);
             load_xtaps<NX1, FP1, kNT>(a, 1, nxt.cb, tid, o1);
         }
+        if (nxt.f != cur.f) ob = out_bases(a, nxt.f);
         cur = nxt;
         idx++;
         left--;
