@@ -588,6 +588,153 @@ class Context:
         return dst
 
 
+class PoolJob:
+    """One submitted job of a Pool: keeps the arrays the library writes into alive until wait()."""
+
+    def __init__(self, pool, job, keep, outs, n):
+        self.pool, self.job, self.keep, self.outs, self.n = pool, job, keep, outs, n
+        t = C.c_uint64()
+        _check(lib().ipx_job_submit(pool.handle, C.byref(job), C.byref(t)))
+        self.ticket = t.value
+        self.released = False
+
+    def done(self):
+        d = C.c_int()
+        _check(lib().ipx_job_poll(self.pool.handle, self.ticket, C.byref(d)))
+        return bool(d.value)
+
+    def wait(self):
+        """-> dict of outputs (arrays for a pixel job; ({operator: [bytes | None]}, status list) for a JPEG job); releases the job"""
+        fd = C.c_int()
+        try:
+            _check(lib().ipx_job_wait(self.pool.handle, self.ticket, C.byref(fd)))
+            if self.job.kind == 0:
+                return self.outs
+            out = {k: [C.string_at(a[j].data, a[j].len) if a[j].data else None for j in range(self.n)] for k, a in self.outs.items()}
+            return out, list(self.keep["status"])[:self.n]
+        finally:
+            self.release()
+
+    def release(self):
+        if not self.released:
+            self.released = True
+            lib().ipx_job_release(self.pool.handle, self.ticket)
+
+
+class Pool:
+    """One process, several GPUs (ipx_pool_*): a context per listed device, feeder threads, one largest-first queue."""
+
+    def __init__(self, devices=(0,), lanes_per_device=0, lane_bytes=0):
+        arr = (C.c_int * len(devices))(*devices)
+        cfg = _lib.PoolConfig(lanes_per_device, lane_bytes)
+        h = C.c_void_p()
+        _check(lib().ipx_pool_create(arr, len(devices), C.byref(cfg), C.byref(h)))
+        self.handle = h.value
+
+    def close(self):
+        if self.handle:
+            lib().ipx_pool_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def slots(self):
+        return lib().ipx_pool_slots(self.handle)
+
+    def frames_done(self, slot):
+        return lib().ipx_pool_frames_done(self.handle, slot)
+
+    def host_alloc(self, slot, shape, dtype=np.uint8):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = lib().ipx_pool_host_alloc(self.handle, slot, max(1, n))
+        if not p:
+            raise IpxError(-2, lib().ipx_last_error().decode())
+        arr = np.frombuffer((C.c_uint8 * n).from_address(p), dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = (slot, p)
+        return arr
+
+    def host_free(self, arr):
+        slot, p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, (None, None))
+        if p:
+            lib().ipx_pool_host_free(self.handle, slot, p)
+
+    @staticmethod
+    def _ops(sw, sh, resize, thumbnail, glyphs, col, watermark):
+        o = _lib.PoolOps()
+        o.sw, o.sh = sw, sh
+        if resize:
+            o.do_resize, o.resize_w, o.resize_h, o.keep_aspect = 1, resize[0], resize[1], int(bool(resize[2]))
+        if thumbnail:
+            o.do_thumbnail, o.thumb_size, o.crop_to_fit = 1, thumbnail[0], int(bool(thumbnail[1]))
+        keep = None
+        if watermark or glyphs:
+            o.do_watermark = 1
+            if glyphs:
+                arr, keep = _glyph_array(list(glyphs))
+                o.glyphs, o.n_glyphs = arr, len(glyphs)
+                keep = (arr, keep)
+                for i in range(4):
+                    o.col[i] = int(col[i])
+        return o, keep
+
+    def submit(self, frames, resize=(1024, 768, True), thumbnail=(200, True), glyphs=None, col=(0, 0, 0, 0), watermark=False, out=None):
+        """frames: n x H x W x 4 uint8 (host).  -> PoolJob; wait() gives {"resize", "thumbnail", "watermark"} arrays."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, sh, sw = frames.shape[:3]
+        ops, keep = self._ops(sw, sh, resize, thumbnail, glyphs, col, watermark)
+        outs = dict(out) if out else {}
+        if resize and "resize" not in outs:
+            outs["resize"] = np.empty((n,) + tuple(reversed(resize_dims(sw, sh, resize[0], resize[1], resize[2]))) + (4,), np.uint8)
+        if thumbnail and "thumbnail" not in outs:
+            _, tw, th = thumb_geometry(sw, sh, thumbnail[0] or 200, thumbnail[1])
+            outs["thumbnail"] = np.empty((n, th, tw, 4), np.uint8)
+        if ops.do_watermark and "watermark" not in outs:
+            outs["watermark"] = np.empty((n, sh, sw, 4), np.uint8)
+        j = _lib.Job()
+        j.kind, j.ops, j.n = 0, ops, n
+        j.src, j.sstride, j.src_frame_stride = frames.ctypes.data, sw * 4, sw * sh * 4
+
+        def fs(a):
+            return int(np.prod(a.shape[1:]))
+        if "resize" in outs:
+            j.resize_out, j.resize_frame_stride = outs["resize"].ctypes.data, fs(outs["resize"])
+        if "thumbnail" in outs:
+            j.thumb_out, j.thumb_frame_stride = outs["thumbnail"].ctypes.data, fs(outs["thumbnail"])
+        if "watermark" in outs:
+            j.wm_out, j.wm_frame_stride = outs["watermark"].ctypes.data, fs(outs["watermark"])
+        return PoolJob(self, j, {"frames": frames, "glyphs": keep}, outs, n)
+
+    def submit_jpeg(self, files, sw, sh, quality=85, resize=(1024, 768, True), thumbnail=(200, True), glyphs=None, col=(0, 0, 0, 0),
+                    watermark=False):
+        """JPEG byte strings of sw x sh images in -> PoolJob; wait() gives ({operator: [bytes | None]}, status list)."""
+        n = len(files)
+        ops, keep = self._ops(sw, sh, resize, thumbnail, glyphs, col, watermark)
+        blobs = [bytes(f) for f in files]
+        arr = (_lib.Bytes * max(1, n))()
+        for i, f in enumerate(blobs):
+            arr[i].data = C.cast(C.c_char_p(f), C.c_void_p)
+            arr[i].len = len(f)
+        status = (C.c_int32 * max(1, n))()
+        outs = {}
+        j = _lib.Job()
+        j.kind, j.ops, j.n, j.files, j.quality, j.status = 1, ops, n, arr, int(quality), status
+        if resize:
+            outs["resize"] = (_lib.Bytes * max(1, n))()
+            j.resize_jpeg = outs["resize"]
+        if thumbnail:
+            outs["thumbnail"] = (_lib.Bytes * max(1, n))()
+            j.thumb_jpeg = outs["thumbnail"]
+        if ops.do_watermark:
+            outs["watermark"] = (_lib.Bytes * max(1, n))()
+            j.wm_jpeg = outs["watermark"]
+        return PoolJob(self, j, {"blobs": blobs, "files": arr, "status": status, "glyphs": keep}, outs, n)
+
+
 def jpeg_entropy_encode(coefs, w, h, quality=85):
     """Host half of jpeg.Encode: quantised coefficients (int16, 6 x 64 per MCU, zig-zag) -> the byte stream."""
     coefs = np.ascontiguousarray(coefs, dtype=np.int16)

@@ -85,6 +85,28 @@ class Processed(C.Structure):
                 ("format", C.c_char * 8), ("image", Image)]
 
 
+class PoolConfig(C.Structure):
+    _fields_ = [("lanes_per_device", C.c_int32), ("lane_bytes", C.c_size_t)]
+
+
+class PoolOps(C.Structure):
+    _fields_ = [("sw", C.c_int32), ("sh", C.c_int32),
+                ("do_resize", C.c_int32), ("resize_w", C.c_int32), ("resize_h", C.c_int32), ("keep_aspect", C.c_int32),
+                ("do_thumbnail", C.c_int32), ("thumb_size", C.c_int32), ("crop_to_fit", C.c_int32),
+                ("do_watermark", C.c_int32), ("glyphs", C.POINTER(Glyph)), ("n_glyphs", C.c_int32), ("col", C.c_uint8 * 4)]
+
+
+class Job(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("ops", PoolOps), ("n", C.c_int32),
+                ("src", C.c_void_p), ("sstride", C.c_int32), ("src_frame_stride", C.c_size_t),
+                ("resize_out", C.c_void_p), ("resize_frame_stride", C.c_size_t),
+                ("thumb_out", C.c_void_p), ("thumb_frame_stride", C.c_size_t),
+                ("wm_out", C.c_void_p), ("wm_frame_stride", C.c_size_t),
+                ("files", C.POINTER(Bytes)), ("quality", C.c_int32),
+                ("resize_jpeg", C.POINTER(Bytes)), ("thumb_jpeg", C.POINTER(Bytes)), ("wm_jpeg", C.POINTER(Bytes)),
+                ("status", C.POINTER(C.c_int32))]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _Z = C.c_size_t
@@ -175,6 +197,17 @@ SIGNATURES = {
                                   C.POINTER(_I), C.POINTER(C.c_int32)]),
     "ipx_font_release_thread": (None, []),
     "ipx_font_rasterizer": (_I, [_P, C.POINTER(TextRasterizer)]),
+    "ipx_pool_create": (_I, [C.POINTER(_I), _I, C.POINTER(PoolConfig), C.POINTER(_P)]),
+    "ipx_pool_destroy": (None, [_P]),
+    "ipx_pool_slots": (_I, [_P]),
+    "ipx_pool_frames_done": (C.c_longlong, [_P, _I]),
+    "ipx_pool_host_alloc": (_P, [_P, _I, _Z]),
+    "ipx_pool_host_free": (_I, [_P, _I, _P]),
+    "ipx_job_submit": (_I, [_P, C.POINTER(Job), C.POINTER(C.c_uint64)]),
+    "ipx_job_poll": (_I, [_P, C.c_uint64, C.POINTER(_I)]),
+    "ipx_job_wait": (_I, [_P, C.c_uint64, C.POINTER(_I)]),
+    "ipx_job_release": (_I, [_P, C.c_uint64]),
+    "ipx_pool_run_host": (_I, [_P, C.POINTER(Job), _I]),
 }
 
 _lib = None

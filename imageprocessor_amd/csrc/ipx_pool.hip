@@ -1,0 +1,511 @@
+// ipx_pool.hip -- one process, several GPUs: a pool of contexts behind ONE largest-first queue, and the asynchronous job entries.
+//
+// The reference worker is one process with WORKER_CONCURRENCY goroutines pulling messages (worker.go:88-96, 112-149); messages are
+// independent, nothing is exchanged.  A Go worker binds this: it submits a job (a batch of equally sized frames, or of JPEG files) and
+// gets a ticket back at once, so no goroutine blocks an OS thread for the length of a batch; ipx_job_wait collects the result.
+//
+// Inside: one ipx_ctx per pool slot (a device may be listed more than once), `lanes_per_device` feeder threads per slot, each with a
+// HIP stream and a grow-only device buffer of its own.  A job is cut into chunks; chunks wait in one priority queue ordered by cost
+// (bytes moved), and a feeder takes the most expensive chunk whenever it is free -- pull scheduling: a mixed batch balances itself
+// (work stealing falls out of it), a uniform batch spreads round-robin over equally fast devices.  No data-path collective exists
+// (SURVEY.md 8(e)): a frame never leaves the GPU it was uploaded to.
+// Feeder threads bind themselves to the CPUs local to their GPU's PCIe root (sysfs local_cpulist) before they allocate and first-touch
+// anything, and ipx_pool_host_alloc runs on such a thread, so pinned staging lands on the GPU's NUMA node.
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <sched.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ipx_runtime_internal.h"
+
+namespace {
+
+struct PoolOps {                 // a deep copy of ipx_pool_ops: the caller may free its own right after submit
+    ipx_pool_ops p{};
+    std::vector<ipx_glyph> glyphs;
+    std::vector<std::vector<uint8_t>> masks;
+    std::string key;             // what a plan depends on, as bytes: the plan cache's key
+};
+
+struct JobState {
+    ipx_job job{};
+    PoolOps ops;
+    uint64_t id = 0;
+    int chunks_left = 0;
+    int status = IPX_OK;
+    std::string error;
+    int frames_done = 0;
+    std::vector<ipx_jpeg_result *> results;   // IPX_JOB_JPEG: pinned blocks the output streams live in, per slot that produced them
+    std::vector<ipx_ctx *> result_ctx;
+    bool waited = false;
+};
+
+struct Chunk {
+    std::shared_ptr<JobState> job;
+    int i0 = 0, m = 0;
+    double cost = 0;
+    uint64_t seq = 0;
+};
+struct ChunkLess {   // the most expensive chunk first; submission order among equals
+    bool operator()(const Chunk &a, const Chunk &b) const { return a.cost != b.cost ? a.cost < b.cost : a.seq > b.seq; }
+};
+
+struct CachedPlan { ipx_glyphset *gs = nullptr; ipx_plan *plan = nullptr; };
+
+struct Slot {
+    int device = 0;
+    ipx_ctx *ctx = nullptr;
+    std::mutex mu;                                  // the plan cache
+    std::map<std::string, CachedPlan> plans;
+};
+
+}  // namespace
+
+struct ipx_pool {
+    std::vector<std::unique_ptr<Slot>> slots;
+    std::vector<std::thread> feeders;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::priority_queue<Chunk, std::vector<Chunk>, ChunkLess> queue;
+    std::map<uint64_t, std::shared_ptr<JobState>> jobs;
+    uint64_t next_id = 1, next_seq = 1;
+    bool stopping = false;
+    size_t lane_bytes = (size_t)256 << 20;
+    std::atomic<long long> frames_by_slot[64];
+};
+
+namespace {
+
+// CPUs local to a device's PCIe root, intersected with what the process may use.  Best effort: nothing happens if sysfs says nothing.
+void bind_near_device(int device)
+{
+    if (env_int("IPX_POOL_NUMA", 1) == 0) return;
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char *c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);
+    char path[128];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    char line[4096] = {0};
+    const bool ok = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!ok) return;
+    cpu_set_t allowed, want;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    CPU_ZERO(&want);
+    for (char *p = line; *p;) {            // "0-31,64-95"
+        char *e = nullptr;
+        long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &want);
+        p = *e == ',' ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    if (CPU_COUNT(&want) > 0) (void)sched_setaffinity(0, sizeof want, &want);
+}
+
+double chunk_cost(const JobState &j, int m)
+{
+    if (j.job.kind == IPX_JOB_JPEG) {
+        double b = 0;
+        for (int i = 0; i < m; i++) b += (double)j.job.files[i].len;   // callers pass the chunk's own slice
+        return b * 24 + (double)m * j.ops.p.sw * j.ops.p.sh * 8;         // decoded size dominates
+    }
+    return (double)m * ((double)j.ops.p.sw * j.ops.p.sh * 8 + 4.0 * 1024 * 768);
+}
+
+int copy_ops(const ipx_pool_ops &in, PoolOps *out)
+{
+    out->p = in;
+    if (in.n_glyphs < 0 || (in.n_glyphs && !in.glyphs)) { set_error("ipx_job_submit: bad glyph list"); return IPX_ERR_INVALID; }
+    out->glyphs.assign(in.glyphs, in.glyphs + in.n_glyphs);
+    out->masks.resize(in.n_glyphs);
+    std::string key((const char *)&in, offsetof(ipx_pool_ops, glyphs));
+    key.append((const char *)in.col, 4);
+    for (int i = 0; i < in.n_glyphs; i++) {
+        ipx_glyph &g = out->glyphs[i];
+        if (g.mw < 0 || g.mh < 0 || (g.mw && g.mh && (!g.mask || g.mstride < g.mw))) { set_error("ipx_job_submit: glyph %d has a bad mask", i); return IPX_ERR_INVALID; }
+        out->masks[i].resize((size_t)g.mw * g.mh);
+        for (int y = 0; y < g.mh; y++) memcpy(out->masks[i].data() + (size_t)y * g.mw, g.mask + (size_t)y * g.mstride, g.mw);
+        g.mask = out->masks[i].data();
+        g.mstride = g.mw;
+        key.append((const char *)&g.mw, sizeof(int32_t) * 3);
+        key.append((const char *)&g.dr, sizeof g.dr + 2 * sizeof(int32_t));
+        key.append((const char *)out->masks[i].data(), out->masks[i].size());
+    }
+    out->p.glyphs = out->glyphs.data();
+    out->key = std::move(key);
+    return IPX_OK;
+}
+
+// the slot's plan for these operators (glyph set uploaded once per slot and content).  The cache holds kMaxCachedPlans entries; past
+// that (a worker whose every task carries its own watermark text) a plan lives for one chunk: *temp receives it for the caller to free.
+constexpr size_t kMaxCachedPlans = 256;
+int slot_plan(Slot &s, const PoolOps &ops, ipx_plan **plan, CachedPlan *temp)
+{
+    std::lock_guard<std::mutex> lk(s.mu);
+    auto it = s.plans.find(ops.key);
+    if (it != s.plans.end()) { *plan = it->second.plan; return IPX_OK; }
+    CachedPlan c;
+    int rc = IPX_OK;
+    if (ops.p.do_watermark && ops.p.n_glyphs > 0) rc = ipx_glyphset_create(s.ctx, ops.glyphs.data(), ops.p.n_glyphs, ops.p.col, &c.gs);
+    if (rc) return rc;
+    ipx_plan_params pp;
+    memset(&pp, 0, sizeof pp);
+    pp.sw = ops.p.sw; pp.sh = ops.p.sh;
+    pp.do_resize = ops.p.do_resize; pp.resize_w = ops.p.resize_w; pp.resize_h = ops.p.resize_h; pp.keep_aspect = ops.p.keep_aspect;
+    pp.do_thumbnail = ops.p.do_thumbnail; pp.thumb_size = ops.p.thumb_size; pp.crop_to_fit = ops.p.crop_to_fit;
+    pp.do_watermark = ops.p.do_watermark; pp.glyphs = c.gs;
+    rc = ipx_plan_create(s.ctx, &pp, &c.plan);
+    if (rc) { if (c.gs) ipx_glyphset_destroy(s.ctx, c.gs); return rc; }
+    if (s.plans.size() < kMaxCachedPlans) s.plans.emplace(ops.key, c);
+    else *temp = c;
+    *plan = c.plan;
+    return IPX_OK;
+}
+
+struct Feeder {
+    hipStream_t stream = nullptr;
+    uint8_t *dev = nullptr;
+    size_t dev_bytes = 0;
+};
+
+int feeder_reserve(Feeder &f, size_t bytes)
+{
+    if (bytes <= f.dev_bytes) return IPX_OK;
+    if (f.dev) { (void)hipStreamSynchronize(f.stream); (void)hipFree(f.dev); f.dev = nullptr; f.dev_bytes = 0; }
+    if (hipMalloc((void **)&f.dev, bytes) != hipSuccess) { (void)hipGetLastError(); set_error("pool: device allocation of %zu bytes failed", bytes); return IPX_ERR_NOMEM; }
+    f.dev_bytes = bytes;
+    return IPX_OK;
+}
+
+// pixels in, pixels out: upload the chunk, one fused pass, download -- all on the feeder's stream
+int run_rgba_chunk(Slot &s, Feeder &f, const JobState &j, ipx_plan *plan, int i0, int m)
+{
+    const ipx_job &q = j.job;
+    ipx_plan_info info;
+    int rc = ipx_plan_query(plan, &info);
+    if (rc) return rc;
+    const int sw = j.ops.p.sw, sh = j.ops.p.sh;
+    const size_t fsrc = align256((size_t)sw * sh * 4);
+    const size_t fres = q.resize_out ? align256(info.resize_bytes) : 0, fth = q.thumb_out ? align256(info.thumb_bytes) : 0;
+    const size_t fwm = q.wm_out ? align256(info.wm_bytes) : 0;
+    rc = feeder_reserve(f, (fsrc + fres + fth + fwm) * (size_t)m + 256);
+    if (rc) return rc;
+    uint8_t *dsrc = f.dev, *dres = fres ? dsrc + fsrc * m : nullptr, *dth = fth ? dsrc + (fsrc + fres) * m : nullptr;
+    uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * m : nullptr;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < m && e == hipSuccess; i++)
+        e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * 4, q.src + (size_t)(i0 + i) * q.src_frame_stride, q.sstride, (size_t)sw * 4, sh,
+                             hipMemcpyHostToDevice, f.stream);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(f.stream); set_error("pool: upload failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
+    rc = ipx_plan_run_dev(s.ctx, f.stream, plan, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm);
+    if (rc) { (void)hipStreamSynchronize(f.stream); return rc; }
+    for (int i = 0; i < m && e == hipSuccess; i++) {
+        if (dres && info.resize_bytes) e = hipMemcpyAsync(q.resize_out + (size_t)(i0 + i) * q.resize_frame_stride, dres + fres * i, info.resize_bytes, hipMemcpyDeviceToHost, f.stream);
+        if (e == hipSuccess && dth && info.thumb_bytes) e = hipMemcpyAsync(q.thumb_out + (size_t)(i0 + i) * q.thumb_frame_stride, dth + fth * i, info.thumb_bytes, hipMemcpyDeviceToHost, f.stream);
+        if (e == hipSuccess && dwm && info.wm_bytes) e = hipMemcpyAsync(q.wm_out + (size_t)(i0 + i) * q.wm_frame_stride, dwm + fwm * i, info.wm_bytes, hipMemcpyDeviceToHost, f.stream);
+    }
+    const hipError_t e2 = hipStreamSynchronize(f.stream);
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) { set_error("pool: download failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
+    return IPX_OK;
+}
+
+// one chunk on this feeder; never throws (an exception becomes a status, as at the ABI)
+int run_chunk(Slot &s, Feeder &f, JobState &j, int i0, int m, ipx_jpeg_result **res) noexcept
+{
+    try {
+        if (!f.stream) { set_error("pool: the feeder has no stream"); return IPX_ERR_HIP; }
+        ipx_plan *plan = nullptr;
+        CachedPlan temp;
+        int rc = slot_plan(s, j.ops, &plan, &temp);
+        if (rc) return rc;
+        if (j.job.kind == IPX_JOB_JPEG)
+            rc = ipx_plan_run_jpeg_jpeg(s.ctx, plan, m, j.job.files + i0, j.job.quality, j.job.resize_jpeg ? j.job.resize_jpeg + i0 : nullptr,
+                                        j.job.thumb_jpeg ? j.job.thumb_jpeg + i0 : nullptr, j.job.wm_jpeg ? j.job.wm_jpeg + i0 : nullptr,
+                                        j.job.status + i0, res);
+        else rc = run_rgba_chunk(s, f, j, plan, i0, m);      // (both return with the chunk's GPU work finished)
+        if (temp.plan) {
+            std::string keep = rc ? ipx_last_error() : "";
+            ipx_plan_destroy(s.ctx, temp.plan);
+            if (temp.gs) ipx_glyphset_destroy(s.ctx, temp.gs);
+            if (rc) set_error("%s", keep.c_str());
+        }
+        return rc;
+    } catch (...) {
+        return status_of_exception();
+    }
+}
+
+void feeder_main(ipx_pool *pool, int slot_index)
+{
+    Slot &s = *pool->slots[slot_index];
+    (void)hipSetDevice(s.device);
+    bind_near_device(s.device);
+    Feeder f;
+    if (hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); f.stream = nullptr; }
+    for (;;) {
+        Chunk c;
+        {
+            std::unique_lock<std::mutex> lk(pool->mu);
+            pool->cv_work.wait(lk, [&] { return pool->stopping || !pool->queue.empty(); });
+            if (pool->queue.empty()) break;          // stopping, and nothing left to drain
+            c = pool->queue.top();
+            pool->queue.pop();
+        }
+        JobState &j = *c.job;
+        ipx_jpeg_result *res = nullptr;
+        const int rc = run_chunk(s, f, j, c.i0, c.m, &res);
+        const std::string text = rc ? ipx_last_error() : "";
+        bool finished = false;
+        {
+            std::lock_guard<std::mutex> lk(pool->mu);
+            if (rc && j.status == IPX_OK) { j.status = rc; j.error = text; }
+            if (!rc) j.frames_done += c.m;
+            if (res) { j.results.push_back(res); j.result_ctx.push_back(s.ctx); }
+            pool->frames_by_slot[slot_index] += c.m;
+            finished = --j.chunks_left == 0;
+        }
+        if (finished) pool->cv_done.notify_all();
+    }
+    if (f.dev) (void)hipFree(f.dev);
+    if (f.stream) { (void)hipStreamSynchronize(f.stream); (void)hipStreamDestroy(f.stream); }
+}
+
+int job_check(const ipx_job *job)
+{
+    if (!job || job->n < 0) { set_error("ipx_job_submit: bad job"); return IPX_ERR_INVALID; }
+    const ipx_pool_ops &o = job->ops;
+    if (o.sw <= 0 || o.sh <= 0) { set_error("ipx_job_submit: frame size %dx%d", o.sw, o.sh); return IPX_ERR_INVALID; }
+    if (job->kind == IPX_JOB_RGBA8) {
+        if (job->n && (!job->src || (long long)job->sstride < (long long)o.sw * 4)) { set_error("ipx_job_submit: bad source frames"); return IPX_ERR_INVALID; }
+        if (!frame_span_ok(o.sw, o.sh, job->sstride, 4)) { set_error("ipx_job_submit: %dx%d frames are beyond the span the kernels address", o.sw, o.sh); return IPX_ERR_UNSUPPORTED; }
+    } else if (job->kind == IPX_JOB_JPEG) {
+        if (job->n && (!job->files || !job->status)) { set_error("ipx_job_submit: a JPEG job needs files and a status array"); return IPX_ERR_INVALID; }
+    } else {
+        set_error("ipx_job_submit: unknown job kind %d", job->kind);
+        return IPX_ERR_INVALID;
+    }
+    return IPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ipx_pool_create(const int *devices, int n_devices, const ipx_pool_config *cfg, ipx_pool **out) try
+{
+    clear_error();
+    if (!out || n_devices <= 0 || n_devices > 64 || !devices) { set_error("ipx_pool_create: bad argument"); return IPX_ERR_INVALID; }
+    *out = nullptr;
+    const int lanes = cfg && cfg->lanes_per_device > 0 ? cfg->lanes_per_device : 3;
+    std::unique_ptr<ipx_pool> pool(new ipx_pool);
+    for (auto &c : pool->frames_by_slot) c = 0;
+    if (cfg && cfg->lane_bytes) pool->lane_bytes = cfg->lane_bytes;
+    for (int i = 0; i < n_devices; i++) {
+        std::unique_ptr<Slot> s(new Slot);
+        s->device = devices[i];
+        ipx_config cc;
+        cc.device = devices[i]; cc.lanes = lanes + 1; cc.lane_bytes = 0;
+        const int rc = ipx_create(&cc, &s->ctx);
+        if (rc) {
+            for (auto &t : pool->slots) ipx_destroy(t->ctx);
+            return rc;
+        }
+        pool->slots.push_back(std::move(s));
+    }
+    for (int i = 0; i < n_devices; i++)
+        for (int l = 0; l < lanes; l++) pool->feeders.emplace_back(feeder_main, pool.get(), i);
+    *out = pool.release();
+    return IPX_OK;
+}
+IPX_CATCH_STATUS
+
+void ipx_pool_destroy(ipx_pool *pool)
+{
+    if (!pool) return;
+    {
+        std::lock_guard<std::mutex> lk(pool->mu);
+        pool->stopping = true;
+    }
+    pool->cv_work.notify_all();
+    for (auto &t : pool->feeders) t.join();      // feeders drain the queue before they leave
+    for (auto &kv : pool->jobs)
+        for (size_t i = 0; i < kv.second->results.size(); i++) ipx_jpeg_result_free(kv.second->result_ctx[i], kv.second->results[i]);
+    for (auto &s : pool->slots) {
+        (void)hipSetDevice(s->device);
+        for (auto &kv : s->plans) {
+            ipx_plan_destroy(s->ctx, kv.second.plan);
+            if (kv.second.gs) ipx_glyphset_destroy(s->ctx, kv.second.gs);
+        }
+        ipx_destroy(s->ctx);
+    }
+    delete pool;
+}
+
+int ipx_pool_slots(const ipx_pool *pool) { return pool ? (int)pool->slots.size() : 0; }
+
+long long ipx_pool_frames_done(const ipx_pool *pool, int slot)
+{
+    return pool && slot >= 0 && slot < (int)pool->slots.size() ? (long long)pool->frames_by_slot[slot] : -1;
+}
+
+void *ipx_pool_host_alloc(ipx_pool *pool, int slot, size_t bytes) try
+{
+    clear_error();
+    if (!pool || slot < 0 || slot >= (int)pool->slots.size() || !bytes) { set_error("ipx_pool_host_alloc: bad argument"); return nullptr; }
+    Slot &s = *pool->slots[slot];
+    void *p = nullptr;
+    std::string text;
+    std::thread t([&] {      // allocate and first-touch on a thread bound next to the slot's GPU
+        (void)hipSetDevice(s.device);
+        bind_near_device(s.device);
+        p = ipx_host_alloc(s.ctx, bytes);
+        if (p) memset(p, 0, bytes);
+        else text = ipx_last_error();
+    });
+    t.join();
+    if (!p) set_error("%s", text.c_str());
+    return p;
+}
+catch (...) { (void)status_of_exception(); return nullptr; }
+
+int ipx_pool_host_free(ipx_pool *pool, int slot, void *p)
+{
+    clear_error();
+    if (!pool || slot < 0 || slot >= (int)pool->slots.size()) { set_error("ipx_pool_host_free: bad argument"); return IPX_ERR_INVALID; }
+    return ipx_host_free(pool->slots[slot]->ctx, p);
+}
+
+int ipx_job_submit(ipx_pool *pool, const ipx_job *job, ipx_ticket *ticket) try
+{
+    clear_error();
+    if (!pool || !ticket) { set_error("ipx_job_submit: bad argument"); return IPX_ERR_INVALID; }
+    int rc = job_check(job);
+    if (rc) return rc;
+    std::shared_ptr<JobState> j(new JobState);
+    j->job = *job;
+    rc = copy_ops(job->ops, &j->ops);
+    if (rc) return rc;
+    if (job->kind == IPX_JOB_JPEG)
+        for (int i = 0; i < job->n; i++) job->status[i] = IPX_OK;
+    // chunks: about lane_bytes of frames each, and at least two per feeder so that uploads, kernels and downloads of different
+    // chunks overlap; a JPEG job goes in parts of a few hundred files (ipx_plan_run_jpeg_jpeg pipelines inside a part)
+    int per;
+    if (job->kind == IPX_JOB_JPEG) per = std::max(1, env_int("IPX_POOL_JPEG_CHUNK", 256));
+    else {
+        const size_t fb = (size_t)job->ops.sw * job->ops.sh * 8 + ((size_t)4 << 20);
+        per = (int)std::max<size_t>(1, pool->lane_bytes / fb);
+        const int want = 2 * (int)pool->feeders.size();
+        per = std::max(1, std::min(per, (job->n + want - 1) / std::max(1, want)));
+    }
+    std::vector<Chunk> chunks;
+    for (int i0 = 0; i0 < job->n; i0 += per) {
+        Chunk c;
+        c.job = j; c.i0 = i0; c.m = std::min(per, job->n - i0);
+        if (job->kind == IPX_JOB_JPEG) {
+            JobState tmp;            // cost of this slice: its own file sizes
+            tmp.job = *job; tmp.job.files = job->files + i0; tmp.ops.p = job->ops;
+            c.cost = chunk_cost(tmp, c.m);
+        } else c.cost = chunk_cost(*j, c.m);
+        chunks.push_back(c);
+    }
+    {
+        std::lock_guard<std::mutex> lk(pool->mu);
+        if (pool->stopping) { set_error("ipx_job_submit: the pool is shutting down"); return IPX_ERR_INVALID; }
+        j->id = pool->next_id++;
+        j->chunks_left = (int)chunks.size();
+        pool->jobs[j->id] = j;
+        for (auto &c : chunks) { c.seq = pool->next_seq++; pool->queue.push(c); }
+        *ticket = j->id;
+    }
+    pool->cv_work.notify_all();
+    if (chunks.empty()) pool->cv_done.notify_all();
+    return IPX_OK;
+}
+IPX_CATCH_STATUS
+
+int ipx_job_wait(ipx_pool *pool, ipx_ticket ticket, int *frames_done) try
+{
+    clear_error();
+    if (!pool) { set_error("ipx_job_wait: null pool"); return IPX_ERR_INVALID; }
+    std::unique_lock<std::mutex> lk(pool->mu);
+    auto it = pool->jobs.find(ticket);
+    if (it == pool->jobs.end()) { set_error("ipx_job_wait: unknown ticket"); return IPX_ERR_INVALID; }
+    std::shared_ptr<JobState> j = it->second;
+    pool->cv_done.wait(lk, [&] { return j->chunks_left == 0; });
+    if (frames_done) *frames_done = j->frames_done;
+    j->waited = true;
+    if (j->status) set_error("%s", j->error.c_str());
+    return j->status;
+}
+IPX_CATCH_STATUS
+
+int ipx_job_poll(ipx_pool *pool, ipx_ticket ticket, int *done)
+{
+    clear_error();
+    if (!pool || !done) { set_error("ipx_job_poll: bad argument"); return IPX_ERR_INVALID; }
+    std::lock_guard<std::mutex> lk(pool->mu);
+    auto it = pool->jobs.find(ticket);
+    if (it == pool->jobs.end()) { set_error("ipx_job_poll: unknown ticket"); return IPX_ERR_INVALID; }
+    *done = it->second->chunks_left == 0;
+    return IPX_OK;
+}
+
+int ipx_job_release(ipx_pool *pool, ipx_ticket ticket) try
+{
+    clear_error();
+    if (!pool) { set_error("ipx_job_release: null pool"); return IPX_ERR_INVALID; }
+    std::shared_ptr<JobState> j;
+    {
+        std::unique_lock<std::mutex> lk(pool->mu);
+        auto it = pool->jobs.find(ticket);
+        if (it == pool->jobs.end()) { set_error("ipx_job_release: unknown ticket"); return IPX_ERR_INVALID; }
+        j = it->second;
+        pool->cv_done.wait(lk, [&] { return j->chunks_left == 0; });     // releasing a running job waits for it
+        pool->jobs.erase(it);
+    }
+    for (size_t i = 0; i < j->results.size(); i++) ipx_jpeg_result_free(j->result_ctx[i], j->results[i]);
+    return IPX_OK;
+}
+IPX_CATCH_STATUS
+
+int ipx_pool_run_host(ipx_pool *pool, const ipx_job *jobs, int n_jobs) try
+{
+    clear_error();
+    if (!pool || n_jobs < 0 || (n_jobs && !jobs)) { set_error("ipx_pool_run_host: bad argument"); return IPX_ERR_INVALID; }
+    for (int i = 0; i < n_jobs; i++)
+        if (jobs[i].kind != IPX_JOB_RGBA8) { set_error("ipx_pool_run_host: pixel jobs only (JPEG jobs keep their outputs until ipx_job_release)"); return IPX_ERR_INVALID; }
+    std::vector<ipx_ticket> tickets;
+    int rc = IPX_OK;
+    std::string text;
+    for (int i = 0; i < n_jobs && !rc; i++) {
+        ipx_ticket t = 0;
+        rc = ipx_job_submit(pool, &jobs[i], &t);
+        if (rc) text = ipx_last_error();
+        else tickets.push_back(t);
+    }
+    for (ipx_ticket t : tickets) {
+        const int r = ipx_job_wait(pool, t, nullptr);
+        if (r && !rc) { rc = r; text = ipx_last_error(); }
+        (void)ipx_job_release(pool, t);
+    }
+    if (rc) set_error("%s", text.c_str());
+    return rc;
+}
+IPX_CATCH_STATUS
+
+}  // extern "C"

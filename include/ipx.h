@@ -446,6 +446,66 @@ int ipx_jpeg_decode_batch(ipx_ctx *ctx, void *stream, const ipx_bytes *jpegs, in
                           ipx_ycbcr_batch *planes, int *status, ipx_jpeg_planes **owner);
 void ipx_jpeg_planes_free(ipx_ctx *ctx, ipx_jpeg_planes *owner);
 
+/* ---- one process, several GPUs, asynchronous jobs ----------------------------------------------------------
+ * The reference worker is ONE process whose goroutines pull independent messages (worker.go:88-96, 112-149); it scales by
+ * running more consumers, nothing is exchanged (kafka/consumer.go:23).  A pool is that shape behind the C ABI: one context per
+ * listed device (a device may be listed more than once), `lanes_per_device` feeder threads per context with a stream each, and ONE
+ * queue of chunks ordered by cost, largest first, that every feeder pulls from when it is free -- a mixed-size batch balances itself
+ * (work stealing falls out of pull scheduling), a uniform batch spreads evenly.  No data-path collective, no xGMI traffic.
+ * Jobs are asynchronous: ipx_job_submit returns a ticket at once, so a goroutine does not hold an OS thread for the length of a batch.
+ * cgo rule: frames, outputs, files and the status array of a job must stay valid (and, for Go, be C-allocated: ipx_pool_host_alloc)
+ * until ipx_job_wait has returned; the operator description and its glyph masks are copied at submit. */
+typedef struct ipx_pool ipx_pool;
+typedef struct {
+    int32_t lanes_per_device;   /* feeder threads (one stream each) per listed device; 0 = 3, the reference's WORKER_CONCURRENCY */
+    size_t lane_bytes;          /* frames per chunk are sized to about this many bytes; 0 = 256 MiB */
+} ipx_pool_config;
+int ipx_pool_create(const int *devices, int n_devices, const ipx_pool_config *cfg, ipx_pool **out);
+void ipx_pool_destroy(ipx_pool *pool);                        /* finishes what is queued, frees what was not released */
+int ipx_pool_slots(const ipx_pool *pool);
+long long ipx_pool_frames_done(const ipx_pool *pool, int slot); /* frames (files) slot `slot` has processed so far */
+/* hipHostMalloc'd memory, allocated and first touched on a thread bound to the CPUs next to slot `slot`'s GPU (sysfs local_cpulist):
+ * staging on the GPU's NUMA node.  Free with ipx_pool_host_free. */
+void *ipx_pool_host_alloc(ipx_pool *pool, int slot, size_t bytes);
+int ipx_pool_host_free(ipx_pool *pool, int slot, void *p);
+
+/* The operators of a job, device independent (ipx_plan_params names a glyph set of ONE context): the same fields, with the
+ * rasterised text as host masks.  Plans and uploaded glyph sets are cached per device by content. */
+typedef struct {
+    int32_t sw, sh;
+    int32_t do_resize, resize_w, resize_h, keep_aspect;
+    int32_t do_thumbnail, thumb_size, crop_to_fit;
+    int32_t do_watermark;
+    const ipx_glyph *glyphs;    /* may be NULL (copy only) */
+    int32_t n_glyphs;
+    uint8_t col[4];             /* parseColor's color.RGBA (watermark.go:93-97) */
+} ipx_pool_ops;
+
+enum { IPX_JOB_RGBA8 = 0,       /* decoded frames in, the operators' RGBA8 outputs back (what ipx_plan_run_host does) */
+       IPX_JOB_JPEG = 1 };      /* uploaded JPEG files in, three JPEG streams per file back (what ipx_plan_run_jpeg_jpeg does) */
+typedef struct {
+    int32_t kind;
+    ipx_pool_ops ops;
+    int32_t n;                  /* frames / files, all of size ops.sw x ops.sh */
+    /* IPX_JOB_RGBA8: frame i at src + i*src_frame_stride; an output pointer may be NULL to skip it */
+    const uint8_t *src; int32_t sstride; size_t src_frame_stride;
+    uint8_t *resize_out; size_t resize_frame_stride;
+    uint8_t *thumb_out; size_t thumb_frame_stride;
+    uint8_t *wm_out; size_t wm_frame_stride;
+    /* IPX_JOB_JPEG: n files; n entries per output array (or NULL), pointing into pinned blocks the pool owns until ipx_job_release;
+     * status[i] as ipx_plan_run_jpeg_jpeg reports it (files Go has to decode itself get IPX_ERR_UNSUPPORTED) */
+    const ipx_bytes *files; int32_t quality;
+    ipx_bytes *resize_jpeg, *thumb_jpeg, *wm_jpeg;
+    int32_t *status;
+} ipx_job;
+typedef uint64_t ipx_ticket;
+int ipx_job_submit(ipx_pool *pool, const ipx_job *job, ipx_ticket *ticket);     /* returns at once */
+int ipx_job_poll(ipx_pool *pool, ipx_ticket ticket, int *done);                 /* *done = 1 when ipx_job_wait would not block */
+int ipx_job_wait(ipx_pool *pool, ipx_ticket ticket, int *frames_done);          /* blocks; the job's status (first failing chunk's) */
+int ipx_job_release(ipx_pool *pool, ipx_ticket ticket);                         /* forgets the job, frees a JPEG job's output blocks */
+/* Synchronous convenience for pixel jobs: submit them all (mixed sizes welcome: the queue runs the largest first), wait, release. */
+int ipx_pool_run_host(ipx_pool *pool, const ipx_job *jobs, int n_jobs);
+
 #ifdef __cplusplus
 }
 #endif
