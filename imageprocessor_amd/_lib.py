@@ -208,6 +208,8 @@ SIGNATURES = {
     "ipx_job_wait": (_I, [_P, C.c_uint64, C.POINTER(_I)]),
     "ipx_job_release": (_I, [_P, C.c_uint64]),
     "ipx_pool_run_host": (_I, [_P, C.POINTER(Job), _I]),
+    "ipx_plan_acquire": (_I, [_P, C.POINTER(PoolOps), C.POINTER(_P), C.POINTER(_I)]),
+    "ipx_plan_release": (None, [_P, _P, _I]),
 }
 
 _lib = None

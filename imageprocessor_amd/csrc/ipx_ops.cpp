@@ -123,13 +123,14 @@ int run_ops(ipx_ctx *ctx, const ipx_image *img, const ResizeReq *rz, const Thumb
         *err = "invalid source frame";
         return IPX_ERR_INVALID;
     }
-    ipx_glyphset *gs = nullptr;
     bool rasterised = false;
     int rc = IPX_OK;
+    ipx_pool_ops po;
+    memset(&po, 0, sizeof po);
+    po.sw = img->w; po.sh = img->h;
     if (wm) {  // addTextWatermark, watermark.go:86-157
         if (!font || !font->measure || !font->glyphs) { *err = "font not loaded"; return IPX_ERR_INVALID; }
-        uint8_t col[4];
-        (void)ipx_parse_color(wm->color.c_str(), wm->opacity, col);  // a parse error falls back to black (:93-97)
+        (void)ipx_parse_color(wm->color.c_str(), wm->opacity, po.col);  // a parse error falls back to black (:93-97)
         int width_px = 0;
         if (font->measure(font->user, wm->text.c_str(), wm->font_size, &width_px)) {
             *err = "failed to draw watermark text: rasteriser failed";
@@ -145,17 +146,15 @@ int run_ops(ipx_ctx *ctx, const ipx_image *img, const ResizeReq *rz, const Thumb
             return IPX_ERR_INVALID;
         }
         rasterised = true;
-        rc = ipx_glyphset_create(ctx, gl, ng, col, &gs);
-        if (rc) { *err = ipx_last_error(); if (font->release) font->release(font->user); return rc; }
+        po.do_watermark = 1; po.glyphs = gl; po.n_glyphs = ng;
     }
-    ipx_plan_params pp;
-    memset(&pp, 0, sizeof pp);
-    pp.sw = img->w; pp.sh = img->h;
-    if (rz) { pp.do_resize = 1; pp.resize_w = rz->w; pp.resize_h = rz->h; pp.keep_aspect = rz->keep; }
-    if (th) { pp.do_thumbnail = 1; pp.thumb_size = th->size; pp.crop_to_fit = th->crop; }
-    if (wm) { pp.do_watermark = 1; pp.glyphs = gs; }
+    if (rz) { po.do_resize = 1; po.resize_w = rz->w; po.resize_h = rz->h; po.keep_aspect = rz->keep; }
+    if (th) { po.do_thumbnail = 1; po.thumb_size = th->size; po.crop_to_fit = th->crop; }
+    // the plan (tap tables, uploaded masks) comes from the context's cache, keyed by content: the same text on the same frame size --
+    // the worker's usual case -- costs no device allocation after the first call
     ipx_plan *plan = nullptr;
-    rc = ipx_plan_create(ctx, &pp, &plan);
+    int cached = 0;
+    rc = ipx_plan_acquire(ctx, &po, &plan, &cached);
     ipx_plan_info info;
     if (!rc) rc = ipx_plan_query(plan, &info);
     if (!rc) {
@@ -169,8 +168,7 @@ int run_ops(ipx_ctx *ctx, const ipx_image *img, const ResizeReq *rz, const Thumb
         rc = ipx_plan_run_host(ctx, plan, 1, img->pix, img->stride, 0, rz ? o_rz->pix : nullptr, 0,
                                th ? o_th->pix : nullptr, 0, wm ? o_wm->pix : nullptr, 0);
     if (rc) *err = ipx_last_error();
-    if (plan) ipx_plan_destroy(ctx, plan);
-    if (gs) ipx_glyphset_destroy(ctx, gs);
+    if (plan) ipx_plan_release(ctx, plan, cached);
     if (rasterised && font->release) font->release(font->user);
     return rc;
 }

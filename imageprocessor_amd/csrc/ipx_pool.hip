@@ -58,13 +58,9 @@ struct ChunkLess {   // the most expensive chunk first; submission order among e
     bool operator()(const Chunk &a, const Chunk &b) const { return a.cost != b.cost ? a.cost < b.cost : a.seq > b.seq; }
 };
 
-struct CachedPlan { ipx_glyphset *gs = nullptr; ipx_plan *plan = nullptr; };
-
 struct Slot {
     int device = 0;
     ipx_ctx *ctx = nullptr;
-    std::mutex mu;                                  // the plan cache
-    std::map<std::string, CachedPlan> plans;
 };
 
 }  // namespace
@@ -150,32 +146,6 @@ int copy_ops(const ipx_pool_ops &in, PoolOps *out)
     return IPX_OK;
 }
 
-// the slot's plan for these operators (glyph set uploaded once per slot and content).  The cache holds kMaxCachedPlans entries; past
-// that (a worker whose every task carries its own watermark text) a plan lives for one chunk: *temp receives it for the caller to free.
-constexpr size_t kMaxCachedPlans = 256;
-int slot_plan(Slot &s, const PoolOps &ops, ipx_plan **plan, CachedPlan *temp)
-{
-    std::lock_guard<std::mutex> lk(s.mu);
-    auto it = s.plans.find(ops.key);
-    if (it != s.plans.end()) { *plan = it->second.plan; return IPX_OK; }
-    CachedPlan c;
-    int rc = IPX_OK;
-    if (ops.p.do_watermark && ops.p.n_glyphs > 0) rc = ipx_glyphset_create(s.ctx, ops.glyphs.data(), ops.p.n_glyphs, ops.p.col, &c.gs);
-    if (rc) return rc;
-    ipx_plan_params pp;
-    memset(&pp, 0, sizeof pp);
-    pp.sw = ops.p.sw; pp.sh = ops.p.sh;
-    pp.do_resize = ops.p.do_resize; pp.resize_w = ops.p.resize_w; pp.resize_h = ops.p.resize_h; pp.keep_aspect = ops.p.keep_aspect;
-    pp.do_thumbnail = ops.p.do_thumbnail; pp.thumb_size = ops.p.thumb_size; pp.crop_to_fit = ops.p.crop_to_fit;
-    pp.do_watermark = ops.p.do_watermark; pp.glyphs = c.gs;
-    rc = ipx_plan_create(s.ctx, &pp, &c.plan);
-    if (rc) { if (c.gs) ipx_glyphset_destroy(s.ctx, c.gs); return rc; }
-    if (s.plans.size() < kMaxCachedPlans) s.plans.emplace(ops.key, c);
-    else *temp = c;
-    *plan = c.plan;
-    return IPX_OK;
-}
-
 struct Feeder {
     hipStream_t stream = nullptr;
     uint8_t *dev = nullptr;
@@ -230,18 +200,17 @@ int run_chunk(Slot &s, Feeder &f, JobState &j, int i0, int m, ipx_jpeg_result **
     try {
         if (!f.stream) { set_error("pool: the feeder has no stream"); return IPX_ERR_HIP; }
         ipx_plan *plan = nullptr;
-        CachedPlan temp;
-        int rc = slot_plan(s, j.ops, &plan, &temp);
+        int cached = 0;
+        int rc = ipx_plan_acquire(s.ctx, &j.ops.p, &plan, &cached);     // plans and glyph sets by content, per context
         if (rc) return rc;
         if (j.job.kind == IPX_JOB_JPEG)
             rc = ipx_plan_run_jpeg_jpeg(s.ctx, plan, m, j.job.files + i0, j.job.quality, j.job.resize_jpeg ? j.job.resize_jpeg + i0 : nullptr,
                                         j.job.thumb_jpeg ? j.job.thumb_jpeg + i0 : nullptr, j.job.wm_jpeg ? j.job.wm_jpeg + i0 : nullptr,
                                         j.job.status + i0, res);
         else rc = run_rgba_chunk(s, f, j, plan, i0, m);      // (both return with the chunk's GPU work finished)
-        if (temp.plan) {
+        if (!cached) {
             std::string keep = rc ? ipx_last_error() : "";
-            ipx_plan_destroy(s.ctx, temp.plan);
-            if (temp.gs) ipx_glyphset_destroy(s.ctx, temp.gs);
+            ipx_plan_release(s.ctx, plan, cached);
             if (rc) set_error("%s", keep.c_str());
         }
         return rc;
@@ -345,14 +314,7 @@ void ipx_pool_destroy(ipx_pool *pool)
     for (auto &t : pool->feeders) t.join();      // feeders drain the queue before they leave
     for (auto &kv : pool->jobs)
         for (size_t i = 0; i < kv.second->results.size(); i++) ipx_jpeg_result_free(kv.second->result_ctx[i], kv.second->results[i]);
-    for (auto &s : pool->slots) {
-        (void)hipSetDevice(s->device);
-        for (auto &kv : s->plans) {
-            ipx_plan_destroy(s->ctx, kv.second.plan);
-            if (kv.second.gs) ipx_glyphset_destroy(s->ctx, kv.second.gs);
-        }
-        ipx_destroy(s->ctx);
-    }
+    for (auto &s : pool->slots) ipx_destroy(s->ctx);     // (with the plans its cache holds)
     delete pool;
 }
 

@@ -211,13 +211,19 @@ int ipx_create(const ipx_config *cfg, ipx_ctx **out) try
     if (!c) { set_error("out of memory"); return IPX_ERR_NOMEM; }
     c->device = dev;
     c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    int lanes = cfg && cfg->lanes > 0 ? cfg->lanes : env_int("IPX_LANES", 3);
+    int lanes = cfg && cfg->lanes > 0 ? cfg->lanes : env_int("IPX_LANES", 4);
     c->lane_bytes = cfg && cfg->lane_bytes ? cfg->lane_bytes : (size_t)64 << 20;
     c->host_cache_limit = (size_t)std::max(0, env_int("IPX_HOST_CACHE_MB", 8192)) << 20;
     c->lanes.resize(lanes);
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    for (auto &l : c->lanes) {
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    for (size_t i = 0; i < c->lanes.size(); i++) {
+        Lane &l = c->lanes[i];
+        // the last lane is the one a batch leaves free: single-frame calls land on it, ahead of the batch's queued work
+        if (e == hipSuccess)
+            e = i + 1 == c->lanes.size() && c->lanes.size() >= 3 ? hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_hi)
+                                                                 : hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&l.flag, sizeof(int));
     }
     if (e == hipSuccess) {
@@ -255,6 +261,8 @@ void ipx_destroy(ipx_ctx *c)
     }
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->flat_chroma) (void)hipFree(c->flat_chroma);
+    for (auto &kv : c->plan_cache) ipx_plan_destroy(c, kv.second.second);     // (their glyph sets go with them)
+    c->plan_cache.clear();
     for (auto &b : c->host_free_blocks) (void)hipHostFree(b.second);
     delete c;
 }
@@ -926,7 +934,68 @@ void ipx_plan_destroy(ipx_ctx *ctx, ipx_plan *plan)
     if (ctx) (void)hipSetDevice(ctx->device);
     if (plan->blob) (void)hipFree(plan->blob);
     if (plan->thumb_only) ipx_plan_destroy(ctx, plan->thumb_only);
+    if (plan->owned_gs) ipx_glyphset_destroy(ctx, plan->owned_gs);
     delete plan;
+}
+
+// ---- plans by content --------------------------------------------------------------------------------------------------------
+// The per-operator entries (ipx_*_process, ipx_processor_process) and the pool describe their operators per call; building a glyph set
+// and a plan per call cost three hipMalloc / hipFree pairs, each of which waits for every stream of the device.  The context keeps
+// plans (with their glyph sets) by content instead: operator parameters, colour, and every glyph's rectangle and mask bytes.
+static constexpr size_t kMaxCachedPlans = 256;
+
+static int ops_key(const ipx_pool_ops &in, std::string *key)
+{
+    if (in.n_glyphs < 0 || (in.n_glyphs && !in.glyphs)) { set_error("bad glyph list"); return IPX_ERR_INVALID; }
+    key->assign((const char *)&in, offsetof(ipx_pool_ops, glyphs));
+    key->append((const char *)in.col, 4);
+    for (int i = 0; i < in.n_glyphs; i++) {
+        const ipx_glyph &g = in.glyphs[i];
+        if (g.mw < 0 || g.mh < 0 || (g.mw && g.mh && (!g.mask || g.mstride < g.mw))) { set_error("glyph %d has a bad mask", i); return IPX_ERR_INVALID; }
+        key->append((const char *)&g.mw, sizeof(int32_t) * 2);
+        key->append((const char *)&g.dr, sizeof g.dr);
+        key->append((const char *)&g.mpx, sizeof(int32_t) * 2);
+        for (int y = 0; y < g.mh; y++) key->append((const char *)g.mask + (size_t)y * g.mstride, (size_t)g.mw);
+    }
+    return IPX_OK;
+}
+
+int ipx_plan_acquire(ipx_ctx *ctx, const ipx_pool_ops *ops, ipx_plan **plan, int *cached) try
+{
+    IPX_ENTER(ctx);
+    if (!ops || !plan || !cached) { set_error("ipx_plan_acquire: bad argument"); return IPX_ERR_INVALID; }
+    *plan = nullptr; *cached = 0;
+    std::string key;
+    int rc = ops_key(*ops, &key);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->plan_mu);      // (a miss builds under the lock: two callers with the same new content build once)
+    const bool use_cache = env_int("IPX_PLAN_CACHE", 1) != 0;     // 0: a plan per call, as before the cache existed (tools/bench_seam.py)
+    auto it = ctx->plan_cache.find(key);
+    if (use_cache && it != ctx->plan_cache.end()) { *plan = it->second.second; *cached = 1; return IPX_OK; }
+    ipx_glyphset *gs = nullptr;
+    if (ops->do_watermark && ops->n_glyphs > 0) {
+        rc = ipx_glyphset_create(ctx, ops->glyphs, ops->n_glyphs, ops->col, &gs);
+        if (rc) return rc;
+    }
+    ipx_plan_params pp;
+    memset(&pp, 0, sizeof pp);
+    pp.sw = ops->sw; pp.sh = ops->sh;
+    pp.do_resize = ops->do_resize; pp.resize_w = ops->resize_w; pp.resize_h = ops->resize_h; pp.keep_aspect = ops->keep_aspect;
+    pp.do_thumbnail = ops->do_thumbnail; pp.thumb_size = ops->thumb_size; pp.crop_to_fit = ops->crop_to_fit;
+    pp.do_watermark = ops->do_watermark; pp.glyphs = gs;
+    ipx_plan *pl = nullptr;
+    rc = ipx_plan_create(ctx, &pp, &pl);
+    if (rc) { if (gs) ipx_glyphset_destroy(ctx, gs); return rc; }
+    pl->owned_gs = gs;
+    if (use_cache && ctx->plan_cache.size() < kMaxCachedPlans) { ctx->plan_cache.emplace(std::move(key), std::make_pair(gs, pl)); *cached = 1; }
+    *plan = pl;
+    return IPX_OK;
+}
+IPX_CATCH_STATUS
+
+void ipx_plan_release(ipx_ctx *ctx, ipx_plan *plan, int cached)
+{
+    if (plan && !cached) ipx_plan_destroy(ctx, plan);   // a plan the full cache did not take lives for one call
 }
 
 int ipx_plan_query(const ipx_plan *plan, ipx_plan_info *info) try
@@ -1082,12 +1151,20 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
     chunk = (int)std::min<size_t>((size_t)chunk, std::max<size_t>(1, ctx->lane_bytes / per_frame));
     chunk = std::max(1, std::min(chunk, env_int("IPX_HOST_CHUNK", 16)));
 
-    // take every lane: this call is the pipeline
+    // This call is the pipeline: it takes the lanes -- all but one when the context has three or more, so that a single-frame call
+    // (the per-operator seam: one chunk, one lane) is served WHILE a batch runs instead of behind it; a call of one chunk takes one.
+    const int nchunks = (n + chunk - 1) / chunk;
+    const int want = nchunks <= 1 ? 1 : std::max(1, nl >= 3 ? nl - 1 : nl);
     std::vector<Lane *> lanes;
     {
         std::unique_lock<std::mutex> lk(ctx->mu);
-        ctx->cv.wait(lk, [&] { for (auto &l : ctx->lanes) if (l.busy) return false; return true; });
-        for (auto &l : ctx->lanes) { l.busy = true; lanes.push_back(&l); }
+        auto free_lanes = [&] { int k = 0; for (auto &l : ctx->lanes) k += !l.busy; return k; };
+        ctx->cv.wait(lk, [&] { return free_lanes() >= want; });
+        if (want == 1) {   // a single chunk: the last free lane (the high-priority one when it is free)
+            for (size_t i = ctx->lanes.size(); i-- > 0;) if (!ctx->lanes[i].busy) { ctx->lanes[i].busy = true; lanes.push_back(&ctx->lanes[i]); break; }
+        } else {
+            for (auto &l : ctx->lanes) if (!l.busy && (int)lanes.size() < want) { l.busy = true; lanes.push_back(&l); }
+        }
     }
     int rc = IPX_OK;
     hipError_t e = hipSuccess;

@@ -49,6 +49,10 @@ struct ipx_ctx {
     // decode step instead of 0.03 s -- whatever serialises there (allocation, synchronisation), a fourth part gains nothing
     int jj_active = 0;
     uint8_t *flat_chroma = nullptr;
+    // plans (tap tables in HBM) and uploaded glyph sets by content, for callers that describe their operators per call
+    // (ipx_plan_acquire: the per-operator seam, the pool): no hipMalloc / hipFree in the steady state
+    std::mutex plan_mu;
+    std::map<std::string, std::pair<ipx_glyphset *, ipx_plan *>> plan_cache;
     static constexpr size_t kFlatChromaBytes = (size_t)64 << 10;
 };
 
@@ -101,6 +105,7 @@ struct ipx_plan {
     ClippedGlyphs glyphs;
     mutable std::mutex mu;
     mutable ipx_plan *thumb_only = nullptr;   // RGBA sub-plan for YCbCr batches (thumbnail of the converted frame)
+    ipx_glyphset *owned_gs = nullptr;         // a glyph set that lives and dies with this plan (ipx_plan_acquire)
 };
 
 inline int env_int(const char *name, int dflt)

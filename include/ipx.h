@@ -56,8 +56,9 @@ typedef struct {
 
 typedef struct {
     int32_t device;        /* HIP device ordinal; -1 = LOCAL_RANK / 0                          */
-    int32_t lanes;         /* concurrent host-pointer calls served without blocking; 0 = 3,
-                              the reference's WORKER_CONCURRENCY (.env.example:38, worker.go:90) */
+    int32_t lanes;         /* staging lanes (a stream + device scratch each); 0 = 4: a host batch pipelines its chunks over three --
+                              the reference's WORKER_CONCURRENCY (.env.example:38, worker.go:90) -- and one stays free, so that a
+                              single-frame call is served while a batch runs */
     size_t lane_bytes;     /* initial pinned+device staging per lane; grows on demand; 0 = 64 MiB */
 } ipx_config;
 
@@ -480,6 +481,13 @@ typedef struct {
     int32_t n_glyphs;
     uint8_t col[4];             /* parseColor's color.RGBA (watermark.go:93-97) */
 } ipx_pool_ops;
+
+/* A plan (and its uploaded glyph set) from the context's cache, keyed by content: what the per-operator entries and the pool use,
+ * so that describing the operators per call costs no hipMalloc / hipFree in the steady state (each of those waits for every stream
+ * of the device).  *cached = 1: the context owns the plan (valid until ipx_destroy); 0: the cache was full and the plan is the
+ * caller's for this call.  Either way hand it back with ipx_plan_release. */
+int ipx_plan_acquire(ipx_ctx *ctx, const ipx_pool_ops *ops, ipx_plan **plan, int *cached);
+void ipx_plan_release(ipx_ctx *ctx, ipx_plan *plan, int cached);
 
 enum { IPX_JOB_RGBA8 = 0,       /* decoded frames in, the operators' RGBA8 outputs back (what ipx_plan_run_host does) */
        IPX_JOB_JPEG = 1 };      /* uploaded JPEG files in, three JPEG streams per file back (what ipx_plan_run_jpeg_jpeg does) */

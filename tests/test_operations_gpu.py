@@ -234,3 +234,72 @@ def test_image_processor_failures_and_quirks(ctx, ops, font):
     # an empty operator list is a completed task with no outputs
     res, err = ip.Process(_task([]), SRC)
     assert err is None and res["Status"] == "completed" and not res["Outputs"]
+
+
+def test_single_image_calls_are_served_while_a_batch_runs(ipx, ops, font):
+    """image_processor.go:64-77 per message next to a batch of the same process: the per-operator seam takes its plan and glyph
+    set from the context's cache (no hipMalloc / hipFree after the first call -- each of those waits for every stream of the
+    device) and ONE staging lane, and a host batch leaves one lane free: single calls finish while the batch is still running,
+    and both produce the oracle's bytes."""
+    import threading
+    import time
+    task = _task([{"Type": "thumbnail", "Parameters": {"size": 200.0, "crop_to_fit": True}},
+                  {"Type": "resize", "Parameters": {"width": 1024.0, "height": 768.0, "keep_aspect": True}},
+                  {"Type": "watermark", "Parameters": {"text": "© ImageProcessor", "opacity": 0.5, "position": "bottom-right"}}])
+    want_wm = expect_watermark(SRC, "© ImageProcessor", "bottom-right", 0.5, 36, "255,255,255")
+    with ipx.Context(device=0) as c:        # default lanes: three for a batch's pipeline, one left for single calls
+        ip = ops.ImageProcessor(c, font)
+        for _ in range(3):                  # first call builds the plan; the later ones come from the cache
+            res, err = ip.Process(task, SRC, "jpeg")
+            assert err is None
+        n, w, h = 384, 1920, 1080
+        frames = c.host_alloc((n, h, w, 4))
+        frames[:] = np.resize(rgba_frames(4, w, h, seed=5), frames.shape)
+        plan = c.plan(w, h, resize=(1024, 768, True), thumbnail=(200, True), watermark=True)
+        outs = {"resize": c.host_alloc((n, 576, 1024, 4)), "thumbnail": c.host_alloc((n, 200, 200, 4)), "watermark": c.host_alloc((n, h, w, 4))}
+        plan.run_host(frames, out=outs)                                     # warm the lanes
+        t0 = time.perf_counter()
+        plan.run_host(frames, out=outs)
+        batch_alone = time.perf_counter() - t0
+        state = {"running": True, "batches": 0}
+
+        def batches():
+            while state["running"]:
+                plan.run_host(frames, out=outs)
+                state["batches"] += 1
+        th = threading.Thread(target=batches)
+        th.start()
+        time.sleep(batch_alone * 0.3)
+        lat = []
+        try:
+            for _ in range(12):
+                t0 = time.perf_counter()
+                res, err = ip.Process(task, SRC, "jpeg")
+                lat.append(time.perf_counter() - t0)
+                assert err is None
+                np.testing.assert_array_equal(res["Outputs"]["watermark"][0], want_wm)
+        finally:
+            state["running"] = False
+            th.join()
+        want = oracle.process(frames[1], resize=(1024, 768, True), thumb=(200, True))
+        np.testing.assert_array_equal(outs["resize"][1], want["resize"])
+        # a call that had to wait for the device to drain would take about batch_alone (every chunk of a batch is queued at once);
+        # what is left is queueing behind the copies that already sit on the link
+        assert sorted(lat)[len(lat) // 2] < 0.5 * batch_alone, (lat, batch_alone)
+        plan.close()
+        for a in [frames] + list(outs.values()):
+            c.host_free(a)
+
+
+def test_fused_failure_falls_back_to_the_sequential_order(ctx, ops):
+    """image_processor.go:64-92: when the watermark fails (here: the rasteriser), the resize before it has already been stored and
+    the error names the watermark operator with its own prefix."""
+    def bad_glyphs(text, size, px, py, w=None, h=None):
+        raise RuntimeError("no outlines")
+    broken = ops.Font(fake_measure, bad_glyphs)
+    res, err = ops.ImageProcessor(ctx, broken).Process(_task([{"Type": "resize", "Parameters": {"width": 64.0, "height": 36.0}},
+                                                              {"Type": "watermark", "Parameters": {}}]), SRC)
+    assert err == ("operation watermark failed: failed to process operation watermark: failed to add watermark: "
+                   "failed to draw watermark text: rasteriser failed")
+    assert list(res["ProcessedPaths"]) == ["resize"] and res["Status"] == "failed"
+    np.testing.assert_array_equal(res["Outputs"]["resize"][0], oracle.scale_bilinear(SRC, 64, 36))
