@@ -383,11 +383,12 @@ int ipx_processor_process(ipx_ctx *ctx, const ipx_task *task, const ipx_image *d
 
 /* ---- jpeg.Encode (encoder side) ------------------------------------------------
  * Every operator of the reference ends in jpeg.Encode(buf, img, &jpeg.Options{Quality: 85}) on its
- * *image.RGBA (resize.go:80, thumbnail.go:70, watermark.go:68,73,76).  Go's writer is restated in two
- * halves: colour conversion, 2x2 chroma box, jfdctint and the quantiser run on the GPU and leave int16
- * coefficients (zig-zag order, 6 x 64 per 16x16 MCU in scan order Y0 Y1 Y2 Y3 Cb Cr); SOI / DQT / SOF0 /
- * DHT / SOS, the Huffman coder with 0xff stuffing and EOI run on the host.  The byte stream is the one
- * Go's encoder writes (no JFIF segment, both DQT tables, 4:2:0, Annex K Huffman tables). */
+ * *image.RGBA (resize.go:80, thumbnail.go:70, watermark.go:68,73,76).  Go's writer is restated on the GPU end to end: colour
+ * conversion, 2x2 chroma box, jfdctint and the quantiser leave int16 coefficients (zig-zag order, 6 x 64 per 16x16 MCU in scan order
+ * Y0 Y1 Y2 Y3 Cb Cr); the Huffman coder sizes every block while it still sits in LDS, places the bits, stuffs 0xff bytes and
+ * prepends SOI / DQT / SOF0 / DHT / SOS in further kernels (ipx_jpeg_encode_batch_dev and the ipx_plan_run_*_jpeg entries), so only
+ * finished streams cross the link.  ipx_jpeg_entropy_encode is the same coder on the host, for coefficients a caller has downloaded.
+ * The byte stream is the one Go's encoder writes (no JFIF segment, both DQT tables, 4:2:0, Annex K Huffman tables). */
 size_t ipx_jpeg_coef_count(int w, int h);                 /* int16 elements per frame                 */
 int ipx_jpeg_quant_tables(int quality, uint8_t out[128]); /* the two DQT tables, zig-zag order         */
 /* n frames resident in HBM -> coefficients in HBM (n * ipx_jpeg_coef_count int16).  Asynchronous. */
