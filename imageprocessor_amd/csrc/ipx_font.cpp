@@ -824,9 +824,8 @@ std::shared_ptr<ipx_font::Mask> rasterize(const ipx_font &f, f26 scale, uint32_t
     return m;
 }
 
-// (c *Context) glyph: integer / fractional split of p, 4 x-subpixel slots and 1 y slot.  The cache slot index
-// only decides WHEN Go re-rasterises; an entry is reused only for equal (glyph, fx, fy), so the values are
-// those of rasterize(glyph, p.X & 63, p.Y & 63).
+// A memo of rasterize(glyph, fx, fy) across calls.  This is NOT freetype's own glyph cache (that one lives per Context and is
+// modelled in ipx_font_draw_string, where it changes results); it only saves rasterising the same (glyph, fx, fy) again.
 std::shared_ptr<ipx_font::Mask> cached_mask(ipx_font &f, f26 scale, uint32_t glyph, f26 fx, f26 fy)
 {
     const auto key = std::make_tuple(scale, glyph, fx, fy);
@@ -971,12 +970,25 @@ int ipx_font_draw_string(ipx_font *f, const char *text, double font_size, int px
     f26 X = (f26)((uint32_t)px << 6), Y = (f26)((uint32_t)py << 6);   // freetype.Pt
     uint32_t prev = 0;
     bool has_prev = false;
+    // (c *Context) glyph keeps a cache of nGlyphs * nXFractions * nYFractions = 256 * 4 * 1 entries, and addTextWatermark makes a
+    // fresh Context per call (watermark.go:98), so the cache lives exactly as long as this DrawString.  Slot t = ((fx / 16) * 1 +
+    // fy / 64) * 256 + glyph % 256; a hit needs `e.valid && e.glyph == glyph` only -- NOT an equal fx: a glyph that comes again with
+    // its fx in the same quarter-pixel bucket reuses the mask (and offset, and advance) rasterised at the FIRST fx.  The default
+    // text "© ImageProcessor" repeats o, r, s and e, so this decides antialiasing pixels of the reference's watermark.
+    struct CacheEntry { bool valid = false; uint32_t glyph = 0; std::shared_ptr<ipx_font::Mask> mask; };
+    std::vector<CacheEntry> cache(256 * 4);
     try {
         for (uint32_t r : runes(text)) {
             const uint32_t index = glyph_index(*f, r);
             if (has_prev) X += kern(*f, scale, prev, index);
             const int ix = (int)(X >> 6), iy = (int)(Y >> 6);
-            auto m = cached_mask(*f, scale, index, X & 0x3f, Y & 0x3f);
+            const f26 fx = X & 0x3f, fy = Y & 0x3f;
+            CacheEntry &e = cache[(size_t)(((int)fx / 16) * 1 + (int)fy / 64) * 256 + index % 256];
+            if (!(e.valid && e.glyph == index)) {
+                e.mask = cached_mask(*f, scale, index, fx, fy);     // a ParseError leaves the slot as it was, like Go's early return
+                e.valid = true; e.glyph = index;
+            }
+            auto m = e.mask;
             X += m->advance;
             // glyphRect = mask.Bounds().Add(offset + (ix, iy)); dr = clip ∩ glyphRect
             const int gx0 = m->offx + ix, gy0 = m->offy + iy, gx1 = gx0 + m->w, gy1 = gy0 + m->h;

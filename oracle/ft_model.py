@@ -378,11 +378,19 @@ def draw_string(font, text, size, px, py, clip_w, clip_h):
     X, Y = px << 6, py << 6
     prev = None
     out = []
+    # (c *Context) glyph: 256 * 4 * 1 cache slots per Context (one per DrawString here: addTextWatermark makes a fresh Context,
+    # watermark.go:98).  A hit needs `e.valid && e.glyph == glyph` only, so a repeated glyph whose fx lands in the same quarter-pixel
+    # bucket reuses the mask, offset and advance rasterised at the FIRST fx.
+    cache = {}
     for ch in text:
         idx = font.index(ord(ch))
         if prev is not None:
             X += font.kern(scale, prev, idx)
-        adv, mask, (ox, oy) = rasterize(font, scale, idx, X & 63, Y & 63)
+        fx, fy = X & 63, Y & 63
+        t = ((fx // 16) * 1 + fy // 64) * 256 + idx % 256
+        if t not in cache or cache[t][0] != idx:
+            cache[t] = (idx, rasterize(font, scale, idx, fx, fy))
+        adv, mask, (ox, oy) = cache[t][1]
         gx0, gy0 = ox + (X >> 6), oy + (Y >> 6)
         X += adv
         mh, mw = mask.shape

@@ -127,6 +127,35 @@ def test_subpixel_x_positions_and_mp_quirk():
     f.close()
 
 
+def test_context_glyph_cache_reuses_the_first_rasterisation_in_a_bucket():
+    """(c *Context) glyph of golang/freetype: 4 sub-pixel slots per glyph, and a hit needs only `e.valid && e.glyph == glyph` -- a
+    repeated glyph whose fx falls into the same quarter-pixel bucket gets the mask rasterised at the FIRST fx of that bucket
+    (addTextWatermark makes a fresh Context per call, watermark.go:98, so the cache lives for one DrawString).  At font size 64
+    one font unit is 1/64 px: an advance of 645 units moves fx by 5 per glyph: 0, 5, 10, 15 (bucket 0), 20 (bucket 1) ..."""
+    from oracle import ft_model
+    ttf = build_font({"A": [box(0, 0, 645 - 64, 640)]}, advance=645)
+    f = TrueTypeFont(ttf)
+    gl, _ = f.draw_string("AAAAAA", 64, 2, 20, 200, 100)
+    assert len(gl) == 6
+    # fx = 0 for the first glyph: its left edge is whole, and the three glyphs that follow in bucket 0 carry the SAME mask although
+    # a rasterisation at their own fx (5, 10, 15) would shade the left column
+    first = gl[0]["mask"]
+    assert (first[:, 0] == 255).all()
+    for k in (1, 2, 3):
+        np.testing.assert_array_equal(gl[k]["mask"], first, err_msg="glyph %d" % k)
+    # the fifth glyph opens bucket 1 and is rasterised at fx = 20: a partially covered left column
+    assert 0 < gl[4]["mask"][0, 0] < 255 and not np.array_equal(gl[4]["mask"], first)
+    np.testing.assert_array_equal(gl[5]["mask"], gl[4]["mask"])          # fx = 25: bucket 1 again
+    # positions still advance by the true pen position (the cached offset is relative to the integer part)
+    assert [g["dr"][0] for g in gl] == [2 + (645 * k) // 64 for k in range(6)]
+    # the Python model carries the same rule
+    want, _ = ft_model.draw_string(ft_model.Font(io.BytesIO(ttf)), "AAAAAA", 64, 2, 20, 200, 100)
+    for g, w_ in zip(gl, want):
+        np.testing.assert_array_equal(g["mask"], w_["mask"])
+        assert g["dr"] == w_["dr"]
+    f.close()
+
+
 def test_quadratic_contour_area():
     """Four quadratic arcs with the controls at the corners of the bounding square: the ink must match the
     analytic area (10/3 R^2) to 0.5 %, i.e. Add2's subdivision is fine enough and closed."""
