@@ -245,6 +245,8 @@ hipError_t launch_jpeg_fdct(const JpegArgs &a, int n, hipStream_t s);
 // ---- image.Decode for baseline JPEGs (ipx_jpeg_dec_host.cpp parses, ipx_jpeg_dec.hip decodes) ------------
 struct JpegDecInfo {
     int w, h, h0, v0, ratio, ri, ncomp;
+    int host_scans;            // 1: not one baseline scan the GPU's Huffman kernels take (progressive, several scans, table ids above 1):
+                               // jpeg_host_decode walks the scans on the host, the coefficients go up, the GPU does the rest
     uint8_t td[3], ta[3];      // kernel table slots of the three components: 0,1 = DC tables, 2,3 = AC tables
     size_t scan_off, scan_len; // entropy-coded data within the file
 };
@@ -270,6 +272,7 @@ struct JpegDecArgs {
     int16_t *coefs; int *status;
     int16_t *dcs;                    // [n][nblk] the DC coefficient of every block (coefs[...][0] stays zero)
     int n, mxx, myy, h0, v0, nblk;   // n = images
+    int w, h;                        // the batch's frame size (progressive images reconstruct only blocks that hold image pixels)
     int bpm, ybl;                    // blocks per MCU and how many of them are luma (Gray: 1, 1)
     int nitems;                      // pieces to decode (>= images)
     int shared_tables, first_valid;   // every valid image carries the Huffman tables of image first_valid
@@ -284,7 +287,7 @@ inline int jpeg_status_key(uint32_t first_mcu, int status) { return -(int)(((0x3
 // lowest priority: any real decoding error elsewhere in the file, which Go fails on as well, wins
 constexpr uint32_t kJpegStatusLast = 0x3ffffffu;
 inline int jpeg_status_of(int key) { return key >= 0 ? 0 : -(int)((uint32_t)(-key) & 7u); }
-struct JpegPlanes { uint8_t *y, *cb, *cr; int ystride, cstride; size_t y_fs, c_fs; const uint8_t *valid; /* per image */ };
+struct JpegPlanes { uint8_t *y, *cb, *cr; int ystride, cstride; size_t y_fs, c_fs; const uint8_t *valid; /* per image: bit 0 decodable, bit 1 progressive */ };
 // Huffman decoding parallel inside a scan (ipx_jpeg_dec_par.hip): per image and per 1 KiB sub-sequence of its scan
 struct JpegParImage { unsigned long long scan_off; uint32_t scan_len, img, nsub; size_t sub_off; uint8_t td[3], ta[3], pad[2]; };
 struct JpegParArgs {
@@ -309,6 +312,11 @@ hipError_t launch_par_sync(const JpegParArgs &a, int round, hipStream_t s);
 hipError_t launch_par_write(const JpegParArgs &a, hipStream_t s);
 hipError_t launch_par_dc(const JpegParArgs &a, hipStream_t s);
 int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *tab);
+}  // namespace ipx
+#include <vector>
+namespace ipx {
+int jpeg_host_decode(const uint8_t *d, size_t len, JpegDecInfo *info, std::vector<int16_t> *coefs, std::vector<int16_t> *dcs,
+                     uint16_t qnat[3][64], bool *progressive);
 hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s);
 // the same pieces through the word-wise reader of the parallel decoder: unstuff each piece into ublob (+ its length into ulen), then one
 // decode pass -- the state at the start of a piece is known, so nothing is speculative.  The 64 pieces of a workgroup share one set

@@ -291,7 +291,9 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegDecArgs a, JpegPlane
     __shared__ __attribute__((aligned(8))) uint8_t ob[32 * 64];
     const int t = threadIdx.x, blk = t >> 3, r = t & 7;
     const int img = blockIdx.y;
-    if (!pl.valid[img]) return;                           // uniform over the workgroup
+    const int vflags = pl.valid[img];
+    if (!vflags) return;                                  // uniform over the workgroup
+    const bool prog = (vflags & 2) != 0;                  // reconstructProgressiveImage: blocks that hold no image pixel stay zero
     const int gb = blockIdx.x * 32 + blk;
     const bool live = gb < a.nblk;
     const int ybl = a.ybl, bpm = a.bpm;
@@ -322,9 +324,17 @@ __global__ __launch_bounds__(256) void jpeg_idct_kernel(JpegDecArgs a, JpegPlane
         const int mx = m % a.mxx, my = m / a.mxx;
         int bx, by, stride;
         uint8_t *plane;
-        if (c == 0) { bx = a.h0 * mx + bi % a.h0; by = a.v0 * my + bi / a.h0; stride = pl.ystride; plane = pl.y + (size_t)img * pl.y_fs; }
-        else { bx = mx; by = my; stride = pl.cstride; plane = (c == 1 ? pl.cb : pl.cr) + (size_t)img * pl.c_fs; }
-        *(uint2 *)(plane + (size_t)(by * 8 + r) * stride + bx * 8) = *(const uint2 *)(ob + blk * 64 + r * 8);
+        bool inside;      // `for by := 0; by*v < d.height` / `bx*h < d.width` with v = 8*v0/vi, h = 8*h0/hi (scan.go, reconstructProgressiveImage)
+        if (c == 0) {
+            bx = a.h0 * mx + bi % a.h0; by = a.v0 * my + bi / a.h0; stride = pl.ystride; plane = pl.y + (size_t)img * pl.y_fs;
+            inside = bx * 8 < a.w && by * 8 < a.h;
+        } else {
+            bx = mx; by = my; stride = pl.cstride; plane = (c == 1 ? pl.cb : pl.cr) + (size_t)img * pl.c_fs;
+            inside = bx * 8 * a.h0 < a.w && by * 8 * a.v0 < a.h;
+        }
+        uint2 row = *(const uint2 *)(ob + blk * 64 + r * 8);
+        if (prog && !inside) row = make_uint2(0u, 0u);    // image.NewYCbCr's zeros: Go never writes these blocks of a progressive image
+        *(uint2 *)(plane + (size_t)(by * 8 + r) * stride + bx * 8) = row;
     }
 }
 

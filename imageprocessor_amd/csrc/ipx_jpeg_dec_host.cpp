@@ -6,8 +6,10 @@
 // tiny: walk the markers, collect the tables the single scan refers to, and lay them out the way the kernels read them
 // (an 8-bit first-level Huffman table plus the canonical mincode / maxcode arrays for longer codes; quantisers
 // de-zig-zagged).  Anything outside the baseline subset the kernels implement is reported as IPX_ERR_UNSUPPORTED for
-// that image, so that the worker keeps Go's CPU path for it: progressive (SOF2), CMYK / RGB (Adobe) files,
-// 4:1:1 / 4:1:0 and other sampling factors, several scans, 12-bit samples, Huffman table ids above 1.
+// that image, so that the worker keeps Go's CPU path for it: CMYK / RGB (Adobe) files, 4:1:1 / 4:1:0 and other sampling factors,
+// 12-bit samples.  Progressive files, files coded in several scans and Huffman table ids above 1 are marked host_scans: their
+// scans are decoded on the host (ipx_jpeg_dec_prog.cpp) and only the transform onwards runs on the GPU.  A file has to end the way
+// Go's marker loop wants it to (EOI after the last scan), or it is malformed here as it is there.
 #include <cstring>
 
 #include "ipx_internal.h"
@@ -57,14 +59,15 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
     memset(info, 0, sizeof *info);
     if (len < 4 || d[0] != 0xff || d[1] != 0xd8) return IPX_ERR_INVALID;
     uint16_t quant[4][64];
-    bool have_q[4] = {false, false, false, false};
+    memset(quant, 0, sizeof quant);                            // a table no DQT defined is all zero in Go's decoder, and the file decodes (to flat grey)
     RawHuff hf[2][4];
     int ncomp = 0, ch[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, ctq[3] = {0, 0, 0}, cid[3] = {0, 0, 0};
     bool jfif = false, adobe = false;
     int adobe_transform = 0;
     size_t i = 2;
     for (;;) {
-        if (i + 2 > len || d[i] != 0xff) return IPX_ERR_INVALID;
+        if (i + 2 > len) return IPX_ERR_INVALID;
+        if (d[i] != 0xff) { i++; continue; }                   // decode(): bytes that belong to no segment are skipped ("libjpeg is liberal")
         while (i + 1 < len && d[i + 1] == 0xff) i++;
         if (i + 2 > len) return IPX_ERR_INVALID;
         const int m = d[i + 1];
@@ -77,7 +80,8 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
         const uint8_t *s = d + i + 2;
         const size_t sn = n - 2;
         switch (m) {
-        case 0xc0: case 0xc1: {
+        case 0xc0: case 0xc1: case 0xc2: {
+            if (m == 0xc2) info->host_scans = 1;               // progressive: the scans refine each other (ipx_jpeg_dec_prog.cpp)
             if (ncomp || sn < 6) return IPX_ERR_INVALID;
             if (s[0] != 8) return IPX_ERR_UNSUPPORTED;
             info->h = (int)be16(s + 1); info->w = (int)be16(s + 3);
@@ -94,7 +98,6 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
             if (ch[1] != 1 || cv[1] != 1 || ch[2] != 1 || cv[2] != 1 || ch[0] > 2 || cv[0] > 2) return IPX_ERR_UNSUPPORTED;
             break;
         }
-        case 0xc2: return IPX_ERR_UNSUPPORTED;
         case 0xc4: {
             size_t k = 0;
             while (k < sn) {
@@ -120,7 +123,6 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
                 const size_t need = pq ? 128 : 64;
                 if (k + 1 + need > sn) return IPX_ERR_INVALID;
                 for (int z = 0; z < 64; z++) quant[tq][z] = pq ? (uint16_t)be16(s + k + 1 + 2 * z) : s[k + 1 + z];
-                have_q[tq] = true;
                 k += 1 + need;
             }
             break;
@@ -134,23 +136,68 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
         case 0xda: {
             if (!ncomp) return IPX_ERR_INVALID;
             if (sn < 1) return IPX_ERR_INVALID;
-            if (s[0] != ncomp) return s[0] >= 1 && s[0] <= 3 ? IPX_ERR_UNSUPPORTED : IPX_ERR_INVALID;   // a frame coded in several scans
-            if (sn != (size_t)(4 + 2 * ncomp)) return IPX_ERR_INVALID;
-            int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
-            for (int c = 0; c < ncomp; c++) {
-                if (s[1 + 2 * c] != cid[c]) return IPX_ERR_UNSUPPORTED;
-                td[c] = s[2 + 2 * c] >> 4; ta[c] = s[2 + 2 * c] & 15;
-                if (td[c] > 3 || ta[c] > 3) return IPX_ERR_INVALID;
-                if (td[c] > 1 || ta[c] > 1) return IPX_ERR_UNSUPPORTED;
-                if (!hf[0][td[c]].ok || !hf[1][ta[c]].ok || !have_q[ctq[c]]) return IPX_ERR_INVALID;
-                info->td[c] = (uint8_t)td[c]; info->ta[c] = (uint8_t)(2 + ta[c]);   // kernel table slots: 0,1 = DC; 2,3 = AC
-            }
-            if (ncomp == 3 && !jfif && ((adobe && adobe_transform == 0) || (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B'))) return IPX_ERR_UNSUPPORTED;
             info->h0 = ch[0]; info->v0 = cv[0];
             info->ncomp = ncomp;
             info->ratio = ncomp == 1 ? IPX_GRAY : ch[0] == 1 ? (cv[0] == 1 ? IPX_YCBCR_444 : IPX_YCBCR_440) : (cv[0] == 1 ? IPX_YCBCR_422 : IPX_YCBCR_420);
+            if (info->host_scans) return IPX_OK;               // the frame is known; the scans are the host decoder's
+            if (s[0] != ncomp) {                               // a sequential frame coded in several scans
+                if (s[0] < 1 || s[0] > 3) return IPX_ERR_INVALID;
+                info->host_scans = 1;
+                return IPX_OK;
+            }
+            if (sn != (size_t)(4 + 2 * ncomp)) return IPX_ERR_INVALID;
+            int td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+            for (int c = 0; c < ncomp; c++) {
+                if (s[1 + 2 * c] != cid[c]) { info->host_scans = 1; return IPX_OK; }           // components out of frame order
+                td[c] = s[2 + 2 * c] >> 4; ta[c] = s[2 + 2 * c] & 15;
+                if (td[c] > 3 || ta[c] > 3) return IPX_ERR_INVALID;
+                if (td[c] > 1 || ta[c] > 1) { info->host_scans = 1; return IPX_OK; }           // extended sequential: four tables per class
+                if (!hf[0][td[c]].ok || !hf[1][ta[c]].ok) return IPX_ERR_INVALID;   // "uninitialized Huffman table"
+                info->td[c] = (uint8_t)td[c]; info->ta[c] = (uint8_t)(2 + ta[c]);   // kernel table slots: 0,1 = DC; 2,3 = AC
+                // processSOS runs ONE block loop for sequential and progressive scans: an AC symbol (r < 15, s = 0) starts an end-of-band
+                // run in a baseline file too, and the next blocks of the scan lose their AC part.  No encoder writes such a symbol into a
+                // sequential file, the GPU decoder reads it as a plain EOB -- so a (damaged) table that holds one goes to the host decoder.
+                const RawHuff &act = hf[1][ta[c]];
+                for (int v = 0; v < act.nvals; v++)
+                    if ((act.vals[v] & 15) == 0 && (act.vals[v] >> 4) != 0 && (act.vals[v] >> 4) != 15) { info->host_scans = 1; return IPX_OK; }
+            }
+            if (ncomp == 3 && !jfif && ((adobe && adobe_transform == 0) || (cid[0] == 'R' && cid[1] == 'G' && cid[2] == 'B'))) return IPX_ERR_UNSUPPORTED;
             info->scan_off = i + n;
-            info->scan_len = len - (i + n);
+            {
+                // The scan ends at the first marker that is not a restart marker; what follows has to be what Go's marker loop accepts
+                // up to EOI (decode() keeps reading segments until it sees one: a file that stops after its scan is
+                // io.ErrUnexpectedEOF there, and a task the reference marks failed).  Another SOS makes it a multi-scan file.
+                const uint8_t *sd = d + info->scan_off;
+                const size_t rest = len - info->scan_off;
+                size_t k = 0, end = rest;
+                while (k + 1 < rest) {
+                    const uint8_t *q = (const uint8_t *)memchr(sd + k, 0xff, rest - 1 - k);
+                    if (!q) break;
+                    k = (size_t)(q - sd);
+                    const uint8_t m2 = sd[k + 1];
+                    if (m2 == 0x00 || (m2 >= 0xd0 && m2 <= 0xd7)) { k += 2; continue; }
+                    end = k;
+                    break;
+                }
+                info->scan_len = end;
+                size_t p = info->scan_off + end;
+                for (;;) {                                     // the tail: Go's marker loop, segments skipped by their length
+                    if (p + 2 > len) return IPX_ERR_INVALID;   // no EOI
+                    if (d[p] != 0xff) { p++; continue; }       // bytes that belong to no segment are skipped
+                    const int m3 = d[p + 1];
+                    if (m3 == 0xff) { p++; continue; }         // fill byte
+                    p += 2;
+                    if (m3 == 0xd9) break;                     // EOI
+                    if (m3 == 0x00 || (m3 >= 0xd0 && m3 <= 0xd7)) continue;
+                    if (m3 == 0xda) { info->host_scans = 1; return IPX_OK; }
+                    if (m3 == 0xc0 || m3 == 0xc1 || m3 == 0xc2) return IPX_ERR_INVALID;        // "multiple SOF markers"
+                    if (!((m3 >= 0xe0 && m3 <= 0xef) || m3 == 0xfe || m3 == 0xc4 || m3 == 0xdb || m3 == 0xdd)) return m3 < 0xc0 ? IPX_ERR_INVALID : IPX_ERR_UNSUPPORTED;
+                    if (p + 2 > len) return IPX_ERR_INVALID;
+                    const size_t n3 = be16(d + p);
+                    if (n3 < 2 || p + n3 > len) return IPX_ERR_INVALID;
+                    p += n3;
+                }
+            }
             for (int tc = 0; tc < 2; tc++)
                 for (int th = 0; th < 2; th++) {
                     const int slot = tc * 2 + th;
@@ -167,7 +214,9 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
                 for (int zig = 0; zig < 64; zig++) tab->qnat[c][kUnzig[zig]] = c < ncomp ? quant[ctq[c]][zig] : 0;
             return IPX_OK;
         }
-        default: break;   // APPn, COM, ...: skipped
+        default:          // APPn and COM are skipped; anything else is "unknown marker": a FormatError below SOF0, an UnsupportedError above
+            if (!((m >= 0xe0 && m <= 0xef) || m == 0xfe)) return m < 0xc0 ? IPX_ERR_INVALID : IPX_ERR_UNSUPPORTED;
+            break;
         }
         i += n;
     }

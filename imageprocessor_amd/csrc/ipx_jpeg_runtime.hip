@@ -461,12 +461,23 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     // pieces of a scan: the whole scan, or one per restart interval.  Inside entropy-coded data 0xff is followed by 0x00 or by a
     // marker, so every 0xff 0xd0..0xd7 pair is an RSTn.
     std::vector<std::vector<uint32_t>> marks(n);
+    // files whose scans are walked on the host (progressive, several scans): quantised coefficients in the IDCT kernel's layout
+    std::vector<std::vector<int16_t>> hcoefs(n), hdcs(n);
+    std::vector<uint8_t> hprog(n, 0);
     const auto td0 = std::chrono::steady_clock::now();
     auto dms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count(); };
     double t_parse = 0, t_alloc = 0, t_pin = 0, t_pack = 0, t_launch = 0;
     parallel_for(n, [&](int i) {
         status[i] = !jpegs[i].data ? IPX_ERR_INVALID : (jpegs[i].len >= ((size_t)1 << 30) ? IPX_ERR_UNSUPPORTED : jpeg_parse(jpegs[i].data, jpegs[i].len, &info[i], &tabs[i]));
         if (status[i] != IPX_OK) return;
+        if (info[i].host_scans) {
+            if (*w > 0 && (info[i].w != *w || info[i].h != *h)) { status[i] = IPX_ERR_UNSUPPORTED; return; }   // a size other than the one asked for: not worth decoding
+            bool prog = false;
+            JpegDecInfo full;
+            status[i] = jpeg_host_decode(jpegs[i].data, jpegs[i].len, &full, &hcoefs[i], &hdcs[i], tabs[i].qnat, &prog);
+            if (status[i] == IPX_OK) { full.host_scans = 1; info[i] = full; hprog[i] = prog ? 1 : 0; }
+            return;
+        }
         const JpegDecInfo &I = info[i];
         const int nmcu = ((I.w + 8 * I.h0 - 1) / (8 * I.h0)) * ((I.h + 8 * I.v0 - 1) / (8 * I.v0));
         if (I.ri <= 0 || nmcu <= I.ri) return;
@@ -500,7 +511,7 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
                    !memcmp(tabs[x].valoff, tabs[y].valoff, sizeof tabs[x].valoff) && !memcmp(tabs[x].vals, tabs[y].vals, sizeof tabs[x].vals);
         };
         for (int i = 0; i < n; i++) {
-            if (status[i] != IPX_OK) continue;
+            if (status[i] != IPX_OK || info[i].host_scans) continue;
             for (size_t k = reps.size(); k-- > 0 && tab_of[i] < 0;)     // newest first: neighbours tend to match
                 if (same(i, reps[k])) tab_of[i] = reps[k];
             if (tab_of[i] < 0) { tab_of[i] = i; reps.push_back(i); }
@@ -519,6 +530,7 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
             else if (ref < 0) status[i] = IPX_ERR_UNSUPPORTED;   // a size other than the one asked for
         }
         if (status[i] != IPX_OK) continue;
+        if (info[i].host_scans) { valid[i] = hprog[i] ? 3 : 1; continue; }     // coefficients come from the host; bit 1: progressive
         const JpegDecInfo &I = info[i];
         const int nmcu = ((I.w + 8 * I.h0 - 1) / (8 * I.h0)) * ((I.h + 8 * I.v0 - 1) / (8 * I.v0));
         auto push = [&](size_t a0, size_t a1, int m0, int cnt) {
@@ -573,7 +585,7 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     const JpegDecInfo &R = info[ref];
     *w = R.w; *h = R.h;
     JpegDecArgs a{};
-    a.n = n; a.h0 = R.h0; a.v0 = R.v0;
+    a.n = n; a.h0 = R.h0; a.v0 = R.v0; a.w = R.w; a.h = R.h;
     a.mxx = (R.w + 8 * R.h0 - 1) / (8 * R.h0); a.myy = (R.h + 8 * R.v0 - 1) / (8 * R.v0);
     const bool gray = R.ncomp == 1;                        // *image.Gray: one block per MCU, no chroma planes
     a.ybl = R.h0 * R.v0; a.bpm = gray ? 1 : a.ybl + 2;
@@ -626,7 +638,7 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     uint8_t *hblob = (uint8_t *)ipx_host_alloc(ctx, blob_bytes + 16);
     t_pin = dms();
     if (!hblob) { ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
-    parallel_for(n, [&](int i) { if (valid[i]) memcpy(hblob + blob_off[i], jpegs[i].data + info[i].scan_off, info[i].scan_len); });
+    parallel_for(n, [&](int i) { if (valid[i] && !info[i].host_scans) memcpy(hblob + blob_off[i], jpegs[i].data + info[i].scan_off, info[i].scan_len); });
     if (prep_failed) { (void)ipx_host_free(ctx, hblob); ipx_jpeg_planes_free(ctx, own.release()); set_error("jpeg decode: host preparation failed"); return prep_failed; }
     t_pack = dms();
     e = hipMemcpyAsync(d_blob, hblob, blob_bytes, hipMemcpyHostToDevice, s);
@@ -639,11 +651,20 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int) * n, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_dcs, 0, (size_t)n * a.nblk * 2, s);
     a.blob = d_blob; a.img = d_img; a.tab = d_tab; a.coefs = d_coefs; a.status = d_status; a.dcs = d_dcs;
-    a.first_valid = ref;
+    for (int i = 0; i < n && e == hipSuccess; i++) {       // host-decoded files: their coefficients go into their slots (after the memsets, same stream)
+        if (!valid[i] || !info[i].host_scans) continue;
+        if (hcoefs[i].size() != (size_t)a.nblk * 64 || hdcs[i].size() != (size_t)a.nblk) return fail(hipErrorInvalidValue, "host-decoded coefficients of another geometry");
+        e = hipMemcpyAsync(d_coefs + (size_t)i * a.nblk * 64, hcoefs[i].data(), (size_t)a.nblk * 128, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_dcs + (size_t)i * a.nblk, hdcs[i].data(), (size_t)a.nblk * 2, hipMemcpyHostToDevice, s);
+    }
+    int ref_gpu = -1;                                        // the first image the Huffman kernels decode: the one whose tables a shared-table launch carries
+    for (int i = 0; i < n && ref_gpu < 0; i++) if (valid[i] && !info[i].host_scans) ref_gpu = i;
+    a.first_valid = ref_gpu >= 0 ? ref_gpu : ref;
     a.shared_tables = env_int("IPX_JPEG_SHARED_TABLES", 1);
-    for (int i = 0; i < n && a.shared_tables; i++)
-        if (valid[i] && (memcmp(tabs[i].lut, tabs[ref].lut, sizeof tabs[i].lut) || memcmp(tabs[i].maxcode, tabs[ref].maxcode, sizeof tabs[i].maxcode) ||
-                              memcmp(tabs[i].valoff, tabs[ref].valoff, sizeof tabs[i].valoff) || memcmp(tabs[i].vals, tabs[ref].vals, sizeof tabs[i].vals)))
+    for (int i = 0; i < n && a.shared_tables && ref_gpu >= 0; i++)
+        if (valid[i] && !info[i].host_scans &&
+            (memcmp(tabs[i].lut, tabs[ref_gpu].lut, sizeof tabs[i].lut) || memcmp(tabs[i].maxcode, tabs[ref_gpu].maxcode, sizeof tabs[i].maxcode) ||
+             memcmp(tabs[i].valoff, tabs[ref_gpu].valoff, sizeof tabs[i].valoff) || memcmp(tabs[i].vals, tabs[ref_gpu].vals, sizeof tabs[i].vals)))
             a.shared_tables = 0;
     if (e == hipSuccess && a.nitems > 0) {
         if (env_int("IPX_JPEG_PIECE", 1)) {

