@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void band_kernel(BandArgs a)
     if (a.nscale == 0 && !glyph_tile) return;
     __syncthreads();
     // the composite goes first so that its few loads are not queued behind the pixel stores
-    if (glyph_tile) glyph_phase(a, t, wframe, lds, tid);
+    if (glyph_tile) glyph_phase<256, 8, TapAsIs>(a, t, wframe, lds, tid);
     if (a.nscale > 0) {
         scale_out<NX, true>(a, 0, t, a.sc[0].out + (size_t)f * a.sc[0].frame_stride, lds, tid, o0, dyA[0], dyB[0]);
         scale_out<NX, true>(a, 1, t, a.sc[1].out + (size_t)f * a.sc[1].frame_stride, lds, tid, o1, dyA[1], dyB[1]);
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(NT, NT / 128) void band_pipe_kernel(BandArgs a)   /
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, t))
-            glyph_phase<NT>(a, t, ob.wm, lds, tid);
+            glyph_phase<NT, (ROWS - 1 > 8 ? 8 : ROWS - 1), TapAsIs>(a, t, ob.wm, lds, tid);
 #if IPX_DIAG
         if (a.nscale > 0 && !(a.dbg & 1)) {
 #else

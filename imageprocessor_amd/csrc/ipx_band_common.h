@@ -6,6 +6,10 @@
 namespace ipx {
 namespace {
 
+#ifndef IPX_WAVE_SKIP
+#define IPX_WAVE_SKIP 1
+#endif
+
 constexpr int kYChunk = 64;  // destination rows whose y taps sit in LDS at a time
 constexpr int kLoadU = 4;    // 16-byte loads in flight per lane in band_kernel's phase 1
 
@@ -72,19 +76,54 @@ __device__ __forceinline__ bool tile_meets_textbox(const BandArgs &a, const Tile
     return t.r0 < a.gbox.y1 && t.r1 > a.gbox.y0 && t.c0 < a.gbox.x1 && t.c1 > a.gbox.x0;
 }
 
-// Step 3: glyph composite over the block's share of the text box, source pixels from LDS.
-template <int NT = 256>
-__device__ __forceinline__ void glyph_phase(const BandArgs &a, const Tile &t, uint8_t *wframe,
-                                            const uint8_t *lds, int tid)
+// Step 3: glyph composite over the tile's share of the text box, source pixels from LDS (read as RGBA8 through Conv).
+// A thread takes one pixel COLUMN of that share and keeps the column's pixels (one per tile row, MAXR >= owned rows) in registers:
+// the glyph list is walked once per column, not once per pixel, four descriptors per step (scalar loads, issued together), and a
+// glyph whose rectangle holds the column loads its mask bytes for all rows at once.  Per pixel the glyphs still apply in string order.
+// (The first version walked the list per pixel: a scalar load and a test per glyph and pixel, every one a full latency -- 25 us per
+// tile that meets the text, 7% of a 1080p run.)
+typedef const __attribute__((address_space(4))) DevGlyph *ConstGlyphs;
+
+template <int NT, int MAXR, class Conv>
+__device__ __forceinline__ void glyph_phase(const BandArgs &a, const Tile &t, uint8_t *wframe, const uint8_t *lds, int tid)
 {
-    const int gy0 = max(a.gbox.y0, t.r0), gy1 = min(a.gbox.y1, t.r1);
+    const int by0 = max(a.gbox.y0, t.r0), by1 = min(a.gbox.y1, t.r1);
     const int gx0 = max(a.gbox.x0 & ~3, t.c0), gx1 = min((a.gbox.x1 + 3) & ~3, t.c1);  // whole skipped chunks
-    const int gw = gx1 - gx0, gn = gw * (gy1 - gy0);
-    for (int i = tid; i < gn; i += NT) {
-        const int yy = i / gw, x = gx0 + (i - yy * gw), y = gy0 + yy;
-        uint32_t d = lds_u32(lds, (y - t.r0) * t.pitch + (x - t.c0) * 4);
-        d = glyph_run(d, x, y, a.glyphs, a.nglyphs, a.cr, a.cg, a.cb, a.ca);
-        *(uint32_t *)(wframe + (size_t)y * a.wm_stride + (size_t)x * 4) = d;
+    const int plane = Conv::plane(t);
+    const ConstGlyphs gl = (ConstGlyphs)(uintptr_t)a.glyphs;
+    for (int gy0 = by0; gy0 < by1; gy0 += MAXR) {          // (one round: MAXR covers the rows a tile owns, except in band_kernel's tall tiles)
+        const int gy1 = min(gy0 + MAXR, by1);
+        for (int x = gx0 + tid; x < gx1; x += NT) {
+            uint32_t d[MAXR];
+#pragma unroll
+            for (int r = 0; r < MAXR; r++) d[r] = Conv::rgba8_at(lds, (min(gy0 + r, gy1 - 1) - t.r0) * t.pitch + (x - t.c0) * 4, plane);
+            for (int g = 0; g < a.nglyphs; g += 4) {
+                int rx0[4], rx1[4], ry0[4], ry1[4], ms[4];
+                const uint8_t *mk[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int gi = min(g + j, a.nglyphs - 1);
+                    rx0[j] = gl[gi].x0; rx1[j] = g + j < a.nglyphs ? gl[gi].x1 : gl[gi].x0;   // (an empty rectangle past the end of the list)
+                    ry0[j] = gl[gi].y0; ry1[j] = min(gl[gi].y1, gy1); ms[j] = gl[gi].mstride; mk[j] = gl[gi].mask;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (x < rx0[j] || x >= rx1[j]) continue;
+                    uint32_t m[MAXR];
+#pragma unroll
+                    for (int r = 0; r < MAXR; r++) {
+                        const int y = gy0 + r;
+                        m[r] = y >= ry0[j] && y < ry1[j] ? mk[j][(size_t)(y - ry0[j]) * ms[j] + (x - rx0[j])] : 0u;
+                    }
+#pragma unroll
+                    for (int r = 0; r < MAXR; r++)
+                        if (m[r]) d[r] = glyph_over(d[r], m[r], a.cr, a.cg, a.cb, a.ca);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < MAXR; r++)
+                if (gy0 + r < gy1) *(uint32_t *)(wframe + (size_t)(gy0 + r) * a.wm_stride + (size_t)x * 4) = d[r];
+        }
     }
 }
 
@@ -157,12 +196,17 @@ __device__ __forceinline__ void load_xtaps(const BandArgs &a, int k, int cb, int
 // rows never decrease, so two H rows (top, bottom) with a scalar tag are all the state there is.
 struct HRow { uint32_t rb, ga; };
 
-struct TapAsIs { static __device__ __forceinline__ uint32_t rgba8(uint32_t p) { return p; } };   // the tile holds RGBA8 pixels
+// How a scale path reads a tap from the LDS tile.  A tile is one or two planes of a dword per pixel with the same pitch (plane(t) =
+// byte distance between them); `off` is the byte offset of the pixel within a plane.
+struct TapAsIs {   // the tile holds RGBA8 pixels
+    static __device__ __forceinline__ int plane(const Tile &) { return 0; }
+    static __device__ __forceinline__ uint32_t rgba8_at(const uint8_t *lds, int off, int) { return lds_u32(lds, off); }
+};
 
 template <class Conv = TapAsIs>
-__device__ __forceinline__ HRow h_row(const uint8_t *lds, int off, uint32_t x0, uint32_t x1)
+__device__ __forceinline__ HRow h_row(const uint8_t *lds, int off, int plane, uint32_t x0, uint32_t x1)
 {
-    const uint32_t p0 = Conv::rgba8(lds_u32(lds, off)), p1 = Conv::rgba8(lds_u32(lds, off + 4));
+    const uint32_t p0 = Conv::rgba8_at(lds, off, plane), p1 = Conv::rgba8_at(lds, off + 4, plane);
     HRow h;
     h.rb = __umul24(p0 & 0x00ff00ffu, x0) + __umul24(p1 & 0x00ff00ffu, x1);
     // v_perm_b32: bytes {p.1, 0, p.3, 0} = (p >> 8) & 0x00ff00ff in one instruction
@@ -219,7 +263,7 @@ template <int NX, bool FP, int NT, class Conv = TapAsIs>
 __device__ __forceinline__ void scale_rows_int(const ScaleOut &S, const Tile &t, const uint8_t *lds, int tid,
                                                const OutCols<NX, FP> &o, __amdgpu_buffer_rsrc_t ors, int dyA, int dyB)
 {
-    const int xbias = S.sr_x0 - t.c0;
+    const int xbias = S.sr_x0 - t.c0, plane = Conv::plane(t);
     const uint32_t m3 = S.imul;
     uint32_t x0[NX], x1[NX];
     int lx[NX], voff[NX];
@@ -245,10 +289,10 @@ __device__ __forceinline__ void scale_rows_int(const ScaleOut &S, const Tile &t,
         if (row.ctl >> 28) {                         // 0: the same pair of tile rows as the row before (an upscaled axis)
             if (row.ctl >> 29) {                     // 2: a gap -- the row that becomes the upper one is not at hand
 #pragma unroll
-                for (int i = 0; i < NX; i++) bot[i] = h_row<Conv>(lds, off + lx[i], x0[i], x1[i]);
+                for (int i = 0; i < NX; i++) bot[i] = h_row<Conv>(lds, off + lx[i], plane, x0[i], x1[i]);
             }
 #pragma unroll
-            for (int i = 0; i < NX; i++) { top[i] = bot[i]; bot[i] = h_row<Conv>(lds, off + t.pitch + lx[i], x0[i], x1[i]); }
+            for (int i = 0; i < NX; i++) { top[i] = bot[i]; bot[i] = h_row<Conv>(lds, off + t.pitch + lx[i], plane, x0[i], x1[i]); }
         }
         uint32_t sum[NX][4], v[NX];
 #pragma unroll
@@ -283,6 +327,11 @@ __device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &
                                           int tid, const OutCols<NX, FP> &o, int dyA, int dyB)
 {
     if (k >= a.nscale || dyA >= dyB) return;
+    // a wave none of whose lanes has a destination column leaves (wave-uniform: the thumbnail's 200 columns keep 4 of a workgroup's 8
+    // waves busy, 2 of 8 on the narrow tiles of the YCbCr kernel; the others ran the whole row loop to store nothing)
+#if IPX_WAVE_SKIP
+    if (o.dxA + __builtin_amdgcn_readfirstlane(tid & ~63) >= o.dxB) return;
+#endif
     const ScaleOut &S = a.sc[k];
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, S.dh * S.ostride, 0x00020000);
     const ConstTaps yt = const_taps(S.yt);
@@ -347,14 +396,34 @@ __device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &
     }
 }
 
-// ---- scaled outputs of the kernels whose tile holds a source type that is converted per tap (ipx_band_ycc.hip, ipx_band_nrgba.hip) ----
+// ---- scaled outputs of the kernels whose tile holds a converted source type (ipx_band_ycc.hip, ipx_band_nrgba.hip) ----
 // Conv::NC        3: the converted alpha is constant 0xffff (YCbCr), 4: it is a channel like the others (NRGBA)
-// Conv::tap16     a tile dword -> the 16-bit channels the reference's scale_RGBA_<type>_* interpolates (mode 0)
-// Conv::rgba8     a tile dword -> the RGBA8 pixel of the reference's copy / draw routine for the type (mode 1: the crop thumbnail scales
+// Conv::tap16_at  a tile pixel -> the 16-bit channels the reference's scale_RGBA_<type>_* interpolates (mode 0)
+// Conv::h16       the horizontal step of mode 0 on dyadic axes: h.c = x0 * tap(off).c + x1 * tap(off + 4).c, iw = x0 | x1 << 16
+// Conv::rgba8_at  a tile pixel -> the RGBA8 pixel of the reference's copy / draw routine for the type (mode 1: the crop thumbnail scales
 //                 the RGBA8 copy cropAndResize made, thumbnail.go:128-131)
+// DwordConv<D>    all of these for a tile of one dword per pixel that D::tap16 / D::rgba8 convert when a tap is read
 // Mode 0 on dyadic axes (kx, ky <= 8) is exact in u32: h.c = x0*t0.c + x1*t1.c (< 2^24), sum.c = y0'*h_top.c + y1'*h_bot.c with the y
 // weights scaled by 2^(16-kx-ky), so that the output byte is the TOP byte of the 32-bit sum; the H rows are reused between output
 // rows exactly as in the packed-integer lerp above (two converted taps per H row instead of four per pixel).
+template <class D>
+struct DwordConv {
+    static __device__ __forceinline__ int plane(const Tile &) { return 0; }
+    static __device__ __forceinline__ uint32_t rgba8_at(const uint8_t *lds, int off, int) { return D::rgba8(lds_u32(lds, off)); }
+    template <int N>
+    static __device__ __forceinline__ void tap16_at(const uint8_t *lds, int off, int, uint32_t (&c)[N]) { D::tap16(lds_u32(lds, off), c); }
+    template <int N>
+    static __device__ __forceinline__ void h16(const uint8_t *lds, int off, int, uint32_t iw, uint32_t (&h)[N])
+    {
+        uint32_t t0[N], t1[N];
+        D::tap16(lds_u32(lds, off), t0);
+        D::tap16(lds_u32(lds, off + 4), t1);
+        const uint32_t x0 = iw & 0xffffu, x1 = iw >> 16;
+#pragma unroll
+        for (int j = 0; j < N; j++) h[j] = __umul24(x0, t0[j]) + __umul24(x1, t1[j]);
+    }
+};
+
 struct IntRow16 { uint32_t ctl, y0, y1, pad; };
 typedef const __attribute__((address_space(4))) IntRow16 *ConstRows16;
 
@@ -363,14 +432,12 @@ __device__ __forceinline__ void scale_rows_int16(const ScaleOut &S, const Tile &
                                                  const OutCols<NX, FP> &o, __amdgpu_buffer_rsrc_t ors, int dyA, int dyB)
 {
     constexpr int NC = Conv::NC;
-    const int xbias = S.sr_x0 - t.c0;
-    uint32_t x0[NX], x1[NX];
+    const int xbias = S.sr_x0 - t.c0, plane = Conv::plane(t);
     int lx[NX], voff[NX];
 #pragma unroll
     for (int i = 0; i < NX; i++) {
         const int dx = o.dxA + tid + NT * i;
         lx[i] = (xbias + o.tx[i].base) * 4;
-        x0[i] = o.tx[i].iw & 0xffffu; x1[i] = o.tx[i].iw >> 16;
         voff[i] = dx < o.dxB ? dx * 4 : kOOB;
     }
     uint32_t top[NX][NC], bot[NX][NC];
@@ -378,13 +445,7 @@ __device__ __forceinline__ void scale_rows_int16(const ScaleOut &S, const Tile &
     for (int i = 0; i < NX; i++)
 #pragma unroll
         for (int j = 0; j < NC; j++) top[i][j] = bot[i][j] = 0;
-    auto h16 = [&](int off, int i, uint32_t (&h)[NC]) {
-        uint32_t t0[NC], t1[NC];
-        Conv::tap16(lds_u32(lds, off), t0);
-        Conv::tap16(lds_u32(lds, off + 4), t1);
-#pragma unroll
-        for (int j = 0; j < NC; j++) h[j] = __umul24(x0[i], t0[j]) + __umul24(x1[i], t1[j]);
-    };
+    auto h16 = [&](int off, int i, uint32_t (&h)[NC]) { Conv::h16(lds, off, plane, o.tx[i].iw, h); };
     ConstRows16 yr = (ConstRows16)(uintptr_t)S.yrow16 + dyA;
     IntRow16 nx = {yr[0].ctl, yr[0].y0, yr[0].y1, 0};
     int soff = dyA * S.ostride;
@@ -420,8 +481,7 @@ __device__ __forceinline__ void scale_rows_int16(const ScaleOut &S, const Tile &
     }
 }
 
-template <class Conv>
-struct ConvRgba8 { static __device__ __forceinline__ uint32_t rgba8(uint32_t p) { return Conv::rgba8(p); } };
+
 
 __device__ __forceinline__ uint32_t lerp16_f64(uint32_t s00, uint32_t s10, uint32_t s01, uint32_t s11, double xw0, double xw1, double yw0,
                                                double yw1)
@@ -436,12 +496,17 @@ __device__ __forceinline__ void scale_out_conv(const BandArgs &a, int k, int mod
                                                const OutCols<NX, FP> &o, int dyA, int dyB)
 {
     if (k >= a.nscale || dyA >= dyB) return;
+    // a wave none of whose lanes has a destination column leaves (wave-uniform: the thumbnail's 200 columns keep 4 of a workgroup's 8
+    // waves busy, 2 of 8 on the narrow tiles of the YCbCr kernel; the others ran the whole row loop to store nothing)
+#if IPX_WAVE_SKIP
+    if (o.dxA + __builtin_amdgcn_readfirstlane(tid & ~63) >= o.dxB) return;
+#endif
     const ScaleOut &S = a.sc[k];
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, S.dh * S.ostride, 0x00020000);
     if (mode == 0 && S.yrow16) { scale_rows_int16<NX, FP, NT, Conv>(S, t, lds, tid, o, ors, dyA, dyB); return; }
-    if (mode == 1 && S.imul) { scale_rows_int<NX, FP, NT, ConvRgba8<Conv>>(S, t, lds, tid, o, ors, dyA, dyB); return; }
+    if (mode == 1 && S.imul) { scale_rows_int<NX, FP, NT, Conv>(S, t, lds, tid, o, ors, dyA, dyB); return; }
     const ConstTaps yt = const_taps(S.yt);
-    const int ybias = S.sr_y0 - t.r0, xbias = S.sr_x0 - t.c0;
+    const int ybias = S.sr_y0 - t.r0, xbias = S.sr_x0 - t.c0, plane = Conv::plane(t);
     int lx[NX], voff[NX];
 #pragma unroll
     for (int i = 0; i < NX; i++) {
@@ -458,8 +523,8 @@ __device__ __forceinline__ void scale_out_conv(const BandArgs &a, int k, int mod
 #pragma unroll
             for (int i = 0; i < NX; i++) {
                 const int off = rowoff + lx[i];
-                const uint32_t p00 = Conv::rgba8(lds_u32(lds, off)), p10 = Conv::rgba8(lds_u32(lds, off + 4));
-                const uint32_t p01 = Conv::rgba8(lds_u32(lds, off + t.pitch)), p11 = Conv::rgba8(lds_u32(lds, off + t.pitch + 4));
+                const uint32_t p00 = Conv::rgba8_at(lds, off, plane), p10 = Conv::rgba8_at(lds, off + 4, plane);
+                const uint32_t p01 = Conv::rgba8_at(lds, off + t.pitch, plane), p11 = Conv::rgba8_at(lds, off + t.pitch + 4, plane);
                 __builtin_amdgcn_raw_buffer_store_b32(lerp_dyadic(p00, p10, p01, p11, o.tx[i].f0, o.tx[i].f1, yf0, yf1, sh), ors, voff[i], soff, 0);
             }
             soff += S.ostride;
@@ -471,19 +536,19 @@ __device__ __forceinline__ void scale_out_conv(const BandArgs &a, int k, int mod
 #pragma unroll
             for (int i = 0; i < NX; i++) {
                 const int off = rowoff + lx[i];
-                const uint32_t q00 = lds_u32(lds, off), q10 = lds_u32(lds, off + 4);
-                const uint32_t q01 = lds_u32(lds, off + t.pitch), q11 = lds_u32(lds, off + t.pitch + 4);
                 const double xw0 = o.tx[i].w0, xw1 = o.tx[i].w1;
                 uint32_t v;
                 if (mode == 0) {
                     uint32_t t00[Conv::NC], t10[Conv::NC], t01[Conv::NC], t11[Conv::NC], pc[4];
-                    Conv::tap16(q00, t00); Conv::tap16(q10, t10); Conv::tap16(q01, t01); Conv::tap16(q11, t11);
+                    Conv::tap16_at(lds, off, plane, t00); Conv::tap16_at(lds, off + 4, plane, t10);
+                    Conv::tap16_at(lds, off + t.pitch, plane, t01); Conv::tap16_at(lds, off + t.pitch + 4, plane, t11);
 #pragma unroll
                     for (int j = 0; j < Conv::NC; j++) pc[j] = lerp16_f64(t00[j], t10[j], t01[j], t11[j], xw0, xw1, yw0, yw1);
                     if constexpr (Conv::NC == 3) pc[3] = 0xffffu;
                     v = pack_src(pc[0], pc[1], pc[2], pc[3]);
                 } else {
-                    const uint32_t p00 = Conv::rgba8(q00), p10 = Conv::rgba8(q10), p01 = Conv::rgba8(q01), p11 = Conv::rgba8(q11);
+                    const uint32_t p00 = Conv::rgba8_at(lds, off, plane), p10 = Conv::rgba8_at(lds, off + 4, plane);
+                    const uint32_t p01 = Conv::rgba8_at(lds, off + t.pitch, plane), p11 = Conv::rgba8_at(lds, off + t.pitch + 4, plane);
                     const uint32_t pr = lerp_channel<0>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
                     const uint32_t pg = lerp_channel<1>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);
                     const uint32_t pb = lerp_channel<2>(p00, p10, p01, p11, xw0, xw1, yw0, yw1);

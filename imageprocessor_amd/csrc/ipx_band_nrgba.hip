@@ -42,8 +42,7 @@ __device__ __forceinline__ uint32_t nrgba_rgba8(uint32_t p)
     return r | (g << 8) | (b << 16) | (p & 0xff000000u);
 }
 // how the shared scale paths (ipx_band_common.h, scale_out_conv) read a tile dword (a non-premultiplied pixel)
-struct NrgbaConv {
-    static constexpr int NC = 4;
+struct NrgbaTaps {
     // a tap as scale_RGBA_NRGBA_* reads it: a16 = a * 0x101, c * a16 / 0xff
     static __device__ __forceinline__ void tap16(uint32_t p, uint32_t (&c)[4])
     {
@@ -54,6 +53,7 @@ struct NrgbaConv {
     }
     static __device__ __forceinline__ uint32_t rgba8(uint32_t p) { return nrgba_rgba8(p); }
 };
+struct NrgbaConv : DwordConv<NrgbaTaps> { static constexpr int NC = 4; };
 
 typedef const __attribute__((address_space(4))) int *ConstIntsN;
 
@@ -103,19 +103,6 @@ __device__ __forceinline__ void drain_tile(const BandArgs &a, const Tile &t, uin
         for (int i = 0; i < 4; i++) rgba[i] = nrgba_rgba8(p[i]);
         const bool skip = in_box && t.r0 + r >= a.gbox.y0 && t.r0 + r < a.gbox.y1;   // chunks that meet the text box are written by the composite step
         __builtin_amdgcn_raw_buffer_store_b128(rgba, wrs, skip ? kOOB : woff + r * a.wm_stride, 0, 0);
-    }
-}
-
-__device__ __forceinline__ void glyph_phase_nrgba(const BandArgs &a, const Tile &t, uint8_t *wframe, const uint8_t *lds, int tid)
-{
-    const int gy0 = max(a.gbox.y0, t.r0), gy1 = min(a.gbox.y1, t.r1);
-    const int gx0 = max(a.gbox.x0 & ~3, t.c0), gx1 = min((a.gbox.x1 + 3) & ~3, t.c1);  // whole skipped chunks
-    const int gw = gx1 - gx0, gn = gw * (gy1 - gy0);
-    for (int i = tid; i < gn; i += kNT) {
-        const int yy = i / gw, x = gx0 + (i - yy * gw), y = gy0 + yy;
-        uint32_t d = nrgba_rgba8(lds_u32(lds, (y - t.r0) * t.pitch + (x - t.c0) * 4));
-        d = glyph_run(d, x, y, a.glyphs, a.nglyphs, a.cr, a.cg, a.cb, a.ca);
-        *(uint32_t *)(wframe + (size_t)y * a.wm_stride + (size_t)x * 4) = d;
     }
 }
 
@@ -197,7 +184,7 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_nrgba_kernel(NrgbaArgs A)
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, cur.t))
-            glyph_phase_nrgba(a, cur.t, ob.wm, lds, tid);
+            glyph_phase<kNT, kRows - 1, NrgbaConv>(a, cur.t, ob.wm, lds, tid);
         if (a.nscale > 0) {
             scale_out_conv<NX0, FP0, kNT, NrgbaConv>(a, 0, A.mode[0], cur.t, ob.o0, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
             scale_out_conv<NX1, FP1, kNT, NrgbaConv>(a, 1, A.mode[1], cur.t, ob.o1, lds, tid, o1, cur.dyA[1], cur.dyB[1]);

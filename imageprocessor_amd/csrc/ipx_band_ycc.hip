@@ -13,11 +13,20 @@
 //   * resize and the non-crop thumbnail: resizeImage on the YCbCr itself = scale_RGBA_YCbCr4xx_Src, every TAP
 //     converted to 16-bit RGB (color.YCbCr.RGBA inlined, clamped) and interpolated in float64 -> mode 0; on
 //     dyadic axes the float64 value is sum(w*tap) / 2^(kx+ky) exactly, computed here in u32.
-// The LDS tile holds one packed dword (Y, Cb, Cr, 0) per source pixel -- chroma replicated -- so the tile,
-// tap tables and item geometry are those of the RGBA kernel and every consumer converts the taps it reads.
+// All three read the SAME clamped 24-bit value per channel, v = clamp(yy1 + chroma term, 0, 0xffffff): the 8-bit pixel is its top
+// byte (Go: r >> 16, or 0 / 0xff outside), the 16-bit tap its top two bytes (Go: r >> 8 clamped to 0..0xffff).  So every source pixel
+// is converted ONCE, on its way from the staging registers to LDS (chroma terms shared by the pixels that share a sample), and the
+// tile holds converted taps: two planes of a dword per pixel, R16 | G16 << 16 and B16 | 0xffff << 16.  The scale steps then cost what
+// they cost for an RGBA source -- a v_perm_b32 pairs the channel of two neighbouring taps for one v_dot2_u32_u16 with the packed x
+// weights -- instead of converting 2 taps per output column and tile row again (that was 55% of the kernel's VALU work, and the
+// kernel was VALU-bound).
+// The price is LDS: 8 bytes per pixel.  The plan carries a second tiling for this kernel (PlanGeom conv, ipx_runtime.hip): column
+// blocks of at most 1020 pixels x 8 rows, 9 x 1024 x 8 B = 72 KB per tile, so that two workgroups still share a CU (one workgroup
+// of 1024 threads on a 147 KB tile was measured: 11% slower than the per-tap conversion -- nothing overlaps its barriers).  A
+// workgroup is 512 threads: thread = (4-pixel chunk, half); the upper half converts tile rows 4..7, the lower half rows 0..3 and
+// the halo row.
 //
-// Bound: HBM writes (1080p 4:2:0, full pipeline: 3.1 MB in, 11.6 MB out per frame) with the integer colour
-// conversion close behind (about 13 VALU ops per watermark pixel, 85 per resized pixel).
+// Bound: HBM writes (1080p 4:2:0, full pipeline: 3.1 MB in, 11.6 MB out per frame).
 #include <algorithm>
 #include <cstdlib>
 
@@ -28,63 +37,74 @@
 #include "ipx_device.h"
 #include "ipx_band_common.h"
 
+#ifndef IPX_DIAG
+#define IPX_DIAG 0      // -DIPX_DIAG=1 (tools/build_diag.sh): ablations by BandArgs::dbg, never in a timed or shipped build
+#endif
+
 namespace ipx {
 
 namespace {
 
-constexpr int kNT = 512;    // threads per workgroup: one 4-pixel chunk per thread and tile row
-constexpr int kRows = 9;    // tile rows incl. the halo row
+constexpr int kNT = 512;        // threads per workgroup
+constexpr int kCPR = kNT / 2;   // 4-pixel chunks per tile row: thread = (chunk, half of the tile's rows)
+constexpr int kRows = 9;        // tile rows incl. the halo row
+static_assert(kCPR * 16 == kConvTilePitch, "a tile row holds one 16-byte slot per chunk index");
+constexpr int kYS = 5;          // y rows a thread stages: half 0: tile rows 0..3 and 8, half 1: rows 4..7
 
-// imageutil.DrawYCbCr / color.YCbCrToRGB for one pixel given the chroma products (shared by the pixels that
-// share a chroma sample).  Go: if uint32(r)&0xff000000 == 0 { r >>= 16 } else { r = ^(r >> 31) } == clamp(r >> 16)
-struct Chroma8 { int r, g, b; };
-__device__ __forceinline__ Chroma8 chroma_products(int cb, int cr)
+// Chroma terms of color.YCbCrToRGB / color.YCbCr.RGBA for one chroma sample, the -128 folded into the constants.
+struct Chroma { int r, g, b; };
+__device__ __forceinline__ Chroma chroma_terms(int cb, int cr)
 {
-    const int cb1 = cb - 128, cr1 = cr - 128;
-    return Chroma8{91881 * cr1, -22554 * cb1 - 46802 * cr1, 116130 * cb1};
+    return Chroma{__mul24(cr, 91881) - 91881 * 128, __mul24(cb, -22554) + (__mul24(cr, -46802) + (22554 + 46802) * 128),
+                  __mul24(cb, 116130) - 116130 * 128};
 }
-// v_ashr_pk_u8_i32 (new on gfx950): the low half of the result is {sat_u8(a >> 16), sat_u8(b >> 16)} -- shift, clamp and pack of two
-// channels in one instruction; the upper half is left as it was, so consumers read the low half only.  (hipcc's own pattern for
-// `r | g << 8 | b << 16` uses this instruction and assumes a zeroed upper half: green bits leaked into blue.  The builtin of the same
-// name masks its result with an extra v_and; inline asm plus a v_perm_b32 that picks the two low bytes needs neither.)
-__device__ __forceinline__ uint32_t ashr16_pk_u8(int a, int b)
+// one pixel: the clamped 24-bit channels -> the two tile dwords
+struct Px { uint32_t lo, hi; };
+__device__ __forceinline__ Px convert_px(uint32_t y, const Chroma &c)
 {
-    uint32_t d;
-    asm("v_ashr_pk_u8_i32 %0, %1, %2, 16" : "=v"(d) : "v"(a), "v"(b));
-    return d;
+    const int yy1 = (int)__umul24(y, 0x10101u);
+    const int r = min(max(yy1 + c.r, 0), 0xffffff), g = min(max(yy1 + c.g, 0), 0xffffff), b = min(max(yy1 + c.b, 0), 0xffffff);
+    Px p;
+    p.lo = __builtin_amdgcn_perm((uint32_t)g, (uint32_t)r, 0x06050201u);     // {r.1, r.2, g.1, g.2}
+    p.hi = __builtin_amdgcn_perm(0u, (uint32_t)b, 0x0d0d0201u);              // {b.1, b.2, 0xff, 0xff}
+    return p;
 }
-__device__ __forceinline__ uint32_t rgba8_of(int y, const Chroma8 &c)
-{
-    const int yy1 = y * 0x10101;
-    const uint32_t rg = ashr16_pk_u8(yy1 + c.r, yy1 + c.g), ba = ashr16_pk_u8(yy1 + c.b, 255 << 16);
-    return __builtin_amdgcn_perm(ba, rg, 0x05040100u);   // {r, g, b, 0xff}
-}
-// a packed (Y, Cb, Cr, 0) tap -> RGBA8
-__device__ __forceinline__ uint32_t ycc_rgba8(uint32_t p)
-{
-    return rgba8_of((int)(p & 0xffu), chroma_products((int)((p >> 8) & 0xffu), (int)((p >> 16) & 0xffu)));
-}
-// how the shared scale paths (ipx_band_common.h, scale_out_conv) read a packed (Y, Cb, Cr, 0) tile dword
+// the RGBA8 pixel of imageutil.DrawYCbCr = the top byte of every channel: {r.2, g.2, b.2, 0xff}
+__device__ __forceinline__ uint32_t rgba8_of(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x0d050301u); }
+
+// how the shared scale paths (ipx_band_common.h) read the two-plane tile
 struct YccConv {
     static constexpr int NC = 3;    // the converted alpha is 0xffff for every tap: the output alpha is 0xff
-    // a packed tap -> 16-bit RGB as scale_RGBA_YCbCr4xx_Src converts it (color.YCbCr.RGBA inlined, clamped)
-    static __device__ __forceinline__ void tap16(uint32_t p, uint32_t (&c)[3])
+    static __device__ __forceinline__ int plane(const Tile &t) { return kRows * t.pitch; }
+    static __device__ __forceinline__ uint32_t rgba8_at(const uint8_t *lds, int off, int plane)
     {
-        const int yy1 = (int)(p & 0xffu) * 0x10101;
-        const int cb1 = (int)((p >> 8) & 0xffu) - 128, cr1 = (int)((p >> 16) & 0xffu) - 128;
-        c[0] = (uint32_t)min(max((yy1 + 91881 * cr1) >> 8, 0), 0xffff);
-        c[1] = (uint32_t)min(max((yy1 - 22554 * cb1 - 46802 * cr1) >> 8, 0), 0xffff);
-        c[2] = (uint32_t)min(max((yy1 + 116130 * cb1) >> 8, 0), 0xffff);
+        return rgba8_of(lds_u32(lds, off), lds_u32(lds, off + plane));
     }
-    static __device__ __forceinline__ uint32_t rgba8(uint32_t p) { return ycc_rgba8(p); }
+    static __device__ __forceinline__ void tap16_at(const uint8_t *lds, int off, int plane, uint32_t (&c)[3])
+    {
+        const uint32_t lo = lds_u32(lds, off), hi = lds_u32(lds, off + plane);
+        c[0] = lo & 0xffffu; c[1] = lo >> 16; c[2] = hi & 0xffffu;
+    }
+    static __device__ __forceinline__ void h16(const uint8_t *lds, int off, int plane, uint32_t iw, uint32_t (&h)[3])
+    {
+        const uint32_t lo0 = lds_u32(lds, off), lo1 = lds_u32(lds, off + 4), hi0 = lds_u32(lds, off + plane), hi1 = lds_u32(lds, off + plane + 4);
+        h[0] = dot2_u16(__builtin_amdgcn_perm(lo1, lo0, 0x05040100u), iw);   // [tap0.r | tap1.r << 16] . [x0 | x1 << 16]
+        h[1] = dot2_u16(__builtin_amdgcn_perm(lo1, lo0, 0x07060302u), iw);
+        h[2] = dot2_u16(__builtin_amdgcn_perm(hi1, hi0, 0x05040100u), iw);
+    }
 };
 
 typedef const __attribute__((address_space(4))) int *ConstIntsY;
 
-struct Stage {
-    uint32_t y[kRows];
-    uint32_t cb[kRows], cr[kRows];   // HS: two samples in the low half; VS: only the first (kRows + 1) / 2 are used
+template <int VS>
+struct StageT {
+    static constexpr int NCS = VS ? 3 : kYS;   // chroma rows a thread stages (VS: one per pair of y rows)
+    uint32_t y[kYS];
+    uint32_t cb[NCS], cr[NCS];                 // HS: two samples in the low half
 };
+
+// tile row of a thread's y slot s: slots 0..3 are the four rows of its half, slot 4 is the halo row (half 0 only)
+__device__ __forceinline__ int slot_row(int half, int s) { return s < 4 ? 4 * half + s : kRows - 1; }
 
 // The tile loads of one item.  Clipping is the descriptors' job: each plane's descriptor starts at the tile's first row and ends with
 // its last one, so row slots past the tile (or the frame) fall out of range by themselves and return 0; a thread whose chunk lies
@@ -96,7 +116,8 @@ __device__ __forceinline__ PlaneBases plane_bases(const YccArgs &A, int f)
 }
 
 template <int HS, int VS>
-__device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, const PlaneBases &pb, bool valid, int tid, Stage &st)
+__device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, const PlaneBases &pb, bool valid, int chunk, int half,
+                                               StageT<VS> &st)
 {
     const BandArgs &a = A.b;
     const int crow0 = t.r0 >> VS, crows = valid ? ((t.rows_ld - 1) >> VS) + 1 : 0;
@@ -105,15 +126,20 @@ __device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, 
     const int cbytes = crows > 0 ? (crows - 1) * A.cstride + A.cw : 0;
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cb + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cr + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
-    const bool in_tile = tid < t.nchunk;
-    const int yoff = in_tile ? t.c0 + tid * 4 : kOOB;
+    const bool in_tile = chunk < t.nchunk;
+    const int yoff = in_tile ? t.c0 + chunk * 4 : kOOB;
 #pragma unroll
-    for (int r = 0; r < kRows; r++) st.y[r] = __builtin_amdgcn_raw_buffer_load_b32(yrs, yoff + r * A.ystride, 0, 0);
-    constexpr int NCR = VS ? (kRows + 1) / 2 : kRows;
-    const int coff = in_tile ? (t.c0 + tid * 4) >> HS : kOOB;
+    for (int s = 0; s < kYS; s++) {
+        const bool mine = s < 4 || half == 0;
+        st.y[s] = __builtin_amdgcn_raw_buffer_load_b32(yrs, mine ? yoff + slot_row(half, s) * A.ystride : kOOB, 0, 0);   // (row in the VGPR offset: the range check ignores the scalar one)
+    }
+    const int coff = in_tile ? (t.c0 + chunk * 4) >> HS : kOOB;
 #pragma unroll
-    for (int j = 0; j < NCR; j++) {
-        const int off = coff + j * A.cstride;
+    for (int j = 0; j < StageT<VS>::NCS; j++) {
+        // chroma row of slot j: VS: rows 2*half, 2*half + 1 and (half 0) the halo row's; else the y slot's own row
+        const int crow = VS ? (j < 2 ? 2 * half + j : (kRows - 1) / 2) : slot_row(half, j);
+        const bool mine = j < StageT<VS>::NCS - 1 || half == 0;
+        const int off = mine ? coff + crow * A.cstride : kOOB;
         if (HS) {
             st.cb[j] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brs, off, 0, 0);
             st.cr[j] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rrs, off, 0, 0);
@@ -124,11 +150,11 @@ __device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, 
     }
 }
 
-// staged planes -> packed tile in LDS (kRows rows are allocated; rows past the tile hold what their loads returned and are never
-// read), and the owned pixels converted to RGBA8 -> watermark frame.  The last tile row is never an owned one (band_rows + 1 <=
-// kRows), so it is neither converted nor stored.
+// staged planes -> converted tile in LDS (kRows rows are allocated; rows past the tile hold what their loads returned and are never
+// read), and the owned pixels' top bytes -> watermark frame.  The last tile row is never an owned one (band_rows + 1 <= kRows): it
+// is converted for the tile only.
 template <int HS, int VS>
-__device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, uint8_t *wframe, int tid, const Stage &st,
+__device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, uint8_t *wframe, int chunk, int half, const StageT<VS> &st,
                                                uint8_t *lds, bool any_glyph)
 {
     const BandArgs &a = A.b;
@@ -136,60 +162,52 @@ __device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, 
         (void *)(a.wm ? wframe + (size_t)t.r0 * a.wm_stride : nullptr), 0,
         a.wm ? (t.own_rows - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);
     const bool gl_rows = any_glyph && t.r0 < a.gbox.y1 && t.r1 > a.gbox.y0;   // wave-uniform
-    const bool in_tile = tid < t.nchunk;
-    const int x = t.c0 + tid * 4;
-    const int woff = tid * 4 < t.own_cols ? x * 4 : kOOB;
-    const bool in_box = gl_rows && x + 4 > a.gbox.x0 && x < a.gbox.x1;
-    const int loff = tid * 16;
-    constexpr int NCR = VS ? (kRows + 1) / 2 : kRows;
+    const int x = t.c0 + chunk * 4;
+    const int woff = chunk * 4 < t.own_cols ? x * 4 : kOOB;
+    // chunks that meet the text box are written by the composite step: their store offset gets the top bit (beyond any frame)
+    const uint32_t in_box = gl_rows && x + 4 > a.gbox.x0 && x < a.gbox.x1 ? 0x80000000u : 0u;
+    const int loff = chunk * 16, plane = kRows * t.pitch;
 #pragma unroll
-    for (int j = 0; j < NCR; j++) {
+    for (int j = 0; j < StageT<VS>::NCS; j++) {
+        if (j == StageT<VS>::NCS - 1 && half) break;       // the halo row's slot: half 0 only (wave-uniform)
         const uint32_t cbw = st.cb[j], crw = st.cr[j];
-        // per pixel of the chunk: the chroma pair as (cb | cr << 8) for the packed tile dword, and the chroma products for the
-        // watermark pixel (shared by the pixels that share a sample)
-        uint32_t c2[4];
-        Chroma8 cp[4];
+        Chroma cp[4];                                      // per pixel of the chunk (shared by the pixels that share a sample)
         if (HS) {
-            c2[0] = c2[1] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0400u);
-            c2[2] = c2[3] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0501u);
-            cp[0] = cp[1] = chroma_products((int)(cbw & 0xffu), (int)(crw & 0xffu));
-            cp[2] = cp[3] = chroma_products((int)((cbw >> 8) & 0xffu), (int)((crw >> 8) & 0xffu));
+            cp[0] = cp[1] = chroma_terms((int)(cbw & 0xffu), (int)(crw & 0xffu));
+            cp[2] = cp[3] = chroma_terms((int)((cbw >> 8) & 0xffu), (int)((crw >> 8) & 0xffu));
         } else {
-            c2[0] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0400u); c2[1] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0501u);
-            c2[2] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0602u); c2[3] = __builtin_amdgcn_perm(crw, cbw, 0x0c0c0703u);
 #pragma unroll
-            for (int i = 0; i < 4; i++) cp[i] = chroma_products((int)((cbw >> (8 * i)) & 0xffu), (int)((crw >> (8 * i)) & 0xffu));
+            for (int i = 0; i < 4; i++) cp[i] = chroma_terms((int)((cbw >> (8 * i)) & 0xffu), (int)((crw >> (8 * i)) & 0xffu));
         }
 #pragma unroll
         for (int rr = 0; rr < (VS ? 2 : 1); rr++) {
-            const int r = VS ? 2 * j + rr : j;
-            if (r >= kRows) continue;
-            const uint32_t yw = st.y[r];
-            v4u packed;     // (Y, Cb, Cr, 0): one v_perm_b32 per pixel
-            packed[0] = __builtin_amdgcn_perm(c2[0], yw, 0x0c050400u); packed[1] = __builtin_amdgcn_perm(c2[1], yw, 0x0c050401u);
-            packed[2] = __builtin_amdgcn_perm(c2[2], yw, 0x0c050402u); packed[3] = __builtin_amdgcn_perm(c2[3], yw, 0x0c050403u);
-            if (in_tile) *(v4u *)(lds + r * t.pitch + loff) = packed;
-            if (r == kRows - 1 || !a.wm) continue;
+            if (VS && j == 2 && rr) continue;
+            const int s = VS ? (j < 2 ? 2 * j + rr : 4) : j;       // y slot
+            const int r = slot_row(half, s);
+            const uint32_t yw = st.y[s];
+            v4u lo, hi;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const Px p = convert_px((yw >> (8 * i)) & 0xffu, cp[i]);
+                lo[i] = p.lo; hi[i] = p.hi;
+            }
+#if IPX_DIAG
+            if (a.dbg & 4) { lo = v4u{yw, cbw, crw, yw}; hi = lo; }          // 4: no conversion arithmetic
+            if (a.dbg & 8) continue;                                          // 8: neither LDS writes nor watermark stores
+#endif
+            // (every chunk index has a slot in the fixed-pitch tile row: threads past the tile's columns write what their loads returned)
+            *(v4u *)(lds + r * t.pitch + loff) = lo;
+            *(v4u *)(lds + plane + r * t.pitch + loff) = hi;
+            if (s == 4 || !a.wm) continue;
             v4u rgba;
 #pragma unroll
-            for (int i = 0; i < 4; i++) rgba[i] = rgba8_of((int)((yw >> (8 * i)) & 0xffu), cp[i]);
-            // chunks that meet the text box are written by the composite step
-            const bool skip = in_box && t.r0 + r >= a.gbox.y0 && t.r0 + r < a.gbox.y1;
-            __builtin_amdgcn_raw_buffer_store_b128(rgba, wrs, skip ? kOOB : woff + r * a.wm_stride, 0, 0);
+            for (int i = 0; i < 4; i++) rgba[i] = rgba8_of(lo[i], hi[i]);
+            const uint32_t row_in_box = t.r0 + r >= a.gbox.y0 && t.r0 + r < a.gbox.y1 ? ~0u : 0u;       // scalar
+#if IPX_DIAG
+            if (a.dbg & 16) continue;                                         // 16: no watermark stores
+#endif
+            __builtin_amdgcn_raw_buffer_store_b128(rgba, wrs, (int)((uint32_t)(woff + r * a.wm_stride) | (in_box & row_in_box)), 0, 0);
         }
-    }
-}
-
-__device__ __forceinline__ void glyph_phase_ycc(const BandArgs &a, const Tile &t, uint8_t *wframe, const uint8_t *lds, int tid)
-{
-    const int gy0 = max(a.gbox.y0, t.r0), gy1 = min(a.gbox.y1, t.r1);
-    const int gx0 = max(a.gbox.x0 & ~3, t.c0), gx1 = min((a.gbox.x1 + 3) & ~3, t.c1);  // whole skipped chunks
-    const int gw = gx1 - gx0, gn = gw * (gy1 - gy0);
-    for (int i = tid; i < gn; i += kNT) {
-        const int yy = i / gw, x = gx0 + (i - yy * gw), y = gy0 + yy;
-        uint32_t d = ycc_rgba8(lds_u32(lds, (y - t.r0) * t.pitch + (x - t.c0) * 4));
-        d = glyph_run(d, x, y, a.glyphs, a.nglyphs, a.cr, a.cg, a.cb, a.ca);
-        *(uint32_t *)(wframe + (size_t)y * a.wm_stride + (size_t)x * 4) = d;
     }
 }
 
@@ -202,6 +220,7 @@ struct ItemY {
 __device__ __forceinline__ void item_setup_ycc(const BandArgs &a, ItemY &it, bool valid)
 {
     it.t = make_tile(a, it.b, it.cb);
+    it.t.pitch = kConvTilePitch;       // one slot per chunk index: no column test on the way into LDS, constant row offsets
 #pragma unroll
     for (int k = 0; k < 2; k++) {   // scalar loads: the tables are read through the constant address space
         const ConstIntsY rb = (ConstIntsY)(uintptr_t)a.sc[k].row_begin;
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = (uint8_t *)lds_raw;
     const BandArgs &a = A.b;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, chunk = tid & (kCPR - 1), half = __builtin_amdgcn_readfirstlane(tid / kCPR);   // (half is wave-uniform)
 
     // one contiguous run of (column block, frame, band) items per workgroup, entered at an offset of its own (band_pipe_kernel has the why)
     const int per_cb = a.nframes * a.nbands;
@@ -243,15 +262,34 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
     OutCols<NX1, FP1> o1;
     if (a.nscale > 0) { load_xtaps<NX0, FP0, kNT>(a, 0, cur.cb, tid, o0); load_xtaps<NX1, FP1, kNT>(a, 1, cur.cb, tid, o1); }
 
-    Stage st;
+    StageT<VS> st;
     PlaneBases pb = plane_bases(A, cur.f);        // of the item whose loads go out next
     OutBases ob = out_bases(a, cur.f);            // of the item being drained / computed
-    issue_tile_ycc<HS, VS>(A, cur.t, pb, true, tid, st);
+    issue_tile_ycc<HS, VS>(A, cur.t, pb, true, chunk, half, st);
 
+    // In-kernel phase stamps exist only in the diagnostic build (-DIPX_DIAG=1, tools/build_diag.sh); the shipped kernel executes none.
+#if IPX_DIAG
+    unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+#define IPX_STAMP(i) do { if (a.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc[i] += now_ - tprev; tprev = now_; } } while (0)
+    unsigned long long tprev = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+#else
+#define IPX_STAMP(i) do { } while (0)
+#endif
     for (;;) {
-        // A: staged planes -> packed LDS tile + converted watermark pixels
-        drain_tile_ycc<HS, VS>(A, cur.t, ob.wm, tid, st, lds, any_glyph);
+        // A: staged planes -> converted LDS tile + watermark pixels
+#if IPX_DIAG
+        if (a.stamps) {                                                       // the wait for the staged loads, on its own
+#pragma unroll
+            for (int q = 0; q < kYS; q++) asm volatile("" : "+v"(st.y[q]));
+#pragma unroll
+            for (int q = 0; q < StageT<VS>::NCS; q++) asm volatile("" : "+v"(st.cb[q]), "+v"(st.cr[q]));
+            IPX_STAMP(0);
+        }
+#endif
+        drain_tile_ycc<HS, VS>(A, cur.t, ob.wm, chunk, half, st, lds, any_glyph);
+        IPX_STAMP(1);
         __syncthreads();
+        IPX_STAMP(2);
 
         // B: the next item's loads
         ItemY nxt;
@@ -266,16 +304,22 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
         }
         item_setup_ycc(a, nxt, has_next);
         if (nxt.f != cur.f) pb = plane_bases(A, nxt.f);
-        issue_tile_ycc<HS, VS>(A, nxt.t, pb, has_next, tid, st);
+        issue_tile_ycc<HS, VS>(A, nxt.t, pb, has_next, chunk, half, st);
+        IPX_STAMP(3);
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, cur.t))
-            glyph_phase_ycc(a, cur.t, ob.wm, lds, tid);
+            glyph_phase<kNT, kRows - 1, YccConv>(a, cur.t, ob.wm, lds, tid);
+#if IPX_DIAG
+        if (!(a.dbg & 1))                                                     // 1: skip scaling
+#endif
         if (a.nscale > 0) {
             scale_out_conv<NX0, FP0, kNT, YccConv>(a, 0, A.mode[0], cur.t, ob.o0, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
             scale_out_conv<NX1, FP1, kNT, YccConv>(a, 1, A.mode[1], cur.t, ob.o1, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
         }
+        IPX_STAMP(4);
         __syncthreads();
+        IPX_STAMP(5);
 
         if (!has_next) break;
         if (nxt.cb != cur.cb && a.nscale > 0) {
@@ -287,6 +331,11 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
         idx++;
         left--;
     }
+#if IPX_DIAG
+    if (a.stamps && (tid & 63) == 0)
+        for (int i = 0; i < 6; i++) atomicAdd(&a.stamps[i], acc[i]);
+#endif
+#undef IPX_STAMP
 }
 
 template <int NX0, bool FP0, int NX1, bool FP1, int HS, int VS>
@@ -310,12 +359,12 @@ template <int HS, int VS>
 hipError_t launch_ycc_cfg(const YccArgs &A, long long items, size_t lds, hipStream_t s, bool *matched)
 {
     const BandArgs &a = A.b;
-    // a.nx_out counts blocks of 256 destination columns per column block; a 512-thread workgroup serves two each
+    // a.nx_out counts blocks of 256 destination columns per column block; the 512-thread workgroup serves two each
     const int need0 = a.nscale > 0 ? (a.nx_out[0] + 1) / 2 : 0, need1 = a.nscale > 1 ? (a.nx_out[1] + 1) / 2 : 0;
     const bool fp0 = a.nscale > 0 && a.sc[0].dyadic_shift < 0;
     *matched = true;
-    if (need0 <= 2 && !fp0 && need1 <= 1) return launch_ycc<2, false, 1, true, HS, VS>(A, items, lds, s);
-    if (need0 <= 2 && need1 <= 1) return launch_ycc<2, true, 1, true, HS, VS>(A, items, lds, s);
+    if (need0 <= 1 && !fp0 && need1 <= 1) return launch_ycc<1, false, 1, true, HS, VS>(A, items, lds, s);
+    if (need0 <= 1 && need1 <= 1) return launch_ycc<1, true, 1, true, HS, VS>(A, items, lds, s);
     *matched = false;
     return hipSuccess;
 }
@@ -327,7 +376,7 @@ bool band_ycc_supported(const YccArgs &A)
 {
     const BandArgs &a = A.b;
     const int hs = A.ratio == IPX_YCBCR_422 || A.ratio == IPX_YCBCR_420, vs = A.ratio == IPX_YCBCR_420 || A.ratio == IPX_YCBCR_440;
-    if ((a.sw & 3) || a.band_rows + 1 > kRows || a.blk_cols / 4 + 1 > kNT || (a.blk_cols & 3)) return false;
+    if ((a.sw & 3) || a.band_rows + 1 > kRows || (a.blk_cols + 4) * 4 > kConvTilePitch || (a.blk_cols & 3)) return false;
     if (vs && (a.band_rows & 1)) return false;
     if ((((uintptr_t)A.y) | (uintptr_t)A.ystride | A.y_fs) & 3) return false;
     const uintptr_t cal = hs ? 1 : 3;
@@ -343,7 +392,7 @@ hipError_t launch_band_ycc(const YccArgs &A, hipStream_t s, bool *matched)
     const long long total = (long long)a.nbands * a.ncolblk * a.nframes;
     if (total <= 0) { *matched = true; return hipSuccess; }
     if (total > 0x7fffffffLL || !band_ycc_supported(A)) return hipSuccess;
-    const size_t lds = (size_t)kRows * (size_t)(a.blk_cols + 4) * 4;     // the packed tile alone (y taps come through scalar loads)
+    const size_t lds = 2 * (size_t)kRows * kConvTilePitch;     // the two planes of the converted tile (y taps come through scalar loads)
     switch (A.ratio) {
     case IPX_YCBCR_444: return launch_ycc_cfg<0, 0>(A, total, lds, s, matched);
     case IPX_YCBCR_422: return launch_ycc_cfg<1, 0>(A, total, lds, s, matched);

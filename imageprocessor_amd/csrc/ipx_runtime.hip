@@ -814,50 +814,67 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
         }
     }
 
-    // block shape: owned columns per workgroup (multiple of 4 pixels = 16 B) and owned rows; a
-    // column block may hold at most 256 * kBandNX destination columns of any scaled output
-    int max_cols = std::max(4, env_int("IPX_BLK_COLS", 2044)) & ~3;
-    const size_t lds_budget = ((size_t)std::max(8, env_int("IPX_LDS_KB", 72)) << 10) - band_lds_bytes(-1, -4);
-    int bc = 0, br = 0;
-    std::vector<int> rb[2], cbv[2];
-    for (;;) {
-        const int ncb = (sw + max_cols - 1) / max_cols;
-        bc = std::max(4, ((sw + ncb - 1) / ncb + 3) & ~3);
-        br = (int)(lds_budget / ((size_t)(bc + 4) * 4)) - 1;
-        br = std::max(1, std::min(br, env_int("IPX_BAND_ROWS_MAX", bc / 4 + 1 > 256 ? 8 : 16)));  // shapes of band_pipe_shape
-        if (env_int("IPX_BAND_ROWS", 0) > 0) br = env_int("IPX_BAND_ROWS", 0);
-        br = std::min(br, sh);
-        pl->blk_cols = bc; pl->band_rows = br;
-        pl->ncolblk = (sw + bc - 1) / bc;
-        pl->nbands = (sh + br - 1) / br;
-        int widest = 0;
-        pl->most_rows = 0;
-        pl->nx_out[0] = pl->nx_out[1] = 0;
-        for (int k = 0; k < 2; k++) {
-            PlanScale &s = pl->sc[k];
-            if (xt[k].empty()) continue;
-            rb[k].assign(pl->nbands + 1, 0); cbv[k].assign(pl->ncolblk + 1, 0);
-            int d = 0;
-            for (int b = 0; b <= pl->nbands; b++) {  // first output row whose tap pair starts in band b or below
-                while (d < s.dh && s.sr.y0 + yt[k][d].base < b * br) d++;
-                rb[k][b] = b == pl->nbands ? s.dh : d;
+    // Tilings of the source frame (PlanGeom) and the tables that depend on them.  A tiling = owned columns per workgroup (multiple of
+    // 4 pixels = 16 B) and owned rows; a column block may hold at most out_cols destination columns of any scaled output.
+    //   pl->g     tiles of one dword per pixel: band_pipe_kernel (RGBA sources) and band_nrgba_kernel; 72 KB of LDS, two workgroups per CU
+    //   pl->conv  tiles of two dwords per pixel (converted taps): band_ycc_kernel; at most 1020 columns x 8 rows, again two per CU
+    struct HostGeom {
+        int bc = 0, br = 0;
+        std::vector<int> rb[2], cbv[2];
+        std::vector<uint32_t> yr[2], y16[2];
+        size_t off_rb[2] = {0, 0}, off_cb[2] = {0, 0}, off_yr[2] = {0, 0}, off_y16[2] = {0, 0};
+    };
+    auto build_geom = [&](PlanGeom &g, HostGeom &hg, int max_cols, size_t lds_budget, int px_bytes, int rows_cap, int out_cols) -> bool {
+        for (;;) {
+            const int ncb = (sw + max_cols - 1) / max_cols;
+            const int bc = std::max(4, ((sw + ncb - 1) / ncb + 3) & ~3);
+            int br = (int)(lds_budget / ((size_t)(bc + 4) * px_bytes)) - 1;
+            br = std::max(1, std::min(br, rows_cap > 0 ? rows_cap : env_int("IPX_BAND_ROWS_MAX", bc / 4 + 1 > 256 ? 8 : 16)));  // shapes of band_pipe_shape
+            if (rows_cap <= 0 && env_int("IPX_BAND_ROWS", 0) > 0) br = env_int("IPX_BAND_ROWS", 0);
+            br = std::min(br, sh);
+            if (rows_cap > 0 && br > 1) br &= ~1;              // whole chroma rows per band (4:2:0, 4:4:0)
+            hg.bc = bc; hg.br = br;
+            g.blk_cols = bc; g.band_rows = br;
+            g.ncolblk = (sw + bc - 1) / bc;
+            g.nbands = (sh + br - 1) / br;
+            int widest = 0;
+            g.most_rows = 0;
+            g.nx_out[0] = g.nx_out[1] = 0;
+            for (int k = 0; k < 2; k++) {
+                PlanScale &sk = pl->sc[k];
+                if (xt[k].empty()) continue;
+                hg.rb[k].assign(g.nbands + 1, 0); hg.cbv[k].assign(g.ncolblk + 1, 0);
+                int d = 0;
+                for (int b2 = 0; b2 <= g.nbands; b2++) {  // first output row whose tap pair starts in band b2 or below
+                    while (d < sk.dh && sk.sr.y0 + yt[k][d].base < b2 * br) d++;
+                    hg.rb[k][b2] = b2 == g.nbands ? sk.dh : d;
+                }
+                d = 0;
+                for (int c = 0; c <= g.ncolblk; c++) {
+                    while (d < sk.dw && sk.sr.x0 + xt[k][d].base < c * bc) d++;
+                    hg.cbv[k][c] = c == g.ncolblk ? sk.dw : d;
+                }
+                int wk = 0;
+                for (int c = 0; c < g.ncolblk; c++) wk = std::max(wk, hg.cbv[k][c + 1] - hg.cbv[k][c]);
+                widest = std::max(widest, wk);
+                g.nx_out[k] = (wk + 255) / 256;
+                for (int b2 = 0; b2 < g.nbands; b2++) g.most_rows = std::max(g.most_rows, hg.rb[k][b2 + 1] - hg.rb[k][b2]);
             }
-            d = 0;
-            for (int c = 0; c <= pl->ncolblk; c++) {
-                while (d < s.dw && s.sr.x0 + xt[k][d].base < c * bc) d++;
-                cbv[k][c] = c == pl->ncolblk ? s.dw : d;
-            }
-            int wk = 0;
-            for (int c = 0; c < pl->ncolblk; c++) wk = std::max(wk, cbv[k][c + 1] - cbv[k][c]);
-            widest = std::max(widest, wk);
-            pl->nx_out[k] = (wk + 255) / 256;
-            for (int b = 0; b < pl->nbands; b++) pl->most_rows = std::max(pl->most_rows, rb[k][b + 1] - rb[k][b]);
+            if (widest <= out_cols) return true;
+            if (bc <= 4) return false;                         // enormous upscale: per-operation kernels
+            max_cols = std::max(4, (int)((long long)bc * out_cols / widest) & ~3);
+            if (max_cols >= bc) max_cols = bc - 4;
         }
-        if (widest <= 256 * kBandNX) break;
-        if (bc <= 4) { pl->fused = false; *out = pl; return IPX_OK; }  // enormous upscale: per-operation kernels
-        max_cols = std::max(4, (int)((long long)bc * 256 * kBandNX / widest) & ~3);
-        if (max_cols >= bc) max_cols = bc - 4;
+    };
+    HostGeom hg[2];
+    if (!build_geom(pl->g, hg[0], std::max(4, env_int("IPX_BLK_COLS", 2044)) & ~3,
+                    ((size_t)std::max(8, env_int("IPX_LDS_KB", 72)) << 10) - band_lds_bytes(-1, -4), 4, 0, 256 * kBandNX)) {
+        pl->fused = false;
+        *out = pl;
+        return IPX_OK;
     }
+    pl->g.ok = true;
+    pl->conv.ok = build_geom(pl->conv, hg[1], std::max(4, std::min(env_int("IPX_CONV_BLK_COLS", 1020), 1020)) & ~3, (size_t)80 << 10, 8, 8, 512);
 
     // host tables -> one device blob
     std::vector<uint8_t> blob;
@@ -867,41 +884,45 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
         memcpy(blob.data() + off, src, bytes);
         return off;
     };
-    size_t off_xt[2] = {0, 0}, off_yt[2] = {0, 0}, off_rb[2] = {0, 0}, off_cb[2] = {0, 0}, off_yr[2] = {0, 0}, off_y16[2] = {0, 0};
-    bool has_y16[2] = {false, false};
+    size_t off_xt[2] = {0, 0}, off_yt[2] = {0, 0};
     for (int k = 0; k < 2; k++) {
         if (xt[k].empty()) continue;
         off_xt[k] = put(xt[k].data(), xt[k].size() * sizeof(AxisTap));
         off_yt[k] = put(yt[k].data(), yt[k].size() * sizeof(AxisTap));
-        off_rb[k] = put(rb[k].data(), rb[k].size() * sizeof(int));
-        off_cb[k] = put(cbv[k].data(), cbv[k].size() * sizeof(int));
+        PlanScale &sk = pl->sc[k];
         // the packed-integer lerp's row table (ScaleOut::yrow): RGBA8 taps, kx <= 8 (16-bit lanes hold 8 + kx bits), ky <= 12
-        PlanScale &s = pl->sc[k];
-        if (s.dyadic_shift < 1 || s.kx > 8 || s.ky > 12 || env_int("IPX_NO_INTLERP", 0)) continue;
-        const int kk = std::max(s.dyadic_shift, 9), ysh = kk - s.dyadic_shift;   // ky + ysh <= 15: the scaled weights stay 16-bit lanes
-        const uint32_t pitch = (uint32_t)(bc + 4) * 4;
-        std::vector<uint32_t> yr((size_t)(s.dh + 1) * 2, 0);
-        for (int d = 0; d < s.dh; d++) {
-            const int row = s.sr.y0 + yt[k][d].base, band = row / br;
-            uint32_t code = 2;                                   // the first row of a band finds nothing at hand
-            if (d > rb[k][band]) {
-                const int step = yt[k][d].base - yt[k][d - 1].base;
-                code = step == 0 ? 0 : step == 1 ? 1 : 2;
+        const bool int_rows = !(sk.dyadic_shift < 1 || sk.kx > 8 || sk.ky > 12 || env_int("IPX_NO_INTLERP", 0));
+        const int kk = std::max(sk.dyadic_shift, 9), ysh = kk - sk.dyadic_shift;   // ky + ysh <= 15: the scaled weights stay 16-bit lanes
+        if (int_rows) sk.imul = 257u << (24 - kk);
+        for (int gi = 0; gi < 2; gi++) {
+            PlanGeom &g = gi ? pl->conv : pl->g;
+            HostGeom &h = hg[gi];
+            if (!g.ok) continue;
+            h.off_rb[k] = put(h.rb[k].data(), h.rb[k].size() * sizeof(int));
+            h.off_cb[k] = put(h.cbv[k].data(), h.cbv[k].size() * sizeof(int));
+            if (!int_rows) continue;
+            const uint32_t pitch = gi ? (uint32_t)kConvTilePitch : (uint32_t)(h.bc + 4) * 4;      // of one plane of the tile
+            h.yr[k].assign((size_t)(sk.dh + 1) * 2, 0);
+            for (int d = 0; d < sk.dh; d++) {
+                const int row = sk.sr.y0 + yt[k][d].base, band = row / h.br;
+                uint32_t code = 2;                                   // the first row of a band finds nothing at hand
+                if (d > h.rb[k][band]) {
+                    const int step = yt[k][d].base - yt[k][d - 1].base;
+                    code = step == 0 ? 0 : step == 1 ? 1 : 2;
+                }
+                h.yr[k][2 * d] = (uint32_t)(row - band * h.br) * pitch | code << 28;
+                h.yr[k][2 * d + 1] = yt[k][d].iw << ysh;
             }
-            yr[2 * d] = (uint32_t)(row - band * br) * pitch | code << 28;
-            yr[2 * d + 1] = yt[k][d].iw << ysh;
-        }
-        s.imul = 257u << (24 - kk);
-        off_yr[k] = put(yr.data(), yr.size() * sizeof(uint32_t));
-        if (s.kx <= 8 && s.ky <= 8) {   // the same walk for 16-bit converted taps (ScaleOut::yrow16)
-            std::vector<uint32_t> y16((size_t)(s.dh + 1) * 4, 0);
-            for (int d = 0; d < s.dh; d++) {
-                y16[4 * d] = yr[2 * d];
-                y16[4 * d + 1] = (yt[k][d].iw & 0xffffu) << (16 - s.dyadic_shift);
-                y16[4 * d + 2] = (yt[k][d].iw >> 16) << (16 - s.dyadic_shift);
+            h.off_yr[k] = put(h.yr[k].data(), h.yr[k].size() * sizeof(uint32_t));
+            if (sk.kx <= 8 && sk.ky <= 8) {   // the same walk for 16-bit converted taps (ScaleOut::yrow16)
+                h.y16[k].assign((size_t)(sk.dh + 1) * 4, 0);
+                for (int d = 0; d < sk.dh; d++) {
+                    h.y16[k][4 * d] = h.yr[k][2 * d];
+                    h.y16[k][4 * d + 1] = (yt[k][d].iw & 0xffffu) << (16 - sk.dyadic_shift);
+                    h.y16[k][4 * d + 2] = (yt[k][d].iw >> 16) << (16 - sk.dyadic_shift);
+                }
+                h.off_y16[k] = put(h.y16[k].data(), h.y16[k].size() * sizeof(uint32_t));
             }
-            off_y16[k] = put(y16.data(), y16.size() * sizeof(uint32_t));
-            has_y16[k] = true;
         }
     }
     if (!blob.empty()) {
@@ -913,14 +934,19 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
             return IPX_ERR_HIP;
         }
         for (int k = 0; k < 2; k++) {
-            PlanScale &s = pl->sc[k];
-            if (!s.on || s.dw <= 0 || s.dh <= 0) continue;
-            s.xt = (AxisTap *)(pl->blob + off_xt[k]);
-            s.yt = (AxisTap *)(pl->blob + off_yt[k]);
-            s.row_begin = (int *)(pl->blob + off_rb[k]);
-            s.col_begin = (int *)(pl->blob + off_cb[k]);
-            if (s.imul) s.yrow = (uint32_t *)(pl->blob + off_yr[k]);
-            if (has_y16[k]) s.yrow16 = (uint32_t *)(pl->blob + off_y16[k]);
+            PlanScale &sk = pl->sc[k];
+            if (!sk.on || sk.dw <= 0 || sk.dh <= 0) continue;
+            sk.xt = (AxisTap *)(pl->blob + off_xt[k]);
+            sk.yt = (AxisTap *)(pl->blob + off_yt[k]);
+            for (int gi = 0; gi < 2; gi++) {
+                PlanGeom &g = gi ? pl->conv : pl->g;
+                const HostGeom &h = hg[gi];
+                if (!g.ok) continue;
+                g.row_begin[k] = (int *)(pl->blob + h.off_rb[k]);
+                g.col_begin[k] = (int *)(pl->blob + h.off_cb[k]);
+                if (!h.yr[k].empty()) g.yrow[k] = (uint32_t *)(pl->blob + h.off_yr[k]);
+                if (!h.y16[k].empty()) g.yrow16[k] = (uint32_t *)(pl->blob + h.off_y16[k]);
+            }
         }
     }
     *out = pl;
@@ -1040,8 +1066,8 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         BandArgs a{};
         a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
         a.sw = sw; a.sh = sh;
-        a.band_rows = pl->band_rows; a.nbands = pl->nbands;
-        a.blk_cols = pl->blk_cols; a.ncolblk = pl->ncolblk;
+        a.band_rows = pl->g.band_rows; a.nbands = pl->g.nbands;
+        a.blk_cols = pl->g.blk_cols; a.ncolblk = pl->g.ncolblk;
         a.nframes = n;
         // the persistent pipelined kernel needs 16-byte aligned rows on both frames and a tile of at
         // most kPipeMaxSlots chunks per thread; otherwise one workgroup per item
@@ -1063,7 +1089,7 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
         const bool aligned = (sw & 3) == 0 && ((((uintptr_t)src) | (uintptr_t)sstride | src_frame_stride) & 15) == 0 &&
                              (!wm || ((((uintptr_t)wm) | wm_frame_stride) & 15) == 0);
         int pr = 0, pc = 0;
-        if (aligned && env_int("IPX_PIPE", 1) && pl->most_rows <= 64 && band_pipe_shape(pl->band_rows, pl->blk_cols, &pr, &pc)) {
+        if (aligned && env_int("IPX_PIPE", 1) && pl->g.most_rows <= 64 && band_pipe_shape(pl->g.band_rows, pl->g.blk_cols, &pr, &pc)) {
             a.pipe_wgs = std::max(1, env_int("IPX_PIPE_WGS", 8));  // clamped to what is resident at launch
             a.pipe_nt = env_int("IPX_PIPE_NT", 512) == 512 ? 512 : 256;
             a.pipe_order = -1;   // chosen below, once the operators are known
@@ -1077,10 +1103,10 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
             ScaleOut &o = a.sc[a.nscale++];
             o.out = outs[k]; o.frame_stride = ostr[k]; o.ostride = ps.dw * 4;
             o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
-            o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
+            o.xt = ps.xt; o.yt = ps.yt; o.row_begin = pl->g.row_begin[k]; o.col_begin = pl->g.col_begin[k];
             o.dyadic_shift = ps.dyadic_shift;
-            o.imul = ps.imul; o.yrow = ps.yrow;
-            a.nx_out[a.nscale - 1] = pl->nx_out[k];
+            o.imul = ps.imul; o.yrow = pl->g.yrow[k];
+            a.nx_out[a.nscale - 1] = pl->g.nx_out[k];
         }
         if (a.nscale == 1) a.sc[1] = a.sc[0];  // keeps the kernel's unconditional tap loads legal
         a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
@@ -1094,7 +1120,7 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
             unsigned long long h[8];
             IPX_HIP(hipMemcpyAsync(h, a.stamps, sizeof h, hipMemcpyDeviceToHost, s));
             IPX_HIP(hipStreamSynchronize(s));
-            const double items = (double)pl->nbands * pl->ncolblk * n, waves = 4.0;
+            const double items = (double)pl->g.nbands * pl->g.ncolblk * n, waves = 4.0;
             fprintf(stderr, "[ipx stamps] cycles per item per wave: drain %.0f  barrier1 %.0f  issue %.0f  compute %.0f  barrier2 %.0f\n",
                     h[0] / items / waves, h[1] / items / waves, h[2] / items / waves, h[3] / items / waves, h[4] / items / waves);
         }
@@ -1293,16 +1319,19 @@ IPX_CATCH_STATUS
 // outputs that are wanted, and per scaled output the conversion rule -- mode 0 = 16-bit taps (resizeImage on the source image itself),
 // mode 1 = 8-bit RGBA first (the crop thumbnail scales the RGBA8 copy cropAndResize made, thumbnail.go:128-131)
 static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, uint8_t *res, size_t resize_frame_stride, uint8_t *th,
-                                      size_t thumb_frame_stride, uint8_t *wm, size_t wm_frame_stride, BandArgs &a, int mode[2])
+                                      size_t thumb_frame_stride, uint8_t *wm, size_t wm_frame_stride, const PlanGeom &g, BandArgs &a, int mode[2])
 {
     const int sw = pl->p.sw, sh = pl->p.sh;
     a.sw = sw; a.sh = sh;
-    a.band_rows = pl->band_rows; a.nbands = pl->nbands;
-    a.blk_cols = pl->blk_cols; a.ncolblk = pl->ncolblk;
+    a.band_rows = g.band_rows; a.nbands = g.nbands;
+    a.blk_cols = g.blk_cols; a.ncolblk = g.ncolblk;
     a.nframes = n;
     a.pipe_wgs = std::max(1, env_int("IPX_PIPE_WGS", 8));
     a.pipe_nt = 512; a.pipe_order = 1;
     a.cus = ctx->cus;
+#if IPX_DIAG
+    a.dbg = env_int("IPX_DBG", 0);
+#endif
     a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
     uint8_t *outs[2] = {res, th};
     const size_t ostr[2] = {resize_frame_stride, thumb_frame_stride};
@@ -1313,13 +1342,13 @@ static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, u
         ScaleOut &o = a.sc[a.nscale++];
         o.out = outs[k]; o.frame_stride = ostr[k]; o.ostride = ps.dw * 4;
         o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
-        o.xt = ps.xt; o.yt = ps.yt; o.row_begin = ps.row_begin; o.col_begin = ps.col_begin;
+        o.xt = ps.xt; o.yt = ps.yt; o.row_begin = g.row_begin[k]; o.col_begin = g.col_begin[k];
         o.dyadic_shift = ps.dyadic_shift;
-        if (mode[a.nscale - 1] == 1) { o.imul = ps.imul; o.yrow = ps.yrow; }   // RGBA8 taps only
-        else o.yrow16 = ps.yrow16;
+        if (mode[a.nscale - 1] == 1) { o.imul = g.yrow[k] ? ps.imul : 0; o.yrow = g.yrow[k]; }   // RGBA8 taps only
+        else o.yrow16 = g.yrow16[k];
         // 16-bit taps in u32: x0*tap + x1*tap < 2^24 and the weights below 2^9 keep every product in 24 x 24 bits
         if (mode[a.nscale - 1] == 0 && (ps.kx > 8 || ps.ky > 8)) o.dyadic_shift = -1;
-        a.nx_out[a.nscale - 1] = pl->nx_out[k];
+        a.nx_out[a.nscale - 1] = g.nx_out[k];
     }
     if (a.nscale == 1) { a.sc[1] = a.sc[0]; mode[1] = mode[0]; }
     const uint8_t *c = pl->p.glyphs ? pl->p.glyphs->col : nullptr;
@@ -1362,17 +1391,35 @@ static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n,
     const bool crop_thumb = th && pl->p.crop_to_fit;
 
     // one fused pass over the planes when the tile shape and alignments allow it (ipx_band_ycc.hip)
-    if (pl->fused && env_int("IPX_YCC_FUSED", 1) && pl->band_rows <= 8 && pl->most_rows <= 64) {
+    if (pl->fused && env_int("IPX_YCC_FUSED", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
         YccArgs A{};
         BandArgs &a = A.b;
-        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, a, A.mode);
+        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, a, A.mode);
         if (!wm && a.nscale == 0) return IPX_OK;
         A.y = src->y; A.cb = src->cb; A.cr = src->cr; A.ystride = src->ystride; A.cstride = src->cstride;
         A.y_fs = src->y_frame_stride; A.c_fs = src->c_frame_stride; A.ratio = src->ratio;
         A.cw = (src->ratio == IPX_YCBCR_422 || src->ratio == IPX_YCBCR_420) ? (sw + 1) / 2 : sw;
         A.ch = (src->ratio == IPX_YCBCR_420 || src->ratio == IPX_YCBCR_440) ? (sh + 1) / 2 : sh;
+#if IPX_DIAG
+        static unsigned long long *stamp_buf = nullptr;   // IPX_STAMPS=1: phase stamps, never in a timed run
+        if (env_int("IPX_STAMPS", 0)) {
+            if (!stamp_buf) IPX_HIP(hipMalloc((void **)&stamp_buf, 8 * sizeof(unsigned long long)));
+            IPX_HIP(hipMemsetAsync(stamp_buf, 0, 8 * sizeof(unsigned long long), s));
+            a.stamps = stamp_buf;
+        }
+#endif
         bool matched = false;
         if (src->cstride >= A.cw || flat_chroma) IPX_HIP(launch_band_ycc(A, s, &matched));
+#if IPX_DIAG
+        if (matched && a.stamps) {
+            unsigned long long h[8];
+            IPX_HIP(hipMemcpyAsync(h, a.stamps, sizeof h, hipMemcpyDeviceToHost, s));
+            IPX_HIP(hipStreamSynchronize(s));
+            const double wi = (double)pl->conv.nbands * pl->conv.ncolblk * n * 8.0;
+            fprintf(stderr, "[ipx stamps ycc] cycles per item per wave: wait-loads %.0f  drain %.0f  barrier1 %.0f  issue %.0f  compute %.0f  barrier2 %.0f\n",
+                    h[0] / wi, h[1] / wi, h[2] / wi, h[3] / wi, h[4] / wi, h[5] / wi);
+        }
+#endif
         if (matched) return IPX_OK;
     }
 
@@ -1443,10 +1490,10 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
     const bool crop_thumb = th && pl->p.crop_to_fit;
     // one fused pass over the frames when the tile shape and alignments allow it (ipx_band_nrgba.hip)
-    if (pl->fused && env_int("IPX_NRGBA_FUSED", 1) && pl->band_rows <= 8 && pl->most_rows <= 64) {
+    if (pl->fused && env_int("IPX_NRGBA_FUSED", 1) && pl->g.band_rows <= 8 && pl->g.most_rows <= 64) {
         NrgbaArgs A{};
         BandArgs &a = A.b;
-        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, a, A.mode);
+        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->g, a, A.mode);
         if (!wm && a.nscale == 0) return IPX_OK;
         a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
         bool matched = false;

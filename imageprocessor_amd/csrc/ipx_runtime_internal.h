@@ -84,22 +84,28 @@ struct PlanScale {
     int dw = 0, dh = 0;
     Rect sr{0, 0, 0, 0};
     AxisTap *xt = nullptr, *yt = nullptr;
-    int *row_begin = nullptr, *col_begin = nullptr;
     int dyadic_shift = -1;
     int kx = -1, ky = -1;   // dyadic bits per axis (dyadic_shift = kx + ky), -1 = not dyadic
-    // the packed-integer lerp (ScaleOut::imul / yrow): set when the axes qualify, see plan_int_rows()
-    uint32_t imul = 0;
-    uint32_t *yrow = nullptr;   // device: dh + 1 entries of {ctl, yw}
-    uint32_t *yrow16 = nullptr; // device: dh + 1 entries of {ctl, y0', y1', 0} (ScaleOut::yrow16), when kx and ky <= 8
+    uint32_t imul = 0;      // the packed-integer lerp (ScaleOut::imul): set when the axes qualify
+};
+
+// One tiling of the source frame and the device tables that depend on it (per scaled output k)
+struct PlanGeom {
+    bool ok = false;
+    int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0;
+    int nx_out[2] = {0, 0}; // per output: ceil(widest column block / 256)
+    int most_rows = 0;      // most destination rows any band owns, over the scaled outputs
+    int *row_begin[2] = {nullptr, nullptr}, *col_begin[2] = {nullptr, nullptr};
+    uint32_t *yrow[2] = {nullptr, nullptr};     // dh + 1 entries of {ctl, yw} (ScaleOut::yrow), when imul is set
+    uint32_t *yrow16[2] = {nullptr, nullptr};   // dh + 1 entries of {ctl, y0', y1', 0} (ScaleOut::yrow16), when kx and ky <= 8
 };
 
 struct ipx_plan {
     ipx_plan_params p{};
     ipx_plan_info info{};
     bool fused = false;
-    int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0;
-    int nx_out[2] = {0, 0}; // per output: ceil(widest column block / 256)
-    int most_rows = 0;    // most destination rows any band owns, over the scaled outputs
+    PlanGeom g;           // tiles of one dword per pixel (RGBA and NRGBA sources)
+    PlanGeom conv;        // tiles of converted taps, two dwords per pixel (YCbCr sources); conv.ok = false: that kernel is not used
     PlanScale sc[2];      // 0 = resize, 1 = thumbnail
     uint8_t *blob = nullptr;
     ClippedGlyphs glyphs;
