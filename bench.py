@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--pool", type=int, default=32, help="distinct seeded frames tiled over the batch")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="seconds per row of the CPU baseline (0 = skip)")
+    ap.add_argument("--copy-gib", type=int, default=4, help="size of the plain-copy ceiling measurement beside the roofline (0 = skip; N = 1 only)")
     ap.add_argument("--e2e-frames", type=int, default=256, help="frames per call of the PCIe-inclusive legs (0 = skip; N = 1 only)")
     ap.add_argument("--e2e-reps", type=int, default=4)
     ap.add_argument("--check", action="store_true", help="compare frame 0 with the oracle after the run")
@@ -46,6 +47,25 @@ def parse():
                     help="BASELINE config 5 instead: N frames per GPU of mixed sizes (480p-8K, seed 0x51), full "
                          "pipeline, pull scheduling over a shared largest-first queue (work stealing across ranks)")
     return ap.parse_args()
+
+
+def copy_ceiling(ctx, gib=4, pairs=3, reps=4):
+    """What a plain streaming copy reaches on THIS box, in this process: the practical ceiling the band kernels are held against next to
+    the 8 TB/s of the data sheet.  It differs from box to box (4.9 .. 5.9 TB/s seen) and by some 8% with where the two buffers happen to
+    land (profiles/r02_ubench_place.txt), so a few pairs of buffers are tried and the best and the worst are reported."""
+    nbytes = gib << 30
+    rates, keep = [], []
+    for _ in range(pairs):
+        a, b = ctx.alloc(nbytes), ctx.alloc(nbytes)
+        keep += [a, b]
+        ctx.stream_copy(b.ptr, a.ptr, nbytes)
+        ctx.device_sync()
+        ms = min(ctx.timed(lambda: ctx.stream_copy(b.ptr, a.ptr, nbytes)) for _ in range(reps))
+        rates.append(2.0 * nbytes / (ms * 1e-3) / 1e9)
+    for b in keep:
+        b.free()
+    return {"best": round(max(rates), 1), "worst": round(min(rates), 1), "unit": "GB/s",
+            "what": "ipx_stream_copy (grid-stride uint4 copy kernel) of %d GiB, read + written bytes / best of %d runs, %d buffer pairs" % (gib, reps, pairs)}
 
 
 def host_info():
@@ -454,6 +474,10 @@ def main():
                          "kernel": "band_pipe_kernel", "algorithmic_bytes_per_launch": alg,
                          "avg_launch_ms": round(avg_ms, 4), "traffic_source": traffic_src},
         }
+        if world == 1 and args.copy_gib > 0:
+            cc = copy_ceiling(ctx, args.copy_gib)
+            out["roofline"]["copy_ceiling"] = cc
+            out["roofline"]["frac_of_copy_ceiling"] = round(achieved / cc["best"], 4)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(pool, glyphs, DEFAULT_COL, resize, thumb,
                                                [k for k, b in (("resize", res), ("thumbnail", th), ("watermark", wm)) if b],

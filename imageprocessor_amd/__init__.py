@@ -425,6 +425,10 @@ class Context:
     def copy_d2d(self, dst_ptr, src_ptr, nbytes):
         _check(lib().ipx_memcpy_d2d(self.handle, dst_ptr, src_ptr, nbytes))
 
+    def stream_copy(self, dst_ptr, src_ptr, nbytes, stream=None):
+        """A plain streaming copy kernel: what this box's HBM gives a copy (bench.py's copy_ceiling)."""
+        _check(lib().ipx_stream_copy(self.handle, stream, dst_ptr, src_ptr, nbytes))
+
     def timed(self, fn, stream=None):
         """Runs fn() bracketed by HIP events on `stream`; returns milliseconds (syncs)."""
         L = lib()

@@ -131,6 +131,7 @@ SIGNATURES = {
     "ipx_memcpy_h2d": (_I, [_P, _P, _P, _Z]),
     "ipx_memcpy_d2h": (_I, [_P, _P, _P, _Z]),
     "ipx_memcpy_d2d": (_I, [_P, _P, _P, _Z]),
+    "ipx_stream_copy": (_I, [_P, _P, _P, _P, _Z]),
     "ipx_device_sync": (_I, [_P]),
     "ipx_stream_sync": (_I, [_P, _P]),
     "ipx_stream_create": (_P, [_P]),

@@ -205,12 +205,7 @@ __device__ __forceinline__ void item_rows(const BandArgs &a, Item &it, bool vali
     it.r0 = it.b * a.band_rows;
     it.own_rows = min(a.band_rows, a.sh - it.r0);
     it.rows_ld = min(it.own_rows + 1, a.sh - it.r0);
-#pragma unroll
-    for (int k = 0; k < 2; k++) {   // scalar loads (the tables are read through the constant address space)
-        const ConstInts rb = (ConstInts)(uintptr_t)a.sc[k].row_begin;
-        it.dyA[k] = a.nscale > 0 ? rb[it.b] : 0;
-        it.dyB[k] = valid && k < a.nscale ? rb[it.b + 1] : it.dyA[k];
-    }
+    band_out_rows(a, it.b, valid, it.dyA, it.dyB);
 }
 
 // what a thread keeps per column block

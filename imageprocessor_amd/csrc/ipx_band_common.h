@@ -127,6 +127,21 @@ __device__ __forceinline__ void glyph_phase(const BandArgs &a, const Tile &t, ui
     }
 }
 
+// Destination rows [dyA, dyB) of band b per scaled output: four scalar loads issued together (one wait, far downstream), not a load and a
+// wait per value -- that chain was 2000 cycles of every item's issue phase.  (a.sc[1] mirrors a.sc[0] when one output is scaled.)
+typedef const __attribute__((address_space(4))) int *ConstRowBegin;
+__device__ __forceinline__ void band_out_rows(const BandArgs &a, int b, bool valid, int (&dyA)[2], int (&dyB)[2])
+{
+    dyA[0] = dyA[1] = dyB[0] = dyB[1] = 0;
+    if (a.nscale > 0) {
+        const ConstRowBegin rb0 = (ConstRowBegin)(uintptr_t)a.sc[0].row_begin, rb1 = (ConstRowBegin)(uintptr_t)a.sc[1].row_begin;
+        const int a0 = rb0[b], b0 = rb0[b + 1], a1 = rb1[b], b1 = rb1[b + 1];
+        dyA[0] = a0; dyA[1] = a1;
+        dyB[0] = valid ? b0 : a0;
+        dyB[1] = valid && a.nscale > 1 ? b1 : a1;
+    }
+}
+
 // Where the frames of one batch index start: 64-bit products of the frame index, recomputed only when the index changes (a
 // workgroup walks the bands of a frame one after the other), not per item.
 struct OutBases { uint8_t *wm, *o0, *o1; };

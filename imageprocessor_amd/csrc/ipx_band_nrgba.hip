@@ -115,12 +115,7 @@ struct ItemN {
 __device__ __forceinline__ void item_setup(const BandArgs &a, ItemN &it, bool valid)
 {
     it.t = make_tile(a, it.b, it.cb);
-#pragma unroll
-    for (int k = 0; k < 2; k++) {   // scalar loads: the tables are read through the constant address space
-        const ConstIntsN rb = (ConstIntsN)(uintptr_t)a.sc[k].row_begin;
-        it.dyA[k] = a.nscale > 0 ? rb[it.b] : 0;
-        it.dyB[k] = valid && k < a.nscale ? rb[it.b + 1] : it.dyA[k];
-    }
+    band_out_rows(a, it.b, valid, it.dyA, it.dyB);
 }
 
 template <int NX0, bool FP0, int NX1, bool FP1>

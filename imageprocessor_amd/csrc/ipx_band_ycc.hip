@@ -221,12 +221,7 @@ __device__ __forceinline__ void item_setup_ycc(const BandArgs &a, ItemY &it, boo
 {
     it.t = make_tile(a, it.b, it.cb);
     it.t.pitch = kConvTilePitch;       // one slot per chunk index: no column test on the way into LDS, constant row offsets
-#pragma unroll
-    for (int k = 0; k < 2; k++) {   // scalar loads: the tables are read through the constant address space
-        const ConstIntsY rb = (ConstIntsY)(uintptr_t)a.sc[k].row_begin;
-        it.dyA[k] = a.nscale > 0 ? rb[it.b] : 0;
-        it.dyB[k] = valid && k < a.nscale ? rb[it.b + 1] : it.dyA[k];
-    }
+    band_out_rows(a, it.b, valid, it.dyA, it.dyB);
 }
 
 template <int NX0, bool FP0, int NX1, bool FP1, int HS, int VS>

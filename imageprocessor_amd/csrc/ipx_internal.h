@@ -117,6 +117,7 @@ struct DevGlyph {           // one clipped DrawMask call, masks resident in HBM
     int x0, y0, x1, y1;     // clipped destination rectangle
 };
 constexpr int kMaxGlyphs = 256;
+hipError_t launch_stream_copy(void *dst, const void *src, size_t bytes, hipStream_t s);   // the box's streaming ceiling (bench.py)
 hipError_t launch_composite(uint8_t *dst, int dstride, size_t frame_stride, int nframes,
                             const DevGlyph *glyphs_dev, int n, Rect bbox, uint32_t sr, uint32_t sg,
                             uint32_t sb, uint32_t sa, hipStream_t s);

@@ -343,6 +343,26 @@ hipError_t launch_draw(uint8_t *dst, int dstride, const uint8_t *src, int sstrid
     return hipGetLastError();
 }
 
+// ---- a plain streaming copy: the ceiling of the box at hand (ipx_stream_copy) ----
+__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (; i + 3 * step < n; i += 4 * step) {
+        const uint4 a = s[i], b = s[i + step], c = s[i + 2 * step], e = s[i + 3 * step];
+        d[i] = a; d[i + step] = b; d[i + 2 * step] = c; d[i + 3 * step] = e;
+    }
+    for (; i < n; i += step) d[i] = s[i];
+}
+
+hipError_t launch_stream_copy(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    const size_t n = bytes / 16;
+    const unsigned blocks = (unsigned)std::min<size_t>(8192, (n + 255) / 256);
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(blocks), dim3(256), 0, s, (const uint4 *)src, (uint4 *)dst, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_composite(uint8_t *dst, int dstride, size_t frame_stride, int nframes,
                             const DevGlyph *glyphs_dev, int n, Rect bbox, uint32_t sr, uint32_t sg,
                             uint32_t sb, uint32_t sa, hipStream_t s)

@@ -375,6 +375,15 @@ int ipx_memcpy_d2d(ipx_ctx *ctx, void *dst_dev, const void *src_dev, size_t byte
 }
 IPX_CATCH_STATUS
 
+int ipx_stream_copy(ipx_ctx *ctx, void *stream, void *dst_dev, const void *src_dev, size_t bytes) try
+{
+    IPX_ENTER(ctx);
+    if (((uintptr_t)dst_dev | (uintptr_t)src_dev | bytes) & 15) { set_error("ipx_stream_copy: pointers and size must be multiples of 16"); return IPX_ERR_INVALID; }
+    if (bytes) IPX_HIP(launch_stream_copy(dst_dev, src_dev, bytes, stream ? (hipStream_t)stream : ctx->stream));
+    return IPX_OK;
+}
+IPX_CATCH_STATUS
+
 int ipx_device_sync(ipx_ctx *ctx) try
 {
     IPX_ENTER(ctx);

@@ -106,6 +106,10 @@ int ipx_dev_free(ipx_ctx *ctx, void *p);
 int ipx_memcpy_h2d(ipx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int ipx_memcpy_d2h(ipx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int ipx_memcpy_d2d(ipx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
+/* A plain streaming copy (grid-stride kernel, 16 bytes per lane; dst, src and bytes multiples of 16), asynchronous on `stream`.  Not
+ * part of the path: bench.py times it on the box it runs on, because the streaming ceiling the band kernels are held against differs
+ * from box to box and with where buffers land. */
+int ipx_stream_copy(ipx_ctx *ctx, void *stream, void *dst_dev, const void *src_dev, size_t bytes);
 /* Blocks until the device is idle (every stream). */
 int ipx_device_sync(ipx_ctx *ctx);
 /* Blocks until everything queued on `stream` (a hipStream_t, NULL = the context's stream) is done. */
