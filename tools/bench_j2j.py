@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Compressed in, compressed out alone (ipx_plan_run_jpeg_jpeg): n 1080p 4:2:0 q85 files -> decode + resize 1024x576 + thumbnail 200 + watermark
 + three jpeg.Encode on the GPU.  For rocprofv3: the kernel sums against the wall time say how much of a call is GPU work.
-usage: tools/bench_j2j.py [files] [reps] [concurrent callers]"""
+usage: tools/bench_j2j.py [files] [reps] [concurrent callers]; IPX_BENCH_PROGRESSIVE=1: progressive files (their scans are decoded on host threads)"""
 import io
 import os
 import sys
@@ -28,7 +28,7 @@ for k in range(4):
     base = np.stack([np.sin(xx / (40.0 + 7 * k)) * 90 + 128, np.cos(yy / (31.0 + 5 * k)) * 90 + 128, ((xx + 2 * yy) / 6.0 + 40 * k) % 256], -1)
     img = (base + np.random.default_rng(k).normal(0, 6, (sh, sw, 3))).clip(0, 255).astype(np.uint8)
     buf = io.BytesIO()
-    Image.fromarray(img).save(buf, "JPEG", quality=85)
+    Image.fromarray(img).save(buf, "JPEG", quality=85, progressive=bool(os.environ.get("IPX_BENCH_PROGRESSIVE")))
     files.append(buf.getvalue())
 batch = [files[i % 4] for i in range(n)]
 plan.run_jpeg_jpeg(batch[:64], copy=False)
@@ -40,7 +40,7 @@ for _ in range(reps):
     if os.environ.get("IPX_BENCH_VERBOSE"):
         print("  repetition: %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
 assert not any(st)
-print("JPEG files (%.0f KB) -> three JPEG streams: %d files in %.1f ms = %.0f images/s" % (len(files[0]) / 1e3, n, best * 1e3, n / best))
+print(("progressive " if os.environ.get("IPX_BENCH_PROGRESSIVE") else "") + "JPEG files (%.0f KB) -> three JPEG streams: %d files in %.1f ms = %.0f images/s" % (len(files[0]) / 1e3, n, best * 1e3, n / best))
 callers = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 if callers:
     import threading
