@@ -6,6 +6,13 @@
 namespace ipx {
 namespace {
 
+#ifndef IPX_DIAG_STORES
+#ifdef IPX_DIAG
+#define IPX_DIAG_STORES IPX_DIAG
+#else
+#define IPX_DIAG_STORES 0
+#endif
+#endif
 #ifndef IPX_WAVE_SKIP
 #define IPX_WAVE_SKIP 1
 #endif
@@ -83,6 +90,10 @@ __device__ __forceinline__ bool tile_meets_textbox(const BandArgs &a, const Tile
 // (The first version walked the list per pixel: a scalar load and a test per glyph and pixel, every one a full latency -- 25 us per
 // tile that meets the text, 7% of a 1080p run.)
 typedef const __attribute__((address_space(4))) DevGlyph *ConstGlyphs;
+#ifndef IPX_GLYPH_STEP
+#define IPX_GLYPH_STEP 4
+#endif
+constexpr int kGlyphStep = IPX_GLYPH_STEP;   // glyph descriptors fetched together (scalar loads): latency against SGPR pressure
 
 template <int NT, int MAXR, class Conv>
 __device__ __forceinline__ void glyph_phase(const BandArgs &a, const Tile &t, uint8_t *wframe, const uint8_t *lds, int tid)
@@ -97,17 +108,17 @@ __device__ __forceinline__ void glyph_phase(const BandArgs &a, const Tile &t, ui
             uint32_t d[MAXR];
 #pragma unroll
             for (int r = 0; r < MAXR; r++) d[r] = Conv::rgba8_at(lds, (min(gy0 + r, gy1 - 1) - t.r0) * t.pitch + (x - t.c0) * 4, plane);
-            for (int g = 0; g < a.nglyphs; g += 4) {
-                int rx0[4], rx1[4], ry0[4], ry1[4], ms[4];
-                const uint8_t *mk[4];
+            for (int g = 0; g < a.nglyphs; g += kGlyphStep) {
+                int rx0[kGlyphStep], rx1[kGlyphStep], ry0[kGlyphStep], ry1[kGlyphStep], ms[kGlyphStep];
+                const uint8_t *mk[kGlyphStep];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < kGlyphStep; j++) {
                     const int gi = min(g + j, a.nglyphs - 1);
                     rx0[j] = gl[gi].x0; rx1[j] = g + j < a.nglyphs ? gl[gi].x1 : gl[gi].x0;   // (an empty rectangle past the end of the list)
                     ry0[j] = gl[gi].y0; ry1[j] = min(gl[gi].y1, gy1); ms[j] = gl[gi].mstride; mk[j] = gl[gi].mask;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < kGlyphStep; j++) {
                     if (x < rx0[j] || x >= rx1[j]) continue;
                     uint32_t m[MAXR];
 #pragma unroll
@@ -348,7 +359,11 @@ __device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &
     if (o.dxA + __builtin_amdgcn_readfirstlane(tid & ~63) >= o.dxB) return;
 #endif
     const ScaleOut &S = a.sc[k];
+#if IPX_DIAG_STORES
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, (a.dbg & 32) ? 0 : S.dh * S.ostride, 0x00020000);   // 32: every store dropped
+#else
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, S.dh * S.ostride, 0x00020000);
+#endif
     const ConstTaps yt = const_taps(S.yt);
     if (S.imul) {   // dyadic axes within the packed-integer limits: the common case (1080p, 4K, 8K, 720p, 1440p to 1024 wide)
         scale_rows_int<NX, FP, NT>(S, t, lds, tid, o, ors, dyA, dyB);
@@ -517,7 +532,11 @@ __device__ __forceinline__ void scale_out_conv(const BandArgs &a, int k, int mod
     if (o.dxA + __builtin_amdgcn_readfirstlane(tid & ~63) >= o.dxB) return;
 #endif
     const ScaleOut &S = a.sc[k];
+#if IPX_DIAG_STORES
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, (a.dbg & 32) ? 0 : S.dh * S.ostride, 0x00020000);   // 32: every store dropped
+#else
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)oframe, 0, S.dh * S.ostride, 0x00020000);
+#endif
     if (mode == 0 && S.yrow16) { scale_rows_int16<NX, FP, NT, Conv>(S, t, lds, tid, o, ors, dyA, dyB); return; }
     if (mode == 1 && S.imul) { scale_rows_int<NX, FP, NT, Conv>(S, t, lds, tid, o, ors, dyA, dyB); return; }
     const ConstTaps yt = const_taps(S.yt);

@@ -103,12 +103,16 @@ struct StageT {
     uint32_t cb[NCS], cr[NCS];                 // HS: two samples in the low half
 };
 
-// tile row of a thread's y slot s: slots 0..3 are the four rows of its half, slot 4 is the halo row (half 0 only)
-__device__ __forceinline__ int slot_row(int half, int s) { return s < 4 ? 4 * half + s : kRows - 1; }
+// Tile row of a thread's y slot s.  A tile is rows 0..8 of its band (8 = the halo row = row 0 of the next band).  Slots 0..3 are rows
+// 4*half + 1 .. 4*half + 4: the lower half of the workgroup converts rows 1..4, the upper half rows 5..8.  Row 0 has two sources: when the
+// workgroup's previous item was the band above (the common case in a run), row 0 IS that item's row 8 and still sits converted in the
+// tile -- it is copied from row slot 8 to row slot 0 inside LDS (**halo carry**: not loaded, not converted again, and its watermark
+// pixels were stored by the previous item); otherwise the lower half loads and converts it through slot 4.
+__device__ __forceinline__ int slot_row(int half, int s) { return s < 4 ? 4 * half + s + 1 : 0; }
 
 // The tile loads of one item.  Clipping is the descriptors' job: each plane's descriptor starts at the tile's first row and ends with
 // its last one, so row slots past the tile (or the frame) fall out of range by themselves and return 0; a thread whose chunk lies
-// outside the tile carries an out-of-range base offset.  valid = false: empty descriptors.
+// outside the tile carries an out-of-range base offset.  valid = false: empty descriptors.  carry: row 0 is not loaded.
 struct PlaneBases { const uint8_t *y, *cb, *cr; };    // the three planes of one frame of the batch
 __device__ __forceinline__ PlaneBases plane_bases(const YccArgs &A, int f)
 {
@@ -116,7 +120,7 @@ __device__ __forceinline__ PlaneBases plane_bases(const YccArgs &A, int f)
 }
 
 template <int HS, int VS>
-__device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, const PlaneBases &pb, bool valid, int chunk, int half,
+__device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, const PlaneBases &pb, bool valid, bool carry, int chunk, int half,
                                                StageT<VS> &st)
 {
     const BandArgs &a = A.b;
@@ -127,18 +131,19 @@ __device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, 
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cb + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cr + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
     const bool in_tile = chunk < t.nchunk;
+    const bool row0_mine = half == 0 && !carry;                           // wave-uniform
     const int yoff = in_tile ? t.c0 + chunk * 4 : kOOB;
 #pragma unroll
     for (int s = 0; s < kYS; s++) {
-        const bool mine = s < 4 || half == 0;
+        const bool mine = s < 4 || row0_mine;
         st.y[s] = __builtin_amdgcn_raw_buffer_load_b32(yrs, mine ? yoff + slot_row(half, s) * A.ystride : kOOB, 0, 0);   // (row in the VGPR offset: the range check ignores the scalar one)
     }
     const int coff = in_tile ? (t.c0 + chunk * 4) >> HS : kOOB;
 #pragma unroll
     for (int j = 0; j < StageT<VS>::NCS; j++) {
-        // chroma row of slot j: VS: rows 2*half, 2*half + 1 and (half 0) the halo row's; else the y slot's own row
-        const int crow = VS ? (j < 2 ? 2 * half + j : (kRows - 1) / 2) : slot_row(half, j);
-        const bool mine = j < StageT<VS>::NCS - 1 || half == 0;
+        // chroma row of slot j: VS: rows 2*half + j; else the row of y slot j
+        const int crow = VS ? 2 * half + j : slot_row(half, j);
+        const bool mine = VS || j < 4 || row0_mine;
         const int off = mine ? coff + crow * A.cstride : kOOB;
         if (HS) {
             st.cb[j] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brs, off, 0, 0);
@@ -151,27 +156,60 @@ __device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, 
 }
 
 // staged planes -> converted tile in LDS (kRows rows are allocated; rows past the tile hold what their loads returned and are never
-// read), and the owned pixels' top bytes -> watermark frame.  The last tile row is never an owned one (band_rows + 1 <= kRows): it
-// is converted for the tile only.
+// read), and the top bytes of every row converted here -> watermark frame (rows 1..8: the halo row's pixels are stored by the item that
+// converts it; row 0 only where it is converted, i.e. not under carry).
 template <int HS, int VS>
-__device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, uint8_t *wframe, int chunk, int half, const StageT<VS> &st,
-                                               uint8_t *lds, bool any_glyph)
+__device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, uint8_t *wframe, bool carry, int chunk, int half,
+                                               const StageT<VS> &st, uint8_t *lds, bool any_glyph)
 {
     const BandArgs &a = A.b;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.wm ? wframe + (size_t)t.r0 * a.wm_stride : nullptr), 0,
-        a.wm ? (t.own_rows - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);
-    const bool gl_rows = any_glyph && t.r0 < a.gbox.y1 && t.r1 > a.gbox.y0;   // wave-uniform
+#if IPX_DIAG
+        a.wm && !(a.dbg & 32) ? (t.rows_ld - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);   // 32: every store dropped by the descriptor
+#else
+        a.wm ? (t.rows_ld - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);        // the tile's rows incl. the halo row, clipped at the frame
+#endif
+    // (the text box test takes the halo row along: its chunks inside the box are the next band's composite step's to write)
+    const bool gl_rows = any_glyph && t.r0 < a.gbox.y1 && t.r0 + t.rows_ld > a.gbox.y0;   // wave-uniform
     const int x = t.c0 + chunk * 4;
     const int woff = chunk * 4 < t.own_cols ? x * 4 : kOOB;
     // chunks that meet the text box are written by the composite step: their store offset gets the top bit (beyond any frame)
     const uint32_t in_box = gl_rows && x + 4 > a.gbox.x0 && x < a.gbox.x1 ? 0x80000000u : 0u;
     const int loff = chunk * 16, plane = kRows * t.pitch;
+    if (carry && half) {                                   // row 8 of the previous item -> row 0, by the thread that overwrites this chunk of row 8 below
+        const v4u lo8 = *(const v4u *)(lds + (kRows - 1) * t.pitch + loff), hi8 = *(const v4u *)(lds + plane + (kRows - 1) * t.pitch + loff);
+        *(v4u *)(lds + loff) = lo8;
+        *(v4u *)(lds + plane + loff) = hi8;
+    }
+    const bool row0_mine = half == 0 && !carry;            // wave-uniform
+    auto row = [&](int s, const Chroma (&cp)[4]) {
+        const int r = slot_row(half, s);
+        const uint32_t yw = st.y[s];
+        v4u lo, hi;
 #pragma unroll
-    for (int j = 0; j < StageT<VS>::NCS; j++) {
-        if (j == StageT<VS>::NCS - 1 && half) break;       // the halo row's slot: half 0 only (wave-uniform)
+        for (int i = 0; i < 4; i++) {
+            const Px p = convert_px((yw >> (8 * i)) & 0xffu, cp[i]);
+            lo[i] = p.lo; hi[i] = p.hi;
+        }
+#if IPX_DIAG
+        if (a.dbg & 8) return;                                            // 8: neither LDS writes nor watermark stores
+#endif
+        // (every chunk index has a slot in the fixed-pitch tile row: threads past the tile's columns write what their loads returned)
+        *(v4u *)(lds + r * t.pitch + loff) = lo;
+        *(v4u *)(lds + plane + r * t.pitch + loff) = hi;
+        if (!a.wm) return;
+        v4u rgba;
+#pragma unroll
+        for (int i = 0; i < 4; i++) rgba[i] = rgba8_of(lo[i], hi[i]);
+        const uint32_t row_in_box = t.r0 + r >= a.gbox.y0 && t.r0 + r < a.gbox.y1 ? ~0u : 0u;       // scalar
+#if IPX_DIAG
+        if (a.dbg & 16) return;                                           // 16: no watermark stores
+#endif
+        __builtin_amdgcn_raw_buffer_store_b128(rgba, wrs, (int)((uint32_t)(woff + r * a.wm_stride) | (in_box & row_in_box)), 0, 0);
+    };
+    auto terms = [&](int j, Chroma (&cp)[4]) {             // per pixel of the chunk (shared by the pixels that share a sample)
         const uint32_t cbw = st.cb[j], crw = st.cr[j];
-        Chroma cp[4];                                      // per pixel of the chunk (shared by the pixels that share a sample)
         if (HS) {
             cp[0] = cp[1] = chroma_terms((int)(cbw & 0xffu), (int)(crw & 0xffu));
             cp[2] = cp[3] = chroma_terms((int)((cbw >> 8) & 0xffu), (int)((crw >> 8) & 0xffu));
@@ -179,35 +217,17 @@ __device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, 
 #pragma unroll
             for (int i = 0; i < 4; i++) cp[i] = chroma_terms((int)((cbw >> (8 * i)) & 0xffu), (int)((crw >> (8 * i)) & 0xffu));
         }
+    };
+    Chroma cp[4];
+    if (VS) {                                              // y slots in the order of their chroma slots: 0 | (row 0) | 1 2 | 3
+        terms(0, cp); row(0, cp);
+        if (row0_mine) row(4, cp);
+        terms(1, cp); row(1, cp); row(2, cp);
+        terms(2, cp); row(3, cp);
+    } else {
 #pragma unroll
-        for (int rr = 0; rr < (VS ? 2 : 1); rr++) {
-            if (VS && j == 2 && rr) continue;
-            const int s = VS ? (j < 2 ? 2 * j + rr : 4) : j;       // y slot
-            const int r = slot_row(half, s);
-            const uint32_t yw = st.y[s];
-            v4u lo, hi;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const Px p = convert_px((yw >> (8 * i)) & 0xffu, cp[i]);
-                lo[i] = p.lo; hi[i] = p.hi;
-            }
-#if IPX_DIAG
-            if (a.dbg & 4) { lo = v4u{yw, cbw, crw, yw}; hi = lo; }          // 4: no conversion arithmetic
-            if (a.dbg & 8) continue;                                          // 8: neither LDS writes nor watermark stores
-#endif
-            // (every chunk index has a slot in the fixed-pitch tile row: threads past the tile's columns write what their loads returned)
-            *(v4u *)(lds + r * t.pitch + loff) = lo;
-            *(v4u *)(lds + plane + r * t.pitch + loff) = hi;
-            if (s == 4 || !a.wm) continue;
-            v4u rgba;
-#pragma unroll
-            for (int i = 0; i < 4; i++) rgba[i] = rgba8_of(lo[i], hi[i]);
-            const uint32_t row_in_box = t.r0 + r >= a.gbox.y0 && t.r0 + r < a.gbox.y1 ? ~0u : 0u;       // scalar
-#if IPX_DIAG
-            if (a.dbg & 16) continue;                                         // 16: no watermark stores
-#endif
-            __builtin_amdgcn_raw_buffer_store_b128(rgba, wrs, (int)((uint32_t)(woff + r * a.wm_stride) | (in_box & row_in_box)), 0, 0);
-        }
+        for (int s = 0; s < 4; s++) { terms(s, cp); row(s, cp); }
+        if (row0_mine) { terms(4, cp); row(4, cp); }
     }
 }
 
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
     int idx = idx0 + (int)((blockIdx.x * 67u) % (unsigned)(idx_end - idx0));
     int left = idx_end - idx0;
 
-    const bool any_glyph = a.nglyphs > 0 && a.wm;
+    const bool any_glyph = IPX_FUSED_GLYPHS && a.nglyphs > 0 && a.wm;
 
     auto decode = [&](int i, ItemY &it) {
         it.cb = i / per_cb;
@@ -260,7 +280,8 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
     StageT<VS> st;
     PlaneBases pb = plane_bases(A, cur.f);        // of the item whose loads go out next
     OutBases ob = out_bases(a, cur.f);            // of the item being drained / computed
-    issue_tile_ycc<HS, VS>(A, cur.t, pb, true, chunk, half, st);
+    issue_tile_ycc<HS, VS>(A, cur.t, pb, true, false, chunk, half, st);
+    bool cur_carry = false;                       // row 0 of `cur` is row 8 of the item this workgroup processed just before
 
     // In-kernel phase stamps exist only in the diagnostic build (-DIPX_DIAG=1, tools/build_diag.sh); the shipped kernel executes none.
 #if IPX_DIAG
@@ -281,7 +302,7 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
             IPX_STAMP(0);
         }
 #endif
-        drain_tile_ycc<HS, VS>(A, cur.t, ob.wm, chunk, half, st, lds, any_glyph);
+        drain_tile_ycc<HS, VS>(A, cur.t, ob.wm, cur_carry, chunk, half, st, lds, any_glyph);
         IPX_STAMP(1);
         __syncthreads();
         IPX_STAMP(2);
@@ -299,7 +320,8 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
         }
         item_setup_ycc(a, nxt, has_next);
         if (nxt.f != cur.f) pb = plane_bases(A, nxt.f);
-        issue_tile_ycc<HS, VS>(A, nxt.t, pb, has_next, chunk, half, st);
+        const bool nxt_carry = has_next && a.band_rows + 1 == kRows && nxt.b == cur.b + 1 && nxt.f == cur.f && nxt.cb == cur.cb;
+        issue_tile_ycc<HS, VS>(A, nxt.t, pb, has_next, nxt_carry, chunk, half, st);
         IPX_STAMP(3);
 
         // C: the current item from LDS
@@ -323,6 +345,7 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
         }
         if (nxt.f != cur.f) ob = out_bases(a, nxt.f);
         cur = nxt;
+        cur_carry = nxt_carry;
         idx++;
         left--;
     }

@@ -5,6 +5,7 @@
 // `lanes` staging lanes (stream + device scratch), blocking only when all lanes are busy;
 // device-pointer calls are plain asynchronous launches on the caller's stream.
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -1051,6 +1052,8 @@ static int plan_src_status(const char *who, const ipx_plan *pl, long long stride
 }
 #define IPX_PLAN_SRC(who, pl, stride, bpp) do { const int rc_ = plan_src_status(who, pl, stride, bpp); if (rc_) return rc_; } while (0)
 
+static bool glyphs_separate();
+
 int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *src,
                      int sstride, size_t src_frame_stride, uint8_t *resize_out,
                      size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride,
@@ -1118,13 +1121,16 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
             a.nx_out[a.nscale - 1] = pl->g.nx_out[k];
         }
         if (a.nscale == 1) a.sc[1] = a.sc[0];  // keeps the kernel's unconditional tap loads legal
-        a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
+        const bool sep_glyphs = wm && pl->glyphs.n > 0 && glyphs_separate();
+        a.glyphs = pl->glyphs.dev; a.nglyphs = wm && !sep_glyphs ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
         a.cr = col[0]; a.cg = col[1]; a.cb = col[2]; a.ca = col[3];
         if (!wm && a.nscale == 0) return IPX_OK;
         // every workgroup of the persistent kernel walks one contiguous run of items; 1 = it enters the run at an offset of its own
         // (IPX_PIPE_ORDER=0: every run from its first item -- bimodal from process to process, see band_pipe_kernel)
         if (a.pipe_order < 0) a.pipe_order = env_int("IPX_PIPE_ORDER", 1) ? 1 : 0;
         IPX_HIP(launch_band(a, s));
+        if (sep_glyphs)
+            IPX_HIP(launch_composite(wm, sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox, col[0], col[1], col[2], col[3], s));
         if (a.stamps) {
             unsigned long long h[8];
             IPX_HIP(hipMemcpyAsync(h, a.stamps, sizeof h, hipMemcpyDeviceToHost, s));
@@ -1191,6 +1197,9 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
     const int nchunks = (n + chunk - 1) / chunk;
     const int want = nchunks <= 1 ? 1 : std::max(1, nl >= 3 ? nl - 1 : nl);
     std::vector<Lane *> lanes;
+    const bool trace = want == 1 && env_int("IPX_DEBUG_SEAM", 0);
+    const auto t_in = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     {
         std::unique_lock<std::mutex> lk(ctx->mu);
         auto free_lanes = [&] { int k = 0; for (auto &l : ctx->lanes) k += !l.busy; return k; };
@@ -1203,10 +1212,12 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
     }
     int rc = IPX_OK;
     hipError_t e = hipSuccess;
+    const double t_lock = trace ? ms_since(t_in) : 0;
     for (auto *l : lanes) {
         rc = lane_reserve(*l, per_frame * chunk + 256);
         if (rc) break;
     }
+    const double t_res = trace ? ms_since(t_in) : 0;
     const bool src_tight = sstride == sw * bpp && src_frame_stride == fsrc;
     auto d2h = [&](uint8_t *host, size_t host_stride, const uint8_t *dev, size_t dev_stride, size_t bytes, int i0, int m,
                    hipStream_t st) {
@@ -1247,10 +1258,14 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
         if (e == hipSuccess) e = d2h(thumb_out, thumb_frame_stride, dth, fth, pl->info.thumb_bytes, i0, m, l.stream);
         if (e == hipSuccess) e = d2h(wm_out, wm_frame_stride, dwm, fwm, pl->info.wm_bytes, i0, m, l.stream);
     }
+    const double t_enq = trace ? ms_since(t_in) : 0;
     for (auto *l : lanes) {
         hipError_t e2 = hipStreamSynchronize(l->stream);
         if (e == hipSuccess) e = e2;
     }
+    if (trace)
+        fprintf(stderr, "[ipx seam] lane %d of %d: lock %.2f ms, reserve %.2f, enqueued %.2f, done %.2f\n", (int)(lanes[0] - &ctx->lanes[0]), nl, t_lock, t_res,
+                t_enq, ms_since(t_in));
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         for (auto *l : lanes) l->busy = false;
@@ -1327,6 +1342,17 @@ IPX_CATCH_STATUS
 // BandArgs of the fused kernels that convert their source on the fly (ipx_band_ycc.hip, ipx_band_nrgba.hip): the plan's tiling, the
 // outputs that are wanted, and per scaled output the conversion rule -- mode 0 = 16-bit taps (resizeImage on the source image itself),
 // mode 1 = 8-bit RGBA first (the crop thumbnail scales the RGBA8 copy cropAndResize made, thumbnail.go:128-131)
+// The text composite as a pass of its own over the watermark frames' text box (composite_kernel) after the band kernel has copied /
+// converted every pixel, instead of inside the band kernel (IPX_FUSED_GLYPHS in ipx_internal.h has the why).
+static bool glyphs_separate() { return !IPX_FUSED_GLYPHS || env_int("IPX_GLYPH_SEPARATE", 0) != 0; }
+static hipError_t composite_after(const ipx_plan *pl, uint8_t *wm, size_t wm_frame_stride, int n, hipStream_t s)
+{
+    if (!wm || pl->glyphs.n <= 0 || !glyphs_separate()) return hipSuccess;
+    const uint8_t *c = pl->p.glyphs ? pl->p.glyphs->col : nullptr;
+    return launch_composite(wm, pl->p.sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox, c ? c[0] * 0x101u : 0,
+                            c ? c[1] * 0x101u : 0, c ? c[2] * 0x101u : 0, c ? c[3] * 0x101u : 0, s);
+}
+
 static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, uint8_t *res, size_t resize_frame_stride, uint8_t *th,
                                       size_t thumb_frame_stride, uint8_t *wm, size_t wm_frame_stride, const PlanGeom &g, BandArgs &a, int mode[2])
 {
@@ -1361,7 +1387,7 @@ static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, u
     }
     if (a.nscale == 1) { a.sc[1] = a.sc[0]; mode[1] = mode[0]; }
     const uint8_t *c = pl->p.glyphs ? pl->p.glyphs->col : nullptr;
-    a.glyphs = pl->glyphs.dev; a.nglyphs = wm ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
+    a.glyphs = pl->glyphs.dev; a.nglyphs = wm && !glyphs_separate() ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
     a.cr = c ? c[0] * 0x101u : 0; a.cg = c ? c[1] * 0x101u : 0; a.cb = c ? c[2] * 0x101u : 0; a.ca = c ? c[3] * 0x101u : 0;
 }
 
@@ -1419,6 +1445,7 @@ static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n,
 #endif
         bool matched = false;
         if (src->cstride >= A.cw || flat_chroma) IPX_HIP(launch_band_ycc(A, s, &matched));
+        if (matched) IPX_HIP(composite_after(pl, wm, wm_frame_stride, n, s));
 #if IPX_DIAG
         if (matched && a.stamps) {
             unsigned long long h[8];
@@ -1507,6 +1534,7 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
         a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
         bool matched = false;
         IPX_HIP(launch_band_nrgba(A, s, &matched));
+        if (matched) IPX_HIP(composite_after(pl, wm, wm_frame_stride, n, s));
         if (matched) return IPX_OK;
     }
     // premultiplied RGBA8 of the whole batch (drawNRGBASrc == drawNRGBAOver onto a zeroed frame), into the watermark frames when wanted
