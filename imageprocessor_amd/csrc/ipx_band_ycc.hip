@@ -71,11 +71,20 @@ __device__ __forceinline__ Px convert_px(uint32_t y, const Chroma &c)
 }
 // the RGBA8 pixel of imageutil.DrawYCbCr = the top byte of every channel: {r.2, g.2, b.2, 0xff}
 __device__ __forceinline__ uint32_t rgba8_of(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x0d050301u); }
+// *image.NRGBA: a tap as scale_RGBA_NRGBA_* reads it -- a16 = a * 0x101, c16 = c * a16 / 0xff -- and the pixel of drawNRGBASrc =
+// the top byte of each (c * a16 / 0xff >> 8, alpha a16 >> 8 = a): the same sharing as for YCbCr, one premultiplication per SOURCE pixel
+__device__ __forceinline__ Px convert_px_nrgba(uint32_t p)
+{
+    const uint32_t a16 = (p >> 24) * 0x101u;
+    const uint32_t r = (p & 0xffu) * a16 / 0xffu, g = ((p >> 8) & 0xffu) * a16 / 0xffu, b = ((p >> 16) & 0xffu) * a16 / 0xffu;
+    return Px{r | g << 16, b | a16 << 16};
+}
 
 // how the shared scale paths (ipx_band_common.h) read the two-plane tile
 struct YccConv {
     static constexpr int NC = 3;    // the converted alpha is 0xffff for every tap: the output alpha is 0xff
     static __device__ __forceinline__ int plane(const Tile &t) { return kRows * t.pitch; }
+    static __device__ __forceinline__ uint32_t rgba8_of(uint32_t lo, uint32_t hi) { return ipx::rgba8_of(lo, hi); }
     static __device__ __forceinline__ uint32_t rgba8_at(const uint8_t *lds, int off, int plane)
     {
         return rgba8_of(lds_u32(lds, off), lds_u32(lds, off + plane));
@@ -94,75 +103,186 @@ struct YccConv {
     }
 };
 
-typedef const __attribute__((address_space(4))) int *ConstIntsY;
-
-template <int VS>
-struct StageT {
-    static constexpr int NCS = VS ? 3 : kYS;   // chroma rows a thread stages (VS: one per pair of y rows)
-    uint32_t y[kYS];
-    uint32_t cb[NCS], cr[NCS];                 // HS: two samples in the low half
+// the same for a tile of premultiplied NRGBA taps: R16 | G16 << 16 and B16 | A16 << 16 (alpha is a channel like the others)
+struct NrgbaConv2 {
+    static constexpr int NC = 4;
+    static __device__ __forceinline__ int plane(const Tile &t) { return kRows * t.pitch; }
+    static __device__ __forceinline__ uint32_t rgba8_of(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07050301u); }
+    static __device__ __forceinline__ uint32_t rgba8_at(const uint8_t *lds, int off, int plane)
+    {
+        return rgba8_of(lds_u32(lds, off), lds_u32(lds, off + plane));
+    }
+    static __device__ __forceinline__ void tap16_at(const uint8_t *lds, int off, int plane, uint32_t (&c)[4])
+    {
+        const uint32_t lo = lds_u32(lds, off), hi = lds_u32(lds, off + plane);
+        c[0] = lo & 0xffffu; c[1] = lo >> 16; c[2] = hi & 0xffffu; c[3] = hi >> 16;
+    }
+    static __device__ __forceinline__ void h16(const uint8_t *lds, int off, int plane, uint32_t iw, uint32_t (&h)[4])
+    {
+        const uint32_t lo0 = lds_u32(lds, off), lo1 = lds_u32(lds, off + 4), hi0 = lds_u32(lds, off + plane), hi1 = lds_u32(lds, off + plane + 4);
+        h[0] = dot2_u16(__builtin_amdgcn_perm(lo1, lo0, 0x05040100u), iw);
+        h[1] = dot2_u16(__builtin_amdgcn_perm(lo1, lo0, 0x07060302u), iw);
+        h[2] = dot2_u16(__builtin_amdgcn_perm(hi1, hi0, 0x05040100u), iw);
+        h[3] = dot2_u16(__builtin_amdgcn_perm(hi1, hi0, 0x07060302u), iw);
+    }
 };
 
-// Tile row of a thread's y slot s.  A tile is rows 0..8 of its band (8 = the halo row = row 0 of the next band).  Slots 0..3 are rows
+typedef const __attribute__((address_space(4))) int *ConstIntsY;
+
+// Tile row of a thread's staging slot s.  A tile is rows 0..8 of its band (8 = the halo row = row 0 of the next band).  Slots 0..3 are rows
 // 4*half + 1 .. 4*half + 4: the lower half of the workgroup converts rows 1..4, the upper half rows 5..8.  Row 0 has two sources: when the
 // workgroup's previous item was the band above (the common case in a run), row 0 IS that item's row 8 and still sits converted in the
 // tile -- it is copied from row slot 8 to row slot 0 inside LDS (**halo carry**: not loaded, not converted again, and its watermark
 // pixels were stored by the previous item); otherwise the lower half loads and converts it through slot 4.
 __device__ __forceinline__ int slot_row(int half, int s) { return s < 4 ? 4 * half + s + 1 : 0; }
 
-// The tile loads of one item.  Clipping is the descriptors' job: each plane's descriptor starts at the tile's first row and ends with
-// its last one, so row slots past the tile (or the frame) fall out of range by themselves and return 0; a thread whose chunk lies
-// outside the tile carries an out-of-range base offset.  valid = false: empty descriptors.  carry: row 0 is not loaded.
-struct PlaneBases { const uint8_t *y, *cb, *cr; };    // the three planes of one frame of the batch
-__device__ __forceinline__ PlaneBases plane_bases(const YccArgs &A, int f)
-{
-    return PlaneBases{A.y + (size_t)f * A.y_fs, A.cb + (size_t)f * A.c_fs, A.cr + (size_t)f * A.c_fs};
-}
+// ---- the two sources --------------------------------------------------------------------------------------------------------------
+// A source type says how a thread stages its rows (Stage, issue) and how the staged rows become converted taps (rows: calls
+// row(s, lo, hi) for each of the thread's staging slots, s = 4 only when the thread owns row 0).  Clipping is the descriptors' job: a
+// descriptor starts at the tile's first row and ends with its last one, so row slots past the tile (or the frame) fall out of range by
+// themselves and return 0; a thread whose chunk lies outside the tile carries an out-of-range base offset.  valid = false: empty
+// descriptors.  carry: row 0 is not loaded.
 
 template <int HS, int VS>
-__device__ __forceinline__ void issue_tile_ycc(const YccArgs &A, const Tile &t, const PlaneBases &pb, bool valid, bool carry, int chunk, int half,
-                                               StageT<VS> &st)
-{
-    const BandArgs &a = A.b;
-    const int crow0 = t.r0 >> VS, crows = valid ? ((t.rows_ld - 1) >> VS) + 1 : 0;
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(pb.y + (size_t)t.r0 * A.ystride), 0, valid ? (t.rows_ld - 1) * A.ystride + a.sw : 0, 0x00020000);
-    const int cbytes = crows > 0 ? (crows - 1) * A.cstride + A.cw : 0;
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cb + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cr + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
-    const bool in_tile = chunk < t.nchunk;
-    const bool row0_mine = half == 0 && !carry;                           // wave-uniform
-    const int yoff = in_tile ? t.c0 + chunk * 4 : kOOB;
-#pragma unroll
-    for (int s = 0; s < kYS; s++) {
-        const bool mine = s < 4 || row0_mine;
-        st.y[s] = __builtin_amdgcn_raw_buffer_load_b32(yrs, mine ? yoff + slot_row(half, s) * A.ystride : kOOB, 0, 0);   // (row in the VGPR offset: the range check ignores the scalar one)
+struct YccSrc {          // *image.YCbCr planes (and *image.Gray as Y + a stride-0 row of 128s)
+    typedef YccArgs Args;
+    typedef YccConv Conv;
+    static constexpr int NCS = VS ? 3 : kYS;   // chroma rows a thread stages (VS: one per pair of y rows)
+    struct Stage {
+        uint32_t y[kYS];
+        uint32_t cb[NCS], cr[NCS];             // HS: two samples in the low half
+    };
+    struct Bases { const uint8_t *y, *cb, *cr; };    // the three planes of one frame of the batch
+    static __device__ __forceinline__ Bases bases(const Args &A, int f)
+    {
+        return Bases{A.y + (size_t)f * A.y_fs, A.cb + (size_t)f * A.c_fs, A.cr + (size_t)f * A.c_fs};
     }
-    const int coff = in_tile ? (t.c0 + chunk * 4) >> HS : kOOB;
+    static __device__ __forceinline__ void issue(const Args &A, const Tile &t, const Bases &pb, bool valid, bool carry, int chunk, int half, Stage &st)
+    {
+        const BandArgs &a = A.b;
+        const int crow0 = t.r0 >> VS, crows = valid ? ((t.rows_ld - 1) >> VS) + 1 : 0;
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(pb.y + (size_t)t.r0 * A.ystride), 0, valid ? (t.rows_ld - 1) * A.ystride + a.sw : 0, 0x00020000);
+        const int cbytes = crows > 0 ? (crows - 1) * A.cstride + A.cw : 0;
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cb + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cr + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
+        const bool in_tile = chunk < t.nchunk;
+        const bool row0_mine = half == 0 && !carry;                           // wave-uniform
+        const int yoff = in_tile ? t.c0 + chunk * 4 : kOOB;
 #pragma unroll
-    for (int j = 0; j < StageT<VS>::NCS; j++) {
-        // chroma row of slot j: VS: rows 2*half + j; else the row of y slot j
-        const int crow = VS ? 2 * half + j : slot_row(half, j);
-        const bool mine = VS || j < 4 || row0_mine;
-        const int off = mine ? coff + crow * A.cstride : kOOB;
-        if (HS) {
-            st.cb[j] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brs, off, 0, 0);
-            st.cr[j] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rrs, off, 0, 0);
-        } else {
-            st.cb[j] = __builtin_amdgcn_raw_buffer_load_b32(brs, off, 0, 0);
-            st.cr[j] = __builtin_amdgcn_raw_buffer_load_b32(rrs, off, 0, 0);
+        for (int s = 0; s < kYS; s++) {
+            const bool mine = s < 4 || row0_mine;
+            st.y[s] = __builtin_amdgcn_raw_buffer_load_b32(yrs, mine ? yoff + slot_row(half, s) * A.ystride : kOOB, 0, 0);   // (row in the VGPR offset: the range check ignores the scalar one)
+        }
+        const int coff = in_tile ? (t.c0 + chunk * 4) >> HS : kOOB;
+#pragma unroll
+        for (int j = 0; j < NCS; j++) {
+            // chroma row of slot j: VS: rows 2*half + j (they serve rows 4*half + 1 .. 4*half + 4, and chroma row 0 serves row 0); else the row of y slot j
+            const int crow = VS ? 2 * half + j : slot_row(half, j);
+            const bool mine = VS || j < 4 || row0_mine;
+            const int off = mine ? coff + crow * A.cstride : kOOB;
+            if (HS) {
+                st.cb[j] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(brs, off, 0, 0);
+                st.cr[j] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rrs, off, 0, 0);
+            } else {
+                st.cb[j] = __builtin_amdgcn_raw_buffer_load_b32(brs, off, 0, 0);
+                st.cr[j] = __builtin_amdgcn_raw_buffer_load_b32(rrs, off, 0, 0);
+            }
         }
     }
-}
+    template <class RowFn>
+    static __device__ __forceinline__ void rows(const Stage &st, bool row0_mine, RowFn row)
+    {
+        auto terms = [&](int j, Chroma (&cp)[4]) {             // per pixel of the chunk (shared by the pixels that share a sample)
+            const uint32_t cbw = st.cb[j], crw = st.cr[j];
+            if (HS) {
+                cp[0] = cp[1] = chroma_terms((int)(cbw & 0xffu), (int)(crw & 0xffu));
+                cp[2] = cp[3] = chroma_terms((int)((cbw >> 8) & 0xffu), (int)((crw >> 8) & 0xffu));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) cp[i] = chroma_terms((int)((cbw >> (8 * i)) & 0xffu), (int)((crw >> (8 * i)) & 0xffu));
+            }
+        };
+        auto conv = [&](int s, const Chroma (&cp)[4]) {
+            const uint32_t yw = st.y[s];
+            v4u lo, hi;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const Px p = convert_px((yw >> (8 * i)) & 0xffu, cp[i]);
+                lo[i] = p.lo; hi[i] = p.hi;
+            }
+            row(s, lo, hi);
+        };
+        Chroma cp[4];
+        if (VS) {                                              // y slots in the order of their chroma slots: 0 | (row 0) | 1 2 | 3
+            terms(0, cp); conv(0, cp);
+            if (row0_mine) conv(4, cp);
+            terms(1, cp); conv(1, cp); conv(2, cp);
+            terms(2, cp); conv(3, cp);
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; s++) { terms(s, cp); conv(s, cp); }
+            if (row0_mine) { terms(4, cp); conv(4, cp); }
+        }
+    }
+    static __device__ __forceinline__ void touch(Stage &st)    // (diagnostic stamps: the wait for the staged loads on its own)
+    {
+#pragma unroll
+        for (int q = 0; q < kYS; q++) asm volatile("" : "+v"(st.y[q]));
+#pragma unroll
+        for (int q = 0; q < NCS; q++) asm volatile("" : "+v"(st.cb[q]), "+v"(st.cr[q]));
+    }
+};
 
-// staged planes -> converted tile in LDS (kRows rows are allocated; rows past the tile hold what their loads returned and are never
+struct NrgbaSrc {        // *image.NRGBA frames (PNGs with alpha; *image.Paletted frames after their palette expansion)
+    typedef NrgbaArgs Args;
+    typedef NrgbaConv2 Conv;
+    struct Stage { v4u px[kYS]; };
+    typedef const uint8_t *Bases;
+    static __device__ __forceinline__ Bases bases(const Args &A, int f) { return A.b.src + (size_t)f * A.b.src_frame_stride; }
+    static __device__ __forceinline__ void issue(const Args &A, const Tile &t, const Bases &sframe, bool valid, bool carry, int chunk, int half, Stage &st)
+    {
+        const BandArgs &a = A.b;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(sframe + (size_t)t.r0 * a.sstride), 0, valid ? (t.rows_ld - 1) * a.sstride + a.sw * 4 : 0, 0x00020000);
+        const bool row0_mine = half == 0 && !carry;                           // wave-uniform
+        const int off = chunk < t.nchunk ? t.c0 * 4 + chunk * 16 : kOOB;
+#pragma unroll
+        for (int s = 0; s < kYS; s++) {
+            const bool mine = s < 4 || row0_mine;
+            st.px[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, mine ? off + slot_row(half, s) * a.sstride : kOOB, 0, 0);
+        }
+    }
+    template <class RowFn>
+    static __device__ __forceinline__ void rows(const Stage &st, bool row0_mine, RowFn row)
+    {
+        auto conv = [&](int s) {
+            v4u lo, hi;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const Px p = convert_px_nrgba(st.px[s][i]);
+                lo[i] = p.lo; hi[i] = p.hi;
+            }
+            row(s, lo, hi);
+        };
+#pragma unroll
+        for (int s = 0; s < 4; s++) conv(s);
+        if (row0_mine) conv(4);
+    }
+    static __device__ __forceinline__ void touch(Stage &st)
+    {
+#pragma unroll
+        for (int q = 0; q < kYS; q++) asm volatile("" : "+v"(st.px[q]));
+    }
+};
+
+// staged rows -> converted tile in LDS (kRows rows are allocated; rows past the tile hold what their loads returned and are never
 // read), and the top bytes of every row converted here -> watermark frame (rows 1..8: the halo row's pixels are stored by the item that
 // converts it; row 0 only where it is converted, i.e. not under carry).
-template <int HS, int VS>
-__device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, uint8_t *wframe, bool carry, int chunk, int half,
-                                               const StageT<VS> &st, uint8_t *lds, bool any_glyph)
+template <class Src>
+__device__ __forceinline__ void drain_tile_conv(const BandArgs &a, const Tile &t, uint8_t *wframe, bool carry, int chunk, int half,
+                                                const typename Src::Stage &st, uint8_t *lds, bool any_glyph)
 {
-    const BandArgs &a = A.b;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.wm ? wframe + (size_t)t.r0 * a.wm_stride : nullptr), 0,
 #if IPX_DIAG
@@ -182,16 +302,8 @@ __device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, 
         *(v4u *)(lds + loff) = lo8;
         *(v4u *)(lds + plane + loff) = hi8;
     }
-    const bool row0_mine = half == 0 && !carry;            // wave-uniform
-    auto row = [&](int s, const Chroma (&cp)[4]) {
+    Src::rows(st, half == 0 && !carry, [&](int s, const v4u &lo, const v4u &hi) {
         const int r = slot_row(half, s);
-        const uint32_t yw = st.y[s];
-        v4u lo, hi;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const Px p = convert_px((yw >> (8 * i)) & 0xffu, cp[i]);
-            lo[i] = p.lo; hi[i] = p.hi;
-        }
 #if IPX_DIAG
         if (a.dbg & 8) return;                                            // 8: neither LDS writes nor watermark stores
 #endif
@@ -201,34 +313,13 @@ __device__ __forceinline__ void drain_tile_ycc(const YccArgs &A, const Tile &t, 
         if (!a.wm) return;
         v4u rgba;
 #pragma unroll
-        for (int i = 0; i < 4; i++) rgba[i] = rgba8_of(lo[i], hi[i]);
+        for (int i = 0; i < 4; i++) rgba[i] = Src::Conv::rgba8_of(lo[i], hi[i]);
         const uint32_t row_in_box = t.r0 + r >= a.gbox.y0 && t.r0 + r < a.gbox.y1 ? ~0u : 0u;       // scalar
 #if IPX_DIAG
         if (a.dbg & 16) return;                                           // 16: no watermark stores
 #endif
         __builtin_amdgcn_raw_buffer_store_b128(rgba, wrs, (int)((uint32_t)(woff + r * a.wm_stride) | (in_box & row_in_box)), 0, 0);
-    };
-    auto terms = [&](int j, Chroma (&cp)[4]) {             // per pixel of the chunk (shared by the pixels that share a sample)
-        const uint32_t cbw = st.cb[j], crw = st.cr[j];
-        if (HS) {
-            cp[0] = cp[1] = chroma_terms((int)(cbw & 0xffu), (int)(crw & 0xffu));
-            cp[2] = cp[3] = chroma_terms((int)((cbw >> 8) & 0xffu), (int)((crw >> 8) & 0xffu));
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) cp[i] = chroma_terms((int)((cbw >> (8 * i)) & 0xffu), (int)((crw >> (8 * i)) & 0xffu));
-        }
-    };
-    Chroma cp[4];
-    if (VS) {                                              // y slots in the order of their chroma slots: 0 | (row 0) | 1 2 | 3
-        terms(0, cp); row(0, cp);
-        if (row0_mine) row(4, cp);
-        terms(1, cp); row(1, cp); row(2, cp);
-        terms(2, cp); row(3, cp);
-    } else {
-#pragma unroll
-        for (int s = 0; s < 4; s++) { terms(s, cp); row(s, cp); }
-        if (row0_mine) { terms(4, cp); row(4, cp); }
-    }
+    });
 }
 
 struct ItemY {
@@ -237,15 +328,15 @@ struct ItemY {
     int dyA[2], dyB[2];
 };
 
-__device__ __forceinline__ void item_setup_ycc(const BandArgs &a, ItemY &it, bool valid)
+__device__ __forceinline__ void item_setup_conv(const BandArgs &a, ItemY &it, bool valid)
 {
     it.t = make_tile(a, it.b, it.cb);
     it.t.pitch = kConvTilePitch;       // one slot per chunk index: no column test on the way into LDS, constant row offsets
     band_out_rows(a, it.b, valid, it.dyA, it.dyB);
 }
 
-template <int NX0, bool FP0, int NX1, bool FP1, int HS, int VS>
-__global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
+template <int NX0, bool FP0, int NX1, bool FP1, class Src>
+__global__ __launch_bounds__(kNT, kNT / 128) void band_conv_kernel(typename Src::Args A)
 {
     extern __shared__ uint4 lds_raw[];
     uint8_t *lds = (uint8_t *)lds_raw;
@@ -271,17 +362,17 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
     };
     ItemY cur;
     decode(idx, cur);
-    item_setup_ycc(a, cur, true);
+    item_setup_conv(a, cur, true);
 
     OutCols<NX0, FP0> o0;
     OutCols<NX1, FP1> o1;
     if (a.nscale > 0) { load_xtaps<NX0, FP0, kNT>(a, 0, cur.cb, tid, o0); load_xtaps<NX1, FP1, kNT>(a, 1, cur.cb, tid, o1); }
 
-    StageT<VS> st;
-    PlaneBases pb = plane_bases(A, cur.f);        // of the item whose loads go out next
-    OutBases ob = out_bases(a, cur.f);            // of the item being drained / computed
-    issue_tile_ycc<HS, VS>(A, cur.t, pb, true, false, chunk, half, st);
-    bool cur_carry = false;                       // row 0 of `cur` is row 8 of the item this workgroup processed just before
+    typename Src::Stage st;
+    typename Src::Bases pb = Src::bases(A, cur.f);   // of the item whose loads go out next
+    OutBases ob = out_bases(a, cur.f);                // of the item being drained / computed
+    Src::issue(A, cur.t, pb, true, false, chunk, half, st);
+    bool cur_carry = false;                           // row 0 of `cur` is row 8 of the item this workgroup processed just before
 
     // In-kernel phase stamps exist only in the diagnostic build (-DIPX_DIAG=1, tools/build_diag.sh); the shipped kernel executes none.
 #if IPX_DIAG
@@ -292,17 +383,11 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
 #define IPX_STAMP(i) do { } while (0)
 #endif
     for (;;) {
-        // A: staged planes -> converted LDS tile + watermark pixels
+        // A: staged rows -> converted LDS tile + watermark pixels
 #if IPX_DIAG
-        if (a.stamps) {                                                       // the wait for the staged loads, on its own
-#pragma unroll
-            for (int q = 0; q < kYS; q++) asm volatile("" : "+v"(st.y[q]));
-#pragma unroll
-            for (int q = 0; q < StageT<VS>::NCS; q++) asm volatile("" : "+v"(st.cb[q]), "+v"(st.cr[q]));
-            IPX_STAMP(0);
-        }
+        if (a.stamps) { Src::touch(st); IPX_STAMP(0); }
 #endif
-        drain_tile_ycc<HS, VS>(A, cur.t, ob.wm, cur_carry, chunk, half, st, lds, any_glyph);
+        drain_tile_conv<Src>(a, cur.t, ob.wm, cur_carry, chunk, half, st, lds, any_glyph);
         IPX_STAMP(1);
         __syncthreads();
         IPX_STAMP(2);
@@ -318,21 +403,21 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
                 if (nxt.b == a.nbands) { nxt.b = 0; if (++nxt.f == a.nframes) { nxt.f = 0; ++nxt.cb; } }
             }
         }
-        item_setup_ycc(a, nxt, has_next);
-        if (nxt.f != cur.f) pb = plane_bases(A, nxt.f);
+        item_setup_conv(a, nxt, has_next);
+        if (nxt.f != cur.f) pb = Src::bases(A, nxt.f);
         const bool nxt_carry = has_next && a.band_rows + 1 == kRows && nxt.b == cur.b + 1 && nxt.f == cur.f && nxt.cb == cur.cb;
-        issue_tile_ycc<HS, VS>(A, nxt.t, pb, has_next, nxt_carry, chunk, half, st);
+        Src::issue(A, nxt.t, pb, has_next, nxt_carry, chunk, half, st);
         IPX_STAMP(3);
 
         // C: the current item from LDS
         if (any_glyph && tile_meets_textbox(a, cur.t))
-            glyph_phase<kNT, kRows - 1, YccConv>(a, cur.t, ob.wm, lds, tid);
+            glyph_phase<kNT, kRows - 1, typename Src::Conv>(a, cur.t, ob.wm, lds, tid);
 #if IPX_DIAG
         if (!(a.dbg & 1))                                                     // 1: skip scaling
 #endif
         if (a.nscale > 0) {
-            scale_out_conv<NX0, FP0, kNT, YccConv>(a, 0, A.mode[0], cur.t, ob.o0, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
-            scale_out_conv<NX1, FP1, kNT, YccConv>(a, 1, A.mode[1], cur.t, ob.o1, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
+            scale_out_conv<NX0, FP0, kNT, typename Src::Conv>(a, 0, A.mode[0], cur.t, ob.o0, lds, tid, o0, cur.dyA[0], cur.dyB[0]);
+            scale_out_conv<NX1, FP1, kNT, typename Src::Conv>(a, 1, A.mode[1], cur.t, ob.o1, lds, tid, o1, cur.dyA[1], cur.dyB[1]);
         }
         IPX_STAMP(4);
         __syncthreads();
@@ -356,35 +441,42 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_ycc_kernel(YccArgs A)
 #undef IPX_STAMP
 }
 
-template <int NX0, bool FP0, int NX1, bool FP1, int HS, int VS>
-hipError_t launch_ycc(const YccArgs &A, long long items, size_t lds, hipStream_t s)
+template <int NX0, bool FP0, int NX1, bool FP1, class Src>
+hipError_t launch_conv(const typename Src::Args &A, const char *what, long long items, size_t lds, hipStream_t s)
 {
     static KernelLaunchCache cache;
     int resident = 1;
-    auto kern = band_ycc_kernel<NX0, FP0, NX1, FP1, HS, VS>;
+    auto kern = band_conv_kernel<NX0, FP0, NX1, FP1, Src>;
     hipError_t e = cache.prepare((const void *)kern, kNT, lds, &resident);
     if (e != hipSuccess) return e;
     const long long grid = std::min<long long>(items, (long long)A.b.cus * std::min(A.b.pipe_wgs, resident));
     if (getenv("IPX_DEBUG") && cache.first_report()) {
-        fprintf(stderr, "[ipx] band_ycc_kernel<%d,%d,%d,%d,hs%d,vs%d>: tile %d rows x %d cols, lds %zu B, resident %d/CU, grid %lld, items %lld\n",
-                NX0, (int)FP0, NX1, (int)FP1, HS, VS, A.b.band_rows, A.b.blk_cols, lds, resident, grid, items);
+        fprintf(stderr, "[ipx] band_conv_kernel<%d,%d,%d,%d,%s>: tile %d rows x %d cols, lds %zu B, resident %d/CU, grid %lld, items %lld\n",
+                NX0, (int)FP0, NX1, (int)FP1, what, A.b.band_rows, A.b.blk_cols, lds, resident, grid, items);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kNT), lds, s, A);
     return hipGetLastError();
 }
 
-template <int HS, int VS>
-hipError_t launch_ycc_cfg(const YccArgs &A, long long items, size_t lds, hipStream_t s, bool *matched)
+template <class Src>
+hipError_t launch_conv_cfg(const typename Src::Args &A, const char *what, long long items, size_t lds, hipStream_t s, bool *matched)
 {
     const BandArgs &a = A.b;
     // a.nx_out counts blocks of 256 destination columns per column block; the 512-thread workgroup serves two each
     const int need0 = a.nscale > 0 ? (a.nx_out[0] + 1) / 2 : 0, need1 = a.nscale > 1 ? (a.nx_out[1] + 1) / 2 : 0;
     const bool fp0 = a.nscale > 0 && a.sc[0].dyadic_shift < 0;
     *matched = true;
-    if (need0 <= 1 && !fp0 && need1 <= 1) return launch_ycc<1, false, 1, true, HS, VS>(A, items, lds, s);
-    if (need0 <= 1 && need1 <= 1) return launch_ycc<1, true, 1, true, HS, VS>(A, items, lds, s);
+    if (need0 <= 1 && !fp0 && need1 <= 1) return launch_conv<1, false, 1, true, Src>(A, what, items, lds, s);
+    if (need0 <= 1 && need1 <= 1) return launch_conv<1, true, 1, true, Src>(A, what, items, lds, s);
     *matched = false;
     return hipSuccess;
+}
+
+bool conv_tiling_ok(const BandArgs &a)
+{
+    if ((a.sw & 3) || a.band_rows + 1 > kRows || (a.blk_cols + 4) * 4 > kConvTilePitch || (a.blk_cols & 3)) return false;
+    if (a.wm && ((((uintptr_t)a.wm) | a.wm_frame_stride | (uintptr_t)a.wm_stride) & 15)) return false;
+    return true;
 }
 
 }  // namespace
@@ -394,12 +486,11 @@ bool band_ycc_supported(const YccArgs &A)
 {
     const BandArgs &a = A.b;
     const int hs = A.ratio == IPX_YCBCR_422 || A.ratio == IPX_YCBCR_420, vs = A.ratio == IPX_YCBCR_420 || A.ratio == IPX_YCBCR_440;
-    if ((a.sw & 3) || a.band_rows + 1 > kRows || (a.blk_cols + 4) * 4 > kConvTilePitch || (a.blk_cols & 3)) return false;
+    if (!conv_tiling_ok(a)) return false;
     if (vs && (a.band_rows & 1)) return false;
     if ((((uintptr_t)A.y) | (uintptr_t)A.ystride | A.y_fs) & 3) return false;
     const uintptr_t cal = hs ? 1 : 3;
     if ((((uintptr_t)A.cb) | ((uintptr_t)A.cr) | (uintptr_t)A.cstride | A.c_fs) & cal) return false;
-    if (a.wm && ((((uintptr_t)a.wm) | a.wm_frame_stride | (uintptr_t)a.wm_stride) & 15)) return false;
     return true;
 }
 
@@ -412,12 +503,25 @@ hipError_t launch_band_ycc(const YccArgs &A, hipStream_t s, bool *matched)
     if (total > 0x7fffffffLL || !band_ycc_supported(A)) return hipSuccess;
     const size_t lds = 2 * (size_t)kRows * kConvTilePitch;     // the two planes of the converted tile (y taps come through scalar loads)
     switch (A.ratio) {
-    case IPX_YCBCR_444: return launch_ycc_cfg<0, 0>(A, total, lds, s, matched);
-    case IPX_YCBCR_422: return launch_ycc_cfg<1, 0>(A, total, lds, s, matched);
-    case IPX_YCBCR_420: return launch_ycc_cfg<1, 1>(A, total, lds, s, matched);
-    case IPX_YCBCR_440: return launch_ycc_cfg<0, 1>(A, total, lds, s, matched);
+    case IPX_YCBCR_444: return launch_conv_cfg<YccSrc<0, 0>>(A, "ycc 4:4:4", total, lds, s, matched);
+    case IPX_YCBCR_422: return launch_conv_cfg<YccSrc<1, 0>>(A, "ycc 4:2:2", total, lds, s, matched);
+    case IPX_YCBCR_420: return launch_conv_cfg<YccSrc<1, 1>>(A, "ycc 4:2:0", total, lds, s, matched);
+    case IPX_YCBCR_440: return launch_conv_cfg<YccSrc<0, 1>>(A, "ycc 4:4:0", total, lds, s, matched);
     default: return hipSuccess;
     }
+}
+
+// *image.NRGBA frames through the same kernel (premultiplied 16-bit taps in the tile); the plan's `conv` tiling.  Not matched: the
+// per-tap kernel of ipx_band_nrgba.hip on the plan's other tiling, then the three-kernel path.
+hipError_t launch_band_nrgba_conv(const NrgbaArgs &A, hipStream_t s, bool *matched)
+{
+    const BandArgs &a = A.b;
+    *matched = false;
+    const long long total = (long long)a.nbands * a.ncolblk * a.nframes;
+    if (total <= 0) { *matched = true; return hipSuccess; }
+    if (total > 0x7fffffffLL || !conv_tiling_ok(a)) return hipSuccess;
+    if ((((uintptr_t)a.src) | (uintptr_t)a.sstride | a.src_frame_stride) & 15) return hipSuccess;
+    return launch_conv_cfg<NrgbaSrc>(A, "nrgba", total, 2 * (size_t)kRows * kConvTilePitch, s, matched);
 }
 
 }  // namespace ipx

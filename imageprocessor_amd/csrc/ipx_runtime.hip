@@ -1525,7 +1525,19 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     uint8_t *th = pl->sc[1].on ? thumb_out : nullptr;
     uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
     const bool crop_thumb = th && pl->p.crop_to_fit;
-    // one fused pass over the frames when the tile shape and alignments allow it (ipx_band_nrgba.hip)
+    // one fused pass over the frames when the tile shape and alignments allow it: the converted-tile kernel (every source pixel
+    // premultiplied once, ipx_band_ycc.hip) on the plan's `conv` tiling, else the per-tap kernel of ipx_band_nrgba.hip
+    if (pl->fused && env_int("IPX_NRGBA_FUSED", 1) && env_int("IPX_NRGBA_CONV", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
+        NrgbaArgs A{};
+        BandArgs &a = A.b;
+        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, a, A.mode);
+        if (!wm && a.nscale == 0) return IPX_OK;
+        a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
+        bool matched = false;
+        IPX_HIP(launch_band_nrgba_conv(A, s, &matched));
+        if (matched) IPX_HIP(composite_after(pl, wm, wm_frame_stride, n, s));
+        if (matched) return IPX_OK;
+    }
     if (pl->fused && env_int("IPX_NRGBA_FUSED", 1) && pl->g.band_rows <= 8 && pl->g.most_rows <= 64) {
         NrgbaArgs A{};
         BandArgs &a = A.b;

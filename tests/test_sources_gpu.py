@@ -164,13 +164,15 @@ def test_ycbcr_batch_plan(ctx, case, fused, monkeypatch):
 @pytest.mark.parametrize("case", [(640, 360, 3, (1024, 768, True), (200, True)), (333, 251, 2, (200, 100, False), (64, False)),
                                   (200, 200, 2, (200, 200, False), (100, True)), (1920, 1080, 2, (1024, 768, False), (200, False)),
                                   (1280, 720, 2, (500, 333, False), (200, True))], ids=lambda c: "%dx%d" % (c[0], c[1]))
-@pytest.mark.parametrize("fused", ["1", "0"], ids=["fused", "three-kernels"])
+@pytest.mark.parametrize("fused", ["conv", "per-tap", "0"], ids=["fused-converted-tile", "fused-per-tap", "three-kernels"])
 def test_nrgba_batch_plan(ctx, case, fused, monkeypatch):
     """ipx_plan_run_dev_nrgba: a batch of *image.NRGBA frames (PNGs with alpha), per operator as the reference's helpers treat the
-    type: 16-bit premultiplied taps for resizeImage, drawNRGBA* first for the crop thumbnail and the watermark.  Both the fused band
-    kernel (ipx_band_nrgba.hip; widths that are multiples of 4) and the three-kernel path."""
+    type: 16-bit premultiplied taps for resizeImage, drawNRGBA* first for the crop thumbnail and the watermark.  The converted-tile
+    kernel (every source pixel premultiplied once, ipx_band_ycc.hip), the per-tap kernel it falls back to (ipx_band_nrgba.hip; both
+    need widths that are multiples of 4) and the three-kernel path."""
     from helpers import DEFAULT_COL, text_glyphs
-    monkeypatch.setenv("IPX_NRGBA_FUSED", fused)
+    monkeypatch.setenv("IPX_NRGBA_FUSED", "0" if fused == "0" else "1")
+    monkeypatch.setenv("IPX_NRGBA_CONV", "1" if fused == "conv" else "0")
     w, h, n, resize, thumb = case
     rng = np.random.default_rng(w)
     frames = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)          # non-premultiplied: colour may exceed alpha

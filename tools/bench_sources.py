@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the batch paths for the other source types image.Decode returns, frames resident in HBM, 1920x1080,
 resize 1024x768 + thumbnail 200 + watermark:
-  *image.NRGBA     ipx_plan_run_dev_nrgba     fused band_nrgba_kernel vs the three-kernel path (IPX_NRGBA_FUSED=0)
+  *image.NRGBA     ipx_plan_run_dev_nrgba     fused converted-tile kernel (IPX_NRGBA_CONV=0: the per-tap kernel) vs the three-kernel path (IPX_NRGBA_FUSED=0)
   *image.Gray      ipx_plan_run_dev_gray      planar kernel with flat chroma vs expansion to RGBA8 (IPX_GRAY_FLAT=0)
   *image.Paletted  ipx_plan_run_dev_paletted  palette expansion + the NRGBA pass
 usage: tools/bench_sources.py [frames]"""
@@ -42,7 +42,7 @@ nr = ctx.alloc(n * w * h * 4).upload(np.resize(rng.integers(0, 256, (pool, h, w,
 for fused in ("1", "0"):
     os.environ["IPX_NRGBA_FUSED"] = fused
     timed(lambda: plan.run_dev_nrgba(n, nr.ptr, res.ptr, th.ptr, wm.ptr),
-          "NRGBA, " + ("fused band_nrgba_kernel" if fused == "1" else "three kernels"), w * h * 4)
+          "NRGBA, " + ("fused, converted-tile kernel" if fused == "1" else "three kernels"), w * h * 4)
 os.environ["IPX_NRGBA_FUSED"] = "1"
 del nr
 gr = ctx.alloc(n * w * h).upload(np.resize(rng.integers(0, 256, (pool, h, w), dtype=np.uint8), (n, h, w)))
