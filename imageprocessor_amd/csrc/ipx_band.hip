@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void band_kernel(BandArgs a)
 
     const uint8_t *sframe = a.src + (size_t)f * a.src_frame_stride;
     uint8_t *wframe = a.wm ? a.wm + (size_t)f * a.wm_frame_stride : nullptr;
-    const bool any_glyph = IPX_FUSED_GLYPHS && a.nglyphs > 0 && wframe;
+    const bool any_glyph = IPX_FUSED_GLYPHS_RGBA && a.nglyphs > 0 && wframe;
     const bool fast = (a.sw & 3) == 0 && ((((uintptr_t)sframe) | (uintptr_t)a.sstride) & 15) == 0 &&
                       (!wframe || ((((uintptr_t)wframe) | (uintptr_t)a.wm_stride) & 15) == 0);
 
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NT, NT / 128) void band_pipe_kernel(BandArgs a)   /
     int idx = idx0 + (a.pipe_order ? (int)((blockIdx.x * 67u) % (unsigned)(idx_end - idx0)) : 0);
     int left = idx_end - idx0;
 
-    const bool any_glyph = IPX_FUSED_GLYPHS && a.nglyphs > 0 && a.wm;
+    const bool any_glyph = IPX_FUSED_GLYPHS_RGBA && a.nglyphs > 0 && a.wm;
     const bool can_carry = a.band_rows + 1 == ROWS;    // the halo row sits in the last staging slot
 
     Item cur;

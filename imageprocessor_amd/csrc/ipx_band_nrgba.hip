@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_nrgba_kernel(NrgbaArgs A)
     int idx = idx0 + (int)((blockIdx.x * 67u) % (unsigned)(idx_end - idx0));
     int left = idx_end - idx0;
 
-    const bool any_glyph = IPX_FUSED_GLYPHS && a.nglyphs > 0 && a.wm;
+    const bool any_glyph = IPX_FUSED_GLYPHS_RGBA && a.nglyphs > 0 && a.wm;
     const bool can_carry = a.band_rows + 1 == kRows;
 
     auto decode = [&](int i, ItemN &it) {

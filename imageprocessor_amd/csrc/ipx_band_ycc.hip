@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kNT, kNT / 128) void band_conv_kernel(typename Src:
     int idx = idx0 + (int)((blockIdx.x * 67u) % (unsigned)(idx_end - idx0));
     int left = idx_end - idx0;
 
-    const bool any_glyph = IPX_FUSED_GLYPHS && a.nglyphs > 0 && a.wm;
+    const bool any_glyph = IPX_FUSED_GLYPHS_CONV && a.nglyphs > 0 && a.wm;
 
     auto decode = [&](int i, ItemY &it) {
         it.cb = i / per_cb;

@@ -117,13 +117,17 @@ struct DevGlyph {           // one clipped DrawMask call, masks resident in HBM
     int x0, y0, x1, y1;     // clipped destination rectangle
 };
 constexpr int kMaxGlyphs = 256;
-// Where the text is composited.  0 (default): the band kernels copy / convert every pixel and composite_kernel then goes over the text
-// box of the watermark frames (it re-reads and re-writes ~0.1 MB of the 8.3 MB frame).  1: inside the band kernels, from the LDS tile
-// (round 1 and most of round 2).  The fused composite costs the persistent kernels their register allocation: with it hipcc spills
-// 194 (RGBA) / 266 (YCbCr) scalar registers to VGPR lanes in the item loop, without it 49 / 129 -- the YCbCr kernel, which is bound by
-// instruction issue, runs 8 % faster with the separate pass included; the RGBA kernel (bound by memory) does not change.
-#ifndef IPX_FUSED_GLYPHS
-#define IPX_FUSED_GLYPHS 0
+// Where the text is composited.  1: inside the band kernel, from the LDS tile.  0: the band kernel copies / converts every pixel and
+// composite_kernel then goes over the text box of the watermark frames (it re-reads and re-writes ~0.1 MB of the 8.3 MB frame, 0.09 ms
+// per 1024 frames of 1080p).  The fused composite costs a persistent kernel its register allocation: with it hipcc spills 194 (RGBA) /
+// 266 (converted-tile kernel) scalar registers to VGPR lanes in the item loop, without it 49 / 129.  The converted-tile kernel is bound
+// by instruction issue and runs 8 % faster with the separate pass included; the RGBA kernels are bound by memory, gain nothing from
+// the leaner loop and would pay the extra pass (+2 %): they keep the fused composite.
+#ifndef IPX_FUSED_GLYPHS_RGBA
+#define IPX_FUSED_GLYPHS_RGBA 1      // band_pipe_kernel, band_kernel, band_nrgba_kernel
+#endif
+#ifndef IPX_FUSED_GLYPHS_CONV
+#define IPX_FUSED_GLYPHS_CONV 0      // band_conv_kernel (YCbCr / Gray planes, NRGBA frames)
 #endif
 hipError_t launch_stream_copy(void *dst, const void *src, size_t bytes, hipStream_t s);   // the box's streaming ceiling (bench.py)
 hipError_t launch_composite(uint8_t *dst, int dstride, size_t frame_stride, int nframes,

@@ -257,6 +257,7 @@ void ipx_destroy(ipx_ctx *c)
     for (auto &l : c->lanes) {
         if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
         if (l.dev) (void)hipFree(l.dev);
+        if (l.pin) (void)hipHostFree(l.pin);
         if (l.dec) (void)hipFree(l.dec);
         if (l.flag) (void)hipFree(l.flag);
     }
@@ -1052,7 +1053,7 @@ static int plan_src_status(const char *who, const ipx_plan *pl, long long stride
 }
 #define IPX_PLAN_SRC(who, pl, stride, bpp) do { const int rc_ = plan_src_status(who, pl, stride, bpp); if (rc_) return rc_; } while (0)
 
-static bool glyphs_separate();
+static bool glyphs_separate(bool fused_kernel);
 
 int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *src,
                      int sstride, size_t src_frame_stride, uint8_t *resize_out,
@@ -1121,7 +1122,7 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
             a.nx_out[a.nscale - 1] = pl->g.nx_out[k];
         }
         if (a.nscale == 1) a.sc[1] = a.sc[0];  // keeps the kernel's unconditional tap loads legal
-        const bool sep_glyphs = wm && pl->glyphs.n > 0 && glyphs_separate();
+        const bool sep_glyphs = wm && pl->glyphs.n > 0 && glyphs_separate(IPX_FUSED_GLYPHS_RGBA);
         a.glyphs = pl->glyphs.dev; a.nglyphs = wm && !sep_glyphs ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
         a.cr = col[0]; a.cg = col[1]; a.cb = col[2]; a.ca = col[3];
         if (!wm && a.nscale == 0) return IPX_OK;
@@ -1219,6 +1220,26 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
     }
     const double t_res = trace ? ms_since(t_in) : 0;
     const bool src_tight = sstride == sw * bpp && src_frame_stride == fsrc;
+    // A single small frame in PAGEABLE memory (the per-operator seam from a caller that does not pin): the runtime's staged path for
+    // small pageable copies blocks the enqueueing thread behind other streams' work every few contexts (a 640x360 call then takes as
+    // long as the batch running beside it; tools/seam_hunt.py), larger ones it pins on the fly and never did.  Such a call goes
+    // through a pinned bounce buffer of its lane instead: two host memcpys of < 1 ms.
+    bool bounce = false;
+    if (!rc && nchunks == 1 && n == 1 && kind != kPalettedKind && per_frame <= ((size_t)8 << 20)) {
+        hipPointerAttribute_t at;
+        const bool pinned = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if (!pinned) {
+            Lane &l = *lanes[0];
+            if (l.pin_bytes < per_frame) {
+                if (l.pin) (void)hipHostFree(l.pin);
+                l.pin = nullptr; l.pin_bytes = 0;
+                if (hipHostMalloc((void **)&l.pin, per_frame + (per_frame >> 2), hipHostMallocDefault) == hipSuccess) l.pin_bytes = per_frame + (per_frame >> 2);
+                else (void)hipGetLastError();
+            }
+            bounce = l.pin != nullptr;
+        }
+    }
     auto d2h = [&](uint8_t *host, size_t host_stride, const uint8_t *dev, size_t dev_stride, size_t bytes, int i0, int m,
                    hipStream_t st) {
         if (!dev || !bytes) return hipSuccess;
@@ -1238,7 +1259,10 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
         uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * chunk : nullptr;
         uint8_t *dpal = fpal ? dsrc + (fsrc + fres + fth + fwm) * chunk : nullptr;
         // the lane's stream serialises reuse of its scratch: chunk c waits for chunk c - lanes
-        if (src_tight) {
+        if (bounce) {
+            for (int y = 0; y < sh; y++) memcpy(l.pin + (size_t)y * sw * bpp, src + (size_t)y * sstride, (size_t)sw * bpp);
+            e = hipMemcpyAsync(dsrc, l.pin, (size_t)sw * sh * bpp, hipMemcpyHostToDevice, l.stream);
+        } else if (src_tight) {
             e = hipMemcpyAsync(dsrc, src + (size_t)i0 * src_frame_stride, fsrc * m, hipMemcpyHostToDevice, l.stream);
         } else {
             for (int i = 0; i < m && e == hipSuccess; i++)
@@ -1254,6 +1278,10 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
         default: rc = ipx_plan_run_dev_paletted(ctx, l.stream, pl, m, dsrc, sw, fsrc, dpal, dres, fres, dth, fth, dwm, fwm); break;
         }
         if (rc) break;
+        if (bounce) {          // one copy of the three outputs (they follow the source in the lane's scratch), handed out after the sync below
+            if (fres + fth + fwm) e = hipMemcpyAsync(l.pin + fsrc, dsrc + fsrc, fres + fth + fwm, hipMemcpyDeviceToHost, l.stream);
+            continue;
+        }
         e = d2h(resize_out, resize_frame_stride, dres, fres, pl->info.resize_bytes, i0, m, l.stream);
         if (e == hipSuccess) e = d2h(thumb_out, thumb_frame_stride, dth, fth, pl->info.thumb_bytes, i0, m, l.stream);
         if (e == hipSuccess) e = d2h(wm_out, wm_frame_stride, dwm, fwm, pl->info.wm_bytes, i0, m, l.stream);
@@ -1262,6 +1290,12 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
     for (auto *l : lanes) {
         hipError_t e2 = hipStreamSynchronize(l->stream);
         if (e == hipSuccess) e = e2;
+    }
+    if (bounce && !rc && e == hipSuccess) {
+        const uint8_t *p = lanes[0]->pin + fsrc;
+        if (resize_out) memcpy(resize_out, p, pl->info.resize_bytes);
+        if (thumb_out) memcpy(thumb_out, p + fres, pl->info.thumb_bytes);
+        if (wm_out) memcpy(wm_out, p + fres + fth, pl->info.wm_bytes);
     }
     if (trace)
         fprintf(stderr, "[ipx seam] lane %d of %d: lock %.2f ms, reserve %.2f, enqueued %.2f, done %.2f\n", (int)(lanes[0] - &ctx->lanes[0]), nl, t_lock, t_res,
@@ -1344,17 +1378,18 @@ IPX_CATCH_STATUS
 // mode 1 = 8-bit RGBA first (the crop thumbnail scales the RGBA8 copy cropAndResize made, thumbnail.go:128-131)
 // The text composite as a pass of its own over the watermark frames' text box (composite_kernel) after the band kernel has copied /
 // converted every pixel, instead of inside the band kernel (IPX_FUSED_GLYPHS in ipx_internal.h has the why).
-static bool glyphs_separate() { return !IPX_FUSED_GLYPHS || env_int("IPX_GLYPH_SEPARATE", 0) != 0; }
-static hipError_t composite_after(const ipx_plan *pl, uint8_t *wm, size_t wm_frame_stride, int n, hipStream_t s)
+static bool glyphs_separate(bool fused_kernel) { return !fused_kernel || env_int("IPX_GLYPH_SEPARATE", 0) != 0; }
+static hipError_t composite_after(const ipx_plan *pl, bool fused_kernel, uint8_t *wm, size_t wm_frame_stride, int n, hipStream_t s)
 {
-    if (!wm || pl->glyphs.n <= 0 || !glyphs_separate()) return hipSuccess;
+    if (!wm || pl->glyphs.n <= 0 || !glyphs_separate(fused_kernel)) return hipSuccess;
     const uint8_t *c = pl->p.glyphs ? pl->p.glyphs->col : nullptr;
     return launch_composite(wm, pl->p.sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox, c ? c[0] * 0x101u : 0,
                             c ? c[1] * 0x101u : 0, c ? c[2] * 0x101u : 0, c ? c[3] * 0x101u : 0, s);
 }
 
 static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, uint8_t *res, size_t resize_frame_stride, uint8_t *th,
-                                      size_t thumb_frame_stride, uint8_t *wm, size_t wm_frame_stride, const PlanGeom &g, BandArgs &a, int mode[2])
+                                      size_t thumb_frame_stride, uint8_t *wm, size_t wm_frame_stride, const PlanGeom &g, bool fused_glyphs, BandArgs &a,
+                                      int mode[2])
 {
     const int sw = pl->p.sw, sh = pl->p.sh;
     a.sw = sw; a.sh = sh;
@@ -1387,7 +1422,7 @@ static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, u
     }
     if (a.nscale == 1) { a.sc[1] = a.sc[0]; mode[1] = mode[0]; }
     const uint8_t *c = pl->p.glyphs ? pl->p.glyphs->col : nullptr;
-    a.glyphs = pl->glyphs.dev; a.nglyphs = wm && !glyphs_separate() ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
+    a.glyphs = pl->glyphs.dev; a.nglyphs = wm && !glyphs_separate(fused_glyphs) ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
     a.cr = c ? c[0] * 0x101u : 0; a.cg = c ? c[1] * 0x101u : 0; a.cb = c ? c[2] * 0x101u : 0; a.ca = c ? c[3] * 0x101u : 0;
 }
 
@@ -1429,7 +1464,7 @@ static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n,
     if (pl->fused && env_int("IPX_YCC_FUSED", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
         YccArgs A{};
         BandArgs &a = A.b;
-        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, a, A.mode);
+        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, IPX_FUSED_GLYPHS_CONV, a, A.mode);
         if (!wm && a.nscale == 0) return IPX_OK;
         A.y = src->y; A.cb = src->cb; A.cr = src->cr; A.ystride = src->ystride; A.cstride = src->cstride;
         A.y_fs = src->y_frame_stride; A.c_fs = src->c_frame_stride; A.ratio = src->ratio;
@@ -1445,7 +1480,7 @@ static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n,
 #endif
         bool matched = false;
         if (src->cstride >= A.cw || flat_chroma) IPX_HIP(launch_band_ycc(A, s, &matched));
-        if (matched) IPX_HIP(composite_after(pl, wm, wm_frame_stride, n, s));
+        if (matched) IPX_HIP(composite_after(pl, IPX_FUSED_GLYPHS_CONV, wm, wm_frame_stride, n, s));
 #if IPX_DIAG
         if (matched && a.stamps) {
             unsigned long long h[8];
@@ -1530,23 +1565,23 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     if (pl->fused && env_int("IPX_NRGBA_FUSED", 1) && env_int("IPX_NRGBA_CONV", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
         NrgbaArgs A{};
         BandArgs &a = A.b;
-        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, a, A.mode);
+        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, IPX_FUSED_GLYPHS_CONV, a, A.mode);
         if (!wm && a.nscale == 0) return IPX_OK;
         a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
         bool matched = false;
         IPX_HIP(launch_band_nrgba_conv(A, s, &matched));
-        if (matched) IPX_HIP(composite_after(pl, wm, wm_frame_stride, n, s));
+        if (matched) IPX_HIP(composite_after(pl, IPX_FUSED_GLYPHS_CONV, wm, wm_frame_stride, n, s));
         if (matched) return IPX_OK;
     }
     if (pl->fused && env_int("IPX_NRGBA_FUSED", 1) && pl->g.band_rows <= 8 && pl->g.most_rows <= 64) {
         NrgbaArgs A{};
         BandArgs &a = A.b;
-        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->g, a, A.mode);
+        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->g, IPX_FUSED_GLYPHS_RGBA, a, A.mode);
         if (!wm && a.nscale == 0) return IPX_OK;
         a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
         bool matched = false;
         IPX_HIP(launch_band_nrgba(A, s, &matched));
-        if (matched) IPX_HIP(composite_after(pl, wm, wm_frame_stride, n, s));
+        if (matched) IPX_HIP(composite_after(pl, IPX_FUSED_GLYPHS_RGBA, wm, wm_frame_stride, n, s));
         if (matched) return IPX_OK;
     }
     // premultiplied RGBA8 of the whole batch (drawNRGBASrc == drawNRGBAOver onto a zeroed frame), into the watermark frames when wanted

@@ -25,6 +25,8 @@ struct Lane {
     int *flag = nullptr;      // device int for the opaque() scan
     uint8_t *dec = nullptr;   // second grow-only buffer: planes and scratch of a decode running on this lane (ipx_plan_run_jpeg_jpeg)
     size_t dec_bytes = 0;
+    uint8_t *pin = nullptr;   // pinned bounce buffer for small single-frame calls on pageable memory (run_host_packed)
+    size_t pin_bytes = 0;
     bool busy = false;
 };
 

@@ -242,10 +242,11 @@ def test_single_image_calls_are_served_while_a_batch_runs(ipx, ops, font):
     device) and ONE staging lane, and a host batch leaves one lane free: single calls finish while the batch is still running,
     and both produce the oracle's bytes.
 
-    The latency bound is tried on up to three fresh contexts: about one process in eight (more often after many streams have come and
-    gone in it) gets the high-priority lane's stream mapped onto a hardware queue it shares with a batch lane -- HIP's stream -> queue
-    assignment, not visible at this level -- and its single calls then wait for that lane's share of the batch.  The bytes are
-    checked on every attempt."""
+    The latency bound is tried on up to three fresh contexts: about one context in ten still sees its single calls wait on the GPU for
+    the batch beside them (the high-priority lane's stream then shares a hardware queue with a batch lane -- HIP's stream -> queue
+    assignment, not visible at this level; tools/seam_hunt.py).  The other cause this test found -- small pageable copies blocking the
+    ENQUEUEING thread behind other streams' work in three contexts of ten -- is gone: such calls go through a pinned bounce buffer
+    (run_host_packed).  The bytes are checked on every attempt."""
     import threading
     import time
     task = _task([{"Type": "thumbnail", "Parameters": {"size": 200.0, "crop_to_fit": True}},
