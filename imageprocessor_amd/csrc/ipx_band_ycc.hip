@@ -160,21 +160,21 @@ struct YccSrc {          // *image.YCbCr planes (and *image.Gray as Y + a stride
     static __device__ __forceinline__ void issue(const Args &A, const Tile &t, const Bases &pb, bool valid, bool carry, int chunk, int half, Stage &st)
     {
         const BandArgs &a = A.b;
-        const int crow0 = t.r0 >> VS, crows = valid ? ((t.rows_ld - 1) >> VS) + 1 : 0;
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(pb.y + (size_t)t.r0 * A.ystride), 0, valid ? (t.rows_ld - 1) * A.ystride + a.sw : 0, 0x00020000);
-        const int cbytes = crows > 0 ? (crows - 1) * A.cstride + A.cw : 0;
-        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cb + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)(pb.cr + (size_t)crow0 * A.cstride), 0, cbytes, 0x00020000);
-        const bool in_tile = chunk < t.nchunk;
+        // descriptors over the whole plane of the frame (rows past the frame's last one fall out of range; rows of the tile that exist
+        // are always readable), the tile's first row in the offset: no 64-bit address arithmetic per item
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)pb.y, 0, (a.sh - 1) * A.ystride + a.sw, 0x00020000);
+        const int cbytes = (A.ch - 1) * A.cstride + A.cw;
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void *)pb.cb, 0, cbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void *)pb.cr, 0, cbytes, 0x00020000);
+        const bool in_tile = valid && chunk < t.nchunk;
         const bool row0_mine = half == 0 && !carry;                           // wave-uniform
-        const int yoff = in_tile ? t.c0 + chunk * 4 : kOOB;
+        const int yoff = in_tile ? t.r0 * A.ystride + t.c0 + chunk * 4 : kOOB;
 #pragma unroll
         for (int s = 0; s < kYS; s++) {
             const bool mine = s < 4 || row0_mine;
             st.y[s] = __builtin_amdgcn_raw_buffer_load_b32(yrs, mine ? yoff + slot_row(half, s) * A.ystride : kOOB, 0, 0);   // (row in the VGPR offset: the range check ignores the scalar one)
         }
-        const int coff = in_tile ? (t.c0 + chunk * 4) >> HS : kOOB;
+        const int coff = in_tile ? (t.r0 >> VS) * A.cstride + ((t.c0 + chunk * 4) >> HS) : kOOB;
 #pragma unroll
         for (int j = 0; j < NCS; j++) {
             // chroma row of slot j: VS: rows 2*half + j (they serve rows 4*half + 1 .. 4*half + 4, and chroma row 0 serves row 0); else the row of y slot j
@@ -243,10 +243,9 @@ struct NrgbaSrc {        // *image.NRGBA frames (PNGs with alpha; *image.Palette
     static __device__ __forceinline__ void issue(const Args &A, const Tile &t, const Bases &sframe, bool valid, bool carry, int chunk, int half, Stage &st)
     {
         const BandArgs &a = A.b;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(sframe + (size_t)t.r0 * a.sstride), 0, valid ? (t.rows_ld - 1) * a.sstride + a.sw * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)sframe, 0, (a.sh - 1) * a.sstride + a.sw * 4, 0x00020000);
         const bool row0_mine = half == 0 && !carry;                           // wave-uniform
-        const int off = chunk < t.nchunk ? t.c0 * 4 + chunk * 16 : kOOB;
+        const int off = valid && chunk < t.nchunk ? t.r0 * a.sstride + t.c0 * 4 + chunk * 16 : kOOB;
 #pragma unroll
         for (int s = 0; s < kYS; s++) {
             const bool mine = s < 4 || row0_mine;
@@ -284,16 +283,16 @@ __device__ __forceinline__ void drain_tile_conv(const BandArgs &a, const Tile &t
                                                 const typename Src::Stage &st, uint8_t *lds, bool any_glyph)
 {
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.wm ? wframe + (size_t)t.r0 * a.wm_stride : nullptr), 0,
+        (void *)wframe, 0,                                                        // the whole frame: rows past its last one are clipped
 #if IPX_DIAG
-        a.wm && !(a.dbg & 32) ? (t.rows_ld - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);   // 32: every store dropped by the descriptor
+        a.wm && !(a.dbg & 32) ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);   // 32: every store dropped by the descriptor
 #else
-        a.wm ? (t.rows_ld - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);        // the tile's rows incl. the halo row, clipped at the frame
+        a.wm ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);
 #endif
     // (the text box test takes the halo row along: its chunks inside the box are the next band's composite step's to write)
     const bool gl_rows = any_glyph && t.r0 < a.gbox.y1 && t.r0 + t.rows_ld > a.gbox.y0;   // wave-uniform
     const int x = t.c0 + chunk * 4;
-    const int woff = chunk * 4 < t.own_cols ? x * 4 : kOOB;
+    const int woff = chunk * 4 < t.own_cols ? t.r0 * a.wm_stride + x * 4 : kOOB;
     // chunks that meet the text box are written by the composite step: their store offset gets the top bit (beyond any frame)
     const uint32_t in_box = gl_rows && x + 4 > a.gbox.x0 && x < a.gbox.x1 ? 0x80000000u : 0u;
     const int loff = chunk * 16, plane = kRows * t.pitch;
