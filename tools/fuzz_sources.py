@@ -57,12 +57,14 @@ for trial in range(trials):
     thumb = (int(rng.integers(1, 300)), bool(rng.integers(0, 2)))
     nw, nh = oracle.resize_dims(w, h, *resize)
     _, tw0, th0 = oracle.thumb_geometry(w, h, *thumb)
-    if nw < 1 or nh < 1 or tw0 < 1 or th0 < 1:
+    if nw < 1 or nh < 1 or tw0 < 1 or th0 < 1 or max(nw, nh, tw0, th0) > 65535:      # (beyond 65535 pixels a side: IPX_ERR_UNSUPPORTED by design)
         continue
-    for k in ("IPX_BLK_COLS", "IPX_BAND_ROWS"):
+    for k in ("IPX_BLK_COLS", "IPX_BAND_ROWS", "IPX_CONV_BLK_COLS"):
         os.environ.pop(k, None)
     if rng.random() < 0.4:
         os.environ["IPX_BLK_COLS"] = str(int(rng.choice([8, 64, 252, 1000, 2044])))
+    if rng.random() < 0.4:
+        os.environ["IPX_CONV_BLK_COLS"] = str(int(rng.choice([8, 64, 252, 508, 1020])))      # the converted-tile kernel's own tiling
     if rng.random() < 0.3:
         os.environ["IPX_BAND_ROWS"] = str(int(rng.choice([2, 4, 8])))
     kind = ["nrgba", "gray", "paletted", "ycbcr", "rgba"][trial % 5]
