@@ -234,6 +234,49 @@ struct YccSrc {          // *image.YCbCr planes (and *image.Gray as Y + a stride
     }
 };
 
+struct GraySrc {         // *image.Gray: the Y plane alone.  drawGray and scale_RGBA_Gray_Src read a pixel as (y, y, y, 0xff); as 16-bit taps
+                         // that is y * 0x101 per colour channel (color.Gray.RGBA) -- one multiply per tile dword, no chroma arithmetic
+    typedef YccArgs Args;
+    typedef YccConv Conv;
+    struct Stage { uint32_t y[kYS]; };
+    typedef const uint8_t *Bases;
+    static __device__ __forceinline__ Bases bases(const Args &A, int f) { return A.y + (size_t)f * A.y_fs; }
+    static __device__ __forceinline__ void issue(const Args &A, const Tile &t, const Bases &py, bool valid, bool carry, int chunk, int half, Stage &st)
+    {
+        const BandArgs &a = A.b;
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void *)py, 0, (a.sh - 1) * A.ystride + a.sw, 0x00020000);
+        const bool row0_mine = half == 0 && !carry;                           // wave-uniform
+        const int yoff = valid && chunk < t.nchunk ? t.r0 * A.ystride + t.c0 + chunk * 4 : kOOB;
+#pragma unroll
+        for (int s = 0; s < kYS; s++) {
+            const bool mine = s < 4 || row0_mine;
+            st.y[s] = __builtin_amdgcn_raw_buffer_load_b32(yrs, mine ? yoff + slot_row(half, s) * A.ystride : kOOB, 0, 0);
+        }
+    }
+    template <class RowFn>
+    static __device__ __forceinline__ void rows(const Stage &st, bool row0_mine, RowFn row)
+    {
+        auto conv = [&](int s) {
+            const uint32_t yw = st.y[s];
+            v4u lo, hi;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                lo[i] = __builtin_amdgcn_perm(0u, yw, 0x01010101u * (uint32_t)i);                  // {y, y, y, y}: R16 | G16 << 16 = y * 0x101 twice
+                hi[i] = __builtin_amdgcn_perm(0u, yw, 0x0d0d0000u | (uint32_t)(i | i << 8));       // {y, y, 0xff, 0xff}: B16 | 0xffff << 16
+            }
+            row(s, lo, hi);
+        };
+#pragma unroll
+        for (int s = 0; s < 4; s++) conv(s);
+        if (row0_mine) conv(4);
+    }
+    static __device__ __forceinline__ void touch(Stage &st)
+    {
+#pragma unroll
+        for (int q = 0; q < kYS; q++) asm volatile("" : "+v"(st.y[q]));
+    }
+};
+
 struct NrgbaSrc {        // *image.NRGBA frames (PNGs with alpha; *image.Paletted frames after their palette expansion)
     typedef NrgbaArgs Args;
     typedef NrgbaConv2 Conv;
@@ -499,8 +542,12 @@ hipError_t launch_band_ycc(const YccArgs &A, hipStream_t s, bool *matched)
     *matched = false;
     const long long total = (long long)a.nbands * a.ncolblk * a.nframes;
     if (total <= 0) { *matched = true; return hipSuccess; }
-    if (total > 0x7fffffffLL || !band_ycc_supported(A)) return hipSuccess;
     const size_t lds = 2 * (size_t)kRows * kConvTilePitch;     // the two planes of the converted tile (y taps come through scalar loads)
+    if (A.ratio == IPX_GRAY) {                                 // the Y plane alone (ipx_plan_run_dev_gray, Gray JPEGs)
+        if (total > 0x7fffffffLL || !conv_tiling_ok(a) || ((((uintptr_t)A.y) | (uintptr_t)A.ystride | A.y_fs) & 3)) return hipSuccess;
+        return launch_conv_cfg<GraySrc>(A, "gray", total, lds, s, matched);
+    }
+    if (total > 0x7fffffffLL || !band_ycc_supported(A)) return hipSuccess;
     switch (A.ratio) {
     case IPX_YCBCR_444: return launch_conv_cfg<YccSrc<0, 0>>(A, "ycc 4:4:4", total, lds, s, matched);
     case IPX_YCBCR_422: return launch_conv_cfg<YccSrc<1, 0>>(A, "ycc 4:2:2", total, lds, s, matched);

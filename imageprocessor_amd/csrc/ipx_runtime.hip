@@ -1677,7 +1677,10 @@ int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n,
     if (env_int("IPX_GRAY_FLAT", 1) && (size_t)(sw + 1) / 2 + 8 <= ipx_ctx::kFlatChromaBytes) {
         ipx_ycbcr_batch b;
         b.y = gray; b.cb = b.cr = ctx->flat_chroma; b.ystride = stride; b.cstride = 0;
-        b.y_frame_stride = frame_stride; b.c_frame_stride = 0; b.ratio = IPX_YCBCR_420;
+        b.y_frame_stride = frame_stride; b.c_frame_stride = 0;
+        // IPX_GRAY: the converted-tile kernel's own Gray source (the Y plane alone, y * 0x101 per channel); IPX_GRAY_SRC=0: the YCbCr
+        // source with the stride-0 row of 128s as both chroma planes (the same bytes, with the chroma arithmetic)
+        b.ratio = env_int("IPX_GRAY_SRC", 1) ? IPX_GRAY : IPX_YCBCR_420;
         const int rc = run_dev_ycbcr(ctx, s, pl, n, &b, true, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride, wm_out,
                                      wm_frame_stride);
         if (rc <= 0) return rc;      // 1: not a shape the planar kernel takes

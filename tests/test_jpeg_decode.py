@@ -293,13 +293,15 @@ def test_gray_close_to_libjpeg():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flat", ["1", "0"], ids=["planar-pass-flat-chroma", "expanded-rgba-pass"])
+@pytest.mark.parametrize("flat", ["gray", "flat", "0"], ids=["planar-pass-gray-source", "planar-pass-flat-chroma", "expanded-rgba-pass"])
 def test_gray_jpegs_on_the_gpu(ctx, flat, monkeypatch):
     """One-component files: decoded on the GPU into an *image.Gray plane and read as (y, y, y, 0xff) -- what image/draw's drawGray and
-    x/image's scale_RGBA_Gray_Src read -- either by the planar kernel with a stride-0 row of 128s as chroma (IPX_GRAY_FLAT=1, the default)
-    or expanded to RGBA8 and run through the RGBA pass; against the oracle on the expanded frame."""
+    x/image's scale_RGBA_Gray_Src read -- by the converted-tile kernel's Gray source (the Y plane alone, the default), by its YCbCr
+    source with a stride-0 row of 128s as chroma (IPX_GRAY_SRC=0), or expanded to RGBA8 and run through the RGBA pass (IPX_GRAY_FLAT=0);
+    against the oracle on the expanded frame."""
     from helpers import DEFAULT_COL, text_glyphs
-    monkeypatch.setenv("IPX_GRAY_FLAT", flat)
+    monkeypatch.setenv("IPX_GRAY_FLAT", "0" if flat == "0" else "1")
+    monkeypatch.setenv("IPX_GRAY_SRC", "1" if flat == "gray" else "0")
     w, h = 320, 200
     files = [pil_jpeg(picture(w, h, seed=60 + i)[..., 0], quality=70 + 5 * i, **({"restart_marker_rows": 2} if i == 1 else {})) for i in range(5)]
     files.append(pil_jpeg(picture(w, h, seed=3)))                       # a colour file in a Gray batch: refused
