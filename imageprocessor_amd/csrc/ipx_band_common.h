@@ -426,7 +426,7 @@ __device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &
     }
 }
 
-// ---- scaled outputs of the kernels whose tile holds a converted source type (ipx_band_ycc.hip, ipx_band_nrgba.hip) ----
+// ---- scaled outputs of the kernels whose tile holds a converted source type (ipx_band_conv.hip, ipx_band_nrgba.hip) ----
 // Conv::NC        3: the converted alpha is constant 0xffff (YCbCr), 4: it is a channel like the others (NRGBA)
 // Conv::tap16_at  a tile pixel -> the 16-bit channels the reference's scale_RGBA_<type>_* interpolates (mode 0)
 // Conv::h16       the horizontal step of mode 0 on dyadic axes: h.c = x0 * tap(off).c + x1 * tap(off + 4).c, iw = x0 | x1 << 16

@@ -1,32 +1,32 @@
-// ipx_band_ycc.hip -- the fused band kernel for decoded JPEG batches (*image.YCbCr sources).
+// ipx_band_conv.hip -- the fused band kernel for the decoded source types that the reference CONVERTS per operator: *image.YCbCr planes
+// (decoded JPEGs), *image.Gray (one plane) and *image.NRGBA frames (PNGs with alpha; *image.Paletted after palette expansion) --
+// SURVEY.md 8(f) N2.
 //
-// Same decomposition as band_pipe_kernel (ipx_band.hip): a persistent workgroup walks (frame, band, column
-// block) items, keeps the next item's loads in flight while it computes the current one from LDS, and one
-// pass over the source produces the watermark frame and both scaled outputs.  What differs is the source:
-// three planes (Y at 1 byte per pixel, Cb / Cr subsampled), so a 1080p 4:2:0 frame is 3.1 MB of reads instead
-// of 8.3 MB, and the reference's per-operator conversion rules (image_processor.go:47 hands every operator
-// the *image.YCbCr itself):
-//   * watermark: draw.Draw(result, b, img, Point{}, draw.Src) (watermark.go:92) = imageutil.DrawYCbCr, the
-//     8-bit color.YCbCrToRGB per pixel -> done in registers on the way to the store;
-//   * crop thumbnail: the equal-size Scale of cropAndResize (thumbnail.go:128-130) is a Copy = DrawYCbCr too,
-//     and resizeImage then scales that RGBA8 copy with scale_RGBA_RGBA_* -> taps converted to RGBA8 (mode 1);
-//   * resize and the non-crop thumbnail: resizeImage on the YCbCr itself = scale_RGBA_YCbCr4xx_Src, every TAP
-//     converted to 16-bit RGB (color.YCbCr.RGBA inlined, clamped) and interpolated in float64 -> mode 0; on
-//     dyadic axes the float64 value is sum(w*tap) / 2^(kx+ky) exactly, computed here in u32.
+// Same decomposition as band_pipe_kernel (ipx_band.hip): a persistent workgroup walks (frame, band, column block) items, keeps the next
+// item's loads in flight while it computes the current one from LDS, and one pass over the source produces the watermark frame and
+// both scaled outputs.  What differs is the source, and the reference's per-operator conversion rules for it (image_processor.go:47
+// hands every operator the decoded image itself).  For *image.YCbCr -- three planes, Y at 1 byte per pixel, Cb / Cr subsampled, so a
+// 1080p 4:2:0 frame is 3.1 MB of reads instead of 8.3 MB:
+//   * watermark: draw.Draw(result, b, img, Point{}, draw.Src) (watermark.go:92) = imageutil.DrawYCbCr, the 8-bit color.YCbCrToRGB;
+//   * crop thumbnail: the equal-size Scale of cropAndResize (thumbnail.go:128-130) is a Copy = DrawYCbCr too, and resizeImage then
+//     scales that RGBA8 copy with scale_RGBA_RGBA_* -> RGBA8 taps (mode 1);
+//   * resize and the non-crop thumbnail: resizeImage on the YCbCr itself = scale_RGBA_YCbCr4xx_Src, every TAP converted to 16-bit RGB
+//     (color.YCbCr.RGBA inlined, clamped) and interpolated in float64 -> mode 0; on dyadic axes the float64 value is
+//     sum(w*tap) / 2^(kx+ky) exactly, computed here in u32.
 // All three read the SAME clamped 24-bit value per channel, v = clamp(yy1 + chroma term, 0, 0xffffff): the 8-bit pixel is its top
 // byte (Go: r >> 16, or 0 / 0xff outside), the 16-bit tap its top two bytes (Go: r >> 8 clamped to 0..0xffff).  So every source pixel
 // is converted ONCE, on its way from the staging registers to LDS (chroma terms shared by the pixels that share a sample), and the
-// tile holds converted taps: two planes of a dword per pixel, R16 | G16 << 16 and B16 | 0xffff << 16.  The scale steps then cost what
-// they cost for an RGBA source -- a v_perm_b32 pairs the channel of two neighbouring taps for one v_dot2_u32_u16 with the packed x
-// weights -- instead of converting 2 taps per output column and tile row again (that was 55% of the kernel's VALU work, and the
-// kernel was VALU-bound).
-// The price is LDS: 8 bytes per pixel.  The plan carries a second tiling for this kernel (PlanGeom conv, ipx_runtime.hip): column
-// blocks of at most 1020 pixels x 8 rows, 9 x 1024 x 8 B = 72 KB per tile, so that two workgroups still share a CU (one workgroup
-// of 1024 threads on a 147 KB tile was measured: 11% slower than the per-tap conversion -- nothing overlaps its barriers).  A
-// workgroup is 512 threads: thread = (4-pixel chunk, half); the upper half converts tile rows 4..7, the lower half rows 0..3 and
-// the halo row.
+// tile holds converted taps: two planes of a dword per pixel, R16 | G16 << 16 and B16 | A16 << 16 (A16 = 0xffff for YCbCr / Gray).  The
+// scale steps then cost what they cost for an RGBA source -- a v_perm_b32 pairs the channel of two neighbouring taps for one
+// v_dot2_u32_u16 with the packed x weights -- instead of converting 2 taps per output column and tile row again.  *image.NRGBA works
+// the same way: drawNRGBASrc's pixel is the top byte of scale_RGBA_NRGBA_*'s premultiplied 16-bit tap (convert_px_nrgba).
 //
-// Bound: HBM writes (1080p 4:2:0, full pipeline: 3.1 MB in, 11.6 MB out per frame).
+// The price is LDS: 8 bytes per pixel.  The plan carries a second tiling for this kernel (PlanGeom conv, ipx_runtime.hip): column
+// blocks of at most 1020 pixels x 8 rows, tile rows of a fixed 4096 bytes per plane, 72 KB per tile, two workgroups per CU.  A
+// workgroup is 512 threads: thread = (4-pixel chunk, half); slot_row() below has the row assignment and the halo carry.
+//
+// Bound: instruction issue (with every store dropped the YCbCr kernel is as slow as with them); the text is composited
+// by composite_kernel afterwards because the fused composite cost the item loop its scalar registers (IPX_FUSED_GLYPHS_CONV).
 #include <algorithm>
 #include <cstdlib>
 
@@ -49,7 +49,7 @@ constexpr int kNT = 512;        // threads per workgroup
 constexpr int kCPR = kNT / 2;   // 4-pixel chunks per tile row: thread = (chunk, half of the tile's rows)
 constexpr int kRows = 9;        // tile rows incl. the halo row
 static_assert(kCPR * 16 == kConvTilePitch, "a tile row holds one 16-byte slot per chunk index");
-constexpr int kYS = 5;          // y rows a thread stages: half 0: tile rows 0..3 and 8, half 1: rows 4..7
+constexpr int kYS = 5;          // rows a thread stages: the four rows of its half (slots 0..3) + row 0 (slot 4: lower half, when not carried)
 
 // Chroma terms of color.YCbCrToRGB / color.YCbCr.RGBA for one chroma sample, the -128 folded into the constants.
 struct Chroma { int r, g, b; };

@@ -179,7 +179,7 @@ hipError_t launch_gray_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, i
 hipError_t launch_palette_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, const uint8_t *palettes, int w,
                                  int h, int n, hipStream_t s);
 
-// the fused band kernel on *image.YCbCr planes (ipx_band_ycc.hip): BandArgs without `src`, plus the planes
+// the fused band kernel on *image.YCbCr planes (ipx_band_conv.hip): BandArgs without `src`, plus the planes
 struct YccArgs {
     BandArgs b;
     const uint8_t *y, *cb, *cr;
@@ -199,7 +199,7 @@ struct NrgbaArgs {
                                //                 1 = premultiplied RGBA8 first (the crop copy), then scale_RGBA_RGBA_*
 };
 hipError_t launch_band_nrgba(const NrgbaArgs &a, hipStream_t s, bool *matched);
-hipError_t launch_band_nrgba_conv(const NrgbaArgs &a, hipStream_t s, bool *matched);   // ipx_band_ycc.hip: premultiplied taps in a two-plane tile
+hipError_t launch_band_nrgba_conv(const NrgbaArgs &a, hipStream_t s, bool *matched);   // ipx_band_conv.hip: premultiplied taps in a two-plane tile
 constexpr int kConvTilePitch = 4096;   // bytes per row and plane of band_ycc_kernel's LDS tile (the plan's row tables for it carry this pitch)
 // Per kernel instantiation and process: the dynamic-LDS limit is raised once (it only has to be at least what a launch asks for) and the
 // occupancy is cached per LDS size.  These are properties of the loaded function, not of the calling thread; done per thread, every

@@ -1373,7 +1373,7 @@ IPX_CATCH_STATUS
 //   watermark: draw.Draw converts to RGBA8 (DrawYCbCr), the glyphs go over that.
 // So: one conversion pass into the watermark frame (or scratch), the RGBA band kernel for the crop
 // thumbnail on the converted frames, the glyph composite in place, and a batched YCbCr scale.
-// BandArgs of the fused kernels that convert their source on the fly (ipx_band_ycc.hip, ipx_band_nrgba.hip): the plan's tiling, the
+// BandArgs of the fused kernels that convert their source on the fly (ipx_band_conv.hip, ipx_band_nrgba.hip): the plan's tiling, the
 // outputs that are wanted, and per scaled output the conversion rule -- mode 0 = 16-bit taps (resizeImage on the source image itself),
 // mode 1 = 8-bit RGBA first (the crop thumbnail scales the RGBA8 copy cropAndResize made, thumbnail.go:128-131)
 // The text composite as a pass of its own over the watermark frames' text box (composite_kernel) after the band kernel has copied /
@@ -1460,7 +1460,7 @@ static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n,
     uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
     const bool crop_thumb = th && pl->p.crop_to_fit;
 
-    // one fused pass over the planes when the tile shape and alignments allow it (ipx_band_ycc.hip)
+    // one fused pass over the planes when the tile shape and alignments allow it (ipx_band_conv.hip)
     if (pl->fused && env_int("IPX_YCC_FUSED", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
         YccArgs A{};
         BandArgs &a = A.b;
@@ -1561,7 +1561,7 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
     const bool crop_thumb = th && pl->p.crop_to_fit;
     // one fused pass over the frames when the tile shape and alignments allow it: the converted-tile kernel (every source pixel
-    // premultiplied once, ipx_band_ycc.hip) on the plan's `conv` tiling, else the per-tap kernel of ipx_band_nrgba.hip
+    // premultiplied once, ipx_band_conv.hip) on the plan's `conv` tiling, else the per-tap kernel of ipx_band_nrgba.hip
     if (pl->fused && env_int("IPX_NRGBA_FUSED", 1) && env_int("IPX_NRGBA_CONV", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
         NrgbaArgs A{};
         BandArgs &a = A.b;

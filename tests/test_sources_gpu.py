@@ -168,7 +168,7 @@ def test_ycbcr_batch_plan(ctx, case, fused, monkeypatch):
 def test_nrgba_batch_plan(ctx, case, fused, monkeypatch):
     """ipx_plan_run_dev_nrgba: a batch of *image.NRGBA frames (PNGs with alpha), per operator as the reference's helpers treat the
     type: 16-bit premultiplied taps for resizeImage, drawNRGBA* first for the crop thumbnail and the watermark.  The converted-tile
-    kernel (every source pixel premultiplied once, ipx_band_ycc.hip), the per-tap kernel it falls back to (ipx_band_nrgba.hip; both
+    kernel (every source pixel premultiplied once, ipx_band_conv.hip), the per-tap kernel it falls back to (ipx_band_nrgba.hip; both
     need widths that are multiples of 4) and the three-kernel path."""
     from helpers import DEFAULT_COL, text_glyphs
     monkeypatch.setenv("IPX_NRGBA_FUSED", "0" if fused == "0" else "1")
