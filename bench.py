@@ -66,7 +66,7 @@ def copy_ceiling(ctx, gib=4, pairs=3, reps=4):
     for b in keep:
         b.free()
     return {"best": round(max(rates), 1), "worst": round(min(rates), 1), "unit": "GB/s",
-            "what": "ipx_stream_copy (grid-stride uint4 copy kernel) of %d GiB, read + written bytes / best of %d runs, %d buffer pairs" % (gib, reps, pairs)}
+            "what": "ipx_stream_copy (uint4 copy kernel, 2048 contiguous streams) of %d GiB, read + written bytes / best of %d runs, %d buffer pairs" % (gib, reps, pairs)}
 
 
 def host_info():

@@ -373,21 +373,25 @@ hipError_t launch_draw(uint8_t *dst, int dstride, const uint8_t *src, int sstrid
 }
 
 // ---- a plain streaming copy: the ceiling of the box at hand (ipx_stream_copy) ----
+// Every workgroup copies a contiguous region of its own, four 16-byte loads in flight per lane: 2048 separate sequential streams.  That
+// is the faster of the two obvious shapes on MI355X (tools/ubench_streams.hip: 5.0 - 5.3 TB/s against 4.8 - 4.9 for a grid-stride copy
+// in which the whole grid moves one window), and it is the shape of the band kernels' own traffic.
 __global__ __launch_bounds__(256) void stream_copy_kernel(const uint4 *__restrict__ s, uint4 *__restrict__ d, size_t n)
 {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t step = (size_t)gridDim.x * 256;
-    for (; i + 3 * step < n; i += 4 * step) {
-        const uint4 a = s[i], b = s[i + step], c = s[i + 2 * step], e = s[i + 3 * step];
-        d[i] = a; d[i + step] = b; d[i + 2 * step] = c; d[i + 3 * step] = e;
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t i0 = (size_t)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    size_t i = i0 + threadIdx.x;
+    for (; i + 768 < i1; i += 1024) {
+        const uint4 a = s[i], b = s[i + 256], c = s[i + 512], e = s[i + 768];
+        d[i] = a; d[i + 256] = b; d[i + 512] = c; d[i + 768] = e;
     }
-    for (; i < n; i += step) d[i] = s[i];
+    for (; i < i1; i += 256) d[i] = s[i];
 }
 
 hipError_t launch_stream_copy(void *dst, const void *src, size_t bytes, hipStream_t s)
 {
     const size_t n = bytes / 16;
-    const unsigned blocks = (unsigned)std::min<size_t>(8192, (n + 255) / 256);
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
     hipLaunchKernelGGL(stream_copy_kernel, dim3(blocks), dim3(256), 0, s, (const uint4 *)src, (uint4 *)dst, n);
     return hipGetLastError();
 }

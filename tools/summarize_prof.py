@@ -42,6 +42,19 @@ print("== kernel-trace --stats")
 for k in out["kernel_stats"]:
     print("  %-70s calls %4s  avg %10.1f us  min %10.1f  max %10.1f  (%s%%)" % (
         k["Name"][:70], k["Calls"], float(k["AverageNs"]) / 1e3, float(k["MinNs"]) / 1e3, float(k["MaxNs"]) / 1e3, k["Percentage"]))
+# the same from the trace itself, without the first launches: bench.py's warm-up steps are each buffer set's first launch (first touch of
+# 20 GB, up to 1.7x slower) and rocprofv3's statistics average them in; bench.py's own clock starts after them
+trace = collections.defaultdict(list)
+for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        trace[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+print("== kernel-trace, launches after the first three of each kernel (bench.py's warm-up steps)")
+for name, v in trace.items():
+    if "ipx" not in name or len(v) <= 3:
+        continue
+    d = [x[1] for x in sorted(v)[3:]]
+    out.setdefault("timed", {})[name] = {"launches": len(d), "avg_us": sum(d) / len(d) / 1e3, "min_us": min(d) / 1e3, "max_us": max(d) / 1e3}
+    print("  %-70s launches %4d  avg %10.1f us  min %10.1f  max %10.1f" % (name[:70], len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3))
 print("== PMC means per launch (separate --pmc passes)")
 for name, c in out["pmc"].items():
     print("  " + name[:100])
