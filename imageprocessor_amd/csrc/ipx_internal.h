@@ -262,6 +262,7 @@ struct JpegDecInfo {
     int w, h, h0, v0, ratio, ri, ncomp;
     int host_scans;            // 1: not one baseline scan the GPU's Huffman kernels take (progressive, several scans, table ids above 1):
                                // jpeg_host_decode walks the scans on the host, the coefficients go up, the GPU does the rest
+    int progressive;           // SOF2 (reconstructProgressiveImage's rule for blocks outside the image applies)
     uint8_t td[3], ta[3];      // kernel table slots of the three components: 0,1 = DC tables, 2,3 = AC tables
     size_t scan_off, scan_len; // entropy-coded data within the file
 };
@@ -330,8 +331,8 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
 }  // namespace ipx
 #include <vector>
 namespace ipx {
-int jpeg_host_decode(const uint8_t *d, size_t len, JpegDecInfo *info, std::vector<int16_t> *coefs, std::vector<int16_t> *dcs,
-                     uint16_t qnat[3][64], bool *progressive);
+int jpeg_host_decode(const uint8_t *d, size_t len, JpegDecInfo *info, int16_t *coefs, int16_t *dcs, size_t nblk, uint16_t qnat[3][64],
+                     bool *progressive);
 hipError_t launch_jpeg_huff(const JpegDecArgs &a, hipStream_t s);
 // the same pieces through the word-wise reader of the parallel decoder: unstuff each piece into ublob (+ its length into ulen), then one
 // decode pass -- the state at the start of a piece is known, so nothing is speculative.  The 64 pieces of a workgroup share one set

@@ -81,7 +81,7 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
         const size_t sn = n - 2;
         switch (m) {
         case 0xc0: case 0xc1: case 0xc2: {
-            if (m == 0xc2) info->host_scans = 1;               // progressive: the scans refine each other (ipx_jpeg_dec_prog.cpp)
+            if (m == 0xc2) info->host_scans = info->progressive = 1;   // progressive: the scans refine each other (ipx_jpeg_dec_prog.cpp)
             if (ncomp || sn < 6) return IPX_ERR_INVALID;
             if (s[0] != 8) return IPX_ERR_UNSUPPORTED;
             info->h = (int)be16(s + 1); info->w = (int)be16(s + 3);

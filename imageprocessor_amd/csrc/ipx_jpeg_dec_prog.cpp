@@ -133,15 +133,29 @@ struct Decoder {
     uint16_t eobrun = 0;
     int mxx = 0, myy = 0, scans = 0;
     bool dqt_after_scan = false;
-    std::vector<int32_t> coef[3];     // per component: blocks of 64, natural order, row-major over the component's block grid
+    // The coefficients live where the IDCT will read them from the start: int16, natural order, blocks in the scan order of an interleaved
+    // baseline scan ([MCU][block of the MCU][64]); the DC term sits in element 0 until the end (jpeg_host_decode moves it to its dense
+    // array).  Go keeps int32: a value that does not fit sets `wide` at the write that produces it and the file is handed back.
+    int16_t *out = nullptr;           // the caller's slice: out_blocks blocks of 64 (pinned memory the upload reads from)
+    size_t out_blocks = 0;
+    bool out_ready = false;           // zeroed at the first scan, once the frame is known to have the geometry the caller expects
+    bool wide = false;
+    int bpm = 0, ybl = 0;             // blocks per MCU in the output layout, luma blocks per MCU
     int status = IPX_OK;
 
     void fail(int s) { if (status == IPX_OK) status = s; }
+    void put(int16_t &dst, int32_t v) { if (v != (int32_t)(int16_t)v) wide = true; dst = (int16_t)v; }
+    int16_t *block(int k, int bx, int by)       // block (bx, by) of component k's grid in the output layout
+    {
+        const int hi = ch[k], vi = cv[k];
+        const size_t gb = ((size_t)(by / vi) * mxx + bx / hi) * bpm + (k == 0 ? (size_t)(by % vi) * hi + bx % hi : (size_t)ybl + k - 1);
+        return out + gb * 64;
+    }
 
-    int32_t refine_nonzeroes(Bits &br, int32_t *b, int32_t zig, int32_t zig_end, int32_t nz, int32_t delta)
+    int32_t refine_nonzeroes(Bits &br, int16_t *b, int32_t zig, int32_t zig_end, int32_t nz, int32_t delta)
     {
         for (; zig <= zig_end; zig++) {
-            int32_t &v = b[kUnzig[zig]];
+            int16_t &v = b[kUnzig[zig]];
             if (v == 0) {
                 if (nz == 0) break;
                 nz--;
@@ -149,15 +163,15 @@ struct Decoder {
             }
             const int bit = br.bit();
             if (br.err) return 0;
-            if (bit) v += v >= 0 ? delta : -delta;
+            if (bit) put(v, (int32_t)v + (v >= 0 ? delta : -delta));
         }
         return zig;
     }
 
-    void refine(Bits &br, int32_t *b, const Huff &h, int32_t zig_start, int32_t zig_end, int32_t delta)
+    void refine(Bits &br, int16_t *b, const Huff &h, int32_t zig_start, int32_t zig_end, int32_t delta)
     {
         if (zig_start == 0) {
-            if (br.bit()) b[0] |= delta;
+            if (br.bit()) put(b[0], (int32_t)b[0] | delta);
             return;
         }
         int32_t zig = zig_start;
@@ -180,7 +194,7 @@ struct Decoder {
                 zig = refine_nonzeroes(br, b, zig, zig_end, run, delta);
                 if (br.err) return;
                 if (zig > zig_end) { br.err = true; return; }          // "too many coefficients"
-                if (z) b[kUnzig[zig]] = z;
+                if (z) put(b[kUnzig[zig]], z);
             }
         }
         if (eobrun > 0) {
@@ -216,9 +230,12 @@ struct Decoder {
             if (zs != 0 && ns != 1) return fail(IPX_ERR_INVALID);
             if (ah != 0 && ah != al + 1) return fail(IPX_ERR_INVALID);
         }
-        for (int i = 0; i < ns; i++) {
-            std::vector<int32_t> &c = coef[ci[i]];
-            if (c.empty()) c.assign((size_t)mxx * myy * ch[ci[i]] * cv[ci[i]] * 64, 0);
+        if (!out_ready) {
+            ybl = ch[0] * cv[0];
+            bpm = ncomp == 1 ? 1 : ybl + 2;
+            if ((size_t)mxx * myy * bpm != out_blocks) return fail(IPX_ERR_UNSUPPORTED);       // not the frame the header parser saw
+            memset(out, 0, out_blocks * 64 * sizeof(int16_t));
+            out_ready = true;
         }
         scans++;
         Bits br{d, len, *pos};
@@ -237,11 +254,11 @@ struct Decoder {
                             block_count++;
                             if (bx * 8 >= w || by * 8 >= h) continue;      // a non-interleaved scan carries no data for blocks outside the image
                         }
-                        int32_t *b = coef[k].data() + ((size_t)by * mxx * hi + bx) * 64;
+                        int16_t *b = block(k, bx, by);
                         if (!progressive && scans > 1) {                   // a sequential scan starts from an empty block (b = block{})
                             // (the blocks of one component are written by one scan in a well-formed file; a second scan over the same
                             // component replaces them, as Go's reconstructBlock overwrites the pixels)
-                            memset(b, 0, 64 * sizeof(int32_t));
+                            memset(b, 0, 64 * sizeof(int16_t));
                         }
                         if (ah != 0) {
                             refine(br, b, hf[1][ta[i]], zs, ze, (int32_t)(1u << al));
@@ -253,7 +270,7 @@ struct Decoder {
                                 if (br.err) break;
                                 if (t > 16) { fail(IPX_ERR_UNSUPPORTED); return; }     // "excessive DC component"
                                 dc[k] += br.receive_extend(t);
-                                b[0] = (int32_t)((uint32_t)dc[k] << al);
+                                put(b[0], (int32_t)((uint32_t)dc[k] << al));
                             }
                             if (zig <= ze && eobrun > 0) eobrun--;
                             else {
@@ -265,7 +282,7 @@ struct Decoder {
                                     if (size) {
                                         zig += run;
                                         if (zig > ze) break;
-                                        b[kUnzig[zig]] = (int32_t)((uint32_t)br.receive_extend(size) << al);
+                                        put(b[kUnzig[zig]], (int32_t)((uint32_t)br.receive_extend(size) << al));
                                     } else {
                                         if (run != 15) {
                                             eobrun = (uint16_t)(1u << run);
@@ -404,39 +421,23 @@ struct Decoder {
 // coefficient order, element 0 left zero -- dcs the nblk DC terms, qnat the FINAL quantisation tables per component in natural order
 // (Go dequantises a progressive image after EOI), and *progressive says whether reconstructProgressiveImage's rule applies (blocks
 // that hold no image pixel are not reconstructed: they stay zero in the MCU-padded planes).
-int jpeg_host_decode(const uint8_t *d, size_t len, JpegDecInfo *info, std::vector<int16_t> *coefs, std::vector<int16_t> *dcs,
-                     uint16_t qnat[3][64], bool *progressive)
+int jpeg_host_decode(const uint8_t *d, size_t len, JpegDecInfo *info, int16_t *coefs, int16_t *dcs, size_t nblk, uint16_t qnat[3][64],
+                     bool *progressive)
 {
     Decoder D;
     memset(D.quant, 0, sizeof D.quant);
     memset(D.cid, 0, sizeof D.cid); memset(D.ch, 0, sizeof D.ch); memset(D.cv, 0, sizeof D.cv); memset(D.ctq, 0, sizeof D.ctq);
     D.d = d; D.len = len;
+    D.out = coefs; D.out_blocks = nblk;
     D.run();
     if (D.status != IPX_OK) return D.status;
+    if (!D.out_ready) return IPX_ERR_INVALID;                                // (no scan at all: the marker parser refuses such a file before)
     memset(info, 0, sizeof *info);
     info->w = D.w; info->h = D.h; info->h0 = D.ch[0]; info->v0 = D.cv[0]; info->ncomp = D.ncomp; info->ri = 0;
     info->ratio = D.ncomp == 1 ? IPX_GRAY : D.ch[0] == 1 ? (D.cv[0] == 1 ? IPX_YCBCR_444 : IPX_YCBCR_440) : (D.cv[0] == 1 ? IPX_YCBCR_422 : IPX_YCBCR_420);
     *progressive = D.progressive;
-    const int h0 = D.ch[0], v0 = D.cv[0], ybl = h0 * v0, bpm = D.ncomp == 1 ? 1 : ybl + 2;
-    const size_t nblk = (size_t)D.mxx * D.myy * bpm;
-    coefs->assign(nblk * 64, 0);
-    dcs->assign(nblk, 0);
-    for (int c = 0; c < D.ncomp; c++) {
-        if (D.coef[c].empty()) continue;                                    // a component no scan touched: all zero
-        const int hi = D.ch[c], vi = D.cv[c], stride = D.mxx * hi;
-        for (int by = 0; by < D.myy * vi; by++)
-            for (int bx = 0; bx < stride; bx++) {
-                const int32_t *b = D.coef[c].data() + ((size_t)by * stride + bx) * 64;
-                const int mx = bx / hi, my = by / vi;
-                const size_t gb = ((size_t)my * D.mxx + mx) * bpm + (c == 0 ? (size_t)(by % vi) * hi + bx % hi : (size_t)ybl + c - 1);
-                int16_t *o = coefs->data() + gb * 64;
-                for (int z = 0; z < 64; z++) {
-                    if (b[z] < -32768 || b[z] > 32767) return IPX_ERR_UNSUPPORTED;   // Go keeps int32; the GPU pipeline holds int16
-                    if (z) o[z] = (int16_t)b[z];
-                }
-                (*dcs)[gb] = (int16_t)b[0];
-            }
-    }
+    if (D.wide) return IPX_ERR_UNSUPPORTED;                                  // Go keeps int32; the GPU pipeline holds int16
+    for (size_t gb = 0; gb < nblk; gb++) { dcs[gb] = coefs[gb * 64]; coefs[gb * 64] = 0; }
     for (int c = 0; c < 3; c++)
         for (int zig = 0; zig < 64; zig++) qnat[c][kUnzig[zig]] = c < D.ncomp ? D.quant[D.ctq[c]][zig] : 0;
     return IPX_OK;

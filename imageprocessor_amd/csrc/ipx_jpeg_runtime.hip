@@ -458,26 +458,32 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
         work();
         for (auto &t : pool) t.join();
     };
+    auto parallel_for_each = [&](int count, const std::function<void(int)> &fn) {      // heavy items (a file's scans): a thread each, up to 16
+        const int nt = std::max(1, std::min({count, (int)std::thread::hardware_concurrency(), 16}));
+        std::atomic<int> next{0};
+        auto work = [&] {
+            const int rc = guarded_status([&] { for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); }, nullptr);
+            if (rc) prep_failed = rc;
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    };
     // pieces of a scan: the whole scan, or one per restart interval.  Inside entropy-coded data 0xff is followed by 0x00 or by a
     // marker, so every 0xff 0xd0..0xd7 pair is an RSTn.
     std::vector<std::vector<uint32_t>> marks(n);
-    // files whose scans are walked on the host (progressive, several scans): quantised coefficients in the IDCT kernel's layout
-    std::vector<std::vector<int16_t>> hcoefs(n), hdcs(n);
-    std::vector<uint8_t> hprog(n, 0);
+    // files whose scans are walked on the host (progressive, several scans): decoded further down, once the batch's geometry is known,
+    // straight into one pinned block in the IDCT kernel's layout (slot hslot[i]): the upload then is plain DMA.  (Uploading from the
+    // pageable vectors the first version decoded into took a quarter of such a call: 6.2 MB of dense coefficients per 1080p file.)
+    std::vector<int> hslot(n, -1);
     const auto td0 = std::chrono::steady_clock::now();
     auto dms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count(); };
     double t_parse = 0, t_alloc = 0, t_pin = 0, t_pack = 0, t_launch = 0;
     parallel_for(n, [&](int i) {
         status[i] = !jpegs[i].data ? IPX_ERR_INVALID : (jpegs[i].len >= ((size_t)1 << 30) ? IPX_ERR_UNSUPPORTED : jpeg_parse(jpegs[i].data, jpegs[i].len, &info[i], &tabs[i]));
         if (status[i] != IPX_OK) return;
-        if (info[i].host_scans) {
-            if (*w > 0 && (info[i].w != *w || info[i].h != *h)) { status[i] = IPX_ERR_UNSUPPORTED; return; }   // a size other than the one asked for: not worth decoding
-            bool prog = false;
-            JpegDecInfo full;
-            status[i] = jpeg_host_decode(jpegs[i].data, jpegs[i].len, &full, &hcoefs[i], &hdcs[i], tabs[i].qnat, &prog);
-            if (status[i] == IPX_OK) { full.host_scans = 1; info[i] = full; hprog[i] = prog ? 1 : 0; }
-            return;
-        }
+        if (info[i].host_scans) return;      // its frame header is known; the scans wait for the batch's geometry
         const JpegDecInfo &I = info[i];
         const int nmcu = ((I.w + 8 * I.h0 - 1) / (8 * I.h0)) * ((I.h + 8 * I.v0 - 1) / (8 * I.v0));
         if (I.ri <= 0 || nmcu <= I.ri) return;
@@ -530,7 +536,7 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
             else if (ref < 0) status[i] = IPX_ERR_UNSUPPORTED;   // a size other than the one asked for
         }
         if (status[i] != IPX_OK) continue;
-        if (info[i].host_scans) { valid[i] = hprog[i] ? 3 : 1; continue; }     // coefficients come from the host; bit 1: progressive
+        if (info[i].host_scans) { valid[i] = info[i].progressive ? 3 : 1; continue; }     // coefficients come from the host; bit 1: progressive
         const JpegDecInfo &I = info[i];
         const int nmcu = ((I.w + 8 * I.h0 - 1) / (8 * I.h0)) * ((I.h + 8 * I.v0 - 1) / (8 * I.v0));
         auto push = [&](size_t a0, size_t a1, int m0, int cnt) {
@@ -636,10 +642,29 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     if ((e = mem.get(&d_dcs, (size_t)n * a.nblk * 2 + 16)) != hipSuccess) return fail(e, "scratch allocation");
     t_alloc = dms();
     uint8_t *hblob = (uint8_t *)ipx_host_alloc(ctx, blob_bytes + 16);
-    t_pin = dms();
     if (!hblob) { ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
+    // the host-decoded files of the batch: scans walked on the preparation threads into slots of one pinned block
+    int nhost = 0;
+    for (int i = 0; i < n; i++) if (valid[i] && info[i].host_scans) hslot[i] = nhost++;
+    int16_t *hpin = nullptr;
+    const size_t hcoef_words = (size_t)a.nblk * 64;
+    if (nhost) {
+        hpin = (int16_t *)ipx_host_alloc(ctx, (size_t)nhost * (hcoef_words + a.nblk) * sizeof(int16_t));
+        if (!hpin) { (void)ipx_host_free(ctx, hblob); ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
+        std::vector<int> hfiles;
+        for (int i = 0; i < n; i++) if (hslot[i] >= 0) hfiles.push_back(i);
+        parallel_for_each(nhost, [&](int j) {
+            const int i = hfiles[j];
+            bool prog = false;
+            JpegDecInfo full;
+            const int rc = jpeg_host_decode(jpegs[i].data, jpegs[i].len, &full, hpin + (size_t)j * hcoef_words, hpin + (size_t)nhost * hcoef_words + (size_t)j * a.nblk,
+                                            (size_t)a.nblk, tabs[i].qnat, &prog);
+            if (rc != IPX_OK) { status[i] = rc; valid[i] = 0; }
+        });
+    }
+    t_pin = dms();
     parallel_for(n, [&](int i) { if (valid[i] && !info[i].host_scans) memcpy(hblob + blob_off[i], jpegs[i].data + info[i].scan_off, info[i].scan_len); });
-    if (prep_failed) { (void)ipx_host_free(ctx, hblob); ipx_jpeg_planes_free(ctx, own.release()); set_error("jpeg decode: host preparation failed"); return prep_failed; }
+    if (prep_failed) { (void)ipx_host_free(ctx, hblob); if (hpin) (void)ipx_host_free(ctx, hpin); ipx_jpeg_planes_free(ctx, own.release()); set_error("jpeg decode: host preparation failed"); return prep_failed; }
     t_pack = dms();
     e = hipMemcpyAsync(d_blob, hblob, blob_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_img, items.data(), sizeof(JpegDecImage) * items.size(), hipMemcpyHostToDevice, s);
@@ -652,10 +677,10 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     if (e == hipSuccess) e = hipMemsetAsync(d_dcs, 0, (size_t)n * a.nblk * 2, s);
     a.blob = d_blob; a.img = d_img; a.tab = d_tab; a.coefs = d_coefs; a.status = d_status; a.dcs = d_dcs;
     for (int i = 0; i < n && e == hipSuccess; i++) {       // host-decoded files: their coefficients go into their slots (after the memsets, same stream)
-        if (!valid[i] || !info[i].host_scans) continue;
-        if (hcoefs[i].size() != (size_t)a.nblk * 64 || hdcs[i].size() != (size_t)a.nblk) return fail(hipErrorInvalidValue, "host-decoded coefficients of another geometry");
-        e = hipMemcpyAsync(d_coefs + (size_t)i * a.nblk * 64, hcoefs[i].data(), (size_t)a.nblk * 128, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_dcs + (size_t)i * a.nblk, hdcs[i].data(), (size_t)a.nblk * 2, hipMemcpyHostToDevice, s);
+        if (!valid[i] || hslot[i] < 0) continue;
+        const size_t j = (size_t)hslot[i];
+        e = hipMemcpyAsync(d_coefs + (size_t)i * hcoef_words, hpin + j * hcoef_words, hcoef_words * 2, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_dcs + (size_t)i * a.nblk, hpin + (size_t)nhost * hcoef_words + j * a.nblk, (size_t)a.nblk * 2, hipMemcpyHostToDevice, s);
     }
     int ref_gpu = -1;                                        // the first image the Huffman kernels decode: the one whose tables a shared-table launch carries
     for (int i = 0; i < n && ref_gpu < 0; i++) if (valid[i] && !info[i].host_scans) ref_gpu = i;
@@ -758,6 +783,7 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     if (getenv("IPX_DEBUG") && dms() > 200.0)
         fprintf(stderr, "[ipx] slow decode of %d files: parsed at %.1f ms, device scratch at %.1f, pinned block at %.1f, packed at %.1f, launched at %.1f, finished at %.1f\n", n, t_parse, t_alloc, t_pin, t_pack, t_launch, dms());
     (void)ipx_host_free(ctx, hblob);
+    if (hpin) (void)ipx_host_free(ctx, hpin);
     if (e != hipSuccess) return fail(e, "jpeg decode");
     for (int i = 0; i < n; i++)
         if (status[i] == IPX_OK && dev_status[i]) status[i] = jpeg_status_of(dev_status[i]);

@@ -424,6 +424,10 @@ static void d_reconstruct(jdec *d, int32_t *blk, int bx, int by, int c)
         }
 }
 
+/* The product holds coefficients in int16 (Go: int32) and hands a file back as soon as ANY value it writes does not fit -- also one a
+ * later scan would overwrite.  The flag follows the same rule, at the same writes, so that the verdicts can be compared. */
+#define D_WIDE(d, v) do { if ((v) < -32768 || (v) > 32767) (d)->out->dc_wide = 1; } while (0)
+
 /* refineNonZeroes: refine the non-zero entries of b in zig-zag order; if nz >= 0 the first nz zero entries are skipped over */
 static int32_t d_refine_nonzeroes(jdec *d, int32_t *b, int32_t zig, int32_t zig_end, int32_t nz, int32_t delta)
 {
@@ -438,6 +442,7 @@ static int32_t d_refine_nonzeroes(jdec *d, int32_t *b, int32_t zig, int32_t zig_
         if (d->err) return 0;
         if (!bit) continue;
         if (b[u] >= 0) b[u] += delta; else b[u] -= delta;
+        D_WIDE(d, b[u]);
     }
     return zig;
 }
@@ -447,7 +452,7 @@ static void d_refine(jdec *d, int32_t *b, const huff2 *h, int32_t zig_start, int
 {
     if (zig_start == 0) {            /* refining a DC component is trivial */
         const int bit = d_next_bit(d);
-        if (!d->err && bit) b[0] |= delta;
+        if (!d->err && bit) { b[0] |= delta; D_WIDE(d, b[0]); }
         return;
     }
     int32_t zig = zig_start;
@@ -569,6 +574,7 @@ static void d_sos(jdec *d, const uint8_t *s, size_t n)
                             if (d->err) return;
                             if (dc[ci] < -32768 || dc[ci] > 32767) d->out->dc_wide = 1;
                             b[0] = (int32_t)((uint32_t)dc[ci] << al);
+                            D_WIDE(d, b[0]);
                         }
                         if (zig <= zig_end && d->eobrun > 0) d->eobrun--;
                         else {
@@ -583,6 +589,7 @@ static void d_sos(jdec *d, const uint8_t *s, size_t n)
                                     const int32_t ac = d_receive_extend(d, val1);
                                     if (d->err) return;
                                     b[k_unzig[zig]] = (int32_t)((uint32_t)ac << al);
+                                    D_WIDE(d, b[k_unzig[zig]]);
                                 } else {
                                     if (val0 != 0x0f) {
                                         d->eobrun = (uint16_t)(1u << val0);

@@ -87,15 +87,20 @@ int main(int argc, char **argv)
                     jpeg_ok++;
                     if (info.w <= 0 || info.h <= 0 || (!info.host_scans && info.scan_off + info.scan_len > v.size())) { fprintf(stderr, "inconsistent parse result\n"); abort(); }
                     if (info.host_scans) {
-                        std::vector<int16_t> coefs, dcs;
+                        // exact-size slices, as the runtime hands them out (one past the end is an ASan report)
+                        const size_t mxx = (info.w + 8 * info.h0 - 1) / (8 * info.h0), myy = (info.h + 8 * info.v0 - 1) / (8 * info.v0);
+                        const size_t nblk = mxx * myy * (info.ncomp == 1 ? 1 : info.h0 * info.v0 + 2);
+                        if (nblk > (size_t)1 << 22) { host_bad++; free(heap); continue; }      // (a mutated size: the runtime's batch geometry check comes first)
+                        int16_t *coefs = (int16_t *)malloc(nblk * 64 * sizeof(int16_t)), *dcs = (int16_t *)malloc(nblk * sizeof(int16_t));
                         uint16_t qnat[3][64];
                         bool prog = false;
                         ipx::JpegDecInfo hi = info;
-                        const int hr = ipx::jpeg_host_decode(heap, v.size(), &hi, &coefs, &dcs, qnat, &prog);
+                        const int hr = ipx::jpeg_host_decode(heap, v.size(), &hi, coefs, dcs, nblk, qnat, &prog);
                         if (hr == IPX_OK) {
                             host_ok++;
-                            if (hi.w != info.w || hi.h != info.h || coefs.empty()) { fprintf(stderr, "host decoder disagrees with the parser\n"); abort(); }
+                            if (hi.w != info.w || hi.h != info.h) { fprintf(stderr, "host decoder disagrees with the parser\n"); abort(); }
                         } else host_bad++;
+                        free(coefs); free(dcs);
                     }
                 } else jpeg_bad++;
                 free(heap);
