@@ -354,7 +354,7 @@ __device__ __forceinline__ void scale_out(const BandArgs &a, int k, const Tile &
 {
     if (k >= a.nscale || dyA >= dyB) return;
     // a wave none of whose lanes has a destination column leaves (wave-uniform: the thumbnail's 200 columns keep 4 of a workgroup's 8
-    // waves busy, 2 of 8 on the narrow tiles of the YCbCr kernel; the others ran the whole row loop to store nothing)
+    // waves busy, 2 of 8 on the narrow tiles of band_conv_kernel; the others ran the whole row loop to store nothing)
 #if IPX_WAVE_SKIP
     if (o.dxA + __builtin_amdgcn_readfirstlane(tid & ~63) >= o.dxB) return;
 #endif
@@ -527,7 +527,7 @@ __device__ __forceinline__ void scale_out_conv(const BandArgs &a, int k, int mod
 {
     if (k >= a.nscale || dyA >= dyB) return;
     // a wave none of whose lanes has a destination column leaves (wave-uniform: the thumbnail's 200 columns keep 4 of a workgroup's 8
-    // waves busy, 2 of 8 on the narrow tiles of the YCbCr kernel; the others ran the whole row loop to store nothing)
+    // waves busy, 2 of 8 on the narrow tiles of band_conv_kernel; the others ran the whole row loop to store nothing)
 #if IPX_WAVE_SKIP
     if (o.dxA + __builtin_amdgcn_readfirstlane(tid & ~63) >= o.dxB) return;
 #endif

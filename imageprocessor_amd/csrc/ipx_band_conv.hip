@@ -523,7 +523,7 @@ bool conv_tiling_ok(const BandArgs &a)
 
 }  // namespace
 
-// Tile shapes and alignments the fused YCbCr kernel is built for; anything else takes the three-kernel path.
+// Tile shapes and alignments band_conv_kernel is built for on YCbCr planes; anything else takes the three-kernel path.
 bool band_ycc_supported(const YccArgs &A)
 {
     const BandArgs &a = A.b;

@@ -1,7 +1,9 @@
-// ipx_band_nrgba.hip -- the fused band kernel for *image.NRGBA batches (PNGs with alpha; *image.Paletted frames after their
-// palette expansion).
+// ipx_band_nrgba.hip -- the PER-TAP band kernel for *image.NRGBA batches (PNGs with alpha; *image.Paletted frames after their
+// palette expansion).  Since round 2 such batches take band_conv_kernel<..., NrgbaSrc> (ipx_band_conv.hip: every
+// source pixel premultiplied once into a tile of 16-bit taps); this kernel is what they fall back to when the plan has no `conv`
+// tiling or IPX_NRGBA_CONV=0 says so, and the tests keep it exercised.
 //
-// Same decomposition as band_pipe_kernel (ipx_band.hip) and band_ycc_kernel (ipx_band_conv.hip): a persistent workgroup walks
+// Same decomposition as band_pipe_kernel (ipx_band.hip) and band_conv_kernel (ipx_band_conv.hip): a persistent workgroup walks
 // (frame, band, column block) items, keeps the next item's loads in flight while it computes the current one from LDS, and one
 // pass over the source produces the watermark frame and both scaled outputs.  The LDS tile holds the source pixels as they are
 // (non-premultiplied R, G, B, A) and every consumer applies the conversion the reference's routine for its operator applies

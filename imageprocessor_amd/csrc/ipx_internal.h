@@ -200,7 +200,7 @@ struct NrgbaArgs {
 };
 hipError_t launch_band_nrgba(const NrgbaArgs &a, hipStream_t s, bool *matched);
 hipError_t launch_band_nrgba_conv(const NrgbaArgs &a, hipStream_t s, bool *matched);   // ipx_band_conv.hip: premultiplied taps in a two-plane tile
-constexpr int kConvTilePitch = 4096;   // bytes per row and plane of band_ycc_kernel's LDS tile (the plan's row tables for it carry this pitch)
+constexpr int kConvTilePitch = 4096;   // bytes per row and plane of band_conv_kernel's LDS tile (the plan's row tables for it carry this pitch)
 // Per kernel instantiation and process: the dynamic-LDS limit is raised once (it only has to be at least what a launch asks for) and the
 // occupancy is cached per LDS size.  These are properties of the loaded function, not of the calling thread; done per thread, every
 // short-lived worker thread repeated hipFuncSetAttribute / hipOccupancy... in the middle of other threads' launches.

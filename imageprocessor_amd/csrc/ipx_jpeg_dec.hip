@@ -21,7 +21,7 @@
 //   jpeg_idct_kernel   parallel over blocks: b[unzig[zig]] *= qt[zig]; idct (the Chen-Wang integer transform of
 //                      idct.go, row pass in registers, column pass through LDS); level shift, clip, 8-byte row stores
 //                      into the MCU-padded planes of image.NewYCbCr.
-// The planes feed band_ycc_kernel directly (ipx_plan_run_dev_ycbcr): decoded pixels never leave HBM.
+// The planes feed band_conv_kernel directly (ipx_plan_run_dev_ycbcr): decoded pixels never leave HBM.
 #include "ipx_internal.h"
 
 namespace ipx {

@@ -828,7 +828,7 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
     // Tilings of the source frame (PlanGeom) and the tables that depend on them.  A tiling = owned columns per workgroup (multiple of
     // 4 pixels = 16 B) and owned rows; a column block may hold at most out_cols destination columns of any scaled output.
     //   pl->g     tiles of one dword per pixel: band_pipe_kernel (RGBA sources) and band_nrgba_kernel; 72 KB of LDS, two workgroups per CU
-    //   pl->conv  tiles of two dwords per pixel (converted taps): band_ycc_kernel; at most 1020 columns x 8 rows, again two per CU
+    //   pl->conv  tiles of two dwords per pixel (converted taps): band_conv_kernel; at most 1020 columns x 8 rows, again two per CU
     struct HostGeom {
         int bc = 0, br = 0;
         std::vector<int> rb[2], cbv[2];
