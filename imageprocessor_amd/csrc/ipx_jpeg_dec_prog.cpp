@@ -61,15 +61,17 @@ void huff_build(Huff &h, const uint8_t counts[16], const uint8_t *vals, int tota
     }
 }
 
-// the entropy decoder's view of the file: bytes are taken one at a time, as late as possible, so that the marker loop finds the file
-// position where Go's decoder would have left it (it unreads what it looked ahead)
+// The entropy decoder's view of the file.  The accumulator is topped up greedily (up to 64 bits) but never across a marker: fill()
+// stops in front of an 0xff that is not followed by 0x00, so whatever is left of a scan's bytes when the scan ends lies before the
+// next marker and the marker loop skips it exactly like Go's does from wherever its own look-ahead had stopped.  A demand for bits the
+// file does not hold in front of the marker is the error, as in Go ("missing 0xff00 sequence" / "short Huffman data").
 struct Bits {
     const uint8_t *d;
     size_t len, pos;
-    uint32_t acc = 0;
+    uint64_t acc = 0;
     int n = 0;
     bool err = false;
-    bool fill()   // one more byte; false at a marker ("missing 0xff00 sequence") or at the end of the file ("short Huffman data")
+    bool fill()   // one more byte; false at a marker or at the end of the file
     {
         if (pos >= len) return false;
         const uint8_t c = d[pos];
@@ -80,24 +82,25 @@ struct Bits {
         acc = acc << 8 | c; n += 8;
         return true;
     }
+    void refill() { while (n <= 56 && fill()) {} }
     int bit()
     {
-        if (n == 0 && !fill()) { err = true; return 0; }
+        if (n == 0) { refill(); if (n == 0) { err = true; return 0; } }
         n--;
         return (int)(acc >> n) & 1;
     }
-    uint32_t bits(int k)
+    uint32_t bits(int k)      // k <= 32
     {
-        while (n < k) if (!fill()) { err = true; return 0; }
+        if (n < k) { refill(); if (n < k) { err = true; return 0; } }
         n -= k;
-        return (acc >> n) & ((1u << k) - 1);
+        return (uint32_t)((acc >> n) & ((1ull << k) - 1));
     }
     int huff(const Huff &h)
     {
         if (!h.ncodes) { err = true; return 0; }
         // first level when nine bits are at hand (or can be had without touching a marker); the bit-serial walk otherwise, which asks
         // for no more bits than the code has -- the end of a scan decodes the same way Go's slow path does
-        while (n < 9) if (!fill()) break;
+        if (n < 9) refill();
         if (n >= 9) {
             const uint16_t e = h.look[(acc >> (n - 9)) & 511];
             if (e) { n -= e >> 8; return e & 255; }
@@ -140,35 +143,51 @@ struct Decoder {
     size_t out_blocks = 0;
     bool out_ready = false;           // zeroed at the first scan, once the frame is known to have the geometry the caller expects
     bool wide = false;
+    std::vector<uint64_t> nzmask;     // per block: which zig-zag positions hold a non-zero coefficient (progressive files)
     int bpm = 0, ybl = 0;             // blocks per MCU in the output layout, luma blocks per MCU
     int status = IPX_OK;
 
     void fail(int s) { if (status == IPX_OK) status = s; }
     void put(int16_t &dst, int32_t v) { if (v != (int32_t)(int16_t)v) wide = true; dst = (int16_t)v; }
-    int16_t *block(int k, int bx, int by)       // block (bx, by) of component k's grid in the output layout
+    size_t block_index(int k, int bx, int by)   // block (bx, by) of component k's grid in the output layout
     {
-        const int hi = ch[k], vi = cv[k];
-        const size_t gb = ((size_t)(by / vi) * mxx + bx / hi) * bpm + (k == 0 ? (size_t)(by % vi) * hi + bx % hi : (size_t)ybl + k - 1);
-        return out + gb * 64;
+        // sampling factors are 1 or 2 here (everything else was refused at the frame header): shifts and masks, no division -- this
+        // runs once per block and scan
+        const int sx = ch[k] - 1, sy = cv[k] - 1;
+        return ((size_t)(by >> sy) * mxx + (bx >> sx)) * bpm + (k == 0 ? (size_t)((by & sy) << sx) + (bx & sx) : (size_t)ybl + k - 1);
     }
 
-    int32_t refine_nonzeroes(Bits &br, int16_t *b, int32_t zig, int32_t zig_end, int32_t nz, int32_t delta)
+    // refineNonZeroes: one bit per coefficient of [zig, zig_end] that is already non-zero, up to where the nz-th zero has been passed
+    // (nz < 0: to the end); returns that position.  Go walks the band coefficient by coefficient; the mask of non-zero positions
+    // (zig-zag order) that every write keeps lets this go straight to the ones that take a bit -- most blocks of a refinement scan
+    // have none -- and the update is arithmetic on the bit, not a branch on it (the bits are as good as random).
+    int32_t refine_nonzeroes(Bits &br, int16_t *b, uint64_t m, int32_t zig, int32_t zig_end, int32_t nz, int32_t delta)
     {
-        for (; zig <= zig_end; zig++) {
-            int16_t &v = b[kUnzig[zig]];
-            if (v == 0) {
-                if (nz == 0) break;
-                nz--;
-                continue;
-            }
-            const int bit = br.bit();
-            if (br.err) return 0;
-            if (bit) put(v, (int32_t)v + (v >= 0 ? delta : -delta));
+        const uint64_t range = (~0ull << zig) & (~0ull >> (63 - zig_end));
+        int32_t stop = zig_end + 1;
+        if (nz >= 0) {
+            uint64_t z = ~m & range;
+            for (; nz > 0 && z; nz--) z &= z - 1;
+            if (z) stop = __builtin_ctzll(z);
         }
-        return zig;
+        uint64_t todo = m & range & (stop >= 64 ? ~0ull : (1ull << stop) - 1);
+        while (todo) {
+            const int cnt = __builtin_popcountll(todo);
+            const int k = cnt < 24 ? cnt : 24;
+            const uint32_t v = br.bits(k);
+            if (br.err) return 0;
+            for (int j = k - 1; j >= 0; j--) {
+                int16_t &c = b[kUnzig[__builtin_ctzll(todo)]];
+                todo &= todo - 1;
+                const int32_t sgn = (int32_t)c >> 31;                                 // -1 for a negative coefficient
+                const int32_t step = ((delta ^ sgn) - sgn) & -(int32_t)((v >> j) & 1);  // +-delta when the bit is set
+                put(c, (int32_t)c + step);
+            }
+        }
+        return stop;
     }
 
-    void refine(Bits &br, int16_t *b, const Huff &h, int32_t zig_start, int32_t zig_end, int32_t delta)
+    void refine(Bits &br, int16_t *b, uint64_t &m, const Huff &h, int32_t zig_start, int32_t zig_end, int32_t delta)
     {
         if (zig_start == 0) {
             if (br.bit()) put(b[0], (int32_t)b[0] | delta);
@@ -191,15 +210,15 @@ struct Decoder {
                     z = br.bit() ? delta : -delta;
                 } else { br.err = true; return; }                      // "unexpected Huffman code"
                 if (br.err) return;
-                zig = refine_nonzeroes(br, b, zig, zig_end, run, delta);
+                zig = refine_nonzeroes(br, b, m, zig, zig_end, run, delta);
                 if (br.err) return;
                 if (zig > zig_end) { br.err = true; return; }          // "too many coefficients"
-                if (z) put(b[kUnzig[zig]], z);
+                if (z) { put(b[kUnzig[zig]], z); m |= 1ull << zig; }
             }
         }
         if (eobrun > 0) {
             eobrun--;
-            (void)refine_nonzeroes(br, b, zig, zig_end, -1, delta);
+            if (zig <= zig_end) (void)refine_nonzeroes(br, b, m, zig, zig_end, -1, delta);
         }
     }
 
@@ -235,33 +254,38 @@ struct Decoder {
             bpm = ncomp == 1 ? 1 : ybl + 2;
             if ((size_t)mxx * myy * bpm != out_blocks) return fail(IPX_ERR_UNSUPPORTED);       // not the frame the header parser saw
             memset(out, 0, out_blocks * 64 * sizeof(int16_t));
+            if (progressive) nzmask.assign(out_blocks, 0);
             out_ready = true;
         }
         scans++;
         Bits br{d, len, *pos};
         int32_t dc[3] = {0, 0, 0};
-        int mcu = 0, expected = 0xd0, block_count = 0;
+        int mcu = 0, expected = 0xd0;
+        int nbx = 0, nby = 0;                 // the next block of a non-interleaved scan, which walks the component's own block grid
+        const int q1 = ns == 1 ? mxx * ch[ci[0]] : 0;
+        uint64_t no_mask = 0;
         for (int my = 0; my < myy; my++)
             for (int mx = 0; mx < mxx; mx++) {
                 for (int i = 0; i < ns; i++) {
                     const int k = ci[i], hi = ch[k], vi = cv[k];
                     for (int j = 0; j < hi * vi; j++) {
                         int bx, by;
-                        if (ns != 1) { bx = hi * mx + j % hi; by = vi * my + j / hi; }
+                        if (ns != 1) { bx = hi * mx + (j & (hi - 1)); by = vi * my + (hi == 2 ? j >> 1 : j); }
                         else {
-                            const int q = mxx * hi;
-                            bx = block_count % q; by = block_count / q;
-                            block_count++;
+                            bx = nbx; by = nby;
+                            if (++nbx == q1) { nbx = 0; nby++; }
                             if (bx * 8 >= w || by * 8 >= h) continue;      // a non-interleaved scan carries no data for blocks outside the image
                         }
-                        int16_t *b = block(k, bx, by);
+                        const size_t gb = block_index(k, bx, by);
+                        int16_t *b = out + gb * 64;
+                        uint64_t &m = progressive ? nzmask[gb] : no_mask;
                         if (!progressive && scans > 1) {                   // a sequential scan starts from an empty block (b = block{})
                             // (the blocks of one component are written by one scan in a well-formed file; a second scan over the same
                             // component replaces them, as Go's reconstructBlock overwrites the pixels)
                             memset(b, 0, 64 * sizeof(int16_t));
                         }
                         if (ah != 0) {
-                            refine(br, b, hf[1][ta[i]], zs, ze, (int32_t)(1u << al));
+                            refine(br, b, m, hf[1][ta[i]], zs, ze, (int32_t)(1u << al));
                         } else {
                             int32_t zig = zs;
                             if (zig == 0) {
@@ -283,6 +307,7 @@ struct Decoder {
                                         zig += run;
                                         if (zig > ze) break;
                                         put(b[kUnzig[zig]], (int32_t)((uint32_t)br.receive_extend(size) << al));
+                                        m |= 1ull << zig;
                                     } else {
                                         if (run != 15) {
                                             eobrun = (uint16_t)(1u << run);
@@ -301,6 +326,14 @@ struct Decoder {
                 }
                 mcu++;
                 if (ri > 0 && mcu % ri == 0 && mcu < mxx * myy) {
+                    // whole bytes still waiting in the accumulator are bytes between the interval's data and the marker: Go's reader,
+                    // which takes bytes as late as it can, would stand in front of them and go looking for the marker (findRST)
+                    if (br.n >= 8) {
+                        size_t at = br.pos;                                 // where that reader stands: in front of the waiting bytes
+                        for (int held = br.n / 8; held > 0; held--) at -= at >= 2 && d[at - 1] == 0 && d[at - 2] == 0xff ? 2 : 1;
+                        fail(at + 2 > len ? IPX_ERR_INVALID : IPX_ERR_UNSUPPORTED);
+                        return;
+                    }
                     if (br.pos + 2 > len) { fail(IPX_ERR_INVALID); return; }
                     if (d[br.pos] != 0xff || d[br.pos + 1] != expected) { fail(IPX_ERR_UNSUPPORTED); return; }   // Go would search for the marker
                     br.pos += 2;
