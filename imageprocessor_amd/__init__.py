@@ -9,6 +9,7 @@ from . import _lib
 from ._lib import Config, Glyph, PlanInfo, PlanParams, Rect
 
 OP_OVER = 0
+DEEP_NRGBA64, DEEP_RGBA64, DEEP_GRAY16, DEEP_CMYK = 0, 1, 2, 3   # ipx.h IPX_DEEP_*
 OP_SRC = 1
 
 
@@ -228,6 +229,15 @@ class Plan:
                                              p("resize"), i.resize_bytes, p("thumbnail"), i.thumb_bytes, p("watermark"), i.wm_bytes))
         return out
 
+    def run_host_deep(self, pix, kind, want=("resize", "thumbnail", "watermark")):
+        """pix: n x H x (W * bpp) uint8, Go's Pix rows of *image.NRGBA64 / RGBA64 / Gray16 / CMYK frames (kind: DEEP_*, host)"""
+        pix = np.ascontiguousarray(pix, dtype=np.uint8)
+        n, i = pix.shape[0], self.info
+        out, p = self._host_outs(n, want)
+        _check(lib().ipx_plan_run_host_deep(self.ctx.handle, self.handle, n, kind, pix.ctypes.data, pix.shape[2], pix.shape[1] * pix.shape[2],
+                                            p("resize"), i.resize_bytes, p("thumbnail"), i.thumb_bytes, p("watermark"), i.wm_bytes))
+        return out
+
     def run_host_gray(self, frames, want=("resize", "thumbnail", "watermark")):
         """frames: n x H x W uint8 (*image.Gray, host) -> dict of output batches"""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
@@ -313,6 +323,12 @@ class Plan:
         i = self.info
         _check(lib().ipx_plan_run_dev_nrgba(self.ctx.handle, stream, self.handle, n, src_ptr, self._sw * 4, self._sw * self._sh * 4,
                                             resize_ptr, i.resize_bytes, thumb_ptr, i.thumb_bytes, wm_ptr, i.wm_bytes))
+
+    def run_dev_deep(self, n, kind, src_ptr, stride, frame_stride, resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
+        """*image.NRGBA64 / RGBA64 / Gray16 / CMYK frames (Go's Pix) resident in HBM (ipx_plan_run_dev_deep)"""
+        i = self.info
+        _check(lib().ipx_plan_run_dev_deep(self.ctx.handle, stream, self.handle, n, kind, src_ptr, stride, frame_stride, resize_ptr,
+                                           i.resize_bytes, thumb_ptr, i.thumb_bytes, wm_ptr, i.wm_bytes))
 
     def run_dev_gray(self, n, gray_ptr, stride, frame_stride, resize_ptr=None, thumb_ptr=None, wm_ptr=None, stream=None):
         """*image.Gray frames resident in HBM (ipx_plan_run_dev_gray)"""
@@ -470,6 +486,28 @@ class Context:
         sh, sw = src.shape[:2]
         _check(lib().ipx_draw_rgba8(self.handle, dst.ctypes.data, dw, dh, dw * 4, _rect(r),
                                     src.ctypes.data, sw, sh, sw * 4, int(sp[0]), int(sp[1]), op))
+        return dst
+
+    # ---- the deep source types: Go's Pix rows (H x W*bpp uint8) of *image.NRGBA64 / RGBA64 / Gray16 / CMYK frames ----------
+    def scale_bilinear_deep(self, pix, kind, dw, dh, sr=None, dr=None, op=OP_OVER, dst=None):
+        pix = np.ascontiguousarray(pix, np.uint8)
+        sh, row = pix.shape
+        sw = row // {DEEP_GRAY16: 2, DEEP_CMYK: 4}.get(kind, 8)
+        if dst is None:
+            dst = np.zeros((dh, dw, 4), np.uint8)
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous and dst.shape == (dh, dw, 4)
+        _check(lib().ipx_scale_bilinear_deep(self.handle, dst.ctypes.data, dw, dh, dw * 4, _rect(dr if dr is not None else (0, 0, dw, dh)),
+                                             pix.ctypes.data, sw, sh, row, kind, _rect(sr if sr is not None else (0, 0, sw, sh)), op))
+        return dst
+
+    def draw_deep(self, dst, r, pix, kind, sp=(0, 0), op=OP_SRC):
+        pix = np.ascontiguousarray(pix, np.uint8)
+        assert dst.dtype == np.uint8 and dst.flags.c_contiguous
+        dh, dw = dst.shape[:2]
+        sh, row = pix.shape
+        sw = row // {DEEP_GRAY16: 2, DEEP_CMYK: 4}.get(kind, 8)
+        _check(lib().ipx_draw_deep(self.handle, dst.ctypes.data, dw, dh, dw * 4, _rect(r), pix.ctypes.data, sw, sh, row, kind,
+                                   int(sp[0]), int(sp[1]), op))
         return dst
 
     # ---- source-type variants: *image.NRGBA and *image.YCbCr sources -------------

@@ -141,6 +141,8 @@ SIGNATURES = {
     "ipx_composite_glyphs_rgba8": (_I, [_P, _P, _I, _I, _I, C.POINTER(Glyph), _I, _P]),
     "ipx_scale_bilinear_nrgba8": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, Rect, _I]),
     "ipx_draw_nrgba8": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, _I, _I, _I]),
+    "ipx_scale_bilinear_deep": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, _I, Rect, _I]),
+    "ipx_draw_deep": (_I, [_P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, _I, _I, _I, _I]),
     "ipx_scale_bilinear_ycbcr": (_I, [_P, _P, _I, _I, _I, Rect, C.POINTER(YCbCr), Rect]),
     "ipx_draw_ycbcr": (_I, [_P, _P, _I, _I, _I, Rect, C.POINTER(YCbCr), _I, _I]),
     "ipx_dev_scale_bilinear_rgba8": (_I, [_P, _P, _P, _I, _I, _I, Rect, _P, _I, _I, _I, Rect, _I]),
@@ -160,6 +162,8 @@ SIGNATURES = {
     "ipx_plan_run_host_gray": (_I, [_P, _P, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
     "ipx_plan_run_host_paletted": (_I, [_P, _P, _I, _P, _I, _Z, _P, _P, _Z, _P, _Z, _P, _Z]),
     "ipx_plan_run_dev_nrgba": (_I, [_P, _P, _P, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
+    "ipx_plan_run_dev_deep": (_I, [_P, _P, _P, _I, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
+    "ipx_plan_run_host_deep": (_I, [_P, _P, _I, _I, _P, _I, _Z, _P, _Z, _P, _Z, _P, _Z]),
     "ipx_plan_run_host_ycbcr": (_I, [_P, _P, _I, C.POINTER(YCbCrBatch), _P, _Z, _P, _Z, _P, _Z]),
     "ipx_event_create": (_P, [_P]),
     "ipx_event_record": (_I, [_P, _P, _P]),

@@ -30,6 +30,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "ipx_internal.h"
 
 #pragma clang fp contract(off)
@@ -318,6 +320,134 @@ struct NrgbaSrc {        // *image.NRGBA frames (PNGs with alpha; *image.Palette
     }
 };
 
+struct Tap64Src {        // frames of ready-made taps: At(x, y).RGBA() as four little-endian uint16 per pixel -- what deep_expand_kernel
+                         // makes of *image.NRGBA64 / RGBA64 / Gray16 / CMYK frames.  The two dwords of a pixel ARE the tile's two planes.
+    typedef NrgbaArgs Args;
+    typedef NrgbaConv2 Conv;
+    struct Stage { v4u a[kYS], b[kYS]; };          // pixels 0 1 | 2 3 of the chunk
+    typedef const uint8_t *Bases;
+    static __device__ __forceinline__ Bases bases(const Args &A, int f) { return A.b.src + (size_t)f * A.b.src_frame_stride; }
+    static __device__ __forceinline__ void issue(const Args &A, const Tile &t, const Bases &sframe, bool valid, bool carry, int chunk, int half, Stage &st)
+    {
+        const BandArgs &a = A.b;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)sframe, 0, (a.sh - 1) * a.sstride + a.sw * 8, 0x00020000);
+        const bool row0_mine = half == 0 && !carry;                           // wave-uniform
+        const int off = valid && chunk < t.nchunk ? t.r0 * a.sstride + t.c0 * 8 + chunk * 32 : kOOB;
+#pragma unroll
+        for (int s = 0; s < kYS; s++) {
+            const bool mine = s < 4 || row0_mine;
+            const int o = mine ? off + slot_row(half, s) * a.sstride : kOOB;
+            st.a[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+            st.b[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((uint32_t)o + 16u), 0, 0);     // (kOOB + 16 stays out of range)
+        }
+    }
+    template <class RowFn>
+    static __device__ __forceinline__ void rows(const Stage &st, bool row0_mine, RowFn row)
+    {
+        auto conv = [&](int s) {
+            const v4u lo = {st.a[s][0], st.a[s][2], st.b[s][0], st.b[s][2]}, hi = {st.a[s][1], st.a[s][3], st.b[s][1], st.b[s][3]};
+            row(s, lo, hi);
+        };
+#pragma unroll
+        for (int s = 0; s < 4; s++) conv(s);
+        if (row0_mine) conv(4);
+    }
+    static __device__ __forceinline__ void touch(Stage &st)
+    {
+#pragma unroll
+        for (int q = 0; q < kYS; q++) asm volatile("" : "+v"(st.a[q]), "+v"(st.b[q]));
+    }
+};
+
+// floor(x / 0xffff) for x <= 0xffff * 0xffff (checked over every quotient boundary): color.NRGBA64.RGBA and color.CMYK.RGBA divide by it
+__device__ __forceinline__ uint32_t div_ffff(uint32_t x) { return (x + (x >> 16) + 1u) >> 16; }
+
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+
+template <int KIND>
+struct DeepSrc {         // *image.NRGBA64 / RGBA64 / Gray16 / CMYK frames as Go's Pix holds them (big-endian 16-bit channels; C M Y K bytes),
+                         // converted to At(x, y).RGBA() on the way into the tile -- the conversions of deep_expand_kernel (ipx_kernels.hip), per
+                         // source pixel, without the trip through HBM
+    typedef NrgbaArgs Args;
+    static constexpr bool kAlpha = KIND == IPX_DEEP_NRGBA64 || KIND == IPX_DEEP_RGBA64;     // the other two are opaque: three channels to interpolate
+    typedef typename std::conditional<kAlpha, NrgbaConv2, YccConv>::type Conv;
+    static constexpr int BPP = KIND == IPX_DEEP_GRAY16 ? 2 : (KIND == IPX_DEEP_CMYK ? 4 : 8);
+    struct Stage { uint32_t w[kYS][BPP]; };        // a chunk of 4 pixels is BPP dwords
+    typedef const uint8_t *Bases;
+    static __device__ __forceinline__ Bases bases(const Args &A, int f) { return A.b.src + (size_t)f * A.b.src_frame_stride; }
+    static __device__ __forceinline__ void issue(const Args &A, const Tile &t, const Bases &sframe, bool valid, bool carry, int chunk, int half, Stage &st)
+    {
+        const BandArgs &a = A.b;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)sframe, 0, (a.sh - 1) * a.sstride + a.sw * BPP, 0x00020000);
+        const bool row0_mine = half == 0 && !carry;                           // wave-uniform
+        const int off = valid && chunk < t.nchunk ? t.r0 * a.sstride + (t.c0 + chunk * 4) * BPP : kOOB;
+#pragma unroll
+        for (int s = 0; s < kYS; s++) {
+            const bool mine = s < 4 || row0_mine;
+            const int o = mine ? off + slot_row(half, s) * a.sstride : kOOB;
+            if constexpr (BPP == 2) {
+                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, o, 0, 0);
+                st.w[s][0] = v[0]; st.w[s][1] = v[1];
+            } else {
+                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) st.w[s][i] = v[i];
+                if constexpr (BPP == 8) {
+                    const v4u u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((uint32_t)o + 16u), 0, 0);     // (kOOB + 16 stays out of range)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) st.w[s][4 + i] = u[i];
+                }
+            }
+        }
+    }
+    static __device__ __forceinline__ Px convert(const uint32_t (&w)[BPP], int i)
+    {
+        Px p;
+        if constexpr (KIND == IPX_DEEP_GRAY16) {
+            const uint32_t v = w[i >> 1];
+            p.lo = __builtin_amdgcn_perm(0u, v, i & 1 ? 0x02030203u : 0x00010001u);         // {y.lo, y.hi} twice: R16 | G16 << 16
+            p.hi = __builtin_amdgcn_perm(0u, v, i & 1 ? 0x0d0d0203u : 0x0d0d0001u);         // B16 | 0xffff << 16
+        } else if constexpr (KIND == IPX_DEEP_CMYK) {
+            const uint32_t v = w[i];
+            const uint32_t wk = 0xffffu - (v >> 24) * 0x101u;
+            const uint32_t r = div_ffff(__umul24(0xffffu - (v & 0xffu) * 0x101u, wk)), g = div_ffff(__umul24(0xffffu - ((v >> 8) & 0xffu) * 0x101u, wk)),
+                           b = div_ffff(__umul24(0xffffu - ((v >> 16) & 0xffu) * 0x101u, wk));
+            p.lo = r | g << 16; p.hi = b | 0xffff0000u;
+        } else {
+            const uint32_t rg = __builtin_amdgcn_perm(0u, w[2 * i], 0x02030001u), ba = __builtin_amdgcn_perm(0u, w[2 * i + 1], 0x02030001u);   // big-endian pairs -> lo | hi << 16
+            if constexpr (KIND == IPX_DEEP_NRGBA64) {
+                const uint32_t al = ba >> 16;
+                const uint32_t r = div_ffff(__umul24(rg & 0xffffu, al)), g = div_ffff(__umul24(rg >> 16, al)), b = div_ffff(__umul24(ba & 0xffffu, al));
+                p.lo = r | g << 16; p.hi = b | (ba & 0xffff0000u);
+            } else { p.lo = rg; p.hi = ba; }
+        }
+        return p;
+    }
+    template <class RowFn>
+    static __device__ __forceinline__ void rows(const Stage &st, bool row0_mine, RowFn row)
+    {
+        auto conv = [&](int s) {
+            v4u lo, hi;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const Px p = convert(st.w[s], i);
+                lo[i] = p.lo; hi[i] = p.hi;
+            }
+            row(s, lo, hi);
+        };
+#pragma unroll
+        for (int s = 0; s < 4; s++) conv(s);
+        if (row0_mine) conv(4);
+    }
+    static __device__ __forceinline__ void touch(Stage &st)
+    {
+#pragma unroll
+        for (int q = 0; q < kYS; q++)
+#pragma unroll
+            for (int i = 0; i < BPP; i++) asm volatile("" : "+v"(st.w[q][i]));
+    }
+};
+
 // staged rows -> converted tile in LDS (kRows rows are allocated; rows past the tile hold what their loads returned and are never
 // read), and the top bytes of every row converted here -> watermark frame (rows 1..8: the halo row's pixels are stored by the item that
 // converts it; row 0 only where it is converted, i.e. not under carry).
@@ -568,6 +698,40 @@ hipError_t launch_band_nrgba_conv(const NrgbaArgs &A, hipStream_t s, bool *match
     if (total > 0x7fffffffLL || !conv_tiling_ok(a)) return hipSuccess;
     if ((((uintptr_t)a.src) | (uintptr_t)a.sstride | a.src_frame_stride) & 15) return hipSuccess;
     return launch_conv_cfg<NrgbaSrc>(A, "nrgba", total, 2 * (size_t)kRows * kConvTilePitch, s, matched);
+}
+
+// The deep source types straight from Go's Pix (a.src / a.sstride / a.src_frame_stride describe it).  Not matched (tile shape, alignment):
+// the expansion pass and launch_band_tap64_conv, then the three-kernel path.
+hipError_t launch_band_deep(const NrgbaArgs &A, int kind, hipStream_t s, bool *matched)
+{
+    const BandArgs &a = A.b;
+    *matched = false;
+    const long long total = (long long)a.nbands * a.ncolblk * a.nframes;
+    if (total <= 0) { *matched = true; return hipSuccess; }
+    if (total > 0x7fffffffLL || !conv_tiling_ok(a)) return hipSuccess;
+    if ((((uintptr_t)a.src) | (uintptr_t)a.sstride | a.src_frame_stride) & 15) return hipSuccess;
+    const size_t lds = 2 * (size_t)kRows * kConvTilePitch;
+    switch (kind) {
+    case IPX_DEEP_NRGBA64: return launch_conv_cfg<DeepSrc<IPX_DEEP_NRGBA64>>(A, "nrgba64", total, lds, s, matched);
+    case IPX_DEEP_RGBA64: return launch_conv_cfg<DeepSrc<IPX_DEEP_RGBA64>>(A, "rgba64", total, lds, s, matched);
+    case IPX_DEEP_GRAY16: return launch_conv_cfg<DeepSrc<IPX_DEEP_GRAY16>>(A, "gray16", total, lds, s, matched);
+    case IPX_DEEP_CMYK: return launch_conv_cfg<DeepSrc<IPX_DEEP_CMYK>>(A, "cmyk", total, lds, s, matched);
+    default: return hipSuccess;
+    }
+}
+
+// Frames of 16-bit taps (the deep source types after their expansion, ipx_plan_run_dev_deep): a.src / a.sstride / a.src_frame_stride
+// describe 8-byte pixels.  Not matched: the three-kernel path.
+hipError_t launch_band_tap64_conv(const NrgbaArgs &A, hipStream_t s, bool *matched)
+{
+    const BandArgs &a = A.b;
+    *matched = false;
+    const long long total = (long long)a.nbands * a.ncolblk * a.nframes;
+    if (total <= 0) { *matched = true; return hipSuccess; }
+    if (total > 0x7fffffffLL || !conv_tiling_ok(a)) return hipSuccess;
+    if ((((uintptr_t)a.src) | (uintptr_t)a.sstride | a.src_frame_stride) & 15) return hipSuccess;
+    if ((long long)(a.sh - 1) * a.sstride + (long long)a.sw * 8 > 0x7fffffffLL - 2 * kConvTilePitch) return hipSuccess;   // one descriptor spans the frame
+    return launch_conv_cfg<Tap64Src>(A, "tap64", total, 2 * (size_t)kRows * kConvTilePitch, s, matched);
 }
 
 }  // namespace ipx

@@ -99,14 +99,20 @@ struct ScaleArgs {
     size_t dst_fs, src_fs, c_fs;    // bytes between frames of a batch (grid z = frame); 0 for one frame
     int nframes;
 };
-enum { IPX_SRC_RGBA = 0, IPX_SRC_NRGBA = 1, IPX_SRC_YCBCR = 2 };
+enum { IPX_SRC_RGBA = 0, IPX_SRC_NRGBA = 1, IPX_SRC_YCBCR = 2,
+       IPX_SRC_TAP64 = 3 /* At(x, y).RGBA() as four little-endian uint16 per pixel: the deep source types after deep_expand_kernel */ };
 hipError_t launch_scale_generic(const ScaleArgs &a, hipStream_t s);
 hipError_t launch_opaque_scan(const uint8_t *src, int sw, int sh, int sstride, int *flag,
                               hipStream_t s);
+hipError_t launch_opaque_scan_tap64(const uint8_t *src, int sw, int sh, int sstride, int *flag, hipStream_t s);
 hipError_t launch_draw(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h,
                        int op, hipStream_t s);
 hipError_t launch_draw_nrgba(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h, int op,
                              hipStream_t s, int nframes = 1, size_t dst_fs = 0, size_t src_fs = 0);
+// deep source types (ipx.h IPX_DEEP_*): Go's Pix -> frames of 16-bit taps (dst rows w * 8 bytes apart), and taps -> RGBA8 (drawRGBA / drawCMYK)
+hipError_t launch_deep_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, int kind, int w, int h, int nframes, hipStream_t s);
+hipError_t launch_draw_tap64(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h, int op, hipStream_t s,
+                             int nframes = 1, size_t dst_fs = 0, size_t src_fs = 0);
 hipError_t launch_draw_ycbcr(uint8_t *dst, int dstride, const uint8_t *y, int ystride, const uint8_t *cb,
                              const uint8_t *cr, int cstride, int ratio, int spx, int spy, int w, int h, hipStream_t s,
                              int nframes = 1, size_t dst_fs = 0, size_t y_fs = 0, size_t c_fs = 0);
@@ -200,6 +206,8 @@ struct NrgbaArgs {
 };
 hipError_t launch_band_nrgba(const NrgbaArgs &a, hipStream_t s, bool *matched);
 hipError_t launch_band_nrgba_conv(const NrgbaArgs &a, hipStream_t s, bool *matched);   // ipx_band_conv.hip: premultiplied taps in a two-plane tile
+hipError_t launch_band_deep(const NrgbaArgs &a, int kind, hipStream_t s, bool *matched);   // the same kernel converting Go's Pix of a deep source type (ipx.h IPX_DEEP_*) on the fly
+hipError_t launch_band_tap64_conv(const NrgbaArgs &a, hipStream_t s, bool *matched);   // the same kernel on frames of ready-made 16-bit taps (8 bytes per pixel)
 constexpr int kConvTilePitch = 4096;   // bytes per row and plane of band_conv_kernel's LDS tile (the plan's row tables for it carry this pitch)
 // Per kernel instantiation and process: the dynamic-LDS limit is raised once (it only has to be at least what a launch asks for) and the
 // occupancy is cached per LDS size.  These are properties of the loaded function, not of the calling thread; done per thread, every

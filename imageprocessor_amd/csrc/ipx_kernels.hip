@@ -45,6 +45,9 @@ __device__ __forceinline__ Tap16 tap16(const ScaleArgs &a, int x, int y)
         t.g = (uint32_t)min(max((yy1 - 22554 * cb1 - 46802 * cr1) >> 8, 0), 0xffff);
         t.b = (uint32_t)min(max((yy1 + 116130 * cb1) >> 8, 0), 0xffff);
         t.a = 0xffffu;
+    } else if (KIND == IPX_SRC_TAP64) {
+        const uint2 p = *(const uint2 *)(a.src + (size_t)y * a.sstride + (size_t)x * 8);
+        t.r = p.x & 0xffffu; t.g = p.x >> 16; t.b = p.y & 0xffffu; t.a = p.y >> 16;
     } else {
         const uint32_t p = *(const uint32_t *)(a.src + (size_t)y * a.sstride + (size_t)x * 4);
         if (KIND == IPX_SRC_NRGBA) {
@@ -118,6 +121,16 @@ __global__ __launch_bounds__(256) void opaque_scan_kernel(const uint8_t *src, in
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
 }
 
+// (*image.NRGBA64).Opaque / (*image.RGBA64).Opaque on the frame of taps: the alpha tap is the stored alpha for both types
+__global__ __launch_bounds__(256) void opaque_scan_tap64_kernel(const uint8_t *src, int sw, int sh, int sstride, int *flag)
+{
+    const int y = blockIdx.y;
+    bool bad = false;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < sw; x += gridDim.x * 256)
+        bad |= *(const uint16_t *)(src + (size_t)y * sstride + (size_t)x * 8 + 6) != 0xffffu;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // draw: DrawMask with a nil mask on pre-clipped rectangles
 // ---------------------------------------------------------------------------------------------
@@ -172,6 +185,66 @@ __global__ __launch_bounds__(256) void draw_nrgba_kernel(uint8_t *dst, int dstri
         const uint32_t g = ((((d >> 8) & 0xffu) * al / kM + sg) >> 8) & 0xffu;
         const uint32_t b = ((((d >> 16) & 0xffu) * al / kM + sb) >> 8) & 0xffu;
         const uint32_t a = (((d >> 24) * al / kM + sa) >> 8) & 0xffu;
+        *dp = r | (g << 8) | (b << 16) | (a << 24);
+    }
+}
+
+// The deep source types (*image.NRGBA64 / RGBA64 / Gray16 from 16-bit PNGs, *image.CMYK from four-component JPEGs): no routine of
+// x/image/draw or image/draw specialises on them, every consumer reads src.At(x, y).RGBA().  One pass turns Go's Pix (big-endian
+// 16-bit channels; C M Y K bytes) into those taps, four little-endian uint16 per pixel:
+//   color.NRGBA64.RGBA  c * a / 0xffff, alpha a            color.RGBA64.RGBA  as stored
+//   color.Gray16.RGBA   (y, y, y, 0xffff)                   color.CMYK.RGBA    w = 0xffff - k * 0x101; (0xffff - c * 0x101) * w / 0xffff, alpha 0xffff
+__device__ __forceinline__ uint32_t be16x2(uint32_t v) { return __builtin_amdgcn_perm(0u, v, 0x02030001u); }   // two big-endian uint16 -> lo | hi << 16
+template <int KIND>
+__global__ __launch_bounds__(256) void deep_expand_kernel(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, int w, int h)
+{
+    const int y = blockIdx.y;
+    dst += blockIdx.z * dst_fs; src += blockIdx.z * src_fs;
+    const uint8_t *row = src + (size_t)y * sstride;
+    uint2 *out = (uint2 *)(dst + (size_t)y * w * 8);
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256) {
+        uint2 o;
+        if (KIND == IPX_DEEP_GRAY16) {
+            const uint32_t v = (uint32_t)row[2 * x] << 8 | row[2 * x + 1];
+            o.x = v | v << 16; o.y = v | 0xffff0000u;
+        } else if (KIND == IPX_DEEP_CMYK) {
+            const uint32_t p = *(const uint32_t *)(row + (size_t)x * 4);           // rows of 4-byte pixels: 4-aligned by the entry's check
+            const uint32_t wk = 0xffffu - (p >> 24) * 0x101u;
+            const uint32_t r = (0xffffu - (p & 0xffu) * 0x101u) * wk / 0xffffu, g = (0xffffu - ((p >> 8) & 0xffu) * 0x101u) * wk / 0xffffu,
+                           b = (0xffffu - ((p >> 16) & 0xffu) * 0x101u) * wk / 0xffffu;
+            o.x = r | g << 16; o.y = b | 0xffff0000u;
+        } else {
+            const uint16_t *p = (const uint16_t *)(row + (size_t)x * 8);           // (2-aligned by the entry's check)
+            const uint32_t rg = be16x2((uint32_t)p[0] | (uint32_t)p[1] << 16), ba = be16x2((uint32_t)p[2] | (uint32_t)p[3] << 16);
+            if (KIND == IPX_DEEP_NRGBA64) {
+                const uint32_t a = ba >> 16;
+                const uint32_t r = (rg & 0xffffu) * a / 0xffffu, g = (rg >> 16) * a / 0xffffu, b = (ba & 0xffffu) * a / 0xffffu;
+                o.x = r | g << 16; o.y = b | a << 16;
+            } else { o.x = rg; o.y = ba; }
+        }
+        out[x] = o;
+    }
+}
+
+// image/draw drawRGBA with a nil mask (and drawCMYK, whose CMYKToRGB is the top byte of color.CMYK.RGBA with alpha 0xffff) on frames of
+// taps: Src keeps the top byte of every tap; Over: a = (m - sa) * 0x101, d = uint8((d * a + s * m) / m >> 8), uint32 wrap-around as in Go
+__global__ __launch_bounds__(256) void draw_tap64_kernel(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h, int op,
+                                                         size_t dst_fs, size_t src_fs)
+{
+    const int y = blockIdx.y;
+    if (y >= h) return;
+    dst += blockIdx.z * dst_fs; src += blockIdx.z * src_fs;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256) {
+        const uint2 t = *(const uint2 *)(src + (size_t)y * sstride + (size_t)x * 8);
+        uint32_t *dp = (uint32_t *)(dst + (size_t)y * dstride + (size_t)x * 4);
+        if (op == IPX_OP_SRC) { *dp = __builtin_amdgcn_perm(t.y, t.x, 0x07050301u); continue; }
+        const uint32_t d = *dp;
+        const uint32_t sr = t.x & 0xffffu, sg = t.x >> 16, sb = t.y & 0xffffu, sa = t.y >> 16;
+        const uint32_t al = (kM - sa) * 0x101u;
+        const uint32_t r = ((((d & 0xffu) * al + sr * kM) / kM) >> 8) & 0xffu;
+        const uint32_t g = (((((d >> 8) & 0xffu) * al + sg * kM) / kM) >> 8) & 0xffu;
+        const uint32_t b = (((((d >> 16) & 0xffu) * al + sb * kM) / kM) >> 8) & 0xffu;
+        const uint32_t a = ((((d >> 24) * al + sa * kM) / kM) >> 8) & 0xffu;
         *dp = r | (g << 8) | (b << 16) | (a << 24);
     }
 }
@@ -268,6 +341,7 @@ hipError_t launch_scale_generic(const ScaleArgs &a, hipStream_t s)
     dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4, a.nframes > 0 ? a.nframes : 1);
     if (a.kind == IPX_SRC_NRGBA) hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_NRGBA>, grid, block, 0, s, a);
     else if (a.kind == IPX_SRC_YCBCR) hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_YCBCR>, grid, block, 0, s, a);
+    else if (a.kind == IPX_SRC_TAP64) hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_TAP64>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_RGBA>, grid, block, 0, s, a);
     return hipGetLastError();
 }
@@ -278,6 +352,29 @@ hipError_t launch_draw_nrgba(uint8_t *dst, int dstride, const uint8_t *src, int 
     if (w <= 0 || h <= 0 || nframes <= 0) return hipSuccess;
     dim3 grid(min(8, (w + 255) / 256), h, nframes);
     hipLaunchKernelGGL(draw_nrgba_kernel, grid, dim3(256), 0, s, dst, dstride, src, sstride, w, h, op, dst_fs, src_fs);
+    return hipGetLastError();
+}
+
+hipError_t launch_deep_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, int kind, int w, int h, int nframes, hipStream_t s)
+{
+    if (w <= 0 || h <= 0 || nframes <= 0) return hipSuccess;
+    dim3 grid(min(2, (w + 255) / 256), h, nframes);   // a few pixels per thread: a workgroup per 256 pixels was launch-bound
+    switch (kind) {
+    case IPX_DEEP_NRGBA64: hipLaunchKernelGGL(deep_expand_kernel<IPX_DEEP_NRGBA64>, grid, dim3(256), 0, s, dst, dst_fs, src, sstride, src_fs, w, h); break;
+    case IPX_DEEP_RGBA64: hipLaunchKernelGGL(deep_expand_kernel<IPX_DEEP_RGBA64>, grid, dim3(256), 0, s, dst, dst_fs, src, sstride, src_fs, w, h); break;
+    case IPX_DEEP_GRAY16: hipLaunchKernelGGL(deep_expand_kernel<IPX_DEEP_GRAY16>, grid, dim3(256), 0, s, dst, dst_fs, src, sstride, src_fs, w, h); break;
+    case IPX_DEEP_CMYK: hipLaunchKernelGGL(deep_expand_kernel<IPX_DEEP_CMYK>, grid, dim3(256), 0, s, dst, dst_fs, src, sstride, src_fs, w, h); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_draw_tap64(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h, int op, hipStream_t s, int nframes,
+                             size_t dst_fs, size_t src_fs)
+{
+    if (w <= 0 || h <= 0 || nframes <= 0) return hipSuccess;
+    dim3 grid(min(2, (w + 255) / 256), h, nframes);   // a few pixels per thread: a workgroup per 256 pixels was launch-bound
+    hipLaunchKernelGGL(draw_tap64_kernel, grid, dim3(256), 0, s, dst, dstride, src, sstride, w, h, op, dst_fs, src_fs);
     return hipGetLastError();
 }
 
@@ -351,6 +448,16 @@ hipError_t launch_opaque_scan(const uint8_t *src, int sw, int sh, int sstride, i
     if (sw <= 0 || sh <= 0) return hipSuccess;
     dim3 grid(min(8, (sw + 255) / 256), sh);
     hipLaunchKernelGGL(opaque_scan_kernel, grid, dim3(256), 0, s, src, sw, sh, sstride, flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_opaque_scan_tap64(const uint8_t *src, int sw, int sh, int sstride, int *flag, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(flag, 1, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    if (sw <= 0 || sh <= 0) return hipSuccess;
+    dim3 grid(min(8, (sw + 255) / 256), sh);
+    hipLaunchKernelGGL(opaque_scan_tap64_kernel, grid, dim3(256), 0, s, src, sw, sh, sstride, flag);
     return hipGetLastError();
 }
 

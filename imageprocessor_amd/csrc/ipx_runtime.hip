@@ -76,6 +76,9 @@ int dev_draw_src(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect 
     else if (src.kind == IPX_SRC_NRGBA)
         IPX_HIP(launch_draw_nrgba(d, dstride, src.pix + (size_t)spy * src.stride + (size_t)spx * 4, src.stride, r.dx(),
                                   r.dy(), op, s, src.nframes, dst_fs, src.frame_stride));
+    else if (src.kind == IPX_SRC_TAP64)
+        IPX_HIP(launch_draw_tap64(d, dstride, src.pix + (size_t)spy * src.stride + (size_t)spx * 8, src.stride, r.dx(), r.dy(), op, s,
+                                  src.nframes, dst_fs, src.frame_stride));
     else
         IPX_HIP(launch_draw(d, dstride, src.pix + (size_t)spy * src.stride + (size_t)spx * 4, src.stride, r.dx(), r.dy(),
                             op, s));
@@ -91,7 +94,8 @@ int dev_scale_src(hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int ds
     if (pr.copy) return dev_draw_src(s, dst, dw, dh, dstride, dr, src, sr.x0, sr.y0, op, dst_fs);
     if (pr.empty) return IPX_OK;
     if (src.kind == IPX_SRC_YCBCR) op = IPX_OP_SRC;   // (*image.YCbCr).Opaque() is always true
-    if (op == IPX_OP_OVER) IPX_HIP(launch_opaque_scan(src.pix, src.w, src.h, src.stride, flag, s));  // RGBA and NRGBA: alpha scan
+    if (op == IPX_OP_OVER && src.kind == IPX_SRC_TAP64) IPX_HIP(launch_opaque_scan_tap64(src.pix, src.w, src.h, src.stride, flag, s));
+    else if (op == IPX_OP_OVER) IPX_HIP(launch_opaque_scan(src.pix, src.w, src.h, src.stride, flag, s));  // RGBA and NRGBA: alpha scan
     ScaleArgs a;
     a.dst = dst; a.dstride = dstride; a.src = src.pix; a.sstride = src.stride;
     a.dr_x0 = dr.x0; a.dr_y0 = dr.y0;
@@ -706,6 +710,58 @@ int ipx_draw_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx
 }
 IPX_CATCH_STATUS
 
+// a deep frame from host memory -> frame of taps in the lane's scratch (the Pix copy sits behind it)
+static int upload_deep(hipStream_t s, const uint8_t *src, int sw, int sh, int sstride, int kind, uint8_t *dsrc, DevSrc *out)
+{
+    const int bpp = kind == IPX_DEEP_GRAY16 ? 2 : (kind == IPX_DEEP_CMYK ? 4 : 8);
+    uint8_t *pix = dsrc + align256((size_t)sw * sh * 8);
+    IPX_HIP(hipMemcpy2DAsync(pix, (size_t)sw * bpp, src, sstride, (size_t)sw * bpp, sh, hipMemcpyHostToDevice, s));
+    IPX_HIP(launch_deep_expand(dsrc, 0, pix, sw * bpp, 0, kind, sw, sh, 1, s));
+    out->kind = IPX_SRC_TAP64; out->pix = dsrc; out->stride = sw * 8; out->w = sw; out->h = sh;
+    return IPX_OK;
+}
+static int deep_args_status(const char *who, const void *dst, int dw, int dh, int dstride, const void *src, int sw, int sh, int sstride, int kind)
+{
+    if (kind != IPX_DEEP_NRGBA64 && kind != IPX_DEEP_RGBA64 && kind != IPX_DEEP_GRAY16 && kind != IPX_DEEP_CMYK) {
+        set_error("%s: unknown source type %d", who, kind);
+        return IPX_ERR_INVALID;
+    }
+    int rc = frame_status(who, "destination", dst, dw, dh, dstride);
+    if (!rc) rc = frame_status(who, "source", src, sw, sh, sstride, kind == IPX_DEEP_GRAY16 ? 2 : (kind == IPX_DEEP_CMYK ? 4 : 8));
+    if (!rc) rc = frame_status(who, "source", src, sw, sh, (long long)sw * 8, 8);       // the frame of taps
+    return rc;
+}
+
+int ipx_scale_bilinear_deep(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr, const uint8_t *src, int sw, int sh,
+                            int sstride, int kind, ipx_rect sr, int op) try
+{
+    IPX_ENTER(ctx);
+    const int rc = deep_args_status("ipx_scale_bilinear_deep", dst, dw, dh, dstride, src, sw, sh, sstride, kind);
+    if (rc) return rc;
+    if (!dw || !dh || !sw || !sh) return IPX_OK;
+    return stage_and_run(ctx, dst, dw, dh, dstride, align256((size_t)sw * sh * 8) * 2, [&](hipStream_t s, int *flag, uint8_t *ddst, uint8_t *dsrc) -> int {
+        DevSrc t;
+        const int r2 = upload_deep(s, src, sw, sh, sstride, kind, dsrc, &t);
+        return r2 ? r2 : dev_scale_src(s, flag, ddst, dw, dh, dw * 4, to_rect(dr), t, to_rect(sr), op);
+    });
+}
+IPX_CATCH_STATUS
+
+int ipx_draw_deep(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r, const uint8_t *src, int sw, int sh, int sstride,
+                  int kind, int spx, int spy, int op) try
+{
+    IPX_ENTER(ctx);
+    const int rc = deep_args_status("ipx_draw_deep", dst, dw, dh, dstride, src, sw, sh, sstride, kind);
+    if (rc) return rc;
+    if (!dw || !dh || !sw || !sh) return IPX_OK;
+    return stage_and_run(ctx, dst, dw, dh, dstride, align256((size_t)sw * sh * 8) * 2, [&](hipStream_t s, int *, uint8_t *ddst, uint8_t *dsrc) -> int {
+        DevSrc t;
+        const int r2 = upload_deep(s, src, sw, sh, sstride, kind, dsrc, &t);
+        return r2 ? r2 : dev_draw_src(s, ddst, dw, dh, dw * 4, to_rect(r), t, spx, spy, op);
+    });
+}
+IPX_CATCH_STATUS
+
 int ipx_scale_bilinear_ycbcr(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
                              const ipx_ycbcr *src, ipx_rect sr) try
 {
@@ -1171,12 +1227,14 @@ IPX_CATCH_STATUS
 // Frames in host memory, any packed source type: chunks over the lanes so that H2D of one chunk, the kernel of another and D2H of
 // a third overlap.  kind: IPX_SRC_RGBA / IPX_SRC_NRGBA (4 bytes per pixel), IPX_GRAY (1), kPalettedKind (1 + 1 KiB palette per frame).
 constexpr int kPalettedKind = 100;
+constexpr int kDeepKind = 200;    // + IPX_DEEP_*
+static int deep_bpp(int kind) { return kind == IPX_DEEP_GRAY16 ? 2 : (kind == IPX_DEEP_CMYK ? 4 : 8); }
 static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, const uint8_t *src, int sstride, size_t src_frame_stride,
                            const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                            size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride, const char *who)
 {
     const int sw = pl->p.sw, sh = pl->p.sh;
-    const int bpp = kind == IPX_SRC_RGBA || kind == IPX_SRC_NRGBA ? 4 : 1;
+    const int bpp = kind >= kDeepKind ? deep_bpp(kind - kDeepKind) : (kind == IPX_SRC_RGBA || kind == IPX_SRC_NRGBA ? 4 : 1);
     // device-side frame strides: tight when that keeps rows 16-byte aligned (then a whole chunk moves
     // with one copy per direction and buffer), padded to 256 otherwise
     auto dstride = [](size_t bytes) { return (bytes & 15) == 0 ? bytes : align256(bytes); };
@@ -1275,7 +1333,8 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
         case IPX_SRC_RGBA: rc = ipx_plan_run_dev(ctx, l.stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm); break;
         case IPX_SRC_NRGBA: rc = ipx_plan_run_dev_nrgba(ctx, l.stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm); break;
         case IPX_GRAY: rc = ipx_plan_run_dev_gray(ctx, l.stream, pl, m, dsrc, sw, fsrc, dres, fres, dth, fth, dwm, fwm); break;
-        default: rc = ipx_plan_run_dev_paletted(ctx, l.stream, pl, m, dsrc, sw, fsrc, dpal, dres, fres, dth, fth, dwm, fwm); break;
+        case kPalettedKind: rc = ipx_plan_run_dev_paletted(ctx, l.stream, pl, m, dsrc, sw, fsrc, dpal, dres, fres, dth, fth, dwm, fwm); break;
+        default: rc = ipx_plan_run_dev_deep(ctx, l.stream, pl, m, kind - kDeepKind, dsrc, sw * bpp, fsrc, dres, fres, dth, fth, dwm, fwm); break;
         }
         if (rc) break;
         if (bounce) {          // one copy of the three outputs (they follow the source in the lane's scratch), handed out after the sync below
@@ -1630,6 +1689,129 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     }
     if (scratch) (void)hipFreeAsync(scratch, s);
     return rc;
+}
+IPX_CATCH_STATUS
+
+// The deep source types: one expansion pass to frames of 16-bit taps (what every consumer of these types reads: At(x, y).RGBA()), then
+// the converted-tile kernel on them, or the three-kernel path -- top bytes into the watermark frames (drawRGBA / drawCMYK with Src), the
+// crop thumbnail from those RGBA8 frames, the text pass, and the per-tap scale from the taps.
+int ipx_plan_run_dev_deep(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, int kind, const uint8_t *src, int sstride, size_t src_frame_stride,
+                          uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                          size_t wm_frame_stride) try
+{
+    IPX_ENTER(ctx);
+    if (kind != IPX_DEEP_NRGBA64 && kind != IPX_DEEP_RGBA64 && kind != IPX_DEEP_GRAY16 && kind != IPX_DEEP_CMYK) {
+        set_error("ipx_plan_run_dev_deep: unknown source type %d", kind);
+        return IPX_ERR_INVALID;
+    }
+    const int bpp = deep_bpp(kind);
+    const uintptr_t al = kind == IPX_DEEP_CMYK ? 3 : 1;
+    if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * bpp || ((((uintptr_t)src) | (uintptr_t)sstride | src_frame_stride) & al)) {
+        set_error("ipx_plan_run_dev_deep: bad argument");
+        return IPX_ERR_INVALID;
+    }
+    IPX_PLAN_SRC("ipx_plan_run_dev_deep", pl, sstride, bpp);
+    IPX_PLAN_SRC("ipx_plan_run_dev_deep", pl, (long long)pl->p.sw * 8, 8);        // the frames of taps
+    if (n == 0) return IPX_OK;
+    if (n > 65535) { set_error("ipx_plan_run_dev_deep: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    uint8_t *res = pl->sc[0].on ? resize_out : nullptr;
+    uint8_t *th = pl->sc[1].on ? thumb_out : nullptr;
+    uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
+    if (!res && !th && !wm) return IPX_OK;
+    const bool crop_thumb = th && pl->p.crop_to_fit;
+    // one fused pass straight from Go's Pix when the tile shape and the alignments allow it
+    if (pl->fused && env_int("IPX_DEEP_FUSED", 1) && env_int("IPX_DEEP_DIRECT", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
+        NrgbaArgs A{};
+        BandArgs &a = A.b;
+        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, IPX_FUSED_GLYPHS_CONV, a, A.mode);
+        a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
+        bool matched = false;
+        IPX_HIP(launch_band_deep(A, kind, s, &matched));
+        if (matched) IPX_HIP(composite_after(pl, IPX_FUSED_GLYPHS_CONV, wm, wm_frame_stride, n, s));
+        if (matched) return IPX_OK;
+    }
+    const size_t tfs = align256((size_t)sw * sh * 8);
+    uint8_t *taps = nullptr;
+    IPX_HIP(hipMallocAsync((void **)&taps, tfs * n, s));
+    struct Free { uint8_t *p; hipStream_t s; ~Free() { if (p) (void)hipFreeAsync(p, s); } } free_taps{taps, s}, free_scratch{nullptr, s};
+    {
+        hipError_t e = launch_deep_expand(taps, tfs, src, sstride, src_frame_stride, kind, sw, sh, n, s);
+        if (e != hipSuccess) { set_error("tap expansion failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
+    }
+    if (pl->fused && env_int("IPX_DEEP_FUSED", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
+        NrgbaArgs A{};
+        BandArgs &a = A.b;
+        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, IPX_FUSED_GLYPHS_CONV, a, A.mode);
+        a.src = taps; a.src_frame_stride = tfs; a.sstride = sw * 8;
+        bool matched = false;
+        IPX_HIP(launch_band_tap64_conv(A, s, &matched));
+        if (matched) IPX_HIP(composite_after(pl, IPX_FUSED_GLYPHS_CONV, wm, wm_frame_stride, n, s));
+        if (matched) return IPX_OK;
+    }
+    uint8_t *conv = wm;
+    size_t conv_fs = wm_frame_stride;
+    if (!conv && crop_thumb) {
+        conv_fs = (size_t)sw * sh * 4;
+        IPX_HIP(hipMallocAsync((void **)&free_scratch.p, conv_fs * n, s));
+        conv = free_scratch.p;
+    }
+    int rc = IPX_OK;
+    if (conv) {
+        hipError_t e = launch_draw_tap64(conv, sw * 4, taps, sw * 8, sw, sh, IPX_OP_SRC, s, n, conv_fs, tfs);
+        if (e != hipSuccess) { set_error("tap narrowing failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
+    }
+    if (crop_thumb) {
+        ipx_plan *sub = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(pl->mu);
+            if (!pl->thumb_only) {
+                ipx_plan_params tp;
+                memset(&tp, 0, sizeof tp);
+                tp.sw = sw; tp.sh = sh; tp.do_thumbnail = 1; tp.thumb_size = pl->p.thumb_size; tp.crop_to_fit = 1;
+                rc = ipx_plan_create(ctx, &tp, &pl->thumb_only);
+            }
+            sub = pl->thumb_only;
+        }
+        if (!rc) rc = ipx_plan_run_dev(ctx, s, sub, n, conv, sw * 4, conv_fs, nullptr, 0, th, thumb_frame_stride, nullptr, 0);
+    }
+    if (!rc && wm && pl->glyphs.n && pl->p.glyphs) {
+        const uint8_t *c = pl->p.glyphs->col;
+        hipError_t e = launch_composite(wm, sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox,
+                                        c[0] * 0x101u, c[1] * 0x101u, c[2] * 0x101u, c[3] * 0x101u, s);
+        if (e != hipSuccess) { set_error("composite launch failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
+    }
+    DevSrc tsrc;
+    tsrc.kind = IPX_SRC_TAP64; tsrc.pix = taps; tsrc.stride = sw * 8; tsrc.w = sw; tsrc.h = sh;
+    tsrc.nframes = n; tsrc.frame_stride = tfs;
+    for (int k = 0; k < 2 && !rc; k++) {   // 16-bit taps; Over onto the zeroed frame == Src
+        const PlanScale &ps = pl->sc[k];
+        uint8_t *o = k == 0 ? res : (crop_thumb ? nullptr : th);
+        const size_t ofs = k == 0 ? resize_frame_stride : thumb_frame_stride;
+        if (!o || ps.dw <= 0 || ps.dh <= 0) continue;
+        rc = dev_scale_src(s, nullptr, o, ps.dw, ps.dh, ps.dw * 4, Rect{0, 0, ps.dw, ps.dh}, tsrc, ps.sr, IPX_OP_SRC, ofs);
+    }
+    return rc;
+}
+IPX_CATCH_STATUS
+
+int ipx_plan_run_host_deep(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, const uint8_t *src, int sstride, size_t src_frame_stride,
+                           uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
+                           size_t wm_frame_stride) try
+{
+    IPX_ENTER(ctx);
+    if (kind != IPX_DEEP_NRGBA64 && kind != IPX_DEEP_RGBA64 && kind != IPX_DEEP_GRAY16 && kind != IPX_DEEP_CMYK) {
+        set_error("ipx_plan_run_host_deep: unknown source type %d", kind);
+        return IPX_ERR_INVALID;
+    }
+    const int bpp = deep_bpp(kind);
+    if (!pl || n < 0 || !src || (long long)sstride < (long long)pl->p.sw * bpp) { set_error("ipx_plan_run_host_deep: bad argument"); return IPX_ERR_INVALID; }
+    IPX_PLAN_SRC("ipx_plan_run_host_deep", pl, sstride, bpp);
+    IPX_PLAN_SRC("ipx_plan_run_host_deep", pl, (long long)pl->p.sw * 8, 8);
+    if (n == 0) return IPX_OK;
+    return run_host_packed(ctx, pl, n, kDeepKind + kind, src, sstride, src_frame_stride, nullptr, resize_out, resize_frame_stride, thumb_out,
+                           thumb_frame_stride, wm_out, wm_frame_stride, "ipx_plan_run_host_deep");
 }
 IPX_CATCH_STATUS
 

@@ -274,6 +274,28 @@ int ipx_plan_run_host_gray(ipx_ctx *ctx, const ipx_plan *plan, int n, const uint
 int ipx_plan_run_host_paletted(ipx_ctx *ctx, const ipx_plan *plan, int n, const uint8_t *index, int stride, size_t frame_stride,
                                const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                                size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
+/* The remaining image types image.Decode returns (image_processor.go:47) -- *image.NRGBA64, *image.RGBA64, *image.Gray16 from 16-bit
+ * PNGs, *image.CMYK from four-component JPEGs ("deep" sources; SURVEY.md 8(f) N2 tail).  resizeImage (resize.go:121-125) takes them
+ * through x/image's generic scale_RGBA_Image_{Src,Over}, which reads every tap as src.At(x, y).RGBA() at full 16-bit precision; the
+ * crop copy (thumbnail.go:128-130) and draw.Draw (watermark.go:92) go through image/draw's drawRGBA (drawCMYK for CMYK) and keep the
+ * top byte of the same value.  `src` is Go's Pix for the type: big-endian 16-bit channels R G B A (8 bytes per pixel; NRGBA64 not
+ * premultiplied, RGBA64 premultiplied), big-endian Y (2 bytes), or C M Y K bytes (4); rows `sstride` bytes apart, 2-byte aligned
+ * (CMYK: 4).  One pass expands the frames to those 16-bit taps in HBM (8 bytes per pixel); the fused converted-tile kernel then reads
+ * them as they are.  Bit for bit the generic routines' outputs (tests/test_deep_gpu.py against the oracle's restatement). */
+enum { IPX_DEEP_NRGBA64 = 0, IPX_DEEP_RGBA64 = 1, IPX_DEEP_GRAY16 = 2, IPX_DEEP_CMYK = 3 };
+/* the per-operation seam for these types (host pointers, one frame; like ipx_scale_bilinear_nrgba8 / ipx_draw_nrgba8): Scale with any
+ * rectangles and either op -- Over turns into Src when (*NRGBA64).Opaque / (*RGBA64).Opaque holds, Gray16 and CMYK are opaque -- and
+ * draw.Draw (drawRGBA; drawCMYK for CMYK) */
+int ipx_scale_bilinear_deep(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr, const uint8_t *src, int sw, int sh,
+                            int sstride, int kind, ipx_rect sr, int op);
+int ipx_draw_deep(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r, const uint8_t *src, int sw, int sh, int sstride,
+                  int kind, int spx, int spy, int op);
+int ipx_plan_run_dev_deep(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, int kind, const uint8_t *src, int sstride,
+                          size_t src_frame_stride, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
+                          size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
+int ipx_plan_run_host_deep(ipx_ctx *ctx, const ipx_plan *plan, int n, int kind, const uint8_t *src, int sstride,
+                           size_t src_frame_stride, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
+                           size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
 int ipx_plan_run_host_ycbcr(ipx_ctx *ctx, const ipx_plan *plan, int n, const ipx_ycbcr_batch *src,
                             uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                             size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);

@@ -233,6 +233,12 @@ def _decl_variants():
     L.ipxo_scale_bilinear_paletted.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, Rect, C.c_int]
     L.ipxo_draw_paletted.restype = None
     L.ipxo_draw_paletted.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.ipxo_scale_bilinear_deep.restype = C.c_int
+    L.ipxo_scale_bilinear_deep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, Rect, C.c_int]
+    L.ipxo_draw_deep.restype = None
+    L.ipxo_draw_deep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ipxo_deep_taps.restype = None
+    L.ipxo_deep_taps.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L._variants = True
     return L
 
@@ -257,6 +263,52 @@ def draw_nrgba(dst, r, src, sp=(0, 0), op=OP_SRC):
     sh, sw = src.shape[:2]
     _decl_variants().ipxo_draw_nrgba8(dst.ctypes.data, dw, dh, dw * 4, _rect(r), src.ctypes.data, sw, sh, sw * 4,
                                       int(sp[0]), int(sp[1]), op)
+    return dst
+
+
+DEEP_NRGBA64, DEEP_RGBA64, DEEP_GRAY16, DEEP_CMYK = 0, 1, 2, 3
+DEEP_BPP = {DEEP_NRGBA64: 8, DEEP_RGBA64: 8, DEEP_GRAY16: 2, DEEP_CMYK: 4}
+
+
+def deep_pix(values, kind):
+    """Go's Pix for a deep image: `values` (h, w, 4) uint16 for NRGBA64 / RGBA64, (h, w) uint16 for Gray16 -> big-endian bytes;
+    (h, w, 4) uint8 C M Y K for CMYK -> as is.  Returns (h, w * bpp) uint8."""
+    v = np.asarray(values)
+    if kind == DEEP_CMYK:
+        return np.ascontiguousarray(v, np.uint8).reshape(v.shape[0], -1)
+    return np.ascontiguousarray(v.astype(">u2")).view(np.uint8).reshape(v.shape[0], -1)
+
+
+def _deep(src, kind):
+    src = np.ascontiguousarray(src, np.uint8)
+    sh, row = src.shape
+    return src, row // DEEP_BPP[kind], sh, row
+
+
+def deep_taps(src, kind):
+    """At(x, y).RGBA() of every pixel of a deep frame (Pix rows as deep_pix makes them) -> (h, w, 4) uint16."""
+    src, sw, sh, row = _deep(src, kind)
+    out = np.zeros((sh, sw, 4), np.uint16)
+    _decl_variants().ipxo_deep_taps(out.ctypes.data, src.ctypes.data, sw, sh, row, kind)
+    return out
+
+
+def scale_bilinear_deep(src, kind, dw, dh, sr=None, dr=None, op=OP_OVER, dst=None):
+    src, sw, sh, row = _deep(src, kind)
+    if dst is None:
+        dst = np.zeros((dh, dw, 4), np.uint8)
+    dst = _u8(dst)
+    rc = _decl_variants().ipxo_scale_bilinear_deep(dst.ctypes.data, dw, dh, dw * 4, _rect(dr if dr is not None else (0, 0, dw, dh)),
+                                                   src.ctypes.data, sw, sh, row, kind, _rect(sr if sr is not None else (0, 0, sw, sh)), op)
+    if rc:
+        raise ValueError("source rectangle leaves the source image")
+    return dst
+
+
+def draw_deep(dst, r, src, kind, sp=(0, 0), op=OP_SRC):
+    src, sw, sh, row = _deep(src, kind)
+    dh, dw = dst.shape[:2]
+    _decl_variants().ipxo_draw_deep(dst.ctypes.data, dw, dh, dw * 4, _rect(r), src.ctypes.data, sw, sh, row, kind, int(sp[0]), int(sp[1]), op)
     return dst
 
 

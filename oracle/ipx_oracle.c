@@ -634,3 +634,113 @@ int ipxo_scale_bilinear_paletted(uint8_t *dst, int dw, int dh, int dstride, ipxo
     scale_core(dst, dstride, dr, adr, &p, tap_paletted, sr, op);
     return 0;
 }
+
+/* ---- the 16-bit image types of the PNG decoder and *image.CMYK ("deep" sources) -----------------------------
+ * image.Decode returns *image.NRGBA64 (16-bit truecolour / gray with alpha or tRNS), *image.RGBA64 (16-bit truecolour), *image.Gray16
+ * (16-bit gray) for PNGs and *image.CMYK for four-component JPEGs (image_processor.go:47).  No routine of x/image/draw or image/draw
+ * specialises on the first three: scale_RGBA_Image_{Src,Over} read every tap as src.At(x, y).RGBA() and DrawMask falls to drawRGBA
+ * (restated for *image.Paletted above; the same code runs here).  *image.CMYK has drawCMYK = color.CMYKToRGB per pixel, which is the
+ * top byte of color.CMYK.RGBA().  Pix layouts are Go's: big-endian 16-bit channels (R G B A / Y), C M Y K bytes.
+ *   color.NRGBA64.RGBA: c * a / 0xffff, alpha a        color.RGBA64.RGBA: as stored
+ *   color.Gray16.RGBA:  (y, y, y, 0xffff)               color.CMYK.RGBA:   w = 0xffff - k*0x101; (0xffff - c*0x101) * w / 0xffff, alpha 0xffff */
+int ipxo_deep_bpp(int kind) { return kind == IPXO_DEEP_GRAY16 ? 2 : (kind == IPXO_DEEP_CMYK ? 4 : 8); }
+
+typedef struct { const uint8_t *pix; int stride, kind; } deep_src;
+
+static void deep_rgba(int kind, const uint8_t *p, uint32_t out[4])
+{
+    if (kind == IPXO_DEEP_GRAY16) {
+        out[0] = out[1] = out[2] = (uint32_t)p[0] << 8 | p[1];
+        out[3] = 0xffff;
+    } else if (kind == IPXO_DEEP_CMYK) {
+        const uint32_t w = 0xffff - (uint32_t)p[3] * 0x101;
+        out[0] = (0xffff - (uint32_t)p[0] * 0x101) * w / 0xffff;
+        out[1] = (0xffff - (uint32_t)p[1] * 0x101) * w / 0xffff;
+        out[2] = (0xffff - (uint32_t)p[2] * 0x101) * w / 0xffff;
+        out[3] = 0xffff;
+    } else {
+        const uint32_t r = (uint32_t)p[0] << 8 | p[1], g = (uint32_t)p[2] << 8 | p[3], b = (uint32_t)p[4] << 8 | p[5], a = (uint32_t)p[6] << 8 | p[7];
+        if (kind == IPXO_DEEP_NRGBA64) { out[0] = r * a / 0xffff; out[1] = g * a / 0xffff; out[2] = b * a / 0xffff; }
+        else { out[0] = r; out[1] = g; out[2] = b; }
+        out[3] = a;
+    }
+}
+
+static void tap_deep(const void *s, int x, int y, uint32_t out[4])
+{
+    const deep_src *d = (const deep_src *)s;
+    deep_rgba(d->kind, d->pix + (size_t)y * d->stride + (size_t)x * ipxo_deep_bpp(d->kind), out);
+}
+
+/* At(x, y).RGBA() of every pixel, as little-endian uint16 quadruples (what the product's expansion kernel must produce) */
+void ipxo_deep_taps(uint16_t *out, const uint8_t *src, int sw, int sh, int sstride, int kind)
+{
+    int x, y, c;
+    for (y = 0; y < sh; y++)
+        for (x = 0; x < sw; x++) {
+            uint32_t t[4];
+            deep_rgba(kind, src + (size_t)y * sstride + (size_t)x * ipxo_deep_bpp(kind), t);
+            for (c = 0; c < 4; c++) out[((size_t)y * sw + x) * 4 + c] = (uint16_t)t[c];
+        }
+}
+
+void ipxo_draw_deep(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r, const uint8_t *src, int sw, int sh, int sstride, int kind,
+                    int spx, int spy, int op)
+{
+    const uint32_t m = 0xffff, ma = 0xffff;
+    const int bpp = ipxo_deep_bpp(kind);
+    ipxo_rect db = {0, 0, dw, dh}, sb = {0, 0, sw, sh};
+    int ox = r.x0, oy = r.y0, x, y, c;
+    r = rect_intersect(r, db);
+    r = rect_intersect(r, rect_add(sb, ox - spx, oy - spy));
+    if (rect_empty(r)) return;
+    spx += r.x0 - ox;
+    spy += r.y0 - oy;
+    for (y = 0; y < r.y1 - r.y0; y++) {
+        uint8_t *d = dst + (size_t)(r.y0 + y) * dstride + (size_t)r.x0 * 4;
+        for (x = 0; x < r.x1 - r.x0; x++, d += 4) {
+            uint32_t s[4];
+            deep_rgba(kind, src + (size_t)(spy + y) * sstride + (size_t)(spx + x) * bpp, s);
+            if (kind == IPXO_DEEP_CMYK) {           /* drawCMYK, for either op: CMYKToRGB, alpha 255 */
+                d[0] = (uint8_t)(s[0] >> 8); d[1] = (uint8_t)(s[1] >> 8); d[2] = (uint8_t)(s[2] >> 8); d[3] = 255;
+            } else if (op == IPXO_OP_SRC) {         /* drawRGBA */
+                for (c = 0; c < 4; c++) d[c] = (uint8_t)(s[c] * ma / m >> 8);
+            } else {
+                uint32_t a = (m - (s[3] * ma / m)) * 0x101;
+                for (c = 0; c < 4; c++) d[c] = (uint8_t)(((uint32_t)d[c] * a + s[c] * ma) / m >> 8);
+            }
+        }
+    }
+}
+
+/* (*NRGBA64).Opaque / (*RGBA64).Opaque: both alpha bytes 0xff everywhere; Gray16 and CMYK are opaque */
+static int deep_opaque(const uint8_t *src, int sw, int sh, int sstride, int kind)
+{
+    int x, y;
+    if (kind == IPXO_DEEP_GRAY16 || kind == IPXO_DEEP_CMYK) return 1;
+    for (y = 0; y < sh; y++)
+        for (x = 0; x < sw; x++) {
+            const uint8_t *p = src + (size_t)y * sstride + (size_t)x * 8;
+            if (p[6] != 0xff || p[7] != 0xff) return 0;
+        }
+    return 1;
+}
+
+int ipxo_scale_bilinear_deep(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr, const uint8_t *src, int sw, int sh, int sstride,
+                             int kind, ipxo_rect sr, int op)
+{
+    ipxo_rect db = {0, 0, dw, dh}, adr;
+    deep_src p;
+    if (dr.x1 - dr.x0 == sr.x1 - sr.x0 && dr.y1 - dr.y0 == sr.y1 - sr.y0) {
+        ipxo_draw_deep(dst, dw, dh, dstride, dr, src, sw, sh, sstride, kind, sr.x0, sr.y0, op);
+        return 0;
+    }
+    adr = rect_intersect(db, dr);
+    if (rect_empty(adr) || rect_empty(sr)) return 0;
+    adr = rect_add(adr, -dr.x0, -dr.y0);
+    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) return -1;
+    if (op == IPXO_OP_OVER && deep_opaque(src, sw, sh, sstride, kind)) op = IPXO_OP_SRC;
+    p.pix = src; p.stride = sstride; p.kind = kind;
+    scale_core(dst, dstride, dr, adr, &p, tap_deep, sr, op);
+    return 0;
+}

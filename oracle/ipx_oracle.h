@@ -102,6 +102,16 @@ int ipxo_scale_bilinear_paletted(uint8_t *dst, int dw, int dh, int dstride, ipxo
 void ipxo_draw_paletted(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r, const uint8_t *src, int sw, int sh,
                         int sstride, const uint16_t pal16[256][4], int spx, int spy, int op);
 
+/* *image.NRGBA64 / *image.RGBA64 / *image.Gray16 (16-bit PNGs) and *image.CMYK through the generic routines (CMYK: drawCMYK); src is
+ * Go's Pix (big-endian 16-bit channels; C M Y K bytes) */
+enum { IPXO_DEEP_NRGBA64 = 0, IPXO_DEEP_RGBA64 = 1, IPXO_DEEP_GRAY16 = 2, IPXO_DEEP_CMYK = 3 };
+int ipxo_deep_bpp(int kind);
+void ipxo_deep_taps(uint16_t *out, const uint8_t *src, int sw, int sh, int sstride, int kind);   /* At(x, y).RGBA() per pixel */
+int ipxo_scale_bilinear_deep(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr, const uint8_t *src, int sw, int sh, int sstride,
+                             int kind, ipxo_rect sr, int op);
+void ipxo_draw_deep(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r, const uint8_t *src, int sw, int sh, int sstride, int kind,
+                    int spx, int spy, int op);
+
 /* *image.YCbCr with Rect.Min = (0,0); ratio = image.YCbCrSubsampleRatio (444=0, 422=1, 420=2, 440=3) */
 typedef struct {
     const uint8_t *y, *cb, *cr;

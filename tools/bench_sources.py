@@ -4,6 +4,7 @@ resize 1024x768 + thumbnail 200 + watermark:
   *image.NRGBA     ipx_plan_run_dev_nrgba     fused converted-tile kernel (IPX_NRGBA_CONV=0: the per-tap kernel) vs the three-kernel path (IPX_NRGBA_FUSED=0)
   *image.Gray      ipx_plan_run_dev_gray      planar kernel with flat chroma vs expansion to RGBA8 (IPX_GRAY_FLAT=0)
   *image.Paletted  ipx_plan_run_dev_paletted  palette expansion + the NRGBA pass
+  NRGBA64 / Gray16 / CMYK  ipx_plan_run_dev_deep  the converted-tile kernel reading Go's Pix; IPX_DEEP_DIRECT=0: expansion to 16-bit taps first; IPX_DEEP_FUSED=0: expansion + the three-kernel path
 usage: tools/bench_sources.py [frames]"""
 import os
 import sys
@@ -55,3 +56,13 @@ pal = rng.integers(0, 256, (n, 256, 4), dtype=np.uint8)
 pal[..., 3] = 255
 dp = ctx.alloc(pal.nbytes).upload(pal)
 timed(lambda: plan.run_dev_paletted(n, gr.ptr, w, w * h, dp.ptr, res.ptr, th.ptr, wm.ptr), "Paletted, palette expansion + fused NRGBA pass", w * h + 1024)
+del gr
+# the deep types (ipx_plan_run_dev_deep): expansion to 16-bit taps + the converted-tile kernel on them, or the three-kernel path
+for name, kind, bpp in (("NRGBA64", ipx.DEEP_NRGBA64, 8), ("Gray16", ipx.DEEP_GRAY16, 2), ("CMYK", ipx.DEEP_CMYK, 4)):
+    dsrc = ctx.alloc(n * w * h * bpp).upload(np.resize(rng.integers(0, 256, (pool, h, w * bpp), dtype=np.uint8), (n, h, w * bpp)))
+    for label, fused, direct in (("fused converted-tile kernel reading Pix", "1", "1"), ("tap expansion + fused converted-tile kernel", "1", "0"),
+                                 ("tap expansion + three kernels", "0", "0")):
+        os.environ["IPX_DEEP_FUSED"], os.environ["IPX_DEEP_DIRECT"] = fused, direct
+        timed(lambda: plan.run_dev_deep(n, kind, dsrc.ptr, w * bpp, w * h * bpp, res.ptr, th.ptr, wm.ptr), name + ", " + label, w * h * bpp)
+    os.environ["IPX_DEEP_FUSED"] = os.environ["IPX_DEEP_DIRECT"] = "1"
+    del dsrc
