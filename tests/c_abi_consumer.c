@@ -106,6 +106,28 @@ int main(void)
             free(d); free(od); free(f0);
         }
 
+        /* ---- 2b. another decoded type through the plan: the RGBA8 bytes read as *image.Gray16 Pix (go/ipx/sources.go RunHostDeep) ---- */
+        {
+            const int gw = W * 2, gb = gw * 2;                     /* a 2W x H frame of big-endian uint16 */
+            ipx_plan_params gp;
+            ipx_plan *gplan = NULL;
+            ipx_plan_info gi;
+            ipxo_rect gdr, gsr;
+            uint8_t *gres, *ogres;
+            memset(&gp, 0, sizeof gp);
+            gp.sw = gw; gp.sh = H; gp.do_resize = 1; gp.resize_w = 400; gp.resize_h = 90; gp.keep_aspect = 0;
+            CHECK(ipx_plan_create(ctx, &gp, &gplan) == IPX_OK && ipx_plan_query(gplan, &gi) == IPX_OK, "plan for Gray16 frames");
+            gres = (uint8_t *)malloc(gi.resize_bytes * N); ogres = (uint8_t *)calloc(gi.resize_bytes, 1);
+            CHECK(gres && ogres, "malloc");
+            CHECK(ipx_plan_run_host_deep(ctx, gplan, N, IPX_DEEP_GRAY16, src, gb, fb, gres, gi.resize_bytes, NULL, 0, NULL, 0) == IPX_OK, "ipx_plan_run_host_deep");
+            gdr.x0 = 0; gdr.y0 = 0; gdr.x1 = 400; gdr.y1 = 90; gsr.x0 = 0; gsr.y0 = 0; gsr.x1 = gw; gsr.y1 = H;
+            CHECK(ipxo_scale_bilinear_deep(ogres, 400, 90, 1600, gdr, src + fb, gw, H, gb, IPXO_DEEP_GRAY16, gsr, IPXO_OP_OVER) == 0, "oracle Gray16 scale");
+            CHECK(!memcmp(gres + gi.resize_bytes, ogres, gi.resize_bytes), "Gray16 resize of frame 1 differs from the oracle");
+            CHECK(ipx_plan_run_host_deep(ctx, gplan, N, 9, src, gb, fb, gres, gi.resize_bytes, NULL, 0, NULL, 0) == IPX_ERR_INVALID, "an unknown deep type is an argument error");
+            free(gres); free(ogres);
+            ipx_plan_destroy(ctx, gplan);
+        }
+
         /* ---- 3. operators + jpeg.Encode on the GPU ---- */
         {
             ipx_bytes jr[N], jt[N], jw[N], files[N], r2[N], t2[N], w2[N];

@@ -33,7 +33,11 @@ def expect(kind, src, resize, thumb, glyphs, w, h):
         rgba = np.dstack([src] * 3 + [np.full_like(src, 255)])
         o = oracle.process(rgba, resize=resize, thumb=thumb, glyphs=glyphs, col=DEFAULT_COL)
         return o["resize"], o["thumbnail"], o["watermark"]
-    if kind == "nrgba":
+    if kind.startswith("deep"):
+        pix, dk = src
+        scale = lambda dw, dh, sr=None: oracle.scale_bilinear_deep(pix, dk, dw, dh, sr=sr)       # noqa: E731
+        draw = lambda: oracle.draw_deep(np.zeros((h, w, 4), np.uint8), (0, 0, w, h), pix, dk)    # noqa: E731
+    elif kind == "nrgba":
         scale = lambda dw, dh, sr=None: oracle.scale_bilinear_nrgba(src, dw, dh, sr=sr)          # noqa: E731
         draw = lambda: oracle.draw_nrgba(np.zeros((h, w, 4), np.uint8), (0, 0, w, h), src)       # noqa: E731
     else:
@@ -59,7 +63,7 @@ for trial in range(trials):
     _, tw0, th0 = oracle.thumb_geometry(w, h, *thumb)
     if nw < 1 or nh < 1 or tw0 < 1 or th0 < 1 or max(nw, nh, tw0, th0) > 65535:      # (beyond 65535 pixels a side: IPX_ERR_UNSUPPORTED by design)
         continue
-    for k in ("IPX_BLK_COLS", "IPX_BAND_ROWS", "IPX_CONV_BLK_COLS"):
+    for k in ("IPX_BLK_COLS", "IPX_BAND_ROWS", "IPX_CONV_BLK_COLS", "IPX_DEEP_DIRECT"):
         os.environ.pop(k, None)
     if rng.random() < 0.4:
         os.environ["IPX_BLK_COLS"] = str(int(rng.choice([8, 64, 252, 1000, 2044])))
@@ -67,12 +71,29 @@ for trial in range(trials):
         os.environ["IPX_CONV_BLK_COLS"] = str(int(rng.choice([8, 64, 252, 508, 1020])))      # the converted-tile kernel's own tiling
     if rng.random() < 0.3:
         os.environ["IPX_BAND_ROWS"] = str(int(rng.choice([2, 4, 8])))
-    kind = ["nrgba", "gray", "paletted", "ycbcr", "rgba"][trial % 5]
+    kind = ["nrgba", "gray", "paletted", "ycbcr", "rgba", "deep"][trial % 6]
     n = int(rng.integers(1, 4))
     glyphs = text_glyphs(w, h, n=5, width_px=min(60, w), height_px=min(20, h))
     gs = ctx.glyphset(glyphs, DEFAULT_COL)
     plan = ctx.plan(w, h, resize=resize, thumbnail=thumb, watermark=gs)
-    if kind == "nrgba":
+    if kind == "deep":
+        dk = int(rng.integers(0, 4))
+        if rng.random() < 0.3:
+            os.environ["IPX_DEEP_DIRECT"] = "0"                 # through the frames of taps
+        if dk == oracle.DEEP_GRAY16:
+            vals = rng.integers(0, 65536, (n, h, w), dtype=np.uint16)
+        elif dk == oracle.DEEP_CMYK:
+            vals = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
+        else:
+            vals = rng.integers(0, 65536, (n, h, w, 4), dtype=np.uint16)
+            if rng.random() < 0.3:
+                vals[..., 3] = 0xffff
+            if dk == oracle.DEEP_RGBA64:
+                vals[..., :3] = np.minimum(vals[..., :3], vals[..., 3:])
+        pix = np.stack([oracle.deep_pix(vals[i], dk) for i in range(n)])
+        got = plan.run_host_deep(pix, dk)
+        srcs = [(pix[i], dk) for i in range(n)]
+    elif kind == "nrgba":
         frames = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
         if rng.random() < 0.3:
             frames[..., 3] = 255
