@@ -73,11 +73,42 @@ func (p *Pool) ops(w, h int, o Ops) (C.ipx_pool_ops, func()) {
 	return c, free
 }
 
+// PixelKind names the packed image type of a pixel job's frames (Pix as Go holds it).
+type PixelKind int
+
+const (
+	PixRGBA    PixelKind = C.IPX_JOB_RGBA8
+	PixNRGBA   PixelKind = C.IPX_JOB_NRGBA8
+	PixGray    PixelKind = C.IPX_JOB_GRAY8
+	PixNRGBA64 PixelKind = C.IPX_JOB_NRGBA64
+	PixRGBA64  PixelKind = C.IPX_JOB_RGBA64
+	PixGray16  PixelKind = C.IPX_JOB_GRAY16
+	PixCMYK    PixelKind = C.IPX_JOB_CMYK
+)
+
+func (k PixelKind) bytesPerPixel() int {
+	switch k {
+	case PixGray:
+		return 1
+	case PixGray16:
+		return 2
+	case PixNRGBA64, PixRGBA64:
+		return 8
+	}
+	return 4
+}
+
 // SubmitPixels queues n decoded RGBA8 frames of w x h (src and the outputs: Pinned memory, valid until Wait returns).
 func (p *Pool) SubmitPixels(w, h, n int, o Ops, src, resizeOut, thumbOut, wmOut []byte, resizeBytes, thumbBytes int) (*Job, error) {
+	return p.SubmitPixelsOf(PixRGBA, w, h, n, o, src, resizeOut, thumbOut, wmOut, resizeBytes, thumbBytes)
+}
+
+// SubmitPixelsOf does the same for frames of any packed type image.Decode returns (rows packed without stride padding).
+func (p *Pool) SubmitPixelsOf(kind PixelKind, w, h, n int, o Ops, src, resizeOut, thumbOut, wmOut []byte, resizeBytes, thumbBytes int) (*Job, error) {
 	ops, free := p.ops(w, h, o)
 	defer free()
-	j := C.ipx_job{kind: C.IPX_JOB_RGBA8, ops: ops, n: C.int32_t(n), src: ptr(src), sstride: C.int32_t(w * 4), src_frame_stride: C.size_t(w * h * 4),
+	bpp := kind.bytesPerPixel()
+	j := C.ipx_job{kind: C.int32_t(kind), ops: ops, n: C.int32_t(n), src: ptr(src), sstride: C.int32_t(w * bpp), src_frame_stride: C.size_t(w * h * bpp),
 		resize_out: ptr(resizeOut), resize_frame_stride: C.size_t(resizeBytes), thumb_out: ptr(thumbOut), thumb_frame_stride: C.size_t(thumbBytes),
 		wm_out: ptr(wmOut), wm_frame_stride: C.size_t(w * h * 4)}
 	job := &Job{p: p, n: n}

@@ -650,7 +650,7 @@ class PoolJob:
         fd = C.c_int()
         try:
             _check(lib().ipx_job_wait(self.pool.handle, self.ticket, C.byref(fd)))
-            if self.job.kind == 0:
+            if self.job.kind != 1:          # every kind but IPX_JOB_JPEG hands pixels back
                 return self.outs
             out = {k: [C.string_at(a[j].data, a[j].len) if a[j].data else None for j in range(self.n)] for k, a in self.outs.items()}
             return out, list(self.keep["status"])[:self.n]
@@ -724,10 +724,18 @@ class Pool:
                     o.col[i] = int(col[i])
         return o, keep
 
-    def submit(self, frames, resize=(1024, 768, True), thumbnail=(200, True), glyphs=None, col=(0, 0, 0, 0), watermark=False, out=None):
-        """frames: n x H x W x 4 uint8 (host).  -> PoolJob; wait() gives {"resize", "thumbnail", "watermark"} arrays."""
+    JOB_KINDS = {"rgba": (0, 4), "nrgba": (2, 4), "gray": (3, 1), "nrgba64": (4, 8), "rgba64": (5, 8), "gray16": (6, 2), "cmyk": (7, 4)}   # IPX_JOB_*: (kind, bytes per pixel)
+
+    def submit(self, frames, resize=(1024, 768, True), thumbnail=(200, True), glyphs=None, col=(0, 0, 0, 0), watermark=False, out=None,
+               kind="rgba"):
+        """frames: n x H x W x 4 uint8 (host); for another `kind` (JOB_KINDS) n x H x (W * bpp) uint8, the type's Pix rows.
+        -> PoolJob; wait() gives {"resize", "thumbnail", "watermark"} arrays."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
-        n, sh, sw = frames.shape[:3]
+        jk, bpp = self.JOB_KINDS[kind]
+        if kind != "rgba":
+            frames = frames.reshape(frames.shape[0], frames.shape[1], -1)
+        n, sh = frames.shape[:2]
+        sw = frames.shape[2] if kind == "rgba" else frames.shape[2] // bpp
         ops, keep = self._ops(sw, sh, resize, thumbnail, glyphs, col, watermark)
         outs = dict(out) if out else {}
         if resize and "resize" not in outs:
@@ -738,8 +746,8 @@ class Pool:
         if ops.do_watermark and "watermark" not in outs:
             outs["watermark"] = np.empty((n, sh, sw, 4), np.uint8)
         j = _lib.Job()
-        j.kind, j.ops, j.n = 0, ops, n
-        j.src, j.sstride, j.src_frame_stride = frames.ctypes.data, sw * 4, sw * sh * 4
+        j.kind, j.ops, j.n = jk, ops, n
+        j.src, j.sstride, j.src_frame_stride = frames.ctypes.data, sw * bpp, sw * sh * bpp
 
         def fs(a):
             return int(np.prod(a.shape[1:]))

@@ -112,6 +112,18 @@ void bind_near_device(int device)
     if (CPU_COUNT(&want) > 0) (void)sched_setaffinity(0, sizeof want, &want);
 }
 
+// bytes per pixel of a pixel job's frames; 0 for a kind that is none
+int pixel_job_bpp(int kind)
+{
+    switch (kind) {
+    case IPX_JOB_RGBA8: case IPX_JOB_NRGBA8: case IPX_JOB_CMYK: return 4;
+    case IPX_JOB_GRAY8: return 1;
+    case IPX_JOB_GRAY16: return 2;
+    case IPX_JOB_NRGBA64: case IPX_JOB_RGBA64: return 8;
+    default: return 0;
+    }
+}
+
 double chunk_cost(const JobState &j, int m)
 {
     if (j.job.kind == IPX_JOB_JPEG) {
@@ -119,7 +131,7 @@ double chunk_cost(const JobState &j, int m)
         for (int i = 0; i < m; i++) b += (double)j.job.files[i].len;   // callers pass the chunk's own slice
         return b * 24 + (double)m * j.ops.p.sw * j.ops.p.sh * 8;         // decoded size dominates
     }
-    return (double)m * ((double)j.ops.p.sw * j.ops.p.sh * 8 + 4.0 * 1024 * 768);
+    return (double)m * ((double)j.ops.p.sw * j.ops.p.sh * (4 + pixel_job_bpp(j.job.kind)) + 4.0 * 1024 * 768);
 }
 
 int copy_ops(const ipx_pool_ops &in, PoolOps *out)
@@ -162,14 +174,15 @@ int feeder_reserve(Feeder &f, size_t bytes)
 }
 
 // pixels in, pixels out: upload the chunk, one fused pass, download -- all on the feeder's stream
-int run_rgba_chunk(Slot &s, Feeder &f, const JobState &j, ipx_plan *plan, int i0, int m)
+int run_pixel_chunk(Slot &s, Feeder &f, const JobState &j, ipx_plan *plan, int i0, int m)
 {
     const ipx_job &q = j.job;
     ipx_plan_info info;
     int rc = ipx_plan_query(plan, &info);
     if (rc) return rc;
     const int sw = j.ops.p.sw, sh = j.ops.p.sh;
-    const size_t fsrc = align256((size_t)sw * sh * 4);
+    const int bpp = pixel_job_bpp(q.kind);
+    const size_t fsrc = align256((size_t)sw * sh * bpp);
     const size_t fres = q.resize_out ? align256(info.resize_bytes) : 0, fth = q.thumb_out ? align256(info.thumb_bytes) : 0;
     const size_t fwm = q.wm_out ? align256(info.wm_bytes) : 0;
     rc = feeder_reserve(f, (fsrc + fres + fth + fwm) * (size_t)m + 256);
@@ -178,10 +191,18 @@ int run_rgba_chunk(Slot &s, Feeder &f, const JobState &j, ipx_plan *plan, int i0
     uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * m : nullptr;
     hipError_t e = hipSuccess;
     for (int i = 0; i < m && e == hipSuccess; i++)
-        e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * 4, q.src + (size_t)(i0 + i) * q.src_frame_stride, q.sstride, (size_t)sw * 4, sh,
+        e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * bpp, q.src + (size_t)(i0 + i) * q.src_frame_stride, q.sstride, (size_t)sw * bpp, sh,
                              hipMemcpyHostToDevice, f.stream);
     if (e != hipSuccess) { (void)hipStreamSynchronize(f.stream); set_error("pool: upload failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
-    rc = ipx_plan_run_dev(s.ctx, f.stream, plan, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm);
+    switch (q.kind) {
+    case IPX_JOB_RGBA8: rc = ipx_plan_run_dev(s.ctx, f.stream, plan, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm); break;
+    case IPX_JOB_NRGBA8: rc = ipx_plan_run_dev_nrgba(s.ctx, f.stream, plan, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm); break;
+    case IPX_JOB_GRAY8: rc = ipx_plan_run_dev_gray(s.ctx, f.stream, plan, m, dsrc, sw, fsrc, dres, fres, dth, fth, dwm, fwm); break;
+    default:
+        rc = ipx_plan_run_dev_deep(s.ctx, f.stream, plan, m, q.kind == IPX_JOB_NRGBA64 ? IPX_DEEP_NRGBA64 : q.kind == IPX_JOB_RGBA64 ? IPX_DEEP_RGBA64 :
+                                   q.kind == IPX_JOB_GRAY16 ? IPX_DEEP_GRAY16 : IPX_DEEP_CMYK, dsrc, sw * bpp, fsrc, dres, fres, dth, fth, dwm, fwm);
+        break;
+    }
     if (rc) { (void)hipStreamSynchronize(f.stream); return rc; }
     for (int i = 0; i < m && e == hipSuccess; i++) {
         if (dres && info.resize_bytes) e = hipMemcpyAsync(q.resize_out + (size_t)(i0 + i) * q.resize_frame_stride, dres + fres * i, info.resize_bytes, hipMemcpyDeviceToHost, f.stream);
@@ -207,7 +228,7 @@ int run_chunk(Slot &s, Feeder &f, JobState &j, int i0, int m, ipx_jpeg_result **
             rc = ipx_plan_run_jpeg_jpeg(s.ctx, plan, m, j.job.files + i0, j.job.quality, j.job.resize_jpeg ? j.job.resize_jpeg + i0 : nullptr,
                                         j.job.thumb_jpeg ? j.job.thumb_jpeg + i0 : nullptr, j.job.wm_jpeg ? j.job.wm_jpeg + i0 : nullptr,
                                         j.job.status + i0, res);
-        else rc = run_rgba_chunk(s, f, j, plan, i0, m);      // (both return with the chunk's GPU work finished)
+        else rc = run_pixel_chunk(s, f, j, plan, i0, m);     // (both return with the chunk's GPU work finished)
         if (!cached) {
             std::string keep = rc ? ipx_last_error() : "";
             ipx_plan_release(s.ctx, plan, cached);
@@ -259,9 +280,12 @@ int job_check(const ipx_job *job)
     if (!job || job->n < 0) { set_error("ipx_job_submit: bad job"); return IPX_ERR_INVALID; }
     const ipx_pool_ops &o = job->ops;
     if (o.sw <= 0 || o.sh <= 0) { set_error("ipx_job_submit: frame size %dx%d", o.sw, o.sh); return IPX_ERR_INVALID; }
-    if (job->kind == IPX_JOB_RGBA8) {
-        if (job->n && (!job->src || (long long)job->sstride < (long long)o.sw * 4)) { set_error("ipx_job_submit: bad source frames"); return IPX_ERR_INVALID; }
-        if (!frame_span_ok(o.sw, o.sh, job->sstride, 4)) { set_error("ipx_job_submit: %dx%d frames are beyond the span the kernels address", o.sw, o.sh); return IPX_ERR_UNSUPPORTED; }
+    if (const int bpp = pixel_job_bpp(job->kind)) {
+        if (job->n && (!job->src || (long long)job->sstride < (long long)o.sw * bpp)) { set_error("ipx_job_submit: bad source frames"); return IPX_ERR_INVALID; }
+        if (!frame_span_ok(o.sw, o.sh, job->sstride, bpp) || (bpp != 1 && !frame_span_ok(o.sw, o.sh, (long long)o.sw * std::max(bpp, 4), std::max(bpp, 4)))) {
+            set_error("ipx_job_submit: %dx%d frames are beyond the span the kernels address", o.sw, o.sh);
+            return IPX_ERR_UNSUPPORTED;
+        }
     } else if (job->kind == IPX_JOB_JPEG) {
         if (job->n && (!job->files || !job->status)) { set_error("ipx_job_submit: a JPEG job needs files and a status array"); return IPX_ERR_INVALID; }
     } else {
@@ -369,7 +393,7 @@ int ipx_job_submit(ipx_pool *pool, const ipx_job *job, ipx_ticket *ticket) try
     int per;
     if (job->kind == IPX_JOB_JPEG) per = std::max(1, env_int("IPX_POOL_JPEG_CHUNK", 256));
     else {
-        const size_t fb = (size_t)job->ops.sw * job->ops.sh * 8 + ((size_t)4 << 20);
+        const size_t fb = (size_t)job->ops.sw * job->ops.sh * (4 + pixel_job_bpp(job->kind)) + ((size_t)4 << 20);
         per = (int)std::max<size_t>(1, pool->lane_bytes / fb);
         const int want = 2 * (int)pool->feeders.size();
         per = std::max(1, std::min(per, (job->n + want - 1) / std::max(1, want)));
@@ -450,7 +474,7 @@ int ipx_pool_run_host(ipx_pool *pool, const ipx_job *jobs, int n_jobs) try
     clear_error();
     if (!pool || n_jobs < 0 || (n_jobs && !jobs)) { set_error("ipx_pool_run_host: bad argument"); return IPX_ERR_INVALID; }
     for (int i = 0; i < n_jobs; i++)
-        if (jobs[i].kind != IPX_JOB_RGBA8) { set_error("ipx_pool_run_host: pixel jobs only (JPEG jobs keep their outputs until ipx_job_release)"); return IPX_ERR_INVALID; }
+        if (!pixel_job_bpp(jobs[i].kind)) { set_error("ipx_pool_run_host: pixel jobs only (JPEG jobs keep their outputs until ipx_job_release)"); return IPX_ERR_INVALID; }
     std::vector<ipx_ticket> tickets;
     int rc = IPX_OK;
     std::string text;

@@ -520,12 +520,16 @@ int ipx_plan_acquire(ipx_ctx *ctx, const ipx_pool_ops *ops, ipx_plan **plan, int
 void ipx_plan_release(ipx_ctx *ctx, ipx_plan *plan, int cached);
 
 enum { IPX_JOB_RGBA8 = 0,       /* decoded frames in, the operators' RGBA8 outputs back (what ipx_plan_run_host does) */
-       IPX_JOB_JPEG = 1 };      /* uploaded JPEG files in, three JPEG streams per file back (what ipx_plan_run_jpeg_jpeg does) */
+       IPX_JOB_JPEG = 1,        /* uploaded JPEG files in, three JPEG streams per file back (what ipx_plan_run_jpeg_jpeg does) */
+       /* decoded frames of the other packed image types, Pix as Go holds it (src / sstride / src_frame_stride describe it), RGBA8
+        * outputs back: what ipx_plan_run_host_nrgba / _gray / _deep do */
+       IPX_JOB_NRGBA8 = 2, IPX_JOB_GRAY8 = 3,
+       IPX_JOB_NRGBA64 = 4, IPX_JOB_RGBA64 = 5, IPX_JOB_GRAY16 = 6, IPX_JOB_CMYK = 7 };
 typedef struct {
     int32_t kind;
     ipx_pool_ops ops;
     int32_t n;                  /* frames / files, all of size ops.sw x ops.sh */
-    /* IPX_JOB_RGBA8: frame i at src + i*src_frame_stride; an output pointer may be NULL to skip it */
+    /* pixel jobs (every kind but IPX_JOB_JPEG): frame i at src + i*src_frame_stride; an output pointer may be NULL to skip it */
     const uint8_t *src; int32_t sstride; size_t src_frame_stride;
     uint8_t *resize_out; size_t resize_frame_stride;
     uint8_t *thumb_out; size_t thumb_frame_stride;

@@ -115,3 +115,48 @@ def test_pool_errors_come_back_as_status(ipx, pool):
     # the pool is fine afterwards
     got = pool.submit(frames, resize=(32, 32, False), thumbnail=None).wait()
     np.testing.assert_array_equal(got["resize"][0], oracle.process(frames[0], resize=(32, 32, False), thumb=(1, False), want=("resize",))["resize"])
+
+
+def test_pool_jobs_of_the_other_decoded_types(pool):
+    """IPX_JOB_NRGBA8 / GRAY8 / NRGBA64 / RGBA64 / GRAY16 / CMYK: frames of every packed image type image.Decode returns, Pix as Go
+    holds it, through the queue; the outputs are the oracle's for that type (the per-type rules of tests/test_sources_gpu.py and
+    tests/test_deep_gpu.py)."""
+    sw, sh, n = 640, 360, 5
+    resize, thumb = (320, 200, False), (64, True)
+    glyphs = text_glyphs(sw, sh, n=6, width_px=150, height_px=30)
+    rng = np.random.default_rng(77)
+    nrgba = rng.integers(0, 256, (n, sh, sw, 4), dtype=np.uint8)
+    gray = rng.integers(0, 256, (n, sh, sw), dtype=np.uint8)
+    v64 = rng.integers(0, 65536, (n, sh, sw, 4), dtype=np.uint16)
+    p64 = np.minimum(v64, v64[..., 3:4])
+    g16 = rng.integers(0, 65536, (n, sh, sw), dtype=np.uint16)
+    cmyk = rng.integers(0, 256, (n, sh, sw, 4), dtype=np.uint8)
+    deep = {"nrgba64": (v64, oracle.DEEP_NRGBA64), "rgba64": (p64, oracle.DEEP_RGBA64), "gray16": (g16, oracle.DEEP_GRAY16), "cmyk": (cmyk, oracle.DEEP_CMYK)}
+    jobs = {"nrgba": pool.submit(nrgba, resize=resize, thumbnail=thumb, glyphs=glyphs, col=DEFAULT_COL, kind="nrgba"),
+            "gray": pool.submit(gray, resize=resize, thumbnail=thumb, glyphs=glyphs, col=DEFAULT_COL, kind="gray")}
+    pix = {}
+    for name, (vals, dk) in deep.items():
+        pix[name] = np.stack([oracle.deep_pix(vals[i], dk) for i in range(n)])
+        jobs[name] = pool.submit(pix[name], resize=resize, thumbnail=thumb, glyphs=glyphs, col=DEFAULT_COL, kind=name)
+    nw, nh = oracle.resize_dims(sw, sh, *resize)
+    crop, tw, th = oracle.thumb_geometry(sw, sh, *thumb)
+    cs = crop[2] - crop[0]
+    zeros = lambda: np.zeros((sh, sw, 4), np.uint8)      # noqa: E731
+    for name, job in jobs.items():
+        got = job.wait()
+        for i in (0, n - 1):
+            if name == "nrgba":
+                want = (oracle.scale_bilinear_nrgba(nrgba[i], nw, nh), oracle.scale_bilinear(oracle.scale_bilinear_nrgba(nrgba[i], cs, cs, sr=crop), tw, th),
+                        oracle.draw_nrgba(zeros(), (0, 0, sw, sh), nrgba[i]))
+            elif name == "gray":
+                rgba = np.dstack([gray[i]] * 3 + [np.full_like(gray[i], 255)])
+                o = oracle.process(rgba, resize=resize, thumb=thumb, glyphs=[], col=DEFAULT_COL)
+                want = (o["resize"], o["thumbnail"], rgba)
+            else:
+                dk = deep[name][1]
+                want = (oracle.scale_bilinear_deep(pix[name][i], dk, nw, nh),
+                        oracle.scale_bilinear(oracle.scale_bilinear_deep(pix[name][i], dk, cs, cs, sr=crop), tw, th),
+                        oracle.draw_deep(zeros(), (0, 0, sw, sh), pix[name][i], dk))
+            np.testing.assert_array_equal(got["resize"][i], want[0], err_msg="%s resize %d" % (name, i))
+            np.testing.assert_array_equal(got["thumbnail"][i], want[1], err_msg="%s thumbnail %d" % (name, i))
+            np.testing.assert_array_equal(got["watermark"][i], oracle.composite_glyphs(want[2].copy(), glyphs, DEFAULT_COL), err_msg="%s watermark %d" % (name, i))
