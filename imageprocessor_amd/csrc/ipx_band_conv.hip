@@ -709,7 +709,8 @@ hipError_t launch_band_deep(const NrgbaArgs &A, int kind, hipStream_t s, bool *m
     const long long total = (long long)a.nbands * a.ncolblk * a.nframes;
     if (total <= 0) { *matched = true; return hipSuccess; }
     if (total > 0x7fffffffLL || !conv_tiling_ok(a)) return hipSuccess;
-    if ((((uintptr_t)a.src) | (uintptr_t)a.sstride | a.src_frame_stride) & 15) return hipSuccess;
+    const uintptr_t al = kind == IPX_DEEP_GRAY16 ? 7 : 15;          // a chunk's load: 8 bytes of Gray16, 16 (twice for the 64-bit types) otherwise
+    if ((((uintptr_t)a.src) | (uintptr_t)a.sstride | a.src_frame_stride) & al) return hipSuccess;
     const size_t lds = 2 * (size_t)kRows * kConvTilePitch;
     switch (kind) {
     case IPX_DEEP_NRGBA64: return launch_conv_cfg<DeepSrc<IPX_DEEP_NRGBA64>>(A, "nrgba64", total, lds, s, matched);

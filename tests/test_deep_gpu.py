@@ -161,3 +161,27 @@ def test_deep_per_operation_seam(ctx, kind):
         np.testing.assert_array_equal(ctx.scale_bilinear_deep(op_pix, kind, 80, 64, op=oracle.OP_OVER, dst=under.copy()), want)
     with pytest.raises(ipa.IpxError):
         ctx.scale_bilinear_deep(pix[0], 9, 10, 10)
+
+
+def test_gray16_rows_that_are_8_byte_aligned_only(ctx):
+    """636 pixels of Gray16 are 1272 bytes: rows (and, with 251 rows, frames) on 8-byte but not 16-byte boundaries -- the fused
+    kernel's chunk loads for this type are 8 bytes, so such frames still take it."""
+    from helpers import DEFAULT_COL, text_glyphs
+    w, h, n = 636, 251, 3
+    pix = _frames(DEEP_GRAY16, n, h, w, seed=3)
+    glyphs = text_glyphs(w, h, n=6, width_px=150, height_px=30)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(w, h, resize=(300, 200, False), thumbnail=(100, True), watermark=gs)
+    out = plan.run_host_deep(pix, DEEP_GRAY16)
+    i = plan.info
+    src = ctx.alloc(pix.nbytes).upload(pix)
+    res, th, wm = ctx.alloc(n * i.resize_bytes), ctx.alloc(n * i.thumb_bytes), ctx.alloc(n * i.wm_bytes)
+    plan.run_dev_deep(n, DEEP_GRAY16, src.ptr, pix.shape[2], pix.shape[1] * pix.shape[2], res.ptr, th.ptr, wm.ptr)
+    ctx.sync()
+    got_r, got_t, got_w = res.download((n, i.resize_h, i.resize_w, 4)), th.download((n, i.thumb_h, i.thumb_w, 4)), wm.download((n, h, w, 4))
+    for k in range(n):
+        want_r, want_t, want_w = _expect(pix[k], DEEP_GRAY16, w, h, (300, 200, False), (100, True), glyphs, DEFAULT_COL)
+        for got, want in ((got_r[k], want_r), (got_t[k], want_t), (got_w[k], want_w), (out["resize"][k], want_r), (out["thumbnail"][k], want_t), (out["watermark"][k], want_w)):
+            np.testing.assert_array_equal(got, want)
+    plan.close()
+    gs.close()
