@@ -283,7 +283,7 @@ def photo_like(n, sw, sh):
     return out
 
 
-def e2e_legs(ipx, device, n, sw, sh, resize, reps, lanes=4):
+def e2e_legs(ipx, device, n, sw, sh, resize, reps, lanes=5):
     """The PCIe-inclusive legs of the north star's pipeline (decode -> H2D -> kernel -> D2H -> encode) on the same workload, through the
     synchronous host entries of the ABI: n frames in pinned host memory per call, chunks pipelined over `lanes` streams.  Never
     `value`: these are bound by the link, not by HBM.  Every repetition is reported, not the best."""

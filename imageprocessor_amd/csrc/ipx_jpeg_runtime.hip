@@ -818,7 +818,7 @@ static int run_jpeg_jpeg_one(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_
         ipx_ctx *c;
         explicit Slot(ipx_ctx *ctx) : c(ctx)
         {
-            const int cap = std::max(1, env_int("IPX_JPEG_JPEG_PARALLEL", 3));
+            const int cap = std::max(1, env_int("IPX_JPEG_JPEG_PARALLEL", 4));
             std::unique_lock<std::mutex> lk(c->mu);
             c->cv.wait(lk, [&] { return c->jj_active < cap; });
             c->jj_active++;
@@ -898,7 +898,10 @@ int ipx_plan_run_jpeg_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_by
     *result = nullptr;
     // a large batch is cut into parts that run on lanes of their own, one host thread each: while one part is in its (host-paced)
     // encode read-backs another decodes.  Two callers with 1024 files each measured 15 k images/s against 11.7 k for one.
-    const int parts = std::max(1, std::min({(int)ctx->lanes.size(), n / std::max(1, env_int("IPX_JPEG_JPEG_PART", 384)), 3}));
+    // Four parts of 256 measured 9 % above two of 512 or three of 341 (tools/j2j_parts.sh: 55.3 ms against 60.4 per 1024 files); more
+    // than four gain nothing.  One lane stays free for a per-operator call that arrives while the batch runs.
+    const int nl = (int)ctx->lanes.size();
+    const int parts = std::max(1, std::min({nl >= 3 ? nl - 1 : nl, n / std::max(1, env_int("IPX_JPEG_JPEG_PART", 256)), env_int("IPX_JPEG_JPEG_MAXPARTS", 4)}));
     if (parts == 1) return run_jpeg_jpeg_one(ctx, pl, n, files, quality, resize_out, thumb_out, wm_out, status, result);
     std::vector<ipx_jpeg_result *> res(parts, nullptr);
     std::vector<int> rcs(parts, IPX_OK);

@@ -216,7 +216,7 @@ int ipx_create(const ipx_config *cfg, ipx_ctx **out) try
     if (!c) { set_error("out of memory"); return IPX_ERR_NOMEM; }
     c->device = dev;
     c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    int lanes = cfg && cfg->lanes > 0 ? cfg->lanes : env_int("IPX_LANES", 4);
+    int lanes = cfg && cfg->lanes > 0 ? cfg->lanes : env_int("IPX_LANES", 5);
     c->lane_bytes = cfg && cfg->lane_bytes ? cfg->lane_bytes : (size_t)64 << 20;
     c->host_cache_limit = (size_t)std::max(0, env_int("IPX_HOST_CACHE_MB", 8192)) << 20;
     c->lanes.resize(lanes);

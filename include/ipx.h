@@ -56,9 +56,10 @@ typedef struct {
 
 typedef struct {
     int32_t device;        /* HIP device ordinal; -1 = LOCAL_RANK / 0                          */
-    int32_t lanes;         /* staging lanes (a stream + device scratch each); 0 = 4: a host batch pipelines its chunks over three --
-                              the reference's WORKER_CONCURRENCY (.env.example:38, worker.go:90) -- and one stays free, so that a
-                              single-frame call is served while a batch runs */
+    int32_t lanes;         /* staging lanes (a stream + device scratch each); 0 = 5: a host batch pipelines its chunks over four
+                              (the reference's WORKER_CONCURRENCY is 3, .env.example:38, worker.go:90; a compressed-in /
+                              compressed-out batch measured best in four parts) and one stays free, so that a single-frame call is
+                              served while a batch runs */
     size_t lane_bytes;     /* initial pinned+device staging per lane; grows on demand; 0 = 64 MiB */
 } ipx_config;
 

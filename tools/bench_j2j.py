@@ -19,7 +19,7 @@ from helpers import DEFAULT_COL, text_glyphs  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 sw, sh = 1920, 1080
-ctx = ipx.Context(lanes=4, lane_bytes=1 << 30)
+ctx = ipx.Context(lanes=int(os.environ.get("IPX_BENCH_LANES", "5")), lane_bytes=1 << 30)
 gs = ctx.glyphset(text_glyphs(sw, sh), DEFAULT_COL)
 plan = ctx.plan(sw, sh, resize=(1024, 768, True), thumbnail=(200, True), watermark=gs)
 yy, xx = np.mgrid[0:sh, 0:sw]
