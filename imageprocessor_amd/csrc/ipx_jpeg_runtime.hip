@@ -127,6 +127,10 @@ static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const 
                             int n, int quality, uint8_t **blob, size_t *offs, size_t *lens)
 {
     const size_t per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
+    const bool trace = env_int("IPX_DEBUG_J2J", 0) != 0;
+    const auto te0 = std::chrono::steady_clock::now();
+    auto ems = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count(); };
+    double t_q1 = 0, t_s1 = 0, t_q2 = 0, t_s2 = 0, t_q3 = 0;
 
     // ---- entropy coding on the GPU: size, scan, place, stuff (ipx_jpeg_entropy.hip); two small read-backs ----
     const int nblk = (int)(per / 128);
@@ -165,7 +169,9 @@ static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const 
     IPX_HIP(launch_scan(d_len, nblk, n, d_tot, s));
     std::vector<uint32_t> tot(n), ubytes(n), ff(n);
     IPX_HIP(hipMemcpyAsync(tot.data(), d_tot, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    t_q1 = ems();
     IPX_HIP(hipStreamSynchronize(s));
+    t_s1 = ems();
     std::vector<unsigned long long> ubase(n), obase(n);
     unsigned long long utotal = 0;
     uint32_t umax = 0;
@@ -186,7 +192,9 @@ static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const 
     IPX_HIP(launch_jpeg_ffcount(d_ustream, d_ubase, d_ubytes, max_chunks, n, d_ff, s));
     IPX_HIP(launch_scan(d_ff, max_chunks, n, d_fftot, s));
     IPX_HIP(hipMemcpyAsync(ff.data(), d_fftot, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    t_q2 = ems();
     IPX_HIP(hipStreamSynchronize(s));
+    t_s2 = ems();
     unsigned long long ototal = 0;
     for (int i = 0; i < n; i++) {
         lens[i] = hdr.size() + ubytes[i] + ff[i] + 2;
@@ -200,7 +208,11 @@ static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const 
     uint8_t *host = (uint8_t *)ipx_host_alloc(ctx, (size_t)ototal ? (size_t)ototal : 1);   // pinned: the download runs at link speed
     if (!host) return IPX_ERR_NOMEM;
     hipError_t e = hipMemcpyAsync(host, d_ostream, (size_t)ototal, hipMemcpyDeviceToHost, s);
+    t_q3 = ems();
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (trace)
+        fprintf(stderr, "[ipx] encode of %d x %dx%d: sized (queued %.2f ms, done %.2f), packed (queued %.2f, done %.2f), stream of %.1f MB queued %.2f, down at %.2f\n",
+                n, w, h, t_q1, t_s1, t_q2, t_s2, (double)ototal / 1e6, t_q3, ems());
     if (e != hipSuccess) { (void)ipx_host_free(ctx, host); set_error("stream download failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
     *blob = host;
     return IPX_OK;
@@ -780,8 +792,8 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     // unconditionally: after a failed enqueue the copies and kernels queued before it may still be reading the pinned blob, the host
     // tables and the lane's arena, all of which are handed back below
     { const hipError_t e2 = hipStreamSynchronize(s); if (e == hipSuccess) e = e2; }
-    if (getenv("IPX_DEBUG") && dms() > 200.0)
-        fprintf(stderr, "[ipx] slow decode of %d files: parsed at %.1f ms, device scratch at %.1f, pinned block at %.1f, packed at %.1f, launched at %.1f, finished at %.1f\n", n, t_parse, t_alloc, t_pin, t_pack, t_launch, dms());
+    if ((getenv("IPX_DEBUG") && dms() > 200.0) || env_int("IPX_DEBUG_J2J", 0))
+        fprintf(stderr, "[ipx] decode of %d files: parsed at %.1f ms, device scratch at %.1f, pinned block at %.1f, packed at %.1f, launched at %.1f, finished at %.1f\n", n, t_parse, t_alloc, t_pin, t_pack, t_launch, dms());
     (void)ipx_host_free(ctx, hblob);
     if (hpin) (void)ipx_host_free(ctx, hpin);
     if (e != hipSuccess) return fail(e, "jpeg decode");
