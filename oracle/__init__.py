@@ -48,8 +48,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()          # (a no-op when the library is newer than its sources; a stale one would miss entry points added since)
         L = C.CDLL(_SO)
         L.ipxo_scale_bilinear_rgba8.restype = C.c_int
         L.ipxo_scale_bilinear_rgba8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, Rect,
