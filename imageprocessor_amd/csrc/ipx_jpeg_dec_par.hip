@@ -417,20 +417,22 @@ __global__ __launch_bounds__(64) void par_write_kernel(JpegParArgs a)
 }
 
 // step 4: DC differences -> DC values, per component in scan order; also the "scan ran out of data" verdict
-__global__ __launch_bounds__(256) void par_dc_kernel(JpegParArgs a)
+constexpr int kDcThreads = 1024;      // a thread walks nmcu / kDcThreads MCUs twice, one dependent 2-byte load after the other: with 256 threads per image the
+                                      // kernel took 0.94 ms per 1024 1080p files at 4 workgroups per CU
+__global__ __launch_bounds__(kDcThreads) void par_dc_kernel(JpegParArgs a)
 {
-    __shared__ int part[256][3];
+    __shared__ int part[kDcThreads][3];
     const JpegParImage im = a.img[blockIdx.x];
     int16_t *dcs = a.dcs + (size_t)im.img * a.nblk;
     const int t = threadIdx.x, nmcu = a.nblk / a.bpm;
     if (t == 0 && a.total_ends[blockIdx.x] < (uint32_t)a.nblk) atomicMin(a.status + im.img, jpeg_status_key(0, IPX_ERR_INVALID));   // "short Huffman data"
-    const int per = (nmcu + 255) / 256, m0 = min(nmcu, t * per), m1 = min(nmcu, m0 + per);
+    const int per = (nmcu + kDcThreads - 1) / kDcThreads, m0 = min(nmcu, t * per), m1 = min(nmcu, m0 + per);
     int sum[3] = {0, 0, 0};
     for (int m = m0; m < m1; m++)
         for (int bi = 0; bi < a.bpm; bi++) sum[bi < a.ybl ? 0 : bi - a.ybl + 1] += dcs[(size_t)m * a.bpm + bi];
     for (int k = 0; k < 3; k++) part[t][k] = sum[k];
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
+    for (int d = 1; d < kDcThreads; d <<= 1) {
         int add[3] = {0, 0, 0};
         if (t >= d) for (int k = 0; k < 3; k++) add[k] = part[t - d][k];
         __syncthreads();
@@ -614,7 +616,7 @@ hipError_t launch_par_write(const JpegParArgs &a, hipStream_t s)
 }
 hipError_t launch_par_dc(const JpegParArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(par_dc_kernel, dim3(a.nimg), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(par_dc_kernel, dim3(a.nimg), dim3(kDcThreads), 0, s, a);
     return hipGetLastError();
 }
 
