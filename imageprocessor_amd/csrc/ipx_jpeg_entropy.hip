@@ -225,36 +225,56 @@ __global__ __launch_bounds__(256) void jpeg_ffcount_kernel(const uint8_t *ustrea
     ffcount[(size_t)f * max_chunks + c] = cnt;
 }
 
-// pass D: header, stuffed scan, EOI
+// pass D: header, stuffed scan, EOI.  A thread stuffs its 64-byte chunk into LDS, at the place its output has inside the workgroup's
+// (contiguous) piece of the stream, shifted so that 16-byte boundaries of the LDS buffer are 16-byte boundaries of the stream; the
+// piece then goes out in whole 16-byte stores, byte stores only for its two ragged ends (the neighbouring workgroups write the bytes
+// next to them).  The first version stored every byte from the chunk loop: 470 M one-byte stores per 1024 x 3 streams, 1.9 ms.
 __global__ __launch_bounds__(256) void jpeg_stuff_kernel(const uint8_t *ustream, const unsigned long long *ubase, const uint32_t *ubytes,
                                                          int max_chunks, const uint32_t *ffoff, const uint8_t *header, int hdr_len,
                                                          const unsigned long long *obase, uint8_t *ostream)
 {
-    const int f = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint8_t buf[256 * 2 * kChunk + 32];
+    __shared__ uint32_t piece_end;
+    const int f = blockIdx.y, t = threadIdx.x, c = blockIdx.x * 256 + t;
     uint8_t *o = ostream + obase[f];
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < hdr_len; i += 256) o[i] = header[i];
-    if (c >= max_chunks) return;
-    const uint32_t nb = ubytes[f], b0 = (uint32_t)c * kChunk;
-    if (b0 >= nb) return;
-    const uint32_t *p = (const uint32_t *)(ustream + ubase[f] + b0);   // word aligned; the tail word is zero padded
-    uint8_t *d = o + hdr_len + b0 + ffoff[(size_t)f * max_chunks + c];
-    const uint32_t n = min(nb - b0, (uint32_t)kChunk);
-    uint32_t wv[kChunk / 4];
+        for (int i = t; i < hdr_len; i += 256) o[i] = header[i];
+    const uint32_t nb = ubytes[f], w0 = (uint32_t)blockIdx.x * 256u * kChunk;          // first input byte of the workgroup
+    if (w0 >= nb || (int)(blockIdx.x * 256) >= max_chunks) return;                     // uniform
+    const size_t out0 = (size_t)hdr_len + w0 + ffoff[(size_t)f * max_chunks + blockIdx.x * 256];   // where the workgroup's piece starts in the frame's stream
+    const uint32_t phase = (uint32_t)((uintptr_t)(o + out0) & 15u);
+    if (t == 0) piece_end = 0;
+    __syncthreads();
+    const uint32_t b0 = (uint32_t)c * kChunk;
+    if (c < max_chunks && b0 < nb) {
+        const uint32_t *p = (const uint32_t *)(ustream + ubase[f] + b0);   // word aligned; the tail word is zero padded
+        const uint32_t n = min(nb - b0, (uint32_t)kChunk);
+        uint32_t at = phase + (b0 - w0) + (ffoff[(size_t)f * max_chunks + c] - ffoff[(size_t)f * max_chunks + blockIdx.x * 256]);
+        uint32_t wv[kChunk / 4];
 #pragma unroll
-    for (int i = 0; i < kChunk / 4; i++) wv[i] = (uint32_t)i * 4 < n ? p[i] : 0u;
+        for (int i = 0; i < kChunk / 4; i++) wv[i] = (uint32_t)i * 4 < n ? p[i] : 0u;
 #pragma unroll
-    for (int i = 0; i < kChunk / 4; i++) {
+        for (int i = 0; i < kChunk / 4; i++) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((uint32_t)(i * 4 + k) < n) {
-                const uint8_t v = (uint8_t)(wv[i] >> (8 * k));
-                *d++ = v;
-                if (v == 0xff) *d++ = 0x00;
+            for (int k = 0; k < 4; k++) {
+                if ((uint32_t)(i * 4 + k) < n) {
+                    const uint8_t v = (uint8_t)(wv[i] >> (8 * k));
+                    buf[at++] = v;
+                    if (v == 0xff) buf[at++] = 0x00;
+                }
             }
         }
+        if (b0 + n == nb) { buf[at++] = 0xff; buf[at++] = 0xd9; }   // EOI
+        if (b0 + n == nb || t == 255) piece_end = at;                // the last chunk of the piece (chunks are consecutive: exactly one thread)
     }
-    if (b0 + n == nb) { d[0] = 0xff; d[1] = 0xd9; }   // EOI
+    __syncthreads();
+    const uint32_t end = piece_end;                                   // buffer offset one past the piece
+    uint8_t *g = o + out0 - phase;                                    // 16-byte aligned; buffer offset i <-> g + i
+    for (uint32_t k = (uint32_t)t * 16u; k < end; k += 256u * 16u) {
+        if (k >= phase && k + 16 <= end) *(uint4 *)(g + k) = *(const uint4 *)(buf + k);
+        else
+            for (uint32_t i = max(k, phase); i < min(k + 16, end); i++) g[i] = buf[i];
+    }
 }
 
 }  // namespace
