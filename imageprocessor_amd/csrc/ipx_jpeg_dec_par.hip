@@ -205,7 +205,7 @@ __device__ __forceinline__ Tables stage(uint8_t *lds, const JpegParArgs &a, cons
     const uint8_t *scan = a.ublob + im.scan_off;           // unstuffed copy: same offsets as the packed scans, zero padded
     const uint32_t base = (uint32_t)first_sub * kSub;
     const uint32_t cap = (im.scan_len + 15u) & ~15u;       // the unstuffed scan is no longer than the stuffed one
-    const uint32_t avail = a.stage_rows && cap > base ? min(cap - base, (uint32_t)(64 * kSub + 16)) : 0u;
+    const uint32_t avail = a.stage_rows == 1 && cap > base ? min(cap - base, (uint32_t)(64 * kSub + 16)) : 0u;
     for (uint32_t ch = lane; ch < (avail >> 4); ch += 64) {
         const uint4 v = *(const uint4 *)(scan + base + ch * 16);
         const uint32_t i = ch * 16;
@@ -389,7 +389,8 @@ struct CoefSink {
         if (d < -32768 || d > 32767) { atomicMin(status, jpeg_status_key(kJpegStatusLast, IPX_ERR_UNSUPPORTED)); return; }   // see kJpegStatusLast
         dcs[g] = (int16_t)d;
     }
-    __device__ __forceinline__ void ac(int z, int v) { if (g < nblk) coefs[(size_t)g * 64 + unz[z]] = (int16_t)v; }
+    bool drop = false;                   // (diagnostic: IPX_JPEG_PAR_STAGE=2 runs the write pass without its coefficient stores)
+    __device__ __forceinline__ void ac(int z, int v) { if (g < nblk && !drop) coefs[(size_t)g * 64 + unz[z]] = (int16_t)v; }
     __device__ __forceinline__ bool end_block() { g++; return g < nblk; }
     __device__ __forceinline__ void bad() { if (g < nblk) atomicMin(status, jpeg_status_key(0, IPX_ERR_INVALID)); }   // "bad Huffman code" in real data
 };
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(64) void par_write_kernel(JpegParArgs a)
     const uint32_t uend = min(((uint32_t)t + 1) * kSub * 8u, r.ubits);
     if (p == kEnd || p >= uend) return;
     CoefSink sink{a.coefs + (size_t)im.img * a.nblk * 64, a.dcs + (size_t)im.img * a.nblk, T.unz, a.ends[(size_t)blockIdx.y * a.max_nsub + t], (uint32_t)a.nblk, a.status + im.img};
+    sink.drop = a.stage_rows == 2;
     if (sink.g >= sink.nblk) return;
     r.seek(p);
     uint32_t ends;
@@ -602,7 +604,7 @@ hipError_t launch_par_sync(const JpegParArgs &a, int round, hipStream_t s)
     hipError_t e = sync_cache.prepare((const void *)par_sync_kernel, 64, kParLds, nullptr);
     if (e == hipSuccess) e = write_cache.prepare((const void *)par_write_kernel, 64, kParLds, nullptr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(par_sync_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows ? kParLds : 4096, s, a, round);
+    hipLaunchKernelGGL(par_sync_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows == 1 ? kParLds : 4096, s, a, round);
     return hipGetLastError();
 }
 hipError_t launch_par_write(const JpegParArgs &a, hipStream_t s)
@@ -611,7 +613,7 @@ hipError_t launch_par_write(const JpegParArgs &a, hipStream_t s)
     // 128-byte line each in flight, and with 2048 lanes per CU those lines do not fit the XCD's 4 MiB L2 -- every line is then written
     // back (and read for the merge) several times
     static const int write_lds = [] { const char *e = getenv("IPX_JPEG_WRITE_LDS"); return e ? atoi(e) : 16384; }();   // measured per 1024 x 1080p files: 4 KiB 8.7 ms, 10 KiB 8.4, 16 KiB 7.9, 20 KiB 8.1, 40 KiB 11.7
-    hipLaunchKernelGGL(par_write_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows ? kParLds : (size_t)std::max(4096, write_lds), s, a);
+    hipLaunchKernelGGL(par_write_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows == 1 ? kParLds : (size_t)std::max(4096, write_lds), s, a);
     return hipGetLastError();
 }
 hipError_t launch_par_dc(const JpegParArgs &a, hipStream_t s)
