@@ -1,4 +1,9 @@
-# A/B of two builds of libipx inside ONE gpurun call, repetitions interleaved.
-# usage: WL="--workload full" REPS=3 tools/ab_lib.sh tools/bin/libipx_prev.so imageprocessor_amd/libipx.so
-run() { IPX_LIB=$PWD/$1 timeout -k 10 200 python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --e2e-frames 0 $WL 2>gpurun_out/err.tmp | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-50s' % sys.argv[1], d['value'], d['roofline']['avg_launch_ms'], d['roofline']['frac'])" "$1"; }
-for rep in $(seq ${REPS:-3}); do for lib in "$@"; do run $lib || exit 1; done; done
+# A/B of two builds of the library on one box: tools/ab_lib.sh <other.so> -- alternates IPX_LIB between the tree's libipx.so and the other one
+other=$1
+for r in 1 2 3; do
+  for lib in "" "$other"; do
+    j=$(IPX_LIB=$lib timeout -k 10 100 python tools/bench_j2j.py 1024 5 2>&1 | grep 'images/s' | sed 's/.*files in//')
+    d=$(IPX_LIB=$lib timeout -k 10 100 python tools/bench_jpeg_dec.py 1024 2>&1 | grep 'GPU decode' | sed 's/.*batch of  1024: //; s/ frames.*//' | tr '\n' ' ')
+    echo "${lib:-tree}: j2j $j | decode $d"
+  done
+done
