@@ -10,12 +10,18 @@
  *
  * Reference call sites (under internal/usecase/processor/operations/):
  *   resize.go:121-125      resizeImage      -> x/image/draw BiLinear.Scale(..., Over, nil)
- *   thumbnail.go:114-132   cropAndResize    -> BiLinear.Scale (equal sizes => Copy) + resizeImage
+ *   thumbnail.go:114-132   cropAndResize    -> BiLinear.Scale (equal sizes: one tap of weight 1 per axis) + resizeImage
  *   watermark.go:90-92     draw.Draw(result, bounds, img, ZP, draw.Src)
  *   watermark.go:151       freetype DrawString -> draw.DrawMask(dst, dr, Uniform, ZP, Alpha, mp, Over)
- * Upstream routines restated: x/image@v0.33.0 draw/impl.go ablInterpolator.Scale and
- * scale_RGBA_RGBA_{Src,Over}; draw/scale.go Copy, opaque; Go 1.24 image/draw/draw.go clip,
- * DrawMask, drawCopyOver, drawCopySrc, drawGlyphOver; image/image.go (*RGBA).Opaque.
+ * Upstream routines restated: x/image@v0.33.0 draw/scale.go -- BiLinear = &Kernel{1, tent}, Kernel.Scale ->
+ * newDistrib, kernelScaler.Scale, opaque -- and draw/impl.go scaleX_{RGBA,NRGBA,Gray,YCbCr4xx,Image},
+ * scaleY_RGBA_{Src,Over}, ftou; Go 1.24 image/draw/draw.go clip, DrawMask, drawCopyOver, drawCopySrc,
+ * drawGlyphOver; image/image.go (*RGBA).Opaque.
+ *
+ * Rounds 1-2 restated ablInterpolator (x/image's ApproxBiLinear) here by mistake: BiLinear is the tent KERNEL,
+ * a two-pass float64 scaler whose tap count grows with the downscale ratio.  thumbnail.go:129's equal-size
+ * Scale runs through the same kernel scaler (a single tap of weight 1 per axis): only nnInterpolator /
+ * ablInterpolator.Scale simplify equal sizes to Copy.
  */
 #include "ipx_oracle.h"
 
@@ -196,7 +202,171 @@ void ipxo_draw_rgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r,
     }
 }
 
-/* ---- x/image/draw: BiLinear.Scale ----------------------------------------------------- */
+/* ---- x/image/draw: BiLinear.Scale = (&Kernel{1, tent}).Scale ---------------------------------------
+ *
+ * draw/scale.go:
+ *   BiLinear = &Kernel{1, func(t float64) float64 { return 1 - t }}
+ *   (q *Kernel).Scale(dst, dr, src, sr, op, opts) = q.newScaler(dr.Dx(), dr.Dy(), sr.Dx(), sr.Dy(), false).Scale(...)
+ *   newDistrib(q, dw, sw): per destination index the contributing source indices and their weights
+ *   kernelScaler.Scale: adr / opaque() / Uniform shortcut, scaleX_<src type> into tmp [][4]float64 (dw x sh),
+ *     then scaleY_RGBA_{Src,Over} down the columns of tmp.
+ */
+
+typedef void (*tap_fn)(const void *src, int x, int y, uint32_t out[4]); /* 16-bit premultiplied RGBA */
+
+typedef struct { int32_t i, j; double inv_total, inv_total_ffff; } ks_source;
+typedef struct { int32_t coord; double weight; } ks_contrib;
+typedef struct { ks_source *sources; ks_contrib *contribs; } ks_distrib;
+
+/* newDistrib with q.Support = 1 and q.At(t) = 1 - t.  0 ok, -1 out of memory. */
+static int ks_new_distrib(ks_distrib *d, int32_t dw, int32_t sw)
+{
+    const double support = 1.0;
+    double scale = (double)sw / (double)dw;
+    double half_width = support, kernel_arg_scale = 1.0;
+    int32_t x, n = 0;
+    size_t nc = 0;
+    /* When shrinking, broaden the effective kernel support so that every source pixel is visited. */
+    if (scale > 1) {
+        half_width *= scale;
+        kernel_arg_scale = 1 / scale;
+    }
+    d->sources = (ks_source *)malloc(sizeof(ks_source) * (size_t)(dw > 0 ? dw : 1));
+    if (!d->sources) return -1;
+    /* first pass: i, j = range of source indices; inv_total temporarily holds the centre */
+    for (x = 0; x < dw; x++) {
+        double center = ((double)x + 0.5) * scale - 0.5;
+        int32_t i = (int32_t)floor(center - half_width);
+        int32_t j;
+        if (i < 0) i = 0;
+        j = (int32_t)ceil(center + half_width);
+        if (j > sw) {
+            j = sw;
+            if (j < i) j = i;
+        }
+        d->sources[x].i = i; d->sources[x].j = j; d->sources[x].inv_total = center;
+        n += j - i;
+    }
+    d->contribs = (ks_contrib *)malloc(sizeof(ks_contrib) * (size_t)(n > 0 ? n : 1));
+    if (!d->contribs) { free(d->sources); return -1; }
+    for (x = 0; x < dw; x++) {
+        ks_source b = d->sources[x];
+        double total = 0.0;
+        int32_t l = (int32_t)nc, coord;
+        for (coord = b.i; coord < b.j; coord++) {
+            double t = (b.inv_total - (double)coord) * kernel_arg_scale, weight;
+            if (t < 0) t = -t;               /* scale.go's own abs() */
+            if (t >= support) continue;
+            weight = 1 - t;                  /* BiLinear's At */
+            if (weight == 0) continue;
+            total += weight;
+            d->contribs[nc].coord = coord; d->contribs[nc].weight = weight; nc++;
+        }
+        total = 1 / total;
+        d->sources[x].i = l; d->sources[x].j = (int32_t)nc;
+        d->sources[x].inv_total = total;
+        d->sources[x].inv_total_ffff = total / 0xffff;
+    }
+    return 0;
+}
+
+static void ks_free(ks_distrib *d) { free(d->sources); free(d->contribs); }
+
+static uint32_t ks_ftou(double f) /* impl.go ftou */
+{
+    int32_t i = (int32_t)(0xffff * f + 0.5);
+    if (i > 0xffff) return 0xffff;
+    if (i > 0) return (uint32_t)i;
+    return 0;
+}
+
+/* kernelScaler.Scale after its adr / opaque() preamble.  adr is relative to dr.Min.  alpha_one: the source type's scaleX writes
+ * a literal 1 into tmp's alpha (scaleX_Gray, scaleX_YCbCr4xx) instead of the weighted sum of 0xffff taps.
+ * 0 ok, -3 out of memory. */
+static int kernel_scale(uint8_t *dst, int dstride, ipxo_rect dr, ipxo_rect adr, const void *src, tap_fn tap, ipxo_rect sr, int op,
+                        int alpha_one)
+{
+    const int32_t dw = dr.x1 - dr.x0, dh = dr.y1 - dr.y0, sw = sr.x1 - sr.x0, sh = sr.y1 - sr.y0;
+    ks_distrib hz, vt;
+    double (*tmp)[4];
+    int32_t x, y, dx, k;
+    size_t t = 0;
+    if (ks_new_distrib(&hz, dw, sw)) return -3;
+    if (ks_new_distrib(&vt, dh, sh)) { ks_free(&hz); return -3; }
+    tmp = (double (*)[4])malloc(sizeof(double[4]) * (size_t)dw * (size_t)sh);   /* makeTmpBuf: z.dw * z.sh */
+    if (!tmp) { ks_free(&hz); ks_free(&vt); return -3; }
+
+    /* scaleX_*: distributes the source image's columns over the temporary image */
+    for (y = 0; y < sh; y++) {
+        for (x = 0; x < dw; x++) {
+            const ks_source *s = &hz.sources[x];
+            double pr = 0, pg = 0, pb = 0, pa = 0;
+            for (k = s->i; k < s->j; k++) {
+                const ks_contrib *c = &hz.contribs[k];
+                uint32_t p[4];
+                tap(src, sr.x0 + c->coord, sr.y0 + y, p);
+                pr += (double)p[0] * c->weight;
+                pg += (double)p[1] * c->weight;
+                pb += (double)p[2] * c->weight;
+                pa += (double)p[3] * c->weight;
+            }
+            tmp[t][0] = pr * s->inv_total_ffff;
+            tmp[t][1] = pg * s->inv_total_ffff;
+            tmp[t][2] = pb * s->inv_total_ffff;
+            tmp[t][3] = alpha_one ? 1.0 : pa * s->inv_total_ffff;
+            t++;
+        }
+    }
+
+    /* scaleY_RGBA_{Src,Over}: distributes the temporary image's rows over the destination image */
+    for (dx = adr.x0; dx < adr.x1; dx++) {
+        uint8_t *d = dst + (size_t)(dr.y0 + adr.y0) * dstride + (size_t)(dr.x0 + dx) * 4;
+        for (y = adr.y0; y < adr.y1; y++, d += dstride) {
+            const ks_source *s = &vt.sources[y];
+            double pr = 0, pg = 0, pb = 0, pa = 0;
+            for (k = s->i; k < s->j; k++) {
+                const ks_contrib *c = &vt.contribs[k];
+                const double *p = tmp[(size_t)c->coord * dw + dx];
+                pr += p[0] * c->weight;
+                pg += p[1] * c->weight;
+                pb += p[2] * c->weight;
+                pa += p[3] * c->weight;
+            }
+            if (pr > pa) pr = pa;
+            if (pg > pa) pg = pa;
+            if (pb > pa) pb = pa;
+            if (op == IPXO_OP_SRC) {
+                d[0] = (uint8_t)(ks_ftou(pr * s->inv_total) >> 8);
+                d[1] = (uint8_t)(ks_ftou(pg * s->inv_total) >> 8);
+                d[2] = (uint8_t)(ks_ftou(pb * s->inv_total) >> 8);
+                d[3] = (uint8_t)(ks_ftou(pa * s->inv_total) >> 8);
+            } else {
+                uint32_t pr0 = ks_ftou(pr * s->inv_total), pg0 = ks_ftou(pg * s->inv_total);
+                uint32_t pb0 = ks_ftou(pb * s->inv_total), pa0 = ks_ftou(pa * s->inv_total);
+                uint32_t pa1 = (0xffff - pa0) * 0x101;
+                d[0] = (uint8_t)(((uint32_t)d[0] * pa1 / 0xffff + pr0) >> 8);
+                d[1] = (uint8_t)(((uint32_t)d[1] * pa1 / 0xffff + pg0) >> 8);
+                d[2] = (uint8_t)(((uint32_t)d[2] * pa1 / 0xffff + pb0) >> 8);
+                d[3] = (uint8_t)(((uint32_t)d[3] * pa1 / 0xffff + pa0) >> 8);
+            }
+        }
+    }
+    free(tmp);
+    ks_free(&hz);
+    ks_free(&vt);
+    return 0;
+}
+
+/* the preamble of kernelScaler.Scale shared by every source type: adr, then the caller's opaque() test */
+static int ks_adr(int dw, int dh, ipxo_rect dr, ipxo_rect sr, int sw, int sh, ipxo_rect *adr)
+{
+    ipxo_rect db = {0, 0, dw, dh};
+    *adr = rect_intersect(db, dr);
+    if (rect_empty(*adr) || rect_empty(sr)) return 1;              /* nothing to do */
+    *adr = rect_add(*adr, -dr.x0, -dr.y0);
+    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) return -1; /* scaleX_Image on a partly outside sr: not restated */
+    return 0;
+}
 
 /* image.(*RGBA).Opaque over the whole source image, as draw/scale.go opaque() asks */
 static int rgba_opaque(const uint8_t *src, int sw, int sh, int sstride)
@@ -208,82 +378,27 @@ static int rgba_opaque(const uint8_t *src, int sw, int sh, int sstride)
     return 1;
 }
 
+typedef struct { const uint8_t *pix; int stride; } rgba_src;
+
+static void tap_rgba(const void *s, int x, int y, uint32_t out[4]) /* scaleX_RGBA: Pix * 0x101 */
+{
+    const rgba_src *n = (const rgba_src *)s;
+    const uint8_t *p = n->pix + (size_t)y * n->stride + (size_t)x * 4;
+    out[0] = (uint32_t)p[0] * 0x101; out[1] = (uint32_t)p[1] * 0x101;
+    out[2] = (uint32_t)p[2] * 0x101; out[3] = (uint32_t)p[3] * 0x101;
+}
+
 int ipxo_scale_bilinear_rgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr,
                               const uint8_t *src, int sw, int sh, int sstride, ipxo_rect sr,
                               int op)
 {
-    ipxo_rect db = {0, 0, dw, dh};
     ipxo_rect adr;
-    int32_t ssw, ssh, dx, dy;
-    double xscale, yscale;
-
-    /* ablInterpolator.Scale: equal sizes simplify to Copy -> image/draw.DrawMask */
-    if (dr.x1 - dr.x0 == sr.x1 - sr.x0 && dr.y1 - dr.y0 == sr.y1 - sr.y0) {
-        ipxo_draw_rgba8(dst, dw, dh, dstride, dr, src, sw, sh, sstride, sr.x0, sr.y0, op);
-        return 0;
-    }
-    adr = rect_intersect(db, dr);
-    if (rect_empty(adr) || rect_empty(sr)) return 0;
-    adr = rect_add(adr, -dr.x0, -dr.y0);
-    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) return -1; /* generic path */
+    rgba_src n;
+    int rc = ks_adr(dw, dh, dr, sr, sw, sh, &adr);
+    if (rc) return rc < 0 ? -1 : 0;
     if (op == IPXO_OP_OVER && rgba_opaque(src, sw, sh, sstride)) op = IPXO_OP_SRC;
-
-    ssw = sr.x1 - sr.x0;
-    ssh = sr.y1 - sr.y0;
-    yscale = (double)ssh / (double)(dr.y1 - dr.y0);
-    xscale = (double)ssw / (double)(dr.x1 - dr.x0);
-
-    for (dy = adr.y0; dy < adr.y1; dy++) {
-        double sy = ((double)dy + 0.5) * yscale - 0.5;
-        int32_t sy0 = (int32_t)sy;
-        double yf0 = sy - (double)sy0;
-        double yf1 = 1 - yf0;
-        int32_t sy1 = sy0 + 1;
-        uint8_t *d;
-        if (sy < 0) { sy0 = 0; sy1 = 0; yf0 = 0; yf1 = 1; }
-        else if (sy1 > ssh - 1) { sy0 = ssh - 1; sy1 = ssh - 1; yf0 = 1; yf1 = 0; }
-        d = dst + (size_t)(dr.y0 + dy) * dstride + (size_t)(dr.x0 + adr.x0) * 4;
-
-        for (dx = adr.x0; dx < adr.x1; dx++, d += 4) {
-            double sx = ((double)dx + 0.5) * xscale - 0.5;
-            int32_t sx0 = (int32_t)sx;
-            double xf0 = sx - (double)sx0;
-            double xf1 = 1 - xf0;
-            int32_t sx1 = sx0 + 1;
-            const uint8_t *p00, *p10, *p01, *p11;
-            uint32_t p[4];
-            int c;
-            if (sx < 0) { sx0 = 0; sx1 = 0; xf0 = 0; xf1 = 1; }
-            else if (sx1 > ssw - 1) { sx0 = ssw - 1; sx1 = ssw - 1; xf0 = 1; xf1 = 0; }
-            p00 = src + (size_t)(sr.y0 + sy0) * sstride + (size_t)(sr.x0 + sx0) * 4;
-            p10 = src + (size_t)(sr.y0 + sy0) * sstride + (size_t)(sr.x0 + sx1) * 4;
-            p01 = src + (size_t)(sr.y0 + sy1) * sstride + (size_t)(sr.x0 + sx0) * 4;
-            p11 = src + (size_t)(sr.y0 + sy1) * sstride + (size_t)(sr.x0 + sx1) * 4;
-            for (c = 0; c < 4; c++) {
-                double s00 = (double)((uint32_t)p00[c] * 0x101);
-                double s10 = (double)((uint32_t)p10[c] * 0x101);
-                double s01 = (double)((uint32_t)p01[c] * 0x101);
-                double s11 = (double)((uint32_t)p11[c] * 0x101);
-                s10 = xf1 * s00 + xf0 * s10;
-                s11 = xf1 * s01 + xf0 * s11;
-                s11 = yf1 * s10 + yf0 * s11;
-                p[c] = (uint32_t)s11;
-            }
-            if (op == IPXO_OP_SRC) {
-                d[0] = (uint8_t)(p[0] >> 8);
-                d[1] = (uint8_t)(p[1] >> 8);
-                d[2] = (uint8_t)(p[2] >> 8);
-                d[3] = (uint8_t)(p[3] >> 8);
-            } else {
-                uint32_t pa1 = (0xffff - p[3]) * 0x101;
-                d[0] = (uint8_t)(((uint32_t)d[0] * pa1 / 0xffff + p[0]) >> 8);
-                d[1] = (uint8_t)(((uint32_t)d[1] * pa1 / 0xffff + p[1]) >> 8);
-                d[2] = (uint8_t)(((uint32_t)d[2] * pa1 / 0xffff + p[2]) >> 8);
-                d[3] = (uint8_t)(((uint32_t)d[3] * pa1 / 0xffff + p[3]) >> 8);
-            }
-        }
-    }
-    return 0;
+    n.pix = src; n.stride = sstride;
+    return kernel_scale(dst, dstride, dr, adr, &n, tap_rgba, sr, op, 0);
 }
 
 /* ---- image/draw: drawGlyphOver, one call per glyph in string order --------------------- */
@@ -372,63 +487,11 @@ int ipxo_process_rgba8(const ipxo_pipeline *p, const uint8_t *src, int sw, int s
 }
 
 /* ======================================================================================================
- * Source-type variants.  Same interpolator, different tap fetch.
- * Upstream routines restated: x/image@v0.33.0 draw/impl.go scale_RGBA_NRGBA_{Src,Over},
- * scale_RGBA_YCbCr{444,422,420,440}_Src; Go 1.24 image/draw drawNRGBAOver / drawNRGBASrc;
+ * Source-type variants.  Same kernel scaler, different scaleX_<type> tap fetch.
+ * Upstream routines restated: x/image@v0.33.0 draw/impl.go scaleX_NRGBA, scaleX_YCbCr{444,422,420,440},
+ * scaleX_Gray, scaleX_Image; Go 1.24 image/draw drawNRGBAOver / drawNRGBASrc;
  * image/internal/imageutil DrawYCbCr; image/color YCbCr.RGBA / YCbCrToRGB.
  * ====================================================================================================== */
-
-typedef void (*tap_fn)(const void *src, int x, int y, uint32_t out[4]); /* 16-bit premultiplied RGBA */
-
-static void scale_core(uint8_t *dst, int dstride, ipxo_rect dr, ipxo_rect adr, const void *src, tap_fn tap,
-                       ipxo_rect sr, int op)
-{
-    const int32_t ssw = sr.x1 - sr.x0, ssh = sr.y1 - sr.y0;
-    const double yscale = (double)ssh / (double)(dr.y1 - dr.y0);
-    const double xscale = (double)ssw / (double)(dr.x1 - dr.x0);
-    int32_t dx, dy;
-    for (dy = adr.y0; dy < adr.y1; dy++) {
-        double sy = ((double)dy + 0.5) * yscale - 0.5;
-        int32_t sy0 = (int32_t)sy;
-        double yf0 = sy - (double)sy0, yf1 = 1 - yf0;
-        int32_t sy1 = sy0 + 1;
-        uint8_t *d;
-        if (sy < 0) { sy0 = 0; sy1 = 0; yf0 = 0; yf1 = 1; }
-        else if (sy1 > ssh - 1) { sy0 = ssh - 1; sy1 = ssh - 1; yf0 = 1; yf1 = 0; }
-        d = dst + (size_t)(dr.y0 + dy) * dstride + (size_t)(dr.x0 + adr.x0) * 4;
-        for (dx = adr.x0; dx < adr.x1; dx++, d += 4) {
-            double sx = ((double)dx + 0.5) * xscale - 0.5;
-            int32_t sx0 = (int32_t)sx;
-            double xf0 = sx - (double)sx0, xf1 = 1 - xf0;
-            int32_t sx1 = sx0 + 1;
-            uint32_t t00[4], t10[4], t01[4], t11[4], p[4];
-            int c;
-            if (sx < 0) { sx0 = 0; sx1 = 0; xf0 = 0; xf1 = 1; }
-            else if (sx1 > ssw - 1) { sx0 = ssw - 1; sx1 = ssw - 1; xf0 = 1; xf1 = 0; }
-            tap(src, sr.x0 + sx0, sr.y0 + sy0, t00);
-            tap(src, sr.x0 + sx1, sr.y0 + sy0, t10);
-            tap(src, sr.x0 + sx0, sr.y0 + sy1, t01);
-            tap(src, sr.x0 + sx1, sr.y0 + sy1, t11);
-            for (c = 0; c < 4; c++) {
-                double s00 = (double)t00[c], s10 = (double)t10[c], s01 = (double)t01[c], s11 = (double)t11[c];
-                s10 = xf1 * s00 + xf0 * s10;
-                s11 = xf1 * s01 + xf0 * s11;
-                s11 = yf1 * s10 + yf0 * s11;
-                p[c] = (uint32_t)s11;
-            }
-            if (op == IPXO_OP_SRC) {
-                d[0] = (uint8_t)(p[0] >> 8); d[1] = (uint8_t)(p[1] >> 8);
-                d[2] = (uint8_t)(p[2] >> 8); d[3] = (uint8_t)(p[3] >> 8);
-            } else {
-                uint32_t pa1 = (0xffff - p[3]) * 0x101;
-                d[0] = (uint8_t)(((uint32_t)d[0] * pa1 / 0xffff + p[0]) >> 8);
-                d[1] = (uint8_t)(((uint32_t)d[1] * pa1 / 0xffff + p[1]) >> 8);
-                d[2] = (uint8_t)(((uint32_t)d[2] * pa1 / 0xffff + p[2]) >> 8);
-                d[3] = (uint8_t)(((uint32_t)d[3] * pa1 / 0xffff + p[3]) >> 8);
-            }
-        }
-    }
-}
 
 /* ---- *image.NRGBA ---------------------------------------------------------------------------------- */
 
@@ -478,20 +541,13 @@ void ipxo_draw_nrgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r,
 int ipxo_scale_bilinear_nrgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr,
                                const uint8_t *src, int sw, int sh, int sstride, ipxo_rect sr, int op)
 {
-    ipxo_rect db = {0, 0, dw, dh}, adr;
+    ipxo_rect adr;
     nrgba_src n;
-    if (dr.x1 - dr.x0 == sr.x1 - sr.x0 && dr.y1 - dr.y0 == sr.y1 - sr.y0) {
-        ipxo_draw_nrgba8(dst, dw, dh, dstride, dr, src, sw, sh, sstride, sr.x0, sr.y0, op);
-        return 0;
-    }
-    adr = rect_intersect(db, dr);
-    if (rect_empty(adr) || rect_empty(sr)) return 0;
-    adr = rect_add(adr, -dr.x0, -dr.y0);
-    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) return -1;
+    int rc = ks_adr(dw, dh, dr, sr, sw, sh, &adr);
+    if (rc) return rc < 0 ? -1 : 0;
     if (op == IPXO_OP_OVER && rgba_opaque(src, sw, sh, sstride)) op = IPXO_OP_SRC; /* (*NRGBA).Opaque: same scan */
     n.pix = src; n.stride = sstride;
-    scale_core(dst, dstride, dr, adr, &n, tap_nrgba, sr, op);
-    return 0;
+    return kernel_scale(dst, dstride, dr, adr, &n, tap_nrgba, sr, op, 0);          /* scaleX_NRGBA */
 }
 
 /* ---- *image.YCbCr ---------------------------------------------------------------------------------- */
@@ -549,22 +605,16 @@ void ipxo_draw_ycbcr(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r, con
 int ipxo_scale_bilinear_ycbcr(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr,
                               const ipxo_ycbcr *src, ipxo_rect sr)
 {
-    ipxo_rect db = {0, 0, dw, dh}, adr;
-    if (dr.x1 - dr.x0 == sr.x1 - sr.x0 && dr.y1 - dr.y0 == sr.y1 - sr.y0) {
-        ipxo_draw_ycbcr(dst, dw, dh, dstride, dr, src, sr.x0, sr.y0);
-        return 0;
-    }
-    adr = rect_intersect(db, dr);
-    if (rect_empty(adr) || rect_empty(sr)) return 0;
-    adr = rect_add(adr, -dr.x0, -dr.y0);
-    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > src->w || sr.y1 > src->h) return -1;
-    scale_core(dst, dstride, dr, adr, src, tap_ycbcr, sr, IPXO_OP_SRC); /* a YCbCr image is opaque */
-    return 0;
+    ipxo_rect adr;
+    int rc = ks_adr(dw, dh, dr, sr, src->w, src->h, &adr);
+    if (rc) return rc < 0 ? -1 : 0;
+    /* a YCbCr image is opaque: Over becomes Src.  scaleX_YCbCr4xx writes tmp alpha = 1 */
+    return kernel_scale(dst, dstride, dr, adr, src, tap_ycbcr, sr, IPXO_OP_SRC, 1);
 }
 
 /* ---- *image.Paletted (GIF uploads, palette PNGs) -----------------------------------------------------
  * No specialised routine exists upstream for this source type, so the GENERIC ones run:
- *   x/image@v0.33.0 draw/impl.go scale_RGBA_Image_{Src,Over}: every tap is src.At(x, y).RGBA(), i.e. the
+ *   x/image@v0.33.0 draw/impl.go scaleX_Image (scaleX_RGBA64Image): every tap is src.At(x, y).RGBA(), i.e. the
  *     palette entry's 16-bit premultiplied colour, then the same float64 lerps and the same stores;
  *   Go 1.24 image/draw drawRGBA (the fallback of DrawMask for dst *image.RGBA): with a nil mask ma = m and
  *     Src stores uint8(sr*ma/m >> 8), Over stores uint8((dr*a + sr*ma)/m >> 8) with a = (m - sa*ma/m)*0x101.
@@ -619,26 +669,19 @@ static int paletted_opaque(const uint8_t *src, int sw, int sh, int sstride, cons
 int ipxo_scale_bilinear_paletted(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr, const uint8_t *src, int sw, int sh,
                                  int sstride, const uint16_t pal16[256][4], ipxo_rect sr, int op)
 {
-    ipxo_rect db = {0, 0, dw, dh}, adr;
+    ipxo_rect adr;
     pal_src p;
-    if (dr.x1 - dr.x0 == sr.x1 - sr.x0 && dr.y1 - dr.y0 == sr.y1 - sr.y0) {
-        ipxo_draw_paletted(dst, dw, dh, dstride, dr, src, sw, sh, sstride, pal16, sr.x0, sr.y0, op);
-        return 0;
-    }
-    adr = rect_intersect(db, dr);
-    if (rect_empty(adr) || rect_empty(sr)) return 0;
-    adr = rect_add(adr, -dr.x0, -dr.y0);
-    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) return -1;
+    int rc = ks_adr(dw, dh, dr, sr, sw, sh, &adr);
+    if (rc) return rc < 0 ? -1 : 0;
     if (op == IPXO_OP_OVER && paletted_opaque(src, sw, sh, sstride, pal16)) op = IPXO_OP_SRC;
     p.pix = src; p.stride = sstride; p.pal = pal16;
-    scale_core(dst, dstride, dr, adr, &p, tap_paletted, sr, op);
-    return 0;
+    return kernel_scale(dst, dstride, dr, adr, &p, tap_paletted, sr, op, 0);       /* scaleX_Image / scaleX_RGBA64Image */
 }
 
 /* ---- the 16-bit image types of the PNG decoder and *image.CMYK ("deep" sources) -----------------------------
  * image.Decode returns *image.NRGBA64 (16-bit truecolour / gray with alpha or tRNS), *image.RGBA64 (16-bit truecolour), *image.Gray16
  * (16-bit gray) for PNGs and *image.CMYK for four-component JPEGs (image_processor.go:47).  No routine of x/image/draw or image/draw
- * specialises on the first three: scale_RGBA_Image_{Src,Over} read every tap as src.At(x, y).RGBA() and DrawMask falls to drawRGBA
+ * specialises on the first three: scaleX_Image (scaleX_RGBA64Image) reads every tap as src.At(x, y).RGBA() and DrawMask falls to drawRGBA
  * (restated for *image.Paletted above; the same code runs here).  *image.CMYK has drawCMYK = color.CMYKToRGB per pixel, which is the
  * top byte of color.CMYK.RGBA().  Pix layouts are Go's: big-endian 16-bit channels (R G B A / Y), C M Y K bytes.
  *   color.NRGBA64.RGBA: c * a / 0xffff, alpha a        color.RGBA64.RGBA: as stored
@@ -729,18 +772,11 @@ static int deep_opaque(const uint8_t *src, int sw, int sh, int sstride, int kind
 int ipxo_scale_bilinear_deep(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr, const uint8_t *src, int sw, int sh, int sstride,
                              int kind, ipxo_rect sr, int op)
 {
-    ipxo_rect db = {0, 0, dw, dh}, adr;
+    ipxo_rect adr;
     deep_src p;
-    if (dr.x1 - dr.x0 == sr.x1 - sr.x0 && dr.y1 - dr.y0 == sr.y1 - sr.y0) {
-        ipxo_draw_deep(dst, dw, dh, dstride, dr, src, sw, sh, sstride, kind, sr.x0, sr.y0, op);
-        return 0;
-    }
-    adr = rect_intersect(db, dr);
-    if (rect_empty(adr) || rect_empty(sr)) return 0;
-    adr = rect_add(adr, -dr.x0, -dr.y0);
-    if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) return -1;
+    int rc = ks_adr(dw, dh, dr, sr, sw, sh, &adr);
+    if (rc) return rc < 0 ? -1 : 0;
     if (op == IPXO_OP_OVER && deep_opaque(src, sw, sh, sstride, kind)) op = IPXO_OP_SRC;
     p.pix = src; p.stride = sstride; p.kind = kind;
-    scale_core(dst, dstride, dr, adr, &p, tap_deep, sr, op);
-    return 0;
+    return kernel_scale(dst, dstride, dr, adr, &p, tap_deep, sr, op, 0);           /* scaleX_Image / scaleX_RGBA64Image */
 }

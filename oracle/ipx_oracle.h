@@ -48,7 +48,8 @@ int ipxo_text_height_px(double font_size);
 /* watermark.go:93-97,159-190; returns 0 ok, 1 = parse error (black fallback applied) */
 int ipxo_parse_color(const char *s, double opacity, uint8_t rgba[4]);
 
-/* x/image/draw BiLinear.Scale for *image.RGBA <- *image.RGBA (resize.go:123, thumbnail.go:129).
+/* x/image/draw BiLinear.Scale -- the tent Kernel's two-pass float64 scaler, NOT ApproxBiLinear -- for *image.RGBA <- *image.RGBA
+ * (resize.go:123, thumbnail.go:129).
  * dst bounds are (0,0)-(dw,dh); src bounds (0,0)-(sw,sh); sr must lie inside src.
  * Returns 0, or -1 when sr leaves the source (the reference would take the generic
  * Image path, which this restatement does not cover). */
@@ -89,14 +90,13 @@ int ipxo_process_rgba8(const ipxo_pipeline *p, const uint8_t *src, int sw, int s
 extern "C" {
 #endif
 
-/* x/image/draw scale_RGBA_NRGBA_{Src,Over}: each tap premultiplied (c * a16 / 0xff) before the lerp.
- * Equal sizes go to image/draw drawNRGBAOver / drawNRGBASrc like Copy does. */
+/* x/image/draw kernelScaler with scaleX_NRGBA: each tap premultiplied (c * a16 / 0xff) before it is weighted. */
 int ipxo_scale_bilinear_nrgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr,
                                const uint8_t *src, int sw, int sh, int sstride, ipxo_rect sr, int op);
 void ipxo_draw_nrgba8(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r,
                       const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op);
 
-/* *image.Paletted through the generic routines (scale_RGBA_Image_{Src,Over}, image/draw drawRGBA); pal16[i] = Palette[i].RGBA() */
+/* *image.Paletted through the generic routines (scaleX_Image + scaleY_RGBA_{Src,Over}, image/draw drawRGBA); pal16[i] = Palette[i].RGBA() */
 int ipxo_scale_bilinear_paletted(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr, const uint8_t *src, int sw, int sh,
                                  int sstride, const uint16_t pal16[256][4], ipxo_rect sr, int op);
 void ipxo_draw_paletted(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r, const uint8_t *src, int sw, int sh,
@@ -117,11 +117,11 @@ typedef struct {
     const uint8_t *y, *cb, *cr;
     int32_t ystride, cstride, w, h, ratio;
 } ipxo_ycbcr;
-/* x/image/draw scale_RGBA_YCbCr{444,422,420,440}_Src (YCbCr is opaque, so Over becomes Src): each tap
+/* x/image/draw kernelScaler with scaleX_YCbCr{444,422,420,440} (YCbCr is opaque, so Over becomes Src): each tap
  * converted with color.YCbCr.RGBA's 16-bit integer formula, alpha 0xffff.  Equal sizes: DrawYCbCr. */
 int ipxo_scale_bilinear_ycbcr(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect dr,
                               const ipxo_ycbcr *src, ipxo_rect sr);
-/* image/internal/imageutil.DrawYCbCr (draw.Draw / Copy from a YCbCr source): 8-bit conversion, A = 255 */
+/* image/internal/imageutil.DrawYCbCr (draw.Draw from a YCbCr source): 8-bit conversion, A = 255 */
 void ipxo_draw_ycbcr(uint8_t *dst, int dw, int dh, int dstride, ipxo_rect r, const ipxo_ycbcr *src,
                      int spx, int spy);
 

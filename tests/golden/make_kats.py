@@ -64,57 +64,94 @@ def model_draw(dst, dw, dh, r, src, sw, sh, sp, op):
                 dst[di + c] = ((((dst[di + c] * a) & U32) // M + s) >> 8) & 0xFF
 
 
-def model_scale(dst, dw, dh, dr, src, sw, sh, sr, op):
-    """x/image/draw ablInterpolator.Scale + scale_RGBA_RGBA_{Src,Over}."""
-    if dr[2] - dr[0] == sr[2] - sr[0] and dr[3] - dr[1] == sr[3] - sr[1]:
-        model_draw(dst, dw, dh, dr, src, sw, sh, (sr[0], sr[1]), op)
-        return
+def new_distrib(dw, sw):
+    """x/image/draw newDistrib for BiLinear = &Kernel{1, tent}: per destination index (contribs, 1/total, 1/total/0xffff)."""
+    import math
+    scale = float(sw) / float(dw)
+    half_width, kernel_arg_scale = 1.0, 1.0
+    if scale > 1:
+        half_width *= scale
+        kernel_arg_scale = 1 / scale
+    out = []
+    for x in range(dw):
+        center = (float(x) + 0.5) * scale - 0.5
+        i = max(int(math.floor(center - half_width)), 0)
+        j = int(math.ceil(center + half_width))
+        if j > sw:
+            j = max(sw, i)
+        contribs, total = [], 0.0
+        for coord in range(i, j):
+            t = abs((center - float(coord)) * kernel_arg_scale)
+            if t >= 1.0:
+                continue
+            w = 1 - t
+            if w == 0:
+                continue
+            total += w
+            contribs.append((coord, w))
+        total = 1 / total
+        out.append((contribs, total, total / 0xFFFF))
+    return out
+
+
+def ftou(f):
+    i = int(0xFFFF * f + 0.5)
+    return 0xFFFF if i > 0xFFFF else (i if i > 0 else 0)
+
+
+def model_kernel_scale(dst, dw, dh, dr, tap, sr, op, alpha_one=False):
+    """kernelScaler.Scale after its preamble: scaleX_<type> into tmp, then scaleY_RGBA_{Src,Over}.
+    tap(x, y) -> 16-bit premultiplied RGBA of the source pixel; op already switched by opaque()."""
     ax0, ay0, ax1, ay1 = max(dr[0], 0), max(dr[1], 0), min(dr[2], dw), min(dr[3], dh)
     if ax0 >= ax1 or ay0 >= ay1 or sr[0] >= sr[2] or sr[1] >= sr[3]:
         return
     ax0, ax1, ay0, ay1 = ax0 - dr[0], ax1 - dr[0], ay0 - dr[1], ay1 - dr[1]
-    if op == OVER and model_opaque(src, sw, sh):
-        op = SRC
-    ssw, ssh = sr[2] - sr[0], sr[3] - sr[1]
-    yscale = float(ssh) / float(dr[3] - dr[1])
-    xscale = float(ssw) / float(dr[2] - dr[0])
-    for dy in range(ay0, ay1):
-        sy = (float(dy) + 0.5) * yscale - 0.5
-        sy0 = trunc_i32(sy)
-        yf0 = sy - float(sy0)
-        yf1 = 1 - yf0
-        sy1 = sy0 + 1
-        if sy < 0:
-            sy0, sy1, yf0, yf1 = 0, 0, 0.0, 1.0
-        elif sy1 > ssh - 1:
-            sy0, sy1, yf0, yf1 = ssh - 1, ssh - 1, 1.0, 0.0
-        for dx in range(ax0, ax1):
-            sx = (float(dx) + 0.5) * xscale - 0.5
-            sx0 = trunc_i32(sx)
-            xf0 = sx - float(sx0)
-            xf1 = 1 - xf0
-            sx1 = sx0 + 1
-            if sx < 0:
-                sx0, sx1, xf0, xf1 = 0, 0, 0.0, 1.0
-            elif sx1 > ssw - 1:
-                sx0, sx1, xf0, xf1 = ssw - 1, ssw - 1, 1.0, 0.0
-            p = []
-            for c in range(4):
-                def tap(xx, yy):
-                    return float(src[((sr[1] + yy) * sw + sr[0] + xx) * 4 + c] * 0x101)
-                s00, s10, s01, s11 = tap(sx0, sy0), tap(sx1, sy0), tap(sx0, sy1), tap(sx1, sy1)
-                s10 = xf1 * s00 + xf0 * s10
-                s11 = xf1 * s01 + xf0 * s11
-                s11 = yf1 * s10 + yf0 * s11
-                p.append(int(s11))
+    zdw, zdh, zsw, zsh = dr[2] - dr[0], dr[3] - dr[1], sr[2] - sr[0], sr[3] - sr[1]
+    hz, vt = new_distrib(zdw, zsw), new_distrib(zdh, zsh)
+    tmp = []
+    for y in range(zsh):
+        for contribs, _, itw_ffff in hz:
+            p = [0.0, 0.0, 0.0, 0.0]
+            for coord, w in contribs:
+                t = tap(sr[0] + coord, sr[1] + y)
+                for c in range(4):
+                    p[c] += float(t[c]) * w
+            q = [v * itw_ffff for v in p]
+            if alpha_one:
+                q[3] = 1.0
+            tmp.append(q)
+    for dx in range(ax0, ax1):
+        for dy in range(ay0, ay1):
+            contribs, itw, _ = vt[dy]
+            p = [0.0, 0.0, 0.0, 0.0]
+            for coord, w in contribs:
+                t = tmp[coord * zdw + dx]
+                for c in range(4):
+                    p[c] += t[c] * w
+            for c in range(3):
+                if p[c] > p[3]:
+                    p[c] = p[3]
+            q = [ftou(v * itw) for v in p]
             di = ((dr[1] + dy) * dw + dr[0] + dx) * 4
             if op == SRC:
                 for c in range(4):
-                    dst[di + c] = (p[c] >> 8) & 0xFF
+                    dst[di + c] = (q[c] >> 8) & 0xFF
             else:
-                pa1 = ((0xFFFF - p[3]) * 0x101) & U32
+                pa1 = ((0xFFFF - q[3]) * 0x101) & U32
                 for c in range(4):
-                    dst[di + c] = ((((dst[di + c] * pa1) & U32) // 0xFFFF + p[c]) >> 8) & 0xFF
+                    dst[di + c] = ((((dst[di + c] * pa1) & U32) // 0xFFFF + q[c]) >> 8) & 0xFF
+
+
+def model_scale(dst, dw, dh, dr, src, sw, sh, sr, op):
+    """x/image/draw BiLinear.Scale (Kernel.Scale) for *image.RGBA <- *image.RGBA: scaleX_RGBA + scaleY_RGBA_{Src,Over}.
+    Equal sizes are NOT simplified to Copy (only nnInterpolator / ablInterpolator.Scale do that)."""
+    if op == OVER and model_opaque(src, sw, sh):
+        op = SRC
+
+    def tap(x, y):
+        i = (y * sw + x) * 4
+        return [src[i] * 0x101, src[i + 1] * 0x101, src[i + 2] * 0x101, src[i + 3] * 0x101]
+    model_kernel_scale(dst, dw, dh, dr, tap, sr, op)
 
 
 def model_glyphs(dst, dw, dh, glyphs, col):
@@ -186,50 +223,9 @@ def ycbcr_to_rgb8(img, x, y):
     return out + [255]
 
 
-def model_scale_taps(dst, dw, dh, dr, tap, sw, sh, sr, op):
-    """ablInterpolator.Scale's loop with a tap function returning 16-bit premultiplied RGBA."""
-    ax0, ay0, ax1, ay1 = max(dr[0], 0), max(dr[1], 0), min(dr[2], dw), min(dr[3], dh)
-    if ax0 >= ax1 or ay0 >= ay1 or sr[0] >= sr[2] or sr[1] >= sr[3]:
-        return
-    ax0, ax1, ay0, ay1 = ax0 - dr[0], ax1 - dr[0], ay0 - dr[1], ay1 - dr[1]
-    ssw, ssh = sr[2] - sr[0], sr[3] - sr[1]
-    yscale = float(ssh) / float(dr[3] - dr[1])
-    xscale = float(ssw) / float(dr[2] - dr[0])
-    for dy in range(ay0, ay1):
-        sy = (float(dy) + 0.5) * yscale - 0.5
-        sy0 = trunc_i32(sy)
-        yf0 = sy - float(sy0)
-        yf1 = 1 - yf0
-        sy1 = sy0 + 1
-        if sy < 0:
-            sy0, sy1, yf0, yf1 = 0, 0, 0.0, 1.0
-        elif sy1 > ssh - 1:
-            sy0, sy1, yf0, yf1 = ssh - 1, ssh - 1, 1.0, 0.0
-        for dx in range(ax0, ax1):
-            sx = (float(dx) + 0.5) * xscale - 0.5
-            sx0 = trunc_i32(sx)
-            xf0 = sx - float(sx0)
-            xf1 = 1 - xf0
-            sx1 = sx0 + 1
-            if sx < 0:
-                sx0, sx1, xf0, xf1 = 0, 0, 0.0, 1.0
-            elif sx1 > ssw - 1:
-                sx0, sx1, xf0, xf1 = ssw - 1, ssw - 1, 1.0, 0.0
-            t00, t10 = tap(sr[0] + sx0, sr[1] + sy0), tap(sr[0] + sx1, sr[1] + sy0)
-            t01, t11 = tap(sr[0] + sx0, sr[1] + sy1), tap(sr[0] + sx1, sr[1] + sy1)
-            p = []
-            for c in range(4):
-                s10 = xf1 * float(t00[c]) + xf0 * float(t10[c])
-                s11 = xf1 * float(t01[c]) + xf0 * float(t11[c])
-                p.append(int(yf1 * s10 + yf0 * s11))
-            di = ((dr[1] + dy) * dw + dr[0] + dx) * 4
-            if op == SRC:
-                for c in range(4):
-                    dst[di + c] = (p[c] >> 8) & 0xFF
-            else:
-                pa1 = ((0xFFFF - p[3]) * 0x101) & U32
-                for c in range(4):
-                    dst[di + c] = ((((dst[di + c] * pa1) & U32) // 0xFFFF + p[c]) >> 8) & 0xFF
+def model_scale_taps(dst, dw, dh, dr, tap, sw, sh, sr, op, alpha_one=False):
+    """Kernel.Scale with a tap function returning 16-bit premultiplied RGBA (scaleX_NRGBA / scaleX_YCbCr4xx / scaleX_Image)."""
+    model_kernel_scale(dst, dw, dh, dr, tap, sr, op, alpha_one)
 
 
 def model_draw_nrgba(dst, dw, dh, r, src, sw, sh, sp, op):
@@ -295,51 +291,85 @@ def main():
         cases.append(scale_case("K1 constant %d %dx%d->%dx%d" % (v, sw, sh, dw, dh), "hand",
                                 sw, sh, src, dw, dh, expect=[v] * (dw * dh * 4)))
 
-    # K2: 2x2 -> 1x1, taps 10,20,30,41: 0.25*sum(tap*257) = 6489.25 -> 6489 >> 8 = 25 (hand)
+    # K2: 2x2 -> 1x1: scale 2, centre 0.5, both taps at t = 0.25 with weight 0.75 on either axis: the plain mean.
+    # taps 10,20,30,41: mean*257 = 6489.25; ftou: int(6489.25 + 0.5) = 6489 -> >> 8 = 25 (hand)
     src = [10] * 4 + [20] * 4 + [30] * 4 + [41] * 4
     cases.append(scale_case("K2 2x2->1x1", "hand", 2, 2, src, 1, 1, expect=[25] * 4))
 
-    # K3: 1920 -> 1024 columns (xscale 1.875): every fraction is a multiple of 1/16, so the
-    # float64 arithmetic is exact and the answer follows in rationals (hand, via Fraction)
+    def tent_axis(dw_, sw_):
+        """the tent weights of one axis in exact rationals: per destination index [(coord, weight)], weights summing to 1"""
+        import math
+        scale = Fraction(sw_, dw_)
+        hw, kas = (scale, 1 / scale) if scale > 1 else (Fraction(1), Fraction(1))
+        out = []
+        for x in range(dw_):
+            center = (Fraction(x) + Fraction(1, 2)) * scale - Fraction(1, 2)
+            i = max(math.floor(center - hw), 0)
+            j = min(math.ceil(center + hw), sw_)
+            ws = [(c, 1 - abs(center - c) * kas) for c in range(i, max(i, j)) if abs(center - c) * kas < 1]
+            tot = sum(w for _, w in ws)
+            out.append([(c, w / tot) for c, w in ws])
+        return out
+
+    def hand_scale(src, sw_, sh_, dw_, dh_):
+        """exact value of the two-pass tent scaler (opaque source, Src), then ftou's int(v + 0.5) >> 8"""
+        hx, vy = tent_axis(dw_, sw_), tent_axis(dh_, sh_)
+        out = []
+        for dy in range(dh_):
+            for dx in range(dw_):
+                for c in range(4):
+                    v = sum(wy * sum(wx * src[(y * sw_ + x) * 4 + c] * 257 for x, wx in hx[dx]) for y, wy in vy[dy])
+                    assert abs((v + Fraction(1, 2)) - round(v + Fraction(1, 2))) > Fraction(1, 10**6), "too close to a rounding step to call by hand"
+                    out.append(min(int(v + Fraction(1, 2)), 0xFFFF) >> 8)
+        return out
+
+    # K2b: 4 -> 2 columns (scale 2): dx = 0 sees columns 0,1,2 with tent weights .75,.75,.25 (column -1 does not exist, so the
+    # weights are renormalised by 1/1.75): (3a + 3b + c)/7; dx = 1 sees 1,2,3 with .25,.75,.75: (b + 3c + 3d)/7 (hand).
+    # The 2-tap ApproxBiLinear would give (a+b)/2, (c+d)/2 here -- this case tells the two apart.
+    src = [7] * 3 + [255] + [70] * 3 + [255] + [140] * 3 + [255] + [250] * 3 + [255]
+    exp = [(int(Fraction(3 * 7 + 3 * 70 + 140, 7) * 257 + Fraction(1, 2)) >> 8)] * 3 + [255] + \
+          [(int(Fraction(70 + 3 * 140 + 3 * 250, 7) * 257 + Fraction(1, 2)) >> 8)] * 3 + [255]
+    assert exp == [53, 53, 53, 255, 177, 177, 177, 255] and exp == hand_scale(src, 4, 1, 2, 1)
+    cases.append(scale_case("K2b 4x1->2x1 tent weights (3a+3b+c)/7", "hand", 4, 1, src, 2, 1, expect=None))
+    assert cases[-1]["expect"] == exp, (cases[-1]["expect"], exp)
+
+    # K3: 1920 -> 1024 columns (scale 1.875): 3 or 4 taps per column, in exact rationals (hand, via Fraction); the float64 model
+    # must agree wherever the exact value is not within 1e-6 of a rounding step (asserted inside hand_scale)
     sw, dw = 1920, 1024
     row = [(x * 7 + 3) & 0xFF for x in range(sw)]
     src = []
     for x in range(sw):
         src += [row[x], (row[x] * 3) & 0xFF, 255 - row[x], 255]
-    exp = []
-    for dx in range(dw):
-        sx = (Fraction(dx) + Fraction(1, 2)) * Fraction(15, 8) - Fraction(1, 2)
-        sx0 = int(sx)
-        f0 = sx - sx0
-        if sx < 0:
-            sx0, sx1, f0 = 0, 0, Fraction(0)
-        elif sx0 + 1 > sw - 1:
-            sx0, sx1, f0 = sw - 1, sw - 1, Fraction(1)
-        else:
-            sx1 = sx0 + 1
-        for c in range(4):
-            v = (1 - f0) * (src[sx0 * 4 + c] * 257) + f0 * (src[sx1 * 4 + c] * 257)
-            exp.append(int(v) >> 8)
-    cases.append(scale_case("K3 1920x1->1024x1 ramp", "hand", sw, 1, src, dw, 1, expect=exp))
-    assert exp[0:1] == [(int((Fraction(9, 16) * row[0] + Fraction(7, 16) * row[1]) * 257)) >> 8]
+    exp = hand_scale(src, sw, 1, dw, 1)
+    cases.append(scale_case("K3 1920x1->1024x1 ramp", "hand~", sw, 1, src, dw, 1, expect=None))
+    assert cases[-1]["expect"] == exp
+    ntaps = [len(t) for t in tent_axis(1024, 1920)]
+    assert min(ntaps) == 3 and max(ntaps) == 4 and max(len(t) for t in tent_axis(200, 1080)) == 11
 
-    # K4: upscale 2 -> 5 columns hits both clamp branches (hand, rationals: scale 0.4)
-    src = [0, 0, 0, 0, 200, 100, 50, 255]
-    exp = []
-    for dx in range(5):
-        sx = (Fraction(dx) + Fraction(1, 2)) * Fraction(2, 5) - Fraction(1, 2)
-        if sx < 0:
-            f0, a, b = Fraction(0), 0, 0
-        elif int(sx) + 1 > 1:
-            f0, a, b = Fraction(1), 1, 1
-        else:
-            f0, a, b = sx - int(sx), int(sx), int(sx) + 1
-        for c in range(4):
-            exp.append(int((1 - f0) * src[a * 4 + c] * 257 + f0 * src[b * 4 + c] * 257) >> 8)
-    cases.append(scale_case("K4 2x1->5x1 clamps", "hand~", 2, 1, src, 5, 1, expect=None))
-    # 0.4 is not dyadic: the rational answer can differ from float64 by one count only where a
-    # value sits within 1e-9 of an integer; none does here, so both derivations must agree.
+    # K4: upscale 2 -> 5 columns (scale 0.4, support stays 1): columns 0 and 4 see one tap, 1..3 blend the two (hand, rationals)
+    src = [0, 0, 0, 255, 200, 100, 50, 255]
+    exp = hand_scale(src, 2, 1, 5, 1)
+    cases.append(scale_case("K4 2x1->5x1 edges", "hand~", 2, 1, src, 5, 1, expect=None))
     assert cases[-1]["expect"] == exp, (cases[-1]["expect"], exp)
+    assert exp[0:4] == [0, 0, 0, 255] and exp[16:20] == [200, 100, 50, 255]
+
+    # K4b: the thumbnail's geometry in small: 27 -> 5 on both axes (scale 5.4, up to 11 x 11 taps per pixel), opaque (hand, rationals)
+    src = []
+    for i in range(27 * 27):
+        v = (i * 37 + 11) & 0xFF
+        src += [v, (v * 5 + 1) & 0xFF, 255 - v, 255]
+    exp = hand_scale(src, 27, 27, 5, 5)
+    cases.append(scale_case("K4b 27x27->5x5 (x5.4 as 1080->200)", "hand~", 27, 27, src, 5, 5, expect=None))
+    assert cases[-1]["expect"] == exp
+
+    # K4c: equal sizes are an identity for premultiplied pixels (one tap of weight 1 per axis; NOT a Copy: an invalid pixel with
+    # a colour above its alpha is clamped to the alpha by scaleY's "if pr > pa") (hand)
+    src = [10, 20, 30, 40, 200, 100, 50, 255, 0, 0, 0, 0, 90, 60, 30, 20]
+    cases.append(scale_case("K4c equal size: identity, colour clamped to alpha", "hand", 4, 1, src, 4, 1,
+                            expect=[10, 20, 30, 40, 200, 100, 50, 255, 0, 0, 0, 0, 20, 20, 20, 20]))
+    chk = [0] * 16
+    model_scale(chk, 4, 1, [0, 0, 4, 1], src, 4, 1, [0, 0, 4, 1], OVER)
+    assert chk == cases[-1]["expect"], chk
 
     # model-derived scale cases
     def add_model(name, sw, sh, dw, dh, opaque=False, **kw):
@@ -354,8 +384,8 @@ def main():
     add_model("down 32x18->17x10 src op", 32, 18, 17, 10, op=SRC)
     add_model("dr inside dst", 9, 7, 12, 10, dr=(2, 1, 9, 8))
     add_model("dr clipped by dst", 9, 7, 6, 6, dr=(-3, -2, 9, 8))
-    add_model("equal size -> Copy over", 6, 5, 6, 5, dst=rnd_frame(rng, 6, 5))
-    add_model("equal size crop -> Copy", 12, 9, 5, 5, sr=(4, 2, 9, 7))
+    add_model("equal size over a used frame", 6, 5, 6, 5, dst=rnd_frame(rng, 6, 5))
+    add_model("equal size crop", 12, 9, 5, 5, sr=(4, 2, 9, 7))
     add_model("over onto non-zero dst, translucent src", 11, 8, 6, 5, dst=rnd_frame(rng, 6, 5))
     add_model("over onto non-zero dst, opaque src (switches to Src)", 11, 8, 6, 5, opaque=True,
               dst=rnd_frame(rng, 6, 5))
@@ -506,7 +536,7 @@ def main():
                       "dh": 9, "r": list(r), "sp": list(sp), "dst": dst0, "expect": exp})
         for dw, dh, sr in ((5, 4, (0, 0, 11, 9)), (13, 14, (0, 0, 11, 9)), (4, 3, (1, 1, 10, 8))):
             exp = [0] * (dw * dh * 4)
-            model_scale_taps(exp, dw, dh, (0, 0, dw, dh), lambda x, y: tap_ycbcr(img, x, y), 11, 9, list(sr), SRC)
+            model_scale_taps(exp, dw, dh, (0, 0, dw, dh), lambda x, y: tap_ycbcr(img, x, y), 11, 9, list(sr), SRC, alpha_one=True)
             cases.append({"kind": "scale_ycbcr", "name": "scale ratio %d -> %dx%d" % (ratio, dw, dh), "origin": "model",
                           "img": img, "dw": dw, "dh": dh, "sr": list(sr), "dr": [0, 0, dw, dh], "dst": [0] * (dw * dh * 4),
                           "expect": exp})

@@ -82,15 +82,16 @@ def test_widened_8bit_frames_take_the_8bit_routines_bytes():
 
 
 def test_known_answers():
-    # one NRGBA64 pixel pair scaled 2 -> 4 wide: taps c*a/0xffff, float64 lerp, >> 8
+    # one NRGBA64 pixel pair scaled 2 -> 4 wide: taps c*a/0xffff, tent weights (scale 0.5, support 1), ftou's round to nearest, >> 8
     vals = np.array([[[0x8000, 0x4000, 0xffff, 0x8000], [0xffff, 0x0000, 0x0001, 0xffff]]], np.uint16)
     pix = oracle.deep_pix(vals, DEEP_NRGBA64)
     taps = oracle.deep_taps(pix, DEEP_NRGBA64)
     assert taps.tolist() == [[[0x8000 * 0x8000 // 0xffff, 0x4000 * 0x8000 // 0xffff, 0xffff * 0x8000 // 0xffff, 0x8000], [0xffff, 0, 1, 0xffff]]]
     out = oracle.scale_bilinear_deep(pix, DEEP_NRGBA64, 4, 1)
-    # dx = 0: sx < 0 -> tap 0; dx = 1: sx = 0.25; dx = 2: sx = 0.75; dx = 3: sx1 > ssw - 1 -> tap 1.  The source is not opaque: Over onto zeros.
+    # centres -0.25, 0.25, 0.75, 1.25: dx = 0 sees only tap 0 (tap -1 does not exist, tap 1 is at t = 1.25), dx = 1 weights 0.75 / 0.25, dx = 2 0.25 / 0.75,
+    # dx = 3 only tap 1 -- every weight dyadic, so the float64 sums are exact.  The source is not opaque: Over onto zeros.
     t0, t1 = taps[0, 0].astype(np.float64), taps[0, 1].astype(np.float64)
-    want = [(t0.astype(np.uint32) >> 8), ((0.75 * t0 + 0.25 * t1).astype(np.uint32) >> 8), ((0.25 * t0 + 0.75 * t1).astype(np.uint32) >> 8), (t1.astype(np.uint32) >> 8)]
+    want = [(t0.astype(np.uint32) >> 8), ((0.75 * t0 + 0.25 * t1 + 0.5).astype(np.uint32) >> 8), ((0.25 * t0 + 0.75 * t1 + 0.5).astype(np.uint32) >> 8), (t1.astype(np.uint32) >> 8)]
     assert out[0].tolist() == [list(map(int, x)) for x in want]
     # CMYK: (c, m, y, k) = (0, 128, 255, 64): w = 0xffff - 64*0x101; r = 0xffff * w / 0xffff = w, ...
     cm = oracle.deep_pix(np.array([[[0, 128, 255, 64]]], np.uint8), DEEP_CMYK)
