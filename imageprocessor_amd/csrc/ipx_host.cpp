@@ -61,50 +61,6 @@ bool draw_clip(Rect &r, int dw, int dh, bool has_src, int sw, int sh, int &spx, 
     return true;
 }
 
-void build_axis_taps(int src_extent, int dst_extent, int d_begin, int d_end, AxisTap *out)
-{
-    // x/image/draw impl.go scale_RGBA_RGBA_*: scale = float64(sw)/float64(dr.Dx());
-    // s = (float64(d)+0.5)*scale - 0.5; s0 = int32(s); frac0 = s - float64(s0); frac1 = 1 - frac0
-    const double scale = (double)src_extent / (double)dst_extent;
-    const int last = src_extent - 1;
-    for (int d = d_begin; d < d_end; d++) {
-        const double s = ((double)d + 0.5) * scale - 0.5;
-        int32_t s0 = (int32_t)s;
-        double f0 = s - (double)s0;
-        double f1 = 1 - f0;
-        AxisTap t;
-        t.iw = 0; t.f0 = 0; t.f1 = 0;
-        if (s < 0) {                 // both taps index 0, weights (1, 0)
-            t.base = 0; t.w0 = 1; t.w1 = 0;
-        } else if (s0 + 1 > last) {  // both taps index last, weights (0, 1)
-            t.base = last - 1; t.w0 = 0; t.w1 = 1;
-        } else {
-            t.base = s0; t.w0 = f1; t.w1 = f0;
-        }
-        out[d - d_begin] = t;
-    }
-}
-
-int axis_dyadic_bits(AxisTap *taps, int n, int max_k, int min_k)
-{
-    for (int k = min_k; k <= max_k; k++) {
-        const double unit = (double)(1 << k);
-        bool ok = true;
-        for (int i = 0; i < n && ok; i++) {
-            const double a = taps[i].w0 * unit, b = taps[i].w1 * unit;  // exact: power-of-two scaling
-            ok = a == std::floor(a) && b == std::floor(b) && a + b == unit && a >= 0 && b >= 0;
-        }
-        if (!ok) continue;
-        for (int i = 0; i < n; i++) {
-            taps[i].f0 = (float)(taps[i].w0 * unit);
-            taps[i].f1 = (float)(taps[i].w1 * unit);
-            taps[i].iw = (uint32_t)(taps[i].w0 * unit) | (uint32_t)(taps[i].w1 * unit) << 16;
-        }
-        return k;
-    }
-    return -1;
-}
-
 }  // namespace ipx
 
 using namespace ipx;

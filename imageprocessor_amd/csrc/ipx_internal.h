@@ -61,47 +61,10 @@ inline Rect to_rect(const ipx_rect &r) { return Rect{r.x0, r.y0, r.x1, r.y1}; }
 bool draw_clip(Rect &r, int dw, int dh, bool has_src, int sw, int sh, int &spx, int &spy,
                bool has_mask, int mw, int mh, int &mpx, int &mpy);
 
-// ---- one axis of ablInterpolator.Scale, tabulated -------------------------------------------
-// For destination index d: the pair of adjacent source indices (base, base+1), relative to the
-// source rectangle, and the float64 weights the reference multiplies them with.  At the clamped
-// edges the reference reads one index twice with weights (1,0) / (0,1); here the pair stays
-// adjacent and the zero weight lands on the neighbour, which yields the same bits
-// (1*a + 0*b == a for finite b).  Needs a source extent >= 2.
-struct AxisTap {
-    double w0;    // weight of src[base]     (xFrac1 / yFrac1 upstream)
-    double w1;    // weight of src[base + 1] (xFrac0 / yFrac0 upstream)
-    int32_t base;
-    float f0, f1; // w0 * 2^k, w1 * 2^k as exact small integers when the axis is dyadic (see below)
-    uint32_t iw;  // the same two integers packed: (w0 * 2^k) | (w1 * 2^k) << 16; 0 when the axis is not dyadic
-};
-static_assert(sizeof(AxisTap) == 32, "AxisTap is loaded as two 16-byte words");
-void build_axis_taps(int src_extent, int dst_extent, int d_begin, int d_end, AxisTap *out);
-// Smallest k <= max_k such that every weight of the axis is an exact multiple of 2^-k and each
-// pair sums to exactly 1; -1 if there is none.  On such an axis every float64 product and sum of
-// the reference's lerp is exact (weights k bits, taps 16 bits), so the result equals the rational
-// value and can be computed in narrower exact arithmetic.  Fills f0 / f1 / iw for that k.  min_k: the smallest k to report
-// (an axis that is exact at k = 0 is also exact at k = 1 with doubled weights).
-int axis_dyadic_bits(AxisTap *taps, int n, int max_k, int min_k = 0);
-
 // ---- kernel launchers (ipx_kernels.hip) --------------------------------------------------------
-struct ScaleArgs {
-    uint8_t *dst; int dstride;      // dst pointer at (0,0)
-    const uint8_t *src; int sstride;
-    int dr_x0, dr_y0;               // dr.Min
-    int adr_x0, adr_y0, adr_x1, adr_y1; // affected rectangle, relative to dr.Min
-    int sr_x0, sr_y0, ssw, ssh;     // source rectangle origin and extent
-    double xscale, yscale;
-    int op;                         // IPX_OP_*
-    const int *opaque_flag;         // device int: nonzero when the whole source is opaque (Over only)
-    int kind;                       // IPX_SRC_*: src is RGBA / NRGBA pixels, or the Y plane of a YCbCr image
-    const uint8_t *cb, *cr;         // YCbCr only
-    int cstride, ratio;
-    size_t dst_fs, src_fs, c_fs;    // bytes between frames of a batch (grid z = frame); 0 for one frame
-    int nframes;
-};
+// how the pixels of a source image in HBM are laid out (the tap kinds built on them: ipx_ks.h)
 enum { IPX_SRC_RGBA = 0, IPX_SRC_NRGBA = 1, IPX_SRC_YCBCR = 2,
        IPX_SRC_TAP64 = 3 /* At(x, y).RGBA() as four little-endian uint16 per pixel: the deep source types after deep_expand_kernel */ };
-hipError_t launch_scale_generic(const ScaleArgs &a, hipStream_t s);
 hipError_t launch_opaque_scan(const uint8_t *src, int sw, int sh, int sstride, int *flag,
                               hipStream_t s);
 hipError_t launch_opaque_scan_tap64(const uint8_t *src, int sw, int sh, int sstride, int *flag, hipStream_t s);
@@ -123,92 +86,15 @@ struct DevGlyph {           // one clipped DrawMask call, masks resident in HBM
     int x0, y0, x1, y1;     // clipped destination rectangle
 };
 constexpr int kMaxGlyphs = 256;
-// Where the text is composited.  1: inside the band kernel, from the LDS tile.  0: the band kernel copies / converts every pixel and
-// composite_kernel then goes over the text box of the watermark frames (it re-reads and re-writes ~0.1 MB of the 8.3 MB frame, 0.09 ms
-// per 1024 frames of 1080p).  The fused composite costs a persistent kernel its register allocation: with it hipcc spills 194 (RGBA) /
-// 266 (converted-tile kernel) scalar registers to VGPR lanes in the item loop, without it 49 / 129.  The converted-tile kernel is bound
-// by instruction issue and runs 8 % faster with the separate pass included; the RGBA kernels are bound by memory, gain nothing from
-// the leaner loop and would pay the extra pass (+2 %): they keep the fused composite.
-#ifndef IPX_FUSED_GLYPHS_RGBA
-#define IPX_FUSED_GLYPHS_RGBA 1      // band_pipe_kernel, band_kernel, band_nrgba_kernel
-#endif
-#ifndef IPX_FUSED_GLYPHS_CONV
-#define IPX_FUSED_GLYPHS_CONV 0      // band_conv_kernel (YCbCr / Gray planes, NRGBA frames)
-#endif
 hipError_t launch_stream_copy(void *dst, const void *src, size_t bytes, hipStream_t s);   // the box's streaming ceiling (bench.py)
 hipError_t launch_composite(uint8_t *dst, int dstride, size_t frame_stride, int nframes,
                             const DevGlyph *glyphs_dev, int n, Rect bbox, uint32_t sr, uint32_t sg,
                             uint32_t sb, uint32_t sa, hipStream_t s);
 
-// fused band kernel (resize + thumbnail + watermark copy in one pass over the source)
-constexpr int kBandNX = 4;  // a column block holds at most 256 * kBandNX destination columns per output
-struct ScaleOut {
-    uint8_t *out;              // frame 0
-    size_t frame_stride;
-    int ostride;               // bytes per output row
-    int dw, dh;
-    int sr_x0, sr_y0;          // source rectangle origin
-    const AxisTap *xt, *yt;    // dw / dh entries, device
-    int dyadic_shift;          // kx + ky when both axes are dyadic, else -1 (float64 lerp)
-    uint32_t imul;             // packed-integer lerp (kx <= 8, ky <= 12, 1 <= kx + ky <= 16): 257 << (24 - k'), k' = max(kx + ky, 9); else 0
-    const uint32_t *yrow;      // with imul: per destination row {ctl, yw}, dh + 1 entries.  yw = the packed y weights scaled by
-                               // 2^(k' - kx - ky), so that the output byte is mul_hi_u24(sum, imul).  ctl = LDS byte offset of the upper
-                               // tap's tile row | code << 28: what the row needs of the two horizontally lerped tile rows a thread keeps --
-                               // 0 both at hand (same pair as the row before), 1 the previous lower row becomes the upper one, 2 both new
-    const uint32_t *yrow16;    // for 16-bit converted taps (YCbCr / NRGBA sources, kx and ky <= 8): {ctl, y0', y1', 0} per row, dh + 1
-                               // entries; the y weights scaled by 2^(16 - kx - ky): the output byte is the top byte of the u32 sum
-    const int *row_begin;      // nbands+1 entries: first output row owned by each band
-    const int *col_begin;      // ncolblk+1 entries
-};
-struct BandArgs {
-    const uint8_t *src; size_t src_frame_stride; int sstride;
-    int sw, sh;
-    int band_rows, nbands;     // owned source rows per workgroup
-    int blk_cols, ncolblk;     // owned source columns per workgroup (multiple of 4)
-    int nframes;
-    int nx_out[2];             // per scaled output: destination columns per thread and column block (of 256)
-    int pipe_wgs;              // > 0: persistent pipelined kernel, this many workgroups per CU wanted
-    int pipe_nt;               // threads per workgroup of the pipelined kernel for wide tiles: 256 or 512
-    int pipe_order;            // 0: contiguous run of items per workgroup; 1: grid-interleaved, XCD-contiguous slots
-    int cus;                   // compute units of the device
-    int dbg;                   // diagnostic build only (-DIPX_DIAG=1): 1 = skip scaling, 2 = skip tile loads
-    unsigned long long *stamps; // diagnostic build only: per-phase cycle sums, else NULL
-    uint8_t *wm; size_t wm_frame_stride; int wm_stride;   // NULL = no watermark copy
-    int nscale;
-    ScaleOut sc[2];
-    // glyphs for the fused composite
-    const DevGlyph *glyphs; int nglyphs; Rect gbox;
-    uint32_t cr, cg, cb, ca;
-};
-hipError_t launch_band(const BandArgs &a, hipStream_t s);
 hipError_t launch_gray_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, int w, int h, int n, hipStream_t s);
 hipError_t launch_palette_expand(uint8_t *dst, size_t dst_fs, const uint8_t *src, int sstride, size_t src_fs, const uint8_t *palettes, int w,
                                  int h, int n, hipStream_t s);
 
-// the fused band kernel on *image.YCbCr planes (ipx_band_conv.hip): BandArgs without `src`, plus the planes
-struct YccArgs {
-    BandArgs b;
-    const uint8_t *y, *cb, *cr;
-    int ystride, cstride;
-    size_t y_fs, c_fs;         // frame strides of the luma / chroma planes
-    int cw, ch;                // chroma plane size
-    int ratio;                 // IPX_YCBCR_*
-    int mode[2];               // per b.sc entry: 0 = taps converted to 16-bit RGB (scale_RGBA_YCbCr4xx_Src),
-                               //                 1 = RGBA8 first (the crop copy), then scale_RGBA_RGBA_Src
-};
-// *matched = false: shape / alignment the kernel is not built for, nothing was launched
-hipError_t launch_band_ycc(const YccArgs &a, hipStream_t s, bool *matched);
-// the fused band kernel on *image.NRGBA frames (ipx_band_nrgba.hip): b.src holds non-premultiplied pixels
-struct NrgbaArgs {
-    BandArgs b;
-    int mode[2];               // per b.sc entry: 0 = taps premultiplied to 16 bit (scale_RGBA_NRGBA_*),
-                               //                 1 = premultiplied RGBA8 first (the crop copy), then scale_RGBA_RGBA_*
-};
-hipError_t launch_band_nrgba(const NrgbaArgs &a, hipStream_t s, bool *matched);
-hipError_t launch_band_nrgba_conv(const NrgbaArgs &a, hipStream_t s, bool *matched);   // ipx_band_conv.hip: premultiplied taps in a two-plane tile
-hipError_t launch_band_deep(const NrgbaArgs &a, int kind, hipStream_t s, bool *matched);   // the same kernel converting Go's Pix of a deep source type (ipx.h IPX_DEEP_*) on the fly
-hipError_t launch_band_tap64_conv(const NrgbaArgs &a, hipStream_t s, bool *matched);   // the same kernel on frames of ready-made 16-bit taps (8 bytes per pixel)
-constexpr int kConvTilePitch = 4096;   // bytes per row and plane of band_conv_kernel's LDS tile (the plan's row tables for it carry this pitch)
 // Per kernel instantiation and process: the dynamic-LDS limit is raised once (it only has to be at least what a launch asks for) and the
 // occupancy is cached per LDS size.  These are properties of the loaded function, not of the calling thread; done per thread, every
 // short-lived worker thread repeated hipFuncSetAttribute / hipOccupancy... in the middle of other threads' launches.
@@ -239,8 +125,6 @@ struct KernelLaunchCache {
     }
     bool first_report() { std::lock_guard<std::mutex> lk(mu); const bool f = !said; said = true; return f; }
 };
-size_t band_lds_bytes(int band_rows, int blk_cols);
-bool band_pipe_shape(int band_rows, int blk_cols, int *rows, int *ch);  // tile shapes the pipelined kernel is built for
 
 
 // ---- jpeg.Encode: transform on the GPU (ipx_jpeg.hip), tables / headers / entropy coder on the host ----

@@ -1,10 +1,7 @@
 // ipx_kernels.hip -- gfx950 (CDNA4) kernels of the pixel path.  No MFMA: every kernel here is a
-// streaming / gather kernel bounded by HBM bandwidth (and, for the bilinear taps, by FP64 VALU).
+// streaming kernel bounded by HBM bandwidth (the scaler lives in ipx_ks_generic.hip / ipx_ks_fused.hip).
 //
 // Arithmetic contracts (restating what the reference's libraries compute):
-//   * bilinear scale: x/image/draw ablInterpolator, scale_RGBA_RGBA_{Src,Over}: taps widened to
-//     16 bit (v*0x101), three float64 lerps with every product rounded before the add (the
-//     reference's amd64 build never fuses), truncation to uint32, >> 8.
 //   * copy: image/draw drawCopySrc / drawCopyOver.
 //   * glyph composite: image/draw drawGlyphOver, uint32 wrap-around preserved.
 // The file is compiled with -ffp-contract=off and the pragma below; check with
@@ -20,95 +17,6 @@
 namespace ipx {
 
 namespace {
-
-// ---------------------------------------------------------------------------------------------
-// Generic scale: any rectangles, Src or Over, one thread per destination pixel, taps straight
-// from global memory.  This is the per-operation seam; the batched path uses band_kernel.
-// ---------------------------------------------------------------------------------------------
-// 16-bit premultiplied RGBA of one source pixel, per source type:
-//   RGBA   scale_RGBA_RGBA_*      c * 0x101
-//   NRGBA  scale_RGBA_NRGBA_*     a16 = a * 0x101; c * a16 / 0xff          (PNG with alpha)
-//   YCbCr  scale_RGBA_YCbCr4xx_Src: color.YCbCr.RGBA inlined, clamped to 16 bit, alpha 0xffff (JPEG)
-struct Tap16 { uint32_t r, g, b, a; };
-
-template <int KIND>
-__device__ __forceinline__ Tap16 tap16(const ScaleArgs &a, int x, int y)
-{
-    Tap16 t;
-    if (KIND == IPX_SRC_YCBCR) {
-        const int cx = (a.ratio == IPX_YCBCR_422 || a.ratio == IPX_YCBCR_420) ? x / 2 : x;
-        const int cy = (a.ratio == IPX_YCBCR_420 || a.ratio == IPX_YCBCR_440) ? y / 2 : y;
-        const size_t ci = (size_t)cy * a.cstride + cx;
-        const int yy1 = (int)a.src[(size_t)y * a.sstride + x] * 0x10101;
-        const int cb1 = (int)a.cb[ci] - 128, cr1 = (int)a.cr[ci] - 128;
-        t.r = (uint32_t)min(max((yy1 + 91881 * cr1) >> 8, 0), 0xffff);
-        t.g = (uint32_t)min(max((yy1 - 22554 * cb1 - 46802 * cr1) >> 8, 0), 0xffff);
-        t.b = (uint32_t)min(max((yy1 + 116130 * cb1) >> 8, 0), 0xffff);
-        t.a = 0xffffu;
-    } else if (KIND == IPX_SRC_TAP64) {
-        const uint2 p = *(const uint2 *)(a.src + (size_t)y * a.sstride + (size_t)x * 8);
-        t.r = p.x & 0xffffu; t.g = p.x >> 16; t.b = p.y & 0xffffu; t.a = p.y >> 16;
-    } else {
-        const uint32_t p = *(const uint32_t *)(a.src + (size_t)y * a.sstride + (size_t)x * 4);
-        if (KIND == IPX_SRC_NRGBA) {
-            t.a = (p >> 24) * 0x101u;
-            t.r = (p & 0xffu) * t.a / 0xffu;
-            t.g = ((p >> 8) & 0xffu) * t.a / 0xffu;
-            t.b = ((p >> 16) & 0xffu) * t.a / 0xffu;
-        } else {
-            t.r = (p & 0xffu) * 0x101u; t.g = ((p >> 8) & 0xffu) * 0x101u;
-            t.b = ((p >> 16) & 0xffu) * 0x101u; t.a = (p >> 24) * 0x101u;
-        }
-    }
-    return t;
-}
-
-__device__ __forceinline__ uint32_t lerp16(uint32_t s00, uint32_t s10, uint32_t s01, uint32_t s11, double xw0,
-                                           double xw1, double yw0, double yw1)
-{
-    const double top = xw0 * (double)s00 + xw1 * (double)s10;
-    const double bot = xw0 * (double)s01 + xw1 * (double)s11;
-    return (uint32_t)(yw0 * top + yw1 * bot);
-}
-
-template <int KIND>
-__global__ __launch_bounds__(256) void scale_generic_kernel(ScaleArgs a)
-{
-    a.dst += blockIdx.z * a.dst_fs;      // frame of a batch (all zero for a single frame)
-    a.src += blockIdx.z * a.src_fs;
-    if (KIND == IPX_SRC_YCBCR) { a.cb += blockIdx.z * a.c_fs; a.cr += blockIdx.z * a.c_fs; }
-    const int dx = a.adr_x0 + (int)(blockIdx.x * 64 + threadIdx.x);
-    const int dy = a.adr_y0 + (int)(blockIdx.y * 4 + threadIdx.y);
-    if (dx >= a.adr_x1 || dy >= a.adr_y1) return;
-
-    const double sy = ((double)dy + 0.5) * a.yscale - 0.5;
-    int sy0 = (int)sy;
-    double yf0 = sy - (double)sy0;
-    double yf1 = 1 - yf0;
-    int sy1 = sy0 + 1;
-    if (sy < 0) { sy0 = 0; sy1 = 0; yf0 = 0; yf1 = 1; }
-    else if (sy1 > a.ssh - 1) { sy0 = a.ssh - 1; sy1 = a.ssh - 1; yf0 = 1; yf1 = 0; }
-
-    const double sx = ((double)dx + 0.5) * a.xscale - 0.5;
-    int sx0 = (int)sx;
-    double xf0 = sx - (double)sx0;
-    double xf1 = 1 - xf0;
-    int sx1 = sx0 + 1;
-    if (sx < 0) { sx0 = 0; sx1 = 0; xf0 = 0; xf1 = 1; }
-    else if (sx1 > a.ssw - 1) { sx0 = a.ssw - 1; sx1 = a.ssw - 1; xf0 = 1; xf1 = 0; }
-
-    const Tap16 t00 = tap16<KIND>(a, a.sr_x0 + sx0, a.sr_y0 + sy0), t10 = tap16<KIND>(a, a.sr_x0 + sx1, a.sr_y0 + sy0);
-    const Tap16 t01 = tap16<KIND>(a, a.sr_x0 + sx0, a.sr_y0 + sy1), t11 = tap16<KIND>(a, a.sr_x0 + sx1, a.sr_y0 + sy1);
-    const uint32_t pr = lerp16(t00.r, t10.r, t01.r, t11.r, xf1, xf0, yf1, yf0);
-    const uint32_t pg = lerp16(t00.g, t10.g, t01.g, t11.g, xf1, xf0, yf1, yf0);
-    const uint32_t pb = lerp16(t00.b, t10.b, t01.b, t11.b, xf1, xf0, yf1, yf0);
-    const uint32_t pa = lerp16(t00.a, t10.a, t01.a, t11.a, xf1, xf0, yf1, yf0);
-
-    uint32_t *d = (uint32_t *)(a.dst + (size_t)(a.dr_y0 + dy) * a.dstride + (size_t)(a.dr_x0 + dx) * 4);
-    int op = a.op;
-    if (op == IPX_OP_OVER && a.opaque_flag && *a.opaque_flag) op = IPX_OP_SRC;  // draw/scale.go opaque()
-    *d = op == IPX_OP_SRC ? pack_src(pr, pg, pb, pa) : blend_over(*d, pr, pg, pb, pa);
-}
 
 // image.(*RGBA).Opaque over the whole source: *flag (preset to 1) is cleared by any alpha != 0xff
 __global__ __launch_bounds__(256) void opaque_scan_kernel(const uint8_t *src, int sw, int sh,
@@ -334,18 +242,6 @@ __global__ __launch_bounds__(256) void composite_kernel(uint8_t *dst, int dstrid
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_scale_generic(const ScaleArgs &a, hipStream_t s)
-{
-    const int w = a.adr_x1 - a.adr_x0, h = a.adr_y1 - a.adr_y0;
-    if (w <= 0 || h <= 0) return hipSuccess;
-    dim3 block(64, 4), grid((w + 63) / 64, (h + 3) / 4, a.nframes > 0 ? a.nframes : 1);
-    if (a.kind == IPX_SRC_NRGBA) hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_NRGBA>, grid, block, 0, s, a);
-    else if (a.kind == IPX_SRC_YCBCR) hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_YCBCR>, grid, block, 0, s, a);
-    else if (a.kind == IPX_SRC_TAP64) hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_TAP64>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(scale_generic_kernel<IPX_SRC_RGBA>, grid, block, 0, s, a);
-    return hipGetLastError();
-}
-
 hipError_t launch_draw_nrgba(uint8_t *dst, int dstride, const uint8_t *src, int sstride, int w, int h, int op,
                              hipStream_t s, int nframes, size_t dst_fs, size_t src_fs)
 {

@@ -1,0 +1,332 @@
+// ipx_ks_host.cpp -- newDistrib of x/image/draw (draw/scale.go) for BiLinear = &Kernel{1, func(t) { return 1 - t }}, on the host.
+//
+// The weights are part of the result's bits, so they are computed here with the reference's own float64 expressions, in its order
+// (this file is compiled with -ffp-contract=off like everything else; there is nothing to fuse anyway), and the kernels only read them.
+// Reference call sites: resize.go:121-125 (resizeImage), thumbnail.go:128-131 (cropAndResize).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "ipx_ks.h"
+
+namespace ipx {
+
+bool ks_build_axis(int dw, int sw, KsAxis *out)
+{
+    if (dw <= 0 || sw <= 0) return false;
+    const double support = 1.0;                       // BiLinear.Support
+    const double scale = (double)sw / (double)dw;
+    double half_width = support, kernel_arg_scale = 1.0;
+    if (scale > 1) {                                  // shrinking: widen the support so that every source pixel is visited
+        half_width *= scale;
+        kernel_arg_scale = 1 / scale;
+    }
+    KsAxis &a = *out;
+    a.dw = dw; a.sw = sw; a.ntap = 0;
+    a.lo.assign(dw, 0); a.cnt.assign(dw, 0); a.itw.assign(dw, 0.0); a.itwffff.assign(dw, 0.0); a.ones.assign(dw, 0.0);
+    std::vector<std::vector<double>> ws(dw);
+    for (int x = 0; x < dw; x++) {
+        const double center = ((double)x + 0.5) * scale - 0.5;
+        int32_t i = (int32_t)std::floor(center - half_width);
+        if (i < 0) i = 0;
+        int32_t j = (int32_t)std::ceil(center + half_width);
+        if (j > sw) {
+            j = sw;
+            if (j < i) j = i;
+        }
+        double total = 0.0;
+        int first = -1, last = -1;
+        for (int32_t coord = i; coord < j; coord++) {
+            double t = (center - (double)coord) * kernel_arg_scale;
+            if (t < 0) t = -t;
+            if (t >= support) continue;
+            const double weight = 1 - t;              // BiLinear.At
+            if (weight == 0) continue;
+            if (first < 0) first = coord;
+            else if (coord != last + 1) return false; // a hole in the range: not the tent
+            last = coord;
+            total += weight;
+            ws[x].push_back(weight);
+        }
+        if (first < 0) return false;                  // no contribution at all: 1 / 0 upstream, cannot happen with sw >= 1
+        a.lo[x] = first;
+        a.cnt[x] = (int32_t)ws[x].size();
+        if (a.cnt[x] > a.ntap) a.ntap = a.cnt[x];
+        total = 1 / total;
+        a.itw[x] = total;
+        a.itwffff[x] = total / 0xffff;
+        double ones = 0.0;                            // scaleY's `pa += p[3] * c.weight` over a column of tmp alphas that are all 1
+        for (double wv : ws[x]) ones += 1.0 * wv;
+        a.ones[x] = ones;
+    }
+    a.w.assign((size_t)dw * a.ntap, 0.0);
+    for (int x = 0; x < dw; x++)
+        for (size_t k = 0; k < ws[x].size(); k++) a.w[(size_t)x * a.ntap + k] = ws[x][k];
+    return true;
+}
+
+static size_t al16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+size_t ks_axis_bytes(const KsAxis &a)
+{
+    return 2 * al16((size_t)a.dw * sizeof(int32_t)) + al16(a.w.size() * sizeof(double)) + 3 * al16((size_t)a.dw * sizeof(double));
+}
+
+void ks_axis_pack(const KsAxis &a, uint8_t *h, const uint8_t *d, KsAxisDev *out)
+{
+    size_t off = 0;
+    auto put = [&](const void *p, size_t bytes) {
+        memcpy(h + off, p, bytes);
+        const uint8_t *dev = d + off;
+        off += al16(bytes);
+        return dev;
+    };
+    out->lo = (const int32_t *)put(a.lo.data(), (size_t)a.dw * sizeof(int32_t));
+    out->cnt = (const int32_t *)put(a.cnt.data(), (size_t)a.dw * sizeof(int32_t));
+    out->w = (const double *)put(a.w.data(), a.w.size() * sizeof(double));
+    out->itw = (const double *)put(a.itw.data(), (size_t)a.dw * sizeof(double));
+    out->itwffff = (const double *)put(a.itwffff.data(), (size_t)a.dw * sizeof(double));
+    out->ones = (const double *)put(a.ones.data(), (size_t)a.dw * sizeof(double));
+    out->ntap = a.ntap;
+}
+
+}  // namespace ipx
+
+// =====================================================================================================================================
+// Tiling of a frame for the one-pass kernel (ipx_ks_fused.hip) and its tables.
+// =====================================================================================================================================
+namespace ipx {
+
+namespace {
+
+size_t blob_put(std::vector<uint8_t> *blob, const void *src, size_t bytes)
+{
+    const size_t off = (blob->size() + 15) & ~(size_t)15;
+    blob->resize(off + bytes);
+    if (bytes) memcpy(blob->data() + off, src, bytes);
+    return off;
+}
+template <class T> const T *as_off(size_t off) { return (const T *)(uintptr_t)off; }
+
+// most destination indices one source index feeds
+int axis_max_active(const KsAxis &a)
+{
+    int best = 0, first = 0;
+    for (int y = 0; y < a.sw; y++) {
+        while (first < a.dw && a.lo[first] + a.cnt[first] <= y) first++;
+        int n = 0;
+        for (int d = first; d < a.dw && a.lo[d] <= y; d++) n += (y < a.lo[d] + a.cnt[d]);
+        if (n > best) best = n;
+    }
+    return best;
+}
+
+// rows of one segmentation for one output: entries for source rows [ys, r1) of every segment, each segment padded to a multiple of B
+template <int NACC>
+void build_rows(const KsFusedIn &o, const std::vector<KsSeg> &segs, int B, std::vector<KsRowT<NACC>> *rows, std::vector<int32_t> *rowoff)
+{
+    const KsAxis &hy = *o.hy;
+    rows->clear(); rowoff->clear();
+    int d0 = 0;
+    for (const KsSeg &sg : segs) {
+        rowoff->push_back((int32_t)rows->size());
+        const int n = ((sg.r1 - sg.ys + B - 1) / B) * B;
+        std::vector<KsRowT<NACC>> e(n);
+        for (auto &r : e)
+            for (int p = 0; p < NACC; p++) { r.w[p] = 0; r.itw[p] = 0; r.ones[p] = 0; r.emit[p] = -1; r.pad[p] = 0; }
+        // destination rows owned by this segment: their LAST source row lies in [r0, r1)
+        while (d0 < o.dh && o.sr_y0 + hy.lo[d0] + hy.cnt[d0] - 1 < sg.r0) d0++;
+        for (int d = d0; d < o.dh && o.sr_y0 + hy.lo[d] + hy.cnt[d] - 1 < sg.r1; d++) {
+            const int p = d % NACC;
+            for (int k = 0; k < hy.cnt[d]; k++) {
+                const int y = o.sr_y0 + hy.lo[d] + k - sg.ys;   // >= 0 by the choice of ys
+                e[y].w[p] = hy.w[(size_t)d * hy.ntap + k];
+                if (k == hy.cnt[d] - 1) { e[y].emit[p] = d; e[y].itw[p] = hy.itw[d]; e[y].ones[p] = hy.ones[d]; }
+            }
+        }
+        rows->insert(rows->end(), e.begin(), e.end());
+    }
+}
+
+void make_segs(int sh, int nseg, const KsFusedIn *const sc[2], std::vector<KsSeg> *segs)
+{
+    segs->clear();
+    for (int i = 0; i < nseg; i++) {
+        KsSeg s;
+        s.r0 = (int)((long long)sh * i / nseg); s.r1 = (int)((long long)sh * (i + 1) / nseg);
+        s.ys = s.r0;
+        for (int k = 0; k < 2; k++) {
+            if (!sc[k]) continue;
+            const KsAxis &hy = *sc[k]->hy;
+            for (int d = 0; d < sc[k]->dh; d++) {               // first destination row whose last source row is in the segment
+                const int last = sc[k]->sr_y0 + hy.lo[d] + hy.cnt[d] - 1;
+                if (last < s.r0) continue;
+                if (last < s.r1) s.ys = std::min(s.ys, sc[k]->sr_y0 + hy.lo[d]);
+                break;
+            }
+        }
+        segs->push_back(s);
+    }
+}
+
+}  // namespace
+
+bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, int px_bytes, std::vector<uint8_t> *blob, KsFusedPlan *out)
+{
+    const KsFusedIn *const sc[2] = {sc0, sc1};
+    KsFusedPlan &P = *out;
+    P = KsFusedPlan();
+    const int B = kKsRows;
+    P.rows = B;
+    int nacc = 1;
+    for (int k = 0; k < 2; k++)
+        if (sc[k]) nacc = std::max(nacc, axis_max_active(*sc[k]->hy));
+    if (nacc > 4) return false;                                   // a large upscale: per-output kernels
+    P.nacc = nacc <= 2 ? 2 : 4;
+    const size_t row_bytes = P.nacc == 2 ? sizeof(KsRowT<2>) : sizeof(KsRowT<4>);
+    const size_t lds_budget = (size_t)150 << 10;
+
+    // test knobs: IPX_KS_STRIPS = start with that many strips; IPX_KS_SPLIT_ROWS = rows per segment of the split segmentation
+    const char *ev = getenv("IPX_KS_STRIPS");
+    const int first_strips = ev && atoi(ev) > 0 ? std::min(atoi(ev), 64) : 1;
+    ev = getenv("IPX_KS_SPLIT_ROWS");
+    const int split_rows = ev && atoi(ev) > 0 ? atoi(ev) : kKsSplitRows;
+    for (int nstrips = first_strips; nstrips <= 64; nstrips++) {
+        const int wc = std::max(4, (((sw + nstrips - 1) / nstrips) + 3) & ~3);
+        const int ns = (sw + wc - 1) / wc;
+        if (ns != nstrips && nstrips > first_strips) continue;    // this count yields the same strips as a smaller one
+        std::vector<KsStrip> strips(ns);
+        std::vector<int32_t> colb[2];
+        int wcols[2] = {0, 0}, twmax = 0;
+        for (int c = 0; c < ns; c++) { strips[c].c0 = c * wc; strips[c].c1 = std::min(sw, (c + 1) * wc); strips[c].t0 = strips[c].c0; strips[c].tw = strips[c].c1 - strips[c].c0; }
+        for (int k = 0; k < 2; k++) {
+            if (!sc[k]) continue;
+            const KsAxis &hx = *sc[k]->hx;
+            colb[k].assign(ns + 1, 0);
+            int d = 0;
+            for (int c = 0; c <= ns; c++) {                        // first destination column whose first tap lies in strip c or beyond
+                while (c < ns && d < sc[k]->dw && sc[k]->sr_x0 + hx.lo[d] < strips[c].c0) d++;
+                colb[k][c] = c == ns ? sc[k]->dw : d;
+            }
+            for (int c = 0; c < ns; c++) {
+                const int n = colb[k][c + 1] - colb[k][c];
+                wcols[k] = std::max(wcols[k], n);
+                if (n > 0) {
+                    const int lastcol = colb[k][c + 1] - 1;
+                    strips[c].tw = std::max(strips[c].tw, sc[k]->sr_x0 + hx.lo[lastcol] + hx.ntap - strips[c].t0);   // padded taps stay in the tile
+                }
+            }
+        }
+        for (auto &s : strips) { s.tw = (s.tw + 3) & ~3; twmax = std::max(twmax, s.tw); }
+        const int pitch = twmax * px_bytes;
+
+        // wave roles: W_k waves for output k, each lane cpl_k columns; the busiest SIMD (waves dealt round-robin) decides
+        int bestW[2] = {0, 0}, bestcpl[2] = {0, 0};
+        double bestT = 1e300;
+        double percol[2] = {0, 0};
+        for (int k = 0; k < 2; k++) if (sc[k]) percol[k] = 12.0 * sc[k]->hx->ntap + 30.0;
+        const bool two = sc[0] && sc[1] && wcols[0] > 0 && wcols[1] > 0;
+        for (int nw = 1; nw <= kKsMaxWaves; nw++) {
+            for (int w0 = two ? 1 : (sc[0] && wcols[0] > 0 ? nw : 0); w0 <= (two ? nw - 1 : (sc[0] && wcols[0] > 0 ? nw : 0)); w0++) {
+                const int W[2] = {w0, nw - w0};
+                int cpl[2] = {0, 0};
+                bool ok = true;
+                for (int k = 0; k < 2; k++) {
+                    if (!sc[k] || wcols[k] <= 0) { ok = ok && W[k] == 0; continue; }
+                    if (W[k] <= 0) { ok = false; continue; }
+                    cpl[k] = (wcols[k] + 64 * W[k] - 1) / (64 * W[k]);
+                    if (cpl[k] > kKsMaxCpl) ok = false;
+                }
+                if (!ok) continue;
+                double simd[4] = {0, 0, 0, 0};
+                for (int i = 0; i < nw; i++) { const int k = i < W[0] ? 0 : 1; simd[i & 3] += cpl[k] * percol[k]; }
+                const double T = std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3])) + 1e-3 * nw;
+                if (T < bestT) { bestT = T; bestW[0] = W[0]; bestW[1] = W[1]; bestcpl[0] = cpl[0]; bestcpl[1] = cpl[1]; }
+            }
+        }
+        int nthreads = 64 * (bestW[0] + bestW[1]);
+        if (nthreads == 0) nthreads = 256;                         // no scaled output: the watermark copy alone
+        else if (bestT >= 1e299) continue;                         // too many columns per strip for kKsMaxWaves waves
+        nthreads = std::max(nthreads, 256);
+        const int chunks = B * (pitch / 16);
+        if (chunks > kKsMaxStage * nthreads) {
+            if (chunks <= kKsMaxStage * kKsMaxThreads) nthreads = ((chunks + kKsMaxStage - 1) / kKsMaxStage + 63) & ~63;
+            else continue;
+        }
+        size_t lds = (size_t)B * pitch;
+        int lds_w[2] = {0, 0};
+        for (int k = 0; k < 2; k++) {
+            lds_w[k] = (int)lds;
+            if (sc[k]) lds += (size_t)sc[k]->hx->ntap * wcols[k] * sizeof(double);
+        }
+        const int lds_rows = (int)lds;
+        lds += 2 * (size_t)B * row_bytes;
+        if (lds > lds_budget) continue;
+
+        // ---- accepted: lay the tables out ----
+        P.nstrips = ns; P.pitch = pitch; P.nthreads = nthreads;
+        P.nstg = (chunks + nthreads - 1) / nthreads;
+        P.lds_w[0] = lds_w[0]; P.lds_w[1] = lds_w[1]; P.lds_rows = lds_rows; P.lds_bytes = (int)lds;
+        P.strips = as_off<KsStrip>(blob_put(blob, strips.data(), strips.size() * sizeof(KsStrip)));
+        for (int k = 0; k < 2; k++) {
+            if (!sc[k]) continue;
+            const KsAxis &hx = *sc[k]->hx;
+            KsFusedPlan::Out &o = P.o[k];
+            o.ntap = hx.ntap; o.waves = bestW[k]; o.cpl = bestcpl[k]; o.wcols = wcols[k];
+            std::vector<double> wx((size_t)ns * hx.ntap * std::max(1, wcols[k]), 0.0);
+            for (int c = 0; c < ns; c++)
+                for (int i = 0; i < colb[k][c + 1] - colb[k][c]; i++)
+                    for (int t = 0; t < hx.ntap; t++)
+                        wx[((size_t)c * hx.ntap + t) * wcols[k] + i] = hx.w[(size_t)(colb[k][c] + i) * hx.ntap + t];
+            o.wx = as_off<double>(blob_put(blob, wx.data(), wx.size() * sizeof(double)));
+            o.itwf = as_off<double>(blob_put(blob, hx.itwffff.data(), hx.itwffff.size() * sizeof(double)));
+            o.xlo = as_off<int32_t>(blob_put(blob, hx.lo.data(), hx.lo.size() * sizeof(int32_t)));
+            o.colb = as_off<int32_t>(blob_put(blob, colb[k].data(), colb[k].size() * sizeof(int32_t)));
+        }
+        for (int gi = 0; gi < 2; gi++) {
+            KsFusedGeom &g = gi ? P.split : P.whole;
+            std::vector<KsSeg> segs;
+            make_segs(sh, gi ? std::max(1, (sh + split_rows / 2) / split_rows) : 1, sc, &segs);
+            g.nseg = (int)segs.size();
+            g.segs = as_off<KsSeg>(blob_put(blob, segs.data(), segs.size() * sizeof(KsSeg)));
+            for (int k = 0; k < 2; k++) {
+                if (!sc[k]) continue;
+                std::vector<int32_t> rowoff;
+                if (P.nacc == 2) {
+                    std::vector<KsRowT<2>> rows;
+                    build_rows<2>(*sc[k], segs, B, &rows, &rowoff);
+                    g.rows[k] = as_off<void>(blob_put(blob, rows.data(), rows.size() * sizeof(rows[0])));
+                } else {
+                    std::vector<KsRowT<4>> rows;
+                    build_rows<4>(*sc[k], segs, B, &rows, &rowoff);
+                    g.rows[k] = as_off<void>(blob_put(blob, rows.data(), rows.size() * sizeof(rows[0])));
+                }
+                g.rowoff[k] = as_off<int32_t>(blob_put(blob, rowoff.data(), rowoff.size() * sizeof(int32_t)));
+            }
+        }
+        P.ok = true;
+        return true;
+    }
+    return false;
+}
+
+void ks_fused_rebase(KsFusedPlan *p, const uint8_t *d)
+{
+    auto fix = [&](auto *&ptr) { ptr = (std::remove_reference_t<decltype(ptr)>)(const void *)(d + (uintptr_t)ptr); };
+    fix(p->strips);
+    for (int k = 0; k < 2; k++) {
+        if (!p->o[k].wx) continue;                // output absent (offset 0 is the strips table, never an output's)
+        fix(p->o[k].wx); fix(p->o[k].itwf); fix(p->o[k].xlo); fix(p->o[k].colb);
+    }
+    for (KsFusedGeom *g : {&p->whole, &p->split}) {
+        fix(g->segs);
+        for (int k = 0; k < 2; k++) {
+            if (!g->rows[k] && !g->rowoff[k]) continue;
+            fix(g->rows[k]); fix(g->rowoff[k]);
+        }
+    }
+}
+
+}  // namespace ipx

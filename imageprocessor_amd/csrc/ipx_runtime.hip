@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "ipx_runtime_internal.h"
+#include "ipx_ks.h"
 
 #ifndef IPX_DIAG
 #define IPX_DIAG 0
@@ -23,30 +24,53 @@
 
 namespace {
 
-// Scale's argument checks and dispatch decisions, shared by host- and device-pointer entries
+// Scale's argument checks, shared by host- and device-pointer entries (kernelScaler.Scale's preamble: adr, empty rectangles)
 struct ScalePrep {
-    bool copy;      // equal sizes: Copy -> DrawMask
     bool empty;
     Rect adr;       // relative to dr.Min
-    double xscale, yscale;
 };
 
 int scale_prepare(int dw, int dh, const Rect &dr, int sw, int sh, const Rect &sr, int op, ScalePrep *o)
 {
     if (op != IPX_OP_OVER && op != IPX_OP_SRC) { set_error("scale: unknown op %d", op); return IPX_ERR_INVALID; }
-    o->copy = dr.dx() == sr.dx() && dr.dy() == sr.dy();
     o->empty = false;
-    if (o->copy) return IPX_OK;
     Rect adr = Rect{0, 0, dw, dh}.intersect(dr);
-    if (adr.empty() || sr.empty()) { o->empty = true; return IPX_OK; }
+    if (adr.empty() || sr.empty() || dr.dx() <= 0 || dr.dy() <= 0) { o->empty = true; return IPX_OK; }
     if (sr.x0 < 0 || sr.y0 < 0 || sr.x1 > sw || sr.y1 > sh) {
         set_error("scale: source rectangle (%d,%d)-(%d,%d) leaves the %dx%d source; the reference's "
                   "generic Image path is not covered", sr.x0, sr.y0, sr.x1, sr.y1, sw, sh);
         return IPX_ERR_UNSUPPORTED;
     }
     o->adr = adr.shifted(-dr.x0, -dr.y0);
-    o->yscale = (double)sr.dy() / (double)dr.dy();
-    o->xscale = (double)sr.dx() / (double)dr.dx();
+    return IPX_OK;
+}
+
+// One axis of the kernel scaler (newDistrib for dw destination and sw source indices) resident in HBM, by (dw, sw): the per-operation
+// seam sees the same few geometries over and over.  Entries live until the context does; past kMaxKsAxes the cache is flushed after a
+// device-wide wait (launches in flight hold raw pointers into it).
+constexpr size_t kMaxKsAxes = 512;
+int ks_axis_get(ipx_ctx *ctx, int dw, int sw, KsAxisDev *out)
+{
+    std::lock_guard<std::mutex> lk(ctx->ks_mu);
+    auto it = ctx->ks_axes.find({dw, sw});
+    if (it != ctx->ks_axes.end()) { *out = it->second.second; return IPX_OK; }
+    KsAxis ax;
+    if (!ks_build_axis(dw, sw, &ax)) { set_error("scale: cannot tabulate an axis of %d <- %d", dw, sw); return IPX_ERR_INVALID; }
+    if (ctx->ks_axes.size() >= kMaxKsAxes) {
+        IPX_HIP(hipDeviceSynchronize());
+        for (auto &e : ctx->ks_axes) (void)hipFree(e.second.first);
+        ctx->ks_axes.clear();
+    }
+    const size_t bytes = ks_axis_bytes(ax);
+    std::vector<uint8_t> h(bytes);
+    uint8_t *d = nullptr;
+    IPX_HIP(hipMalloc((void **)&d, bytes));
+    KsAxisDev dev;
+    ks_axis_pack(ax, h.data(), d, &dev);
+    hipError_t e = hipMemcpy(d, h.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); set_error("axis table upload failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
+    ctx->ks_axes[{dw, sw}] = {d, dev};
+    *out = dev;
     return IPX_OK;
 }
 
@@ -80,32 +104,39 @@ int dev_draw_src(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect 
         IPX_HIP(launch_draw_tap64(d, dstride, src.pix + (size_t)spy * src.stride + (size_t)spx * 8, src.stride, r.dx(), r.dy(), op, s,
                                   src.nframes, dst_fs, src.frame_stride));
     else
-        IPX_HIP(launch_draw(d, dstride, src.pix + (size_t)spy * src.stride + (size_t)spx * 4, src.stride, r.dx(), r.dy(),
-                            op, s));
+        for (int i = 0; i < std::max(1, src.nframes); i++)
+            IPX_HIP(launch_draw(d + (size_t)i * dst_fs, dstride, src.pix + (size_t)i * src.frame_stride + (size_t)spy * src.stride + (size_t)spx * 4,
+                                src.stride, r.dx(), r.dy(), op, s));
     return IPX_OK;
 }
 
-int dev_scale_src(hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int dstride, const Rect &dr,
-                  const DevSrc &src, const Rect &sr, int op, size_t dst_fs = 0)
+// xdraw.BiLinear.Scale(dst, dr, src, sr, op, nil) on device frames.  kind_override >= 0: the tap kind to read the source with (the
+// crop thumbnail's second scale, ipx_ks.h); axes: the plan's own tables, or NULL to take them from the context's cache
+int dev_scale_src(ipx_ctx *ctx, hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int dstride, const Rect &dr,
+                  const DevSrc &src, const Rect &sr, int op, size_t dst_fs = 0, int kind_override = -1, const KsAxisDev *axes = nullptr)
 {
     ScalePrep pr;
     int rc = scale_prepare(dw, dh, dr, src.w, src.h, sr, op, &pr);
     if (rc) return rc;
-    if (pr.copy) return dev_draw_src(s, dst, dw, dh, dstride, dr, src, sr.x0, sr.y0, op, dst_fs);
     if (pr.empty) return IPX_OK;
     if (src.kind == IPX_SRC_YCBCR) op = IPX_OP_SRC;   // (*image.YCbCr).Opaque() is always true
     if (op == IPX_OP_OVER && src.kind == IPX_SRC_TAP64) IPX_HIP(launch_opaque_scan_tap64(src.pix, src.w, src.h, src.stride, flag, s));
     else if (op == IPX_OP_OVER) IPX_HIP(launch_opaque_scan(src.pix, src.w, src.h, src.stride, flag, s));  // RGBA and NRGBA: alpha scan
-    ScaleArgs a;
+    KsGenArgs a{};
+    if (axes) { a.ax = axes[0]; a.ay = axes[1]; }
+    else {
+        if ((rc = ks_axis_get(ctx, dr.dx(), sr.dx(), &a.ax))) return rc;
+        if ((rc = ks_axis_get(ctx, dr.dy(), sr.dy(), &a.ay))) return rc;
+    }
     a.dst = dst; a.dstride = dstride; a.src = src.pix; a.sstride = src.stride;
     a.dr_x0 = dr.x0; a.dr_y0 = dr.y0;
     a.adr_x0 = pr.adr.x0; a.adr_y0 = pr.adr.y0; a.adr_x1 = pr.adr.x1; a.adr_y1 = pr.adr.y1;
-    a.sr_x0 = sr.x0; a.sr_y0 = sr.y0; a.ssw = sr.dx(); a.ssh = sr.dy();
-    a.xscale = pr.xscale; a.yscale = pr.yscale;
+    a.sr_x0 = sr.x0; a.sr_y0 = sr.y0;
     a.op = op; a.opaque_flag = op == IPX_OP_OVER ? flag : nullptr;
-    a.kind = src.kind; a.cb = src.cb; a.cr = src.cr; a.cstride = src.cstride; a.ratio = src.ratio;
+    a.kind = kind_override >= 0 ? kind_override : src.kind;
+    a.cb = src.cb; a.cr = src.cr; a.cstride = src.cstride; a.ratio = src.ratio;
     a.nframes = src.nframes; a.src_fs = src.frame_stride; a.c_fs = src.c_frame_stride; a.dst_fs = dst_fs;
-    IPX_HIP(launch_scale_generic(a, s));
+    IPX_HIP(launch_ks_generic(a, s));
     return IPX_OK;
 }
 
@@ -123,10 +154,10 @@ int dev_draw(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect r, c
     return dev_draw_src(s, dst, dw, dh, dstride, r, rgba_src(src, sw, sh, sstride), spx, spy, op);
 }
 
-int dev_scale(hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int dstride, const Rect &dr,
+int dev_scale(ipx_ctx *ctx, hipStream_t s, int *flag, uint8_t *dst, int dw, int dh, int dstride, const Rect &dr,
               const uint8_t *src, int sw, int sh, int sstride, const Rect &sr, int op)
 {
-    return dev_scale_src(s, flag, dst, dw, dh, dstride, dr, rgba_src(src, sw, sh, sstride), sr, op);
+    return dev_scale_src(ctx, s, flag, dst, dw, dh, dstride, dr, rgba_src(src, sw, sh, sstride), sr, op);
 }
 
 // clip every glyph against a dw x dh frame (image/draw.clip) and cache the device table
@@ -267,6 +298,7 @@ void ipx_destroy(ipx_ctx *c)
     }
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->flat_chroma) (void)hipFree(c->flat_chroma);
+    for (auto &e : c->ks_axes) (void)hipFree(e.second.first);
     for (auto &kv : c->plan_cache) ipx_plan_destroy(c, kv.second.second);     // (their glyph sets go with them)
     c->plan_cache.clear();
     for (auto &b : c->host_free_blocks) (void)hipHostFree(b.second);
@@ -476,7 +508,7 @@ int ipx_dev_scale_bilinear_rgba8(ipx_ctx *ctx, void *stream, uint8_t *dst, int d
         // the opaque() flag must outlive the launch: one device int per call, freed stream-ordered
         IPX_HIP(hipMallocAsync((void **)&flag, sizeof(int), s));
     }
-    int rc = dev_scale(s, flag, dst, dw, dh, dstride, to_rect(dr), src, sw, sh, sstride, to_rect(sr), op);
+    int rc = dev_scale(ctx, s, flag, dst, dw, dh, dstride, to_rect(dr), src, sw, sh, sstride, to_rect(sr), op);
     if (flag) (void)hipFreeAsync(flag, s);
     return rc;
 }
@@ -571,9 +603,9 @@ int ipx_scale_bilinear_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dst
     uint8_t *dsrc = lane->dev, *ddst = lane->dev + sbytes;
     hipStream_t s = lane->stream;
     if (sw && sh) IPX_HIP(hipMemcpy2DAsync(dsrc, (size_t)sw * 4, src, sstride, (size_t)sw * 4, sh, hipMemcpyHostToDevice, s));
-    // Over (and the Copy path's Over) reads the destination; Src leaves pixels outside adr untouched
+    // Over reads the destination; Src leaves pixels outside adr untouched
     IPX_HIP(hipMemcpy2DAsync(ddst, (size_t)dw * 4, dst, dstride, (size_t)dw * 4, dh, hipMemcpyHostToDevice, s));
-    rc = dev_scale(s, lane->flag, ddst, dw, dh, dw * 4, to_rect(dr), dsrc, sw, sh, sw * 4, to_rect(sr), op);
+    rc = dev_scale(ctx, s, lane->flag, ddst, dw, dh, dw * 4, to_rect(dr), dsrc, sw, sh, sw * 4, to_rect(sr), op);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
     IPX_HIP(hipMemcpy2DAsync(dst, dstride, ddst, (size_t)dw * 4, (size_t)dw * 4, dh, hipMemcpyDeviceToHost, s));
     IPX_HIP(hipStreamSynchronize(s));
@@ -691,7 +723,7 @@ int ipx_scale_bilinear_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int ds
     if (!dw || !dh || !sw || !sh) return IPX_OK;
     return stage_and_run(ctx, dst, dw, dh, dstride, align256((size_t)sw * sh * 4), [&](hipStream_t s, int *flag, uint8_t *ddst, uint8_t *dsrc) -> int {
         IPX_HIP(hipMemcpy2DAsync(dsrc, (size_t)sw * 4, src, sstride, (size_t)sw * 4, sh, hipMemcpyHostToDevice, s));
-        return dev_scale_src(s, flag, ddst, dw, dh, dw * 4, to_rect(dr), rgba_src(dsrc, sw, sh, sw * 4, IPX_SRC_NRGBA), to_rect(sr), op);
+        return dev_scale_src(ctx, s, flag, ddst, dw, dh, dw * 4, to_rect(dr), rgba_src(dsrc, sw, sh, sw * 4, IPX_SRC_NRGBA), to_rect(sr), op);
     });
 }
 IPX_CATCH_STATUS
@@ -742,7 +774,7 @@ int ipx_scale_bilinear_deep(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstr
     return stage_and_run(ctx, dst, dw, dh, dstride, align256((size_t)sw * sh * 8) * 2, [&](hipStream_t s, int *flag, uint8_t *ddst, uint8_t *dsrc) -> int {
         DevSrc t;
         const int r2 = upload_deep(s, src, sw, sh, sstride, kind, dsrc, &t);
-        return r2 ? r2 : dev_scale_src(s, flag, ddst, dw, dh, dw * 4, to_rect(dr), t, to_rect(sr), op);
+        return r2 ? r2 : dev_scale_src(ctx, s, flag, ddst, dw, dh, dw * 4, to_rect(dr), t, to_rect(sr), op);
     });
 }
 IPX_CATCH_STATUS
@@ -776,7 +808,7 @@ int ipx_scale_bilinear_ycbcr(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dst
         DevSrc d;
         int rc = upload_ycbcr(s, src, cw, ch, dsrc, &d);
         if (rc) return rc;
-        return dev_scale_src(s, flag, ddst, dw, dh, dw * 4, to_rect(dr), d, to_rect(sr), IPX_OP_SRC);
+        return dev_scale_src(ctx, s, flag, ddst, dw, dh, dw * 4, to_rect(dr), d, to_rect(sr), IPX_OP_SRC);
     });
 }
 IPX_CATCH_STATUS
@@ -857,163 +889,59 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
     }
     pl->info.algorithmic_bytes = (size_t)sw * sh * 4 + pl->info.resize_bytes + pl->info.thumb_bytes + pl->info.wm_bytes;
 
-    // The band kernel needs a tap pair per axis (source extents >= 2) and non-empty outputs; an
-    // output with a zero dimension (resize.go:70-72 has no guard) is simply empty.
-    pl->fused = true;
-    for (auto &s : pl->sc)
-        if (s.on && s.dw > 0 && s.dh > 0 && (s.sr.dx() < 2 || s.sr.dy() < 2)) pl->fused = false;
-    if (env_int("IPX_NO_FUSE", 0)) pl->fused = false;
-    if (!pl->fused) { *out = pl; return IPX_OK; }
-
-    // taps per axis, with the reference's float64 arithmetic; dyadic axes get the exact fp32 path
-    std::vector<AxisTap> xt[2], yt[2];
-    for (int k = 0; k < 2; k++) {
-        PlanScale &s = pl->sc[k];
-        s.dyadic_shift = -1;
-        if (!s.on || s.dw <= 0 || s.dh <= 0) continue;
-        xt[k].resize(s.dw); yt[k].resize(s.dh);
-        build_axis_taps(s.sr.dx(), s.dw, 0, s.dw, xt[k].data());
-        build_axis_taps(s.sr.dy(), s.dh, 0, s.dh, yt[k].data());
-        if (!env_int("IPX_NO_DYADIC", 0)) {
-            const int kx = axis_dyadic_bits(xt[k].data(), s.dw, 12, 1);   // kx >= 1 keeps kx + ky >= 1 for the packed-integer lerp
-            const int ky = axis_dyadic_bits(yt[k].data(), s.dh, 12);
-            if (kx >= 0 && ky >= 0 && kx + ky <= 16) { s.dyadic_shift = kx + ky; s.kx = kx; s.ky = ky; }  // 8 + kx + ky <= 24 bits
-        }
-    }
-
-    // Tilings of the source frame (PlanGeom) and the tables that depend on them.  A tiling = owned columns per workgroup (multiple of
-    // 4 pixels = 16 B) and owned rows; a column block may hold at most out_cols destination columns of any scaled output.
-    //   pl->g     tiles of one dword per pixel: band_pipe_kernel (RGBA sources) and band_nrgba_kernel; 72 KB of LDS, two workgroups per CU
-    //   pl->conv  tiles of two dwords per pixel (converted taps): band_conv_kernel; at most 1020 columns x 8 rows, again two per CU
-    struct HostGeom {
-        int bc = 0, br = 0;
-        std::vector<int> rb[2], cbv[2];
-        std::vector<uint32_t> yr[2], y16[2];
-        size_t off_rb[2] = {0, 0}, off_cb[2] = {0, 0}, off_yr[2] = {0, 0}, off_y16[2] = {0, 0};
-    };
-    auto build_geom = [&](PlanGeom &g, HostGeom &hg, int max_cols, size_t lds_budget, int px_bytes, int rows_cap, int out_cols) -> bool {
-        for (;;) {
-            const int ncb = (sw + max_cols - 1) / max_cols;
-            const int bc = std::max(4, ((sw + ncb - 1) / ncb + 3) & ~3);
-            int br = (int)(lds_budget / ((size_t)(bc + 4) * px_bytes)) - 1;
-            br = std::max(1, std::min(br, rows_cap > 0 ? rows_cap : env_int("IPX_BAND_ROWS_MAX", bc / 4 + 1 > 256 ? 8 : 16)));  // shapes of band_pipe_shape
-            if (rows_cap <= 0 && env_int("IPX_BAND_ROWS", 0) > 0) br = env_int("IPX_BAND_ROWS", 0);
-            br = std::min(br, sh);
-            if (rows_cap > 0 && br > 1) br &= ~1;              // whole chroma rows per band (4:2:0, 4:4:0)
-            hg.bc = bc; hg.br = br;
-            g.blk_cols = bc; g.band_rows = br;
-            g.ncolblk = (sw + bc - 1) / bc;
-            g.nbands = (sh + br - 1) / br;
-            int widest = 0;
-            g.most_rows = 0;
-            g.nx_out[0] = g.nx_out[1] = 0;
-            for (int k = 0; k < 2; k++) {
-                PlanScale &sk = pl->sc[k];
-                if (xt[k].empty()) continue;
-                hg.rb[k].assign(g.nbands + 1, 0); hg.cbv[k].assign(g.ncolblk + 1, 0);
-                int d = 0;
-                for (int b2 = 0; b2 <= g.nbands; b2++) {  // first output row whose tap pair starts in band b2 or below
-                    while (d < sk.dh && sk.sr.y0 + yt[k][d].base < b2 * br) d++;
-                    hg.rb[k][b2] = b2 == g.nbands ? sk.dh : d;
-                }
-                d = 0;
-                for (int c = 0; c <= g.ncolblk; c++) {
-                    while (d < sk.dw && sk.sr.x0 + xt[k][d].base < c * bc) d++;
-                    hg.cbv[k][c] = c == g.ncolblk ? sk.dw : d;
-                }
-                int wk = 0;
-                for (int c = 0; c < g.ncolblk; c++) wk = std::max(wk, hg.cbv[k][c + 1] - hg.cbv[k][c]);
-                widest = std::max(widest, wk);
-                g.nx_out[k] = (wk + 255) / 256;
-                for (int b2 = 0; b2 < g.nbands; b2++) g.most_rows = std::max(g.most_rows, hg.rb[k][b2 + 1] - hg.rb[k][b2]);
-            }
-            if (widest <= out_cols) return true;
-            if (bc <= 4) return false;                         // enormous upscale: per-operation kernels
-            max_cols = std::max(4, (int)((long long)bc * out_cols / widest) & ~3);
-            if (max_cols >= bc) max_cols = bc - 4;
-        }
-    };
-    HostGeom hg[2];
-    if (!build_geom(pl->g, hg[0], std::max(4, env_int("IPX_BLK_COLS", 2044)) & ~3,
-                    ((size_t)std::max(8, env_int("IPX_LDS_KB", 72)) << 10) - band_lds_bytes(-1, -4), 4, 0, 256 * kBandNX)) {
-        pl->fused = false;
-        *out = pl;
-        return IPX_OK;
-    }
-    pl->g.ok = true;
-    pl->conv.ok = build_geom(pl->conv, hg[1], std::max(4, std::min(env_int("IPX_CONV_BLK_COLS", 1020), 1020)) & ~3, (size_t)80 << 10, 8, 8, 512);
-
-    // host tables -> one device blob
+    // newDistrib of both axes of every scaled output (an output with a zero dimension -- resize.go:70-72 has no guard -- is simply empty)
     std::vector<uint8_t> blob;
-    auto put = [&](const void *src, size_t bytes) {
+    auto put = [&](size_t bytes) {
         const size_t off = (blob.size() + 15) & ~(size_t)15;
         blob.resize(off + bytes);
-        memcpy(blob.data() + off, src, bytes);
         return off;
     };
-    size_t off_xt[2] = {0, 0}, off_yt[2] = {0, 0};
+    size_t axoff[2][2] = {{0, 0}, {0, 0}};
+    bool have[2] = {false, false};
     for (int k = 0; k < 2; k++) {
-        if (xt[k].empty()) continue;
-        off_xt[k] = put(xt[k].data(), xt[k].size() * sizeof(AxisTap));
-        off_yt[k] = put(yt[k].data(), yt[k].size() * sizeof(AxisTap));
         PlanScale &sk = pl->sc[k];
-        // the packed-integer lerp's row table (ScaleOut::yrow): RGBA8 taps, kx <= 8 (16-bit lanes hold 8 + kx bits), ky <= 12
-        const bool int_rows = !(sk.dyadic_shift < 1 || sk.kx > 8 || sk.ky > 12 || env_int("IPX_NO_INTLERP", 0));
-        const int kk = std::max(sk.dyadic_shift, 9), ysh = kk - sk.dyadic_shift;   // ky + ysh <= 15: the scaled weights stay 16-bit lanes
-        if (int_rows) sk.imul = 257u << (24 - kk);
-        for (int gi = 0; gi < 2; gi++) {
-            PlanGeom &g = gi ? pl->conv : pl->g;
-            HostGeom &h = hg[gi];
-            if (!g.ok) continue;
-            h.off_rb[k] = put(h.rb[k].data(), h.rb[k].size() * sizeof(int));
-            h.off_cb[k] = put(h.cbv[k].data(), h.cbv[k].size() * sizeof(int));
-            if (!int_rows) continue;
-            const uint32_t pitch = gi ? (uint32_t)kConvTilePitch : (uint32_t)(h.bc + 4) * 4;      // of one plane of the tile
-            h.yr[k].assign((size_t)(sk.dh + 1) * 2, 0);
-            for (int d = 0; d < sk.dh; d++) {
-                const int row = sk.sr.y0 + yt[k][d].base, band = row / h.br;
-                uint32_t code = 2;                                   // the first row of a band finds nothing at hand
-                if (d > h.rb[k][band]) {
-                    const int step = yt[k][d].base - yt[k][d - 1].base;
-                    code = step == 0 ? 0 : step == 1 ? 1 : 2;
-                }
-                h.yr[k][2 * d] = (uint32_t)(row - band * h.br) * pitch | code << 28;
-                h.yr[k][2 * d + 1] = yt[k][d].iw << ysh;
-            }
-            h.off_yr[k] = put(h.yr[k].data(), h.yr[k].size() * sizeof(uint32_t));
-            if (sk.kx <= 8 && sk.ky <= 8) {   // the same walk for 16-bit converted taps (ScaleOut::yrow16)
-                h.y16[k].assign((size_t)(sk.dh + 1) * 4, 0);
-                for (int d = 0; d < sk.dh; d++) {
-                    h.y16[k][4 * d] = h.yr[k][2 * d];
-                    h.y16[k][4 * d + 1] = (yt[k][d].iw & 0xffffu) << (16 - sk.dyadic_shift);
-                    h.y16[k][4 * d + 2] = (yt[k][d].iw >> 16) << (16 - sk.dyadic_shift);
-                }
-                h.off_y16[k] = put(h.y16[k].data(), h.y16[k].size() * sizeof(uint32_t));
-            }
+        if (!sk.on || sk.dw <= 0 || sk.dh <= 0) continue;
+        if (!ks_build_axis(sk.dw, sk.sr.dx(), &sk.hx) || !ks_build_axis(sk.dh, sk.sr.dy(), &sk.hy)) {
+            set_error("ipx_plan_create: cannot tabulate the axes of a %dx%d <- %dx%d scale", sk.dw, sk.dh, sk.sr.dx(), sk.sr.dy());
+            delete pl;
+            return IPX_ERR_INVALID;
+        }
+        have[k] = true;
+        axoff[k][0] = put(ks_axis_bytes(sk.hx));
+        axoff[k][1] = put(ks_axis_bytes(sk.hy));
+    }
+    // the one-pass kernel's tiling and tables (source pixels of 4 bytes in LDS)
+    KsFusedIn fin[2];
+    for (int k = 0; k < 2; k++) {
+        const PlanScale &sk = pl->sc[k];
+        fin[k].dw = sk.dw; fin[k].dh = sk.dh; fin[k].sr_x0 = sk.sr.x0; fin[k].sr_y0 = sk.sr.y0; fin[k].hx = &sk.hx; fin[k].hy = &sk.hy;
+    }
+    if (!env_int("IPX_NO_FUSE", 0)) {
+        std::vector<uint8_t> fblob;
+        if (ks_fused_plan(sw, sh, have[0] ? &fin[0] : nullptr, have[1] ? &fin[1] : nullptr, 4, &fblob, &pl->fused)) {
+            const size_t off = put(fblob.size());
+            memcpy(blob.data() + off, fblob.data(), fblob.size());
+            pl->fused_off = off;
         }
     }
     if (!blob.empty()) {
         hipError_t e = hipMalloc((void **)&pl->blob, blob.size());
-        if (e == hipSuccess) e = hipMemcpy(pl->blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("plan table allocation failed: %s", hipGetErrorString(e));
+            ipx_plan_destroy(ctx, pl);
+            return IPX_ERR_NOMEM;
+        }
+        for (int k = 0; k < 2; k++) {
+            if (!have[k]) continue;
+            ks_axis_pack(pl->sc[k].hx, blob.data() + axoff[k][0], pl->blob + axoff[k][0], &pl->sc[k].ax[0]);
+            ks_axis_pack(pl->sc[k].hy, blob.data() + axoff[k][1], pl->blob + axoff[k][1], &pl->sc[k].ax[1]);
+        }
+        if (pl->fused.ok) ks_fused_rebase(&pl->fused, pl->blob + pl->fused_off);
+        e = hipMemcpy(pl->blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("plan table upload failed: %s", hipGetErrorString(e));
             ipx_plan_destroy(ctx, pl);
             return IPX_ERR_HIP;
-        }
-        for (int k = 0; k < 2; k++) {
-            PlanScale &sk = pl->sc[k];
-            if (!sk.on || sk.dw <= 0 || sk.dh <= 0) continue;
-            sk.xt = (AxisTap *)(pl->blob + off_xt[k]);
-            sk.yt = (AxisTap *)(pl->blob + off_yt[k]);
-            for (int gi = 0; gi < 2; gi++) {
-                PlanGeom &g = gi ? pl->conv : pl->g;
-                const HostGeom &h = hg[gi];
-                if (!g.ok) continue;
-                g.row_begin[k] = (int *)(pl->blob + h.off_rb[k]);
-                g.col_begin[k] = (int *)(pl->blob + h.off_cb[k]);
-                if (!h.yr[k].empty()) g.yrow[k] = (uint32_t *)(pl->blob + h.off_yr[k]);
-                if (!h.y16[k].empty()) g.yrow16[k] = (uint32_t *)(pl->blob + h.off_y16[k]);
-            }
         }
     }
     *out = pl;
@@ -1026,7 +954,6 @@ void ipx_plan_destroy(ipx_ctx *ctx, ipx_plan *plan)
     if (!plan) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     if (plan->blob) (void)hipFree(plan->blob);
-    if (plan->thumb_only) ipx_plan_destroy(ctx, plan->thumb_only);
     if (plan->owned_gs) ipx_glyphset_destroy(ctx, plan->owned_gs);
     delete plan;
 }
@@ -1109,7 +1036,72 @@ static int plan_src_status(const char *who, const ipx_plan *pl, long long stride
 }
 #define IPX_PLAN_SRC(who, pl, stride, bpp) do { const int rc_ = plan_src_status(who, pl, stride, bpp); if (rc_) return rc_; } while (0)
 
-static bool glyphs_separate(bool fused_kernel);
+// ---- one batch of decoded frames of any source type through a plan --------------------------------------------------------------------
+// The one-pass kernel where it is built for the source type and the shapes; else per output: draw.Draw into the watermark frames
+// (launch_draw*), the text, and one generic Scale per scaled output -- the crop thumbnail (thumbnail.go:128-131) reads the source
+// through the `_CROP` tap kind of its type (ipx_ks.h), which is its 8-bit crop copy without the copy.
+static hipError_t composite_text(const ipx_plan *pl, uint8_t *wm, size_t wm_frame_stride, int n, hipStream_t s)
+{
+    if (!wm || pl->glyphs.n <= 0 || !pl->p.glyphs) return hipSuccess;
+    const uint8_t *c = pl->p.glyphs->col;
+    return launch_composite(wm, pl->p.sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox, c[0] * 0x101u, c[1] * 0x101u,
+                            c[2] * 0x101u, c[3] * 0x101u, s);
+}
+
+static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, const DevSrc &src, uint8_t *resize_out, size_t resize_frame_stride,
+                       uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride)
+{
+    const int sw = pl->p.sw, sh = pl->p.sh;
+    uint8_t *outs[2] = {pl->sc[0].on ? resize_out : nullptr, pl->sc[1].on ? thumb_out : nullptr};
+    const size_t ostr[2] = {resize_frame_stride, thumb_frame_stride};
+    uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
+    for (int k = 0; k < 2; k++)
+        if (pl->sc[k].dw <= 0 || pl->sc[k].dh <= 0) outs[k] = nullptr;
+    if (!wm && !outs[0] && !outs[1]) return IPX_OK;
+    int kinds[2] = {src.kind, pl->p.crop_to_fit ? ks_crop_kind(src.kind) : src.kind};
+
+    if (pl->fused.ok && src.kind == IPX_SRC_RGBA && env_int("IPX_FUSED", 1)) {
+        KsFusedArgs a{};
+        a.src = src.pix; a.src_fs = src.frame_stride; a.sstride = src.stride; a.sw = sw; a.sh = sh;
+        a.wm = wm; a.wm_fs = wm_frame_stride; a.wm_stride = sw * 4;
+        a.nframes = n;
+        for (int k = 0; k < 2; k++) {
+            if (!outs[k]) continue;
+            const PlanScale &ps = pl->sc[k];
+            KsFusedOut &o = a.o[a.nout++];
+            o.out = outs[k]; o.frame_stride = ostr[k]; o.ostride = ps.dw * 4; o.obytes = ps.dw * ps.dh * 4;
+            o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
+            o.kind = kinds[k]; o.pk = k;
+        }
+        // the speculative opaque pass first (IPX_KS_SPEC=0: the general kernel alone): one flag per item
+        int *redo = nullptr;
+        const int max_items = n * pl->fused.nstrips * std::max(pl->fused.whole.nseg, pl->fused.split.nseg);
+        if (env_int("IPX_KS_SPEC", 1)) IPX_HIP(hipMallocAsync((void **)&redo, (size_t)max_items * sizeof(int), s));
+        a.redo = redo;
+        bool matched = false;
+        hipError_t e = launch_ks_fused(pl->fused, a, ctx->cus, s, &matched);
+        if (redo) (void)hipFreeAsync(redo, s);
+        if (e != hipSuccess) { set_error("one-pass kernel launch failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
+        if (matched) {
+            IPX_HIP(composite_text(pl, wm, wm_frame_stride, n, s));
+            return IPX_OK;
+        }
+    }
+
+    if (wm) {   // draw.Draw(result, bounds, img, ZP, draw.Src) for the batch
+        const int rc = dev_draw_src(s, wm, sw, sh, sw * 4, Rect{0, 0, sw, sh}, src, 0, 0, IPX_OP_SRC, wm_frame_stride);
+        if (rc) return rc;
+        IPX_HIP(composite_text(pl, wm, wm_frame_stride, n, s));
+    }
+    for (int k = 0; k < 2; k++) {   // Over onto the zeroed frame of image.NewRGBA == Src
+        if (!outs[k]) continue;
+        const PlanScale &ps = pl->sc[k];
+        const int rc = dev_scale_src(ctx, s, nullptr, outs[k], ps.dw, ps.dh, ps.dw * 4, Rect{0, 0, ps.dw, ps.dh}, src, ps.sr, IPX_OP_SRC, ostr[k],
+                                     kinds[k], ps.ax);
+        if (rc) return rc;
+    }
+    return IPX_OK;
+}
 
 int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *src,
                      int sstride, size_t src_frame_stride, uint8_t *resize_out,
@@ -1123,104 +1115,11 @@ int ipx_plan_run_dev(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, cons
     }
     IPX_PLAN_SRC("ipx_plan_run_dev", pl, sstride, 4);
     if (n == 0) return IPX_OK;
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    const int sw = pl->p.sw, sh = pl->p.sh;
-    uint8_t *outs[2] = {pl->sc[0].on ? resize_out : nullptr, pl->sc[1].on ? thumb_out : nullptr};
-    const size_t ostr[2] = {resize_frame_stride, thumb_frame_stride};
-    uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
-    const uint32_t col[4] = {pl->p.glyphs ? pl->p.glyphs->col[0] * 0x101u : 0, pl->p.glyphs ? pl->p.glyphs->col[1] * 0x101u : 0,
-                             pl->p.glyphs ? pl->p.glyphs->col[2] * 0x101u : 0, pl->p.glyphs ? pl->p.glyphs->col[3] * 0x101u : 0};
-
-    if (pl->fused) {
-        BandArgs a{};
-        a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
-        a.sw = sw; a.sh = sh;
-        a.band_rows = pl->g.band_rows; a.nbands = pl->g.nbands;
-        a.blk_cols = pl->g.blk_cols; a.ncolblk = pl->g.ncolblk;
-        a.nframes = n;
-        // the persistent pipelined kernel needs 16-byte aligned rows on both frames and a tile of at
-        // most kPipeMaxSlots chunks per thread; otherwise one workgroup per item
-        a.pipe_wgs = 0;
-        a.pipe_nt = 256;
-        a.pipe_order = 0;
-        a.cus = ctx->cus;
-        a.dbg = 0;
-        a.stamps = nullptr;
-#if IPX_DIAG
-        a.dbg = env_int("IPX_DBG", 0);
-        static unsigned long long *stamp_buf = nullptr;   // IPX_STAMPS=1: phase stamps, never in a timed run
-        if (env_int("IPX_STAMPS", 0)) {
-            if (!stamp_buf) IPX_HIP(hipMalloc((void **)&stamp_buf, 8 * sizeof(unsigned long long)));
-            IPX_HIP(hipMemsetAsync(stamp_buf, 0, 8 * sizeof(unsigned long long), s));
-            a.stamps = stamp_buf;
-        }
-#endif
-        const bool aligned = (sw & 3) == 0 && ((((uintptr_t)src) | (uintptr_t)sstride | src_frame_stride) & 15) == 0 &&
-                             (!wm || ((((uintptr_t)wm) | wm_frame_stride) & 15) == 0);
-        int pr = 0, pc = 0;
-        if (aligned && env_int("IPX_PIPE", 1) && pl->g.most_rows <= 64 && band_pipe_shape(pl->g.band_rows, pl->g.blk_cols, &pr, &pc)) {
-            a.pipe_wgs = std::max(1, env_int("IPX_PIPE_WGS", 8));  // clamped to what is resident at launch
-            a.pipe_nt = env_int("IPX_PIPE_NT", 512) == 512 ? 512 : 256;
-            a.pipe_order = -1;   // chosen below, once the operators are known
-        }
-        a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
-        a.nscale = 0;
-        a.nx_out[0] = a.nx_out[1] = 0;
-        for (int k = 0; k < 2; k++) {
-            const PlanScale &ps = pl->sc[k];
-            if (!outs[k] || ps.dw <= 0 || ps.dh <= 0) continue;
-            ScaleOut &o = a.sc[a.nscale++];
-            o.out = outs[k]; o.frame_stride = ostr[k]; o.ostride = ps.dw * 4;
-            o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
-            o.xt = ps.xt; o.yt = ps.yt; o.row_begin = pl->g.row_begin[k]; o.col_begin = pl->g.col_begin[k];
-            o.dyadic_shift = ps.dyadic_shift;
-            o.imul = ps.imul; o.yrow = pl->g.yrow[k];
-            a.nx_out[a.nscale - 1] = pl->g.nx_out[k];
-        }
-        if (a.nscale == 1) a.sc[1] = a.sc[0];  // keeps the kernel's unconditional tap loads legal
-        const bool sep_glyphs = wm && pl->glyphs.n > 0 && glyphs_separate(IPX_FUSED_GLYPHS_RGBA);
-        a.glyphs = pl->glyphs.dev; a.nglyphs = wm && !sep_glyphs ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
-        a.cr = col[0]; a.cg = col[1]; a.cb = col[2]; a.ca = col[3];
-        if (!wm && a.nscale == 0) return IPX_OK;
-        // every workgroup of the persistent kernel walks one contiguous run of items; 1 = it enters the run at an offset of its own
-        // (IPX_PIPE_ORDER=0: every run from its first item -- bimodal from process to process, see band_pipe_kernel)
-        if (a.pipe_order < 0) a.pipe_order = env_int("IPX_PIPE_ORDER", 1) ? 1 : 0;
-        IPX_HIP(launch_band(a, s));
-        if (sep_glyphs)
-            IPX_HIP(launch_composite(wm, sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox, col[0], col[1], col[2], col[3], s));
-        if (a.stamps) {
-            unsigned long long h[8];
-            IPX_HIP(hipMemcpyAsync(h, a.stamps, sizeof h, hipMemcpyDeviceToHost, s));
-            IPX_HIP(hipStreamSynchronize(s));
-            const double items = (double)pl->g.nbands * pl->g.ncolblk * n, waves = 4.0;
-            fprintf(stderr, "[ipx stamps] cycles per item per wave: drain %.0f  barrier1 %.0f  issue %.0f  compute %.0f  barrier2 %.0f\n",
-                    h[0] / items / waves, h[1] / items / waves, h[2] / items / waves, h[3] / items / waves, h[4] / items / waves);
-        }
-        return IPX_OK;
-    }
-
-    // unfused fallback (1-pixel-wide sources and the like): the per-operation kernels, frame by frame
-    for (int i = 0; i < n; i++) {
-        const uint8_t *f = src + (size_t)i * src_frame_stride;
-        for (int k = 0; k < 2; k++) {
-            const PlanScale &ps = pl->sc[k];
-            if (!outs[k] || ps.dw <= 0 || ps.dh <= 0) continue;
-            uint8_t *o = outs[k] + (size_t)i * ostr[k];
-            IPX_HIP(hipMemsetAsync(o, 0, (size_t)ps.dw * ps.dh * 4, s));  // image.NewRGBA
-            int rc = dev_scale(s, nullptr, o, ps.dw, ps.dh, ps.dw * 4, Rect{0, 0, ps.dw, ps.dh}, f, sw, sh,
-                               sstride, ps.sr, IPX_OP_SRC);  // Over on a zeroed frame == Src
-            if (rc) return rc;
-        }
-        if (wm) {
-            uint8_t *o = wm + (size_t)i * wm_frame_stride;
-            int rc = dev_draw(s, o, sw, sh, sw * 4, Rect{0, 0, sw, sh}, f, sw, sh, sstride, 0, 0, IPX_OP_SRC);
-            if (rc) return rc;
-        }
-    }
-    if (wm && pl->glyphs.n)
-        IPX_HIP(launch_composite(wm, sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox,
-                                 col[0], col[1], col[2], col[3], s));
-    return IPX_OK;
+    if (n > 65535) { set_error("ipx_plan_run_dev: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
+    DevSrc d = rgba_src(src, pl->p.sw, pl->p.sh, sstride);
+    d.nframes = n; d.frame_stride = src_frame_stride;
+    return run_dev_any(ctx, stream ? (hipStream_t)stream : ctx->stream, pl, n, d, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride,
+                       wm_out, wm_frame_stride);
 }
 IPX_CATCH_STATUS
 
@@ -1437,59 +1336,6 @@ IPX_CATCH_STATUS
 // mode 1 = 8-bit RGBA first (the crop thumbnail scales the RGBA8 copy cropAndResize made, thumbnail.go:128-131)
 // The text composite as a pass of its own over the watermark frames' text box (composite_kernel) after the band kernel has copied /
 // converted every pixel, instead of inside the band kernel (IPX_FUSED_GLYPHS in ipx_internal.h has the why).
-static bool glyphs_separate(bool fused_kernel) { return !fused_kernel || env_int("IPX_GLYPH_SEPARATE", 0) != 0; }
-static hipError_t composite_after(const ipx_plan *pl, bool fused_kernel, uint8_t *wm, size_t wm_frame_stride, int n, hipStream_t s)
-{
-    if (!wm || pl->glyphs.n <= 0 || !glyphs_separate(fused_kernel)) return hipSuccess;
-    const uint8_t *c = pl->p.glyphs ? pl->p.glyphs->col : nullptr;
-    return launch_composite(wm, pl->p.sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox, c ? c[0] * 0x101u : 0,
-                            c ? c[1] * 0x101u : 0, c ? c[2] * 0x101u : 0, c ? c[3] * 0x101u : 0, s);
-}
-
-static void fill_converting_band_args(ipx_ctx *ctx, const ipx_plan *pl, int n, uint8_t *res, size_t resize_frame_stride, uint8_t *th,
-                                      size_t thumb_frame_stride, uint8_t *wm, size_t wm_frame_stride, const PlanGeom &g, bool fused_glyphs, BandArgs &a,
-                                      int mode[2])
-{
-    const int sw = pl->p.sw, sh = pl->p.sh;
-    a.sw = sw; a.sh = sh;
-    a.band_rows = g.band_rows; a.nbands = g.nbands;
-    a.blk_cols = g.blk_cols; a.ncolblk = g.ncolblk;
-    a.nframes = n;
-    a.pipe_wgs = std::max(1, env_int("IPX_PIPE_WGS", 8));
-    a.pipe_nt = 512; a.pipe_order = 1;
-    a.cus = ctx->cus;
-#if IPX_DIAG
-    a.dbg = env_int("IPX_DBG", 0);
-#endif
-    a.wm = wm; a.wm_frame_stride = wm_frame_stride; a.wm_stride = sw * 4;
-    uint8_t *outs[2] = {res, th};
-    const size_t ostr[2] = {resize_frame_stride, thumb_frame_stride};
-    for (int k = 0; k < 2; k++) {
-        const PlanScale &ps = pl->sc[k];
-        if (!outs[k] || ps.dw <= 0 || ps.dh <= 0) continue;
-        mode[a.nscale] = k == 1 && pl->p.crop_to_fit ? 1 : 0;
-        ScaleOut &o = a.sc[a.nscale++];
-        o.out = outs[k]; o.frame_stride = ostr[k]; o.ostride = ps.dw * 4;
-        o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
-        o.xt = ps.xt; o.yt = ps.yt; o.row_begin = g.row_begin[k]; o.col_begin = g.col_begin[k];
-        o.dyadic_shift = ps.dyadic_shift;
-        if (mode[a.nscale - 1] == 1) { o.imul = g.yrow[k] ? ps.imul : 0; o.yrow = g.yrow[k]; }   // RGBA8 taps only
-        else o.yrow16 = g.yrow16[k];
-        // 16-bit taps in u32: x0*tap + x1*tap < 2^24 and the weights below 2^9 keep every product in 24 x 24 bits
-        if (mode[a.nscale - 1] == 0 && (ps.kx > 8 || ps.ky > 8)) o.dyadic_shift = -1;
-        a.nx_out[a.nscale - 1] = g.nx_out[k];
-    }
-    if (a.nscale == 1) { a.sc[1] = a.sc[0]; mode[1] = mode[0]; }
-    const uint8_t *c = pl->p.glyphs ? pl->p.glyphs->col : nullptr;
-    a.glyphs = pl->glyphs.dev; a.nglyphs = wm && !glyphs_separate(fused_glyphs) ? pl->glyphs.n : 0; a.gbox = pl->glyphs.bbox;
-    a.cr = c ? c[0] * 0x101u : 0; a.cg = c ? c[1] * 0x101u : 0; a.cb = c ? c[2] * 0x101u : 0; a.ca = c ? c[3] * 0x101u : 0;
-}
-
-// flat_chroma: cb == cr == one row of 128s read with stride 0 (a Gray frame seen as YCbCr); everything else as the public entry
-static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, bool flat_chroma,
-                         uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
-                         size_t wm_frame_stride);
-
 int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src,
                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                            size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride) try
@@ -1504,105 +1350,14 @@ int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     if (!frame_span_ok(pl->p.sw, pl->p.sh, src->cstride, 1)) { set_error("ipx_plan_run_dev_ycbcr: chroma planes beyond the addressable span"); return IPX_ERR_UNSUPPORTED; }
     if (n == 0) return IPX_OK;
     if (n > 65535) { set_error("ipx_plan_run_dev_ycbcr: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
-    return run_dev_ycbcr(ctx, stream ? (hipStream_t)stream : ctx->stream, pl, n, src, false, resize_out, resize_frame_stride, thumb_out,
-                         thumb_frame_stride, wm_out, wm_frame_stride);
+    DevSrc d;
+    d.kind = IPX_SRC_YCBCR; d.pix = src->y; d.stride = src->ystride; d.cb = src->cb; d.cr = src->cr;
+    d.cstride = src->cstride; d.ratio = src->ratio; d.w = pl->p.sw; d.h = pl->p.sh;
+    d.nframes = n; d.frame_stride = src->y_frame_stride; d.c_frame_stride = src->c_frame_stride;
+    return run_dev_any(ctx, stream ? (hipStream_t)stream : ctx->stream, pl, n, d, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride,
+                       wm_out, wm_frame_stride);
 }
 IPX_CATCH_STATUS
-
-static int run_dev_ycbcr(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, const ipx_ycbcr_batch *src, bool flat_chroma,
-                         uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
-                         size_t wm_frame_stride)
-{
-    const int sw = pl->p.sw, sh = pl->p.sh;
-    uint8_t *res = pl->sc[0].on ? resize_out : nullptr;
-    uint8_t *th = pl->sc[1].on ? thumb_out : nullptr;
-    uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
-    const bool crop_thumb = th && pl->p.crop_to_fit;
-
-    // one fused pass over the planes when the tile shape and alignments allow it (ipx_band_conv.hip)
-    if (pl->fused && env_int("IPX_YCC_FUSED", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
-        YccArgs A{};
-        BandArgs &a = A.b;
-        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, IPX_FUSED_GLYPHS_CONV, a, A.mode);
-        if (!wm && a.nscale == 0) return IPX_OK;
-        A.y = src->y; A.cb = src->cb; A.cr = src->cr; A.ystride = src->ystride; A.cstride = src->cstride;
-        A.y_fs = src->y_frame_stride; A.c_fs = src->c_frame_stride; A.ratio = src->ratio;
-        A.cw = (src->ratio == IPX_YCBCR_422 || src->ratio == IPX_YCBCR_420) ? (sw + 1) / 2 : sw;
-        A.ch = (src->ratio == IPX_YCBCR_420 || src->ratio == IPX_YCBCR_440) ? (sh + 1) / 2 : sh;
-#if IPX_DIAG
-        static unsigned long long *stamp_buf = nullptr;   // IPX_STAMPS=1: phase stamps, never in a timed run
-        if (env_int("IPX_STAMPS", 0)) {
-            if (!stamp_buf) IPX_HIP(hipMalloc((void **)&stamp_buf, 8 * sizeof(unsigned long long)));
-            IPX_HIP(hipMemsetAsync(stamp_buf, 0, 8 * sizeof(unsigned long long), s));
-            a.stamps = stamp_buf;
-        }
-#endif
-        bool matched = false;
-        if (src->cstride >= A.cw || flat_chroma) IPX_HIP(launch_band_ycc(A, s, &matched));
-        if (matched) IPX_HIP(composite_after(pl, IPX_FUSED_GLYPHS_CONV, wm, wm_frame_stride, n, s));
-#if IPX_DIAG
-        if (matched && a.stamps) {
-            unsigned long long h[8];
-            IPX_HIP(hipMemcpyAsync(h, a.stamps, sizeof h, hipMemcpyDeviceToHost, s));
-            IPX_HIP(hipStreamSynchronize(s));
-            const double wi = (double)pl->conv.nbands * pl->conv.ncolblk * n * 8.0;
-            fprintf(stderr, "[ipx stamps ycc] cycles per item per wave: wait-loads %.0f  drain %.0f  barrier1 %.0f  issue %.0f  compute %.0f  barrier2 %.0f\n",
-                    h[0] / wi, h[1] / wi, h[2] / wi, h[3] / wi, h[4] / wi, h[5] / wi);
-        }
-#endif
-        if (matched) return IPX_OK;
-    }
-
-    if (flat_chroma) return 1;   // Gray frames the fused kernel does not take: the caller expands them and uses the RGBA pass
-
-    DevSrc ysrc;
-    ysrc.kind = IPX_SRC_YCBCR; ysrc.pix = src->y; ysrc.stride = src->ystride; ysrc.cb = src->cb; ysrc.cr = src->cr;
-    ysrc.cstride = src->cstride; ysrc.ratio = src->ratio; ysrc.w = sw; ysrc.h = sh;
-    ysrc.nframes = n; ysrc.frame_stride = src->y_frame_stride; ysrc.c_frame_stride = src->c_frame_stride;
-
-    // RGBA8 conversion of the whole batch, straight into the watermark frames when they are wanted
-    uint8_t *conv = wm;
-    size_t conv_fs = wm_frame_stride;
-    uint8_t *scratch = nullptr;
-    if (!conv && crop_thumb) {
-        conv_fs = (size_t)sw * sh * 4;
-        IPX_HIP(hipMallocAsync((void **)&scratch, conv_fs * n, s));
-        conv = scratch;
-    }
-    int rc = IPX_OK;
-    if (conv)
-        IPX_HIP(launch_draw_ycbcr(conv, sw * 4, src->y, src->ystride, src->cb, src->cr, src->cstride, src->ratio, 0, 0, sw,
-                                  sh, s, n, conv_fs, src->y_frame_stride, src->c_frame_stride));
-    if (crop_thumb) {
-        ipx_plan *sub = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(pl->mu);
-            if (!pl->thumb_only) {
-                ipx_plan_params tp;
-                memset(&tp, 0, sizeof tp);
-                tp.sw = sw; tp.sh = sh; tp.do_thumbnail = 1; tp.thumb_size = pl->p.thumb_size; tp.crop_to_fit = 1;
-                rc = ipx_plan_create(ctx, &tp, &pl->thumb_only);
-            }
-            sub = pl->thumb_only;
-        }
-        if (!rc) rc = ipx_plan_run_dev(ctx, s, sub, n, conv, sw * 4, conv_fs, nullptr, 0, th, thumb_frame_stride, nullptr, 0);
-    }
-    if (!rc && wm && pl->glyphs.n && pl->p.glyphs) {
-        const uint8_t *c = pl->p.glyphs->col;
-        hipError_t e = launch_composite(wm, sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox,
-                                        c[0] * 0x101u, c[1] * 0x101u, c[2] * 0x101u, c[3] * 0x101u, s);
-        if (e != hipSuccess) { set_error("composite launch failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
-    }
-    for (int k = 0; k < 2 && !rc; k++) {   // 16-bit-tap scales straight from the planes
-        const PlanScale &ps = pl->sc[k];
-        uint8_t *o = k == 0 ? res : (crop_thumb ? nullptr : th);
-        const size_t ofs = k == 0 ? resize_frame_stride : thumb_frame_stride;
-        if (!o || ps.dw <= 0 || ps.dh <= 0) continue;
-        rc = dev_scale_src(s, nullptr, o, ps.dw, ps.dh, ps.dw * 4, Rect{0, 0, ps.dw, ps.dh}, ysrc, ps.sr, IPX_OP_SRC, ofs);
-    }
-    if (scratch) (void)hipFreeAsync(scratch, s);
-    return rc;
-}
 
 int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, const uint8_t *src, int sstride, size_t src_frame_stride,
                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
@@ -1613,88 +1368,15 @@ int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n
     IPX_PLAN_SRC("ipx_plan_run_dev_nrgba", pl, sstride, 4);
     if (n == 0) return IPX_OK;
     if (n > 65535) { set_error("ipx_plan_run_dev_nrgba: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    const int sw = pl->p.sw, sh = pl->p.sh;
-    uint8_t *res = pl->sc[0].on ? resize_out : nullptr;
-    uint8_t *th = pl->sc[1].on ? thumb_out : nullptr;
-    uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
-    const bool crop_thumb = th && pl->p.crop_to_fit;
-    // one fused pass over the frames when the tile shape and alignments allow it: the converted-tile kernel (every source pixel
-    // premultiplied once, ipx_band_conv.hip) on the plan's `conv` tiling, else the per-tap kernel of ipx_band_nrgba.hip
-    if (pl->fused && env_int("IPX_NRGBA_FUSED", 1) && env_int("IPX_NRGBA_CONV", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
-        NrgbaArgs A{};
-        BandArgs &a = A.b;
-        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, IPX_FUSED_GLYPHS_CONV, a, A.mode);
-        if (!wm && a.nscale == 0) return IPX_OK;
-        a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
-        bool matched = false;
-        IPX_HIP(launch_band_nrgba_conv(A, s, &matched));
-        if (matched) IPX_HIP(composite_after(pl, IPX_FUSED_GLYPHS_CONV, wm, wm_frame_stride, n, s));
-        if (matched) return IPX_OK;
-    }
-    if (pl->fused && env_int("IPX_NRGBA_FUSED", 1) && pl->g.band_rows <= 8 && pl->g.most_rows <= 64) {
-        NrgbaArgs A{};
-        BandArgs &a = A.b;
-        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->g, IPX_FUSED_GLYPHS_RGBA, a, A.mode);
-        if (!wm && a.nscale == 0) return IPX_OK;
-        a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
-        bool matched = false;
-        IPX_HIP(launch_band_nrgba(A, s, &matched));
-        if (matched) IPX_HIP(composite_after(pl, IPX_FUSED_GLYPHS_RGBA, wm, wm_frame_stride, n, s));
-        if (matched) return IPX_OK;
-    }
-    // premultiplied RGBA8 of the whole batch (drawNRGBASrc == drawNRGBAOver onto a zeroed frame), into the watermark frames when wanted
-    uint8_t *conv = wm;
-    size_t conv_fs = wm_frame_stride;
-    uint8_t *scratch = nullptr;
-    if (!conv && crop_thumb) {
-        conv_fs = (size_t)sw * sh * 4;
-        IPX_HIP(hipMallocAsync((void **)&scratch, conv_fs * n, s));
-        conv = scratch;
-    }
-    int rc = IPX_OK;
-    if (conv) {
-        hipError_t e = launch_draw_nrgba(conv, sw * 4, src, sstride, sw, sh, IPX_OP_SRC, s, n, conv_fs, src_frame_stride);
-        if (e != hipSuccess) { set_error("premultiply launch failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
-    }
-    if (!rc && crop_thumb) {
-        ipx_plan *sub = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(pl->mu);
-            if (!pl->thumb_only) {
-                ipx_plan_params tp;
-                memset(&tp, 0, sizeof tp);
-                tp.sw = sw; tp.sh = sh; tp.do_thumbnail = 1; tp.thumb_size = pl->p.thumb_size; tp.crop_to_fit = 1;
-                rc = ipx_plan_create(ctx, &tp, &pl->thumb_only);
-            }
-            sub = pl->thumb_only;
-        }
-        if (!rc) rc = ipx_plan_run_dev(ctx, s, sub, n, conv, sw * 4, conv_fs, nullptr, 0, th, thumb_frame_stride, nullptr, 0);
-    }
-    if (!rc && wm && pl->glyphs.n && pl->p.glyphs) {
-        const uint8_t *c = pl->p.glyphs->col;
-        hipError_t e = launch_composite(wm, sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox,
-                                        c[0] * 0x101u, c[1] * 0x101u, c[2] * 0x101u, c[3] * 0x101u, s);
-        if (e != hipSuccess) { set_error("composite launch failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
-    }
-    DevSrc nsrc;
-    nsrc.kind = IPX_SRC_NRGBA; nsrc.pix = src; nsrc.stride = sstride; nsrc.w = sw; nsrc.h = sh;
-    nsrc.nframes = n; nsrc.frame_stride = src_frame_stride;
-    for (int k = 0; k < 2 && !rc; k++) {   // 16-bit premultiplied taps straight from the source; Over onto the zeroed frame == Src
-        const PlanScale &ps = pl->sc[k];
-        uint8_t *o = k == 0 ? res : (crop_thumb ? nullptr : th);
-        const size_t ofs = k == 0 ? resize_frame_stride : thumb_frame_stride;
-        if (!o || ps.dw <= 0 || ps.dh <= 0) continue;
-        rc = dev_scale_src(s, nullptr, o, ps.dw, ps.dh, ps.dw * 4, Rect{0, 0, ps.dw, ps.dh}, nsrc, ps.sr, IPX_OP_SRC, ofs);
-    }
-    if (scratch) (void)hipFreeAsync(scratch, s);
-    return rc;
+    DevSrc d = rgba_src(src, pl->p.sw, pl->p.sh, sstride, IPX_SRC_NRGBA);
+    d.nframes = n; d.frame_stride = src_frame_stride;
+    return run_dev_any(ctx, stream ? (hipStream_t)stream : ctx->stream, pl, n, d, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride,
+                       wm_out, wm_frame_stride);
 }
 IPX_CATCH_STATUS
 
 // The deep source types: one expansion pass to frames of 16-bit taps (what every consumer of these types reads: At(x, y).RGBA()), then
-// the converted-tile kernel on them, or the three-kernel path -- top bytes into the watermark frames (drawRGBA / drawCMYK with Src), the
-// crop thumbnail from those RGBA8 frames, the text pass, and the per-tap scale from the taps.
+// the batch runner on them: top bytes into the watermark frames (drawRGBA / drawCMYK with Src), the scales from the taps.
 int ipx_plan_run_dev_deep(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n, int kind, const uint8_t *src, int sstride, size_t src_frame_stride,
                           uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out, size_t thumb_frame_stride, uint8_t *wm_out,
                           size_t wm_frame_stride) try
@@ -1716,83 +1398,18 @@ int ipx_plan_run_dev_deep(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n,
     if (n > 65535) { set_error("ipx_plan_run_dev_deep: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     const int sw = pl->p.sw, sh = pl->p.sh;
-    uint8_t *res = pl->sc[0].on ? resize_out : nullptr;
-    uint8_t *th = pl->sc[1].on ? thumb_out : nullptr;
-    uint8_t *wm = pl->p.do_watermark ? wm_out : nullptr;
-    if (!res && !th && !wm) return IPX_OK;
-    const bool crop_thumb = th && pl->p.crop_to_fit;
-    // one fused pass straight from Go's Pix when the tile shape and the alignments allow it
-    if (pl->fused && env_int("IPX_DEEP_FUSED", 1) && env_int("IPX_DEEP_DIRECT", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
-        NrgbaArgs A{};
-        BandArgs &a = A.b;
-        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, IPX_FUSED_GLYPHS_CONV, a, A.mode);
-        a.src = src; a.src_frame_stride = src_frame_stride; a.sstride = sstride;
-        bool matched = false;
-        IPX_HIP(launch_band_deep(A, kind, s, &matched));
-        if (matched) IPX_HIP(composite_after(pl, IPX_FUSED_GLYPHS_CONV, wm, wm_frame_stride, n, s));
-        if (matched) return IPX_OK;
-    }
     const size_t tfs = align256((size_t)sw * sh * 8);
     uint8_t *taps = nullptr;
     IPX_HIP(hipMallocAsync((void **)&taps, tfs * n, s));
-    struct Free { uint8_t *p; hipStream_t s; ~Free() { if (p) (void)hipFreeAsync(p, s); } } free_taps{taps, s}, free_scratch{nullptr, s};
+    struct Free { uint8_t *p; hipStream_t s; ~Free() { if (p) (void)hipFreeAsync(p, s); } } free_taps{taps, s};
     {
         hipError_t e = launch_deep_expand(taps, tfs, src, sstride, src_frame_stride, kind, sw, sh, n, s);
         if (e != hipSuccess) { set_error("tap expansion failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
     }
-    if (pl->fused && env_int("IPX_DEEP_FUSED", 1) && pl->conv.ok && pl->conv.most_rows <= 64) {
-        NrgbaArgs A{};
-        BandArgs &a = A.b;
-        fill_converting_band_args(ctx, pl, n, res, resize_frame_stride, th, thumb_frame_stride, wm, wm_frame_stride, pl->conv, IPX_FUSED_GLYPHS_CONV, a, A.mode);
-        a.src = taps; a.src_frame_stride = tfs; a.sstride = sw * 8;
-        bool matched = false;
-        IPX_HIP(launch_band_tap64_conv(A, s, &matched));
-        if (matched) IPX_HIP(composite_after(pl, IPX_FUSED_GLYPHS_CONV, wm, wm_frame_stride, n, s));
-        if (matched) return IPX_OK;
-    }
-    uint8_t *conv = wm;
-    size_t conv_fs = wm_frame_stride;
-    if (!conv && crop_thumb) {
-        conv_fs = (size_t)sw * sh * 4;
-        IPX_HIP(hipMallocAsync((void **)&free_scratch.p, conv_fs * n, s));
-        conv = free_scratch.p;
-    }
-    int rc = IPX_OK;
-    if (conv) {
-        hipError_t e = launch_draw_tap64(conv, sw * 4, taps, sw * 8, sw, sh, IPX_OP_SRC, s, n, conv_fs, tfs);
-        if (e != hipSuccess) { set_error("tap narrowing failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
-    }
-    if (crop_thumb) {
-        ipx_plan *sub = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(pl->mu);
-            if (!pl->thumb_only) {
-                ipx_plan_params tp;
-                memset(&tp, 0, sizeof tp);
-                tp.sw = sw; tp.sh = sh; tp.do_thumbnail = 1; tp.thumb_size = pl->p.thumb_size; tp.crop_to_fit = 1;
-                rc = ipx_plan_create(ctx, &tp, &pl->thumb_only);
-            }
-            sub = pl->thumb_only;
-        }
-        if (!rc) rc = ipx_plan_run_dev(ctx, s, sub, n, conv, sw * 4, conv_fs, nullptr, 0, th, thumb_frame_stride, nullptr, 0);
-    }
-    if (!rc && wm && pl->glyphs.n && pl->p.glyphs) {
-        const uint8_t *c = pl->p.glyphs->col;
-        hipError_t e = launch_composite(wm, sw * 4, wm_frame_stride, n, pl->glyphs.dev, pl->glyphs.n, pl->glyphs.bbox,
-                                        c[0] * 0x101u, c[1] * 0x101u, c[2] * 0x101u, c[3] * 0x101u, s);
-        if (e != hipSuccess) { set_error("composite launch failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
-    }
-    DevSrc tsrc;
-    tsrc.kind = IPX_SRC_TAP64; tsrc.pix = taps; tsrc.stride = sw * 8; tsrc.w = sw; tsrc.h = sh;
-    tsrc.nframes = n; tsrc.frame_stride = tfs;
-    for (int k = 0; k < 2 && !rc; k++) {   // 16-bit taps; Over onto the zeroed frame == Src
-        const PlanScale &ps = pl->sc[k];
-        uint8_t *o = k == 0 ? res : (crop_thumb ? nullptr : th);
-        const size_t ofs = k == 0 ? resize_frame_stride : thumb_frame_stride;
-        if (!o || ps.dw <= 0 || ps.dh <= 0) continue;
-        rc = dev_scale_src(s, nullptr, o, ps.dw, ps.dh, ps.dw * 4, Rect{0, 0, ps.dw, ps.dh}, tsrc, ps.sr, IPX_OP_SRC, ofs);
-    }
-    return rc;
+    DevSrc d;
+    d.kind = IPX_SRC_TAP64; d.pix = taps; d.stride = sw * 8; d.w = sw; d.h = sh;
+    d.nframes = n; d.frame_stride = tfs;
+    return run_dev_any(ctx, s, pl, n, d, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride, wm_out, wm_frame_stride);
 }
 IPX_CATCH_STATUS
 
@@ -1851,31 +1468,16 @@ int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n,
     IPX_PLAN_SRC("ipx_plan_run_dev_gray", pl, stride, 1);
     if (n == 0) return IPX_OK;
     if (n > 65535) { set_error("ipx_plan_run_dev_gray: at most 65535 frames per call"); return IPX_ERR_UNSUPPORTED; }
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    const int sw = pl->p.sw, sh = pl->p.sh;
-    // A Gray pixel read as YCbCr with Cb = Cr = 128 converts to (y, y, y, 0xff) in both of the reference's conversions --
-    // color.YCbCrToRGB: (y*0x10101) >> 16 = y; color.YCbCr.RGBA: (y*0x10101) >> 8 = y*0x101 = color.Gray.RGBA -- so the batch takes the
-    // planar pass with a stride-0 row of 128s as both chroma planes: 1 byte per pixel is read and nothing is expanded in HBM.
-    if (env_int("IPX_GRAY_FLAT", 1) && (size_t)(sw + 1) / 2 + 8 <= ipx_ctx::kFlatChromaBytes) {
-        ipx_ycbcr_batch b;
-        b.y = gray; b.cb = b.cr = ctx->flat_chroma; b.ystride = stride; b.cstride = 0;
-        b.y_frame_stride = frame_stride; b.c_frame_stride = 0;
-        // IPX_GRAY: the converted-tile kernel's own Gray source (the Y plane alone, y * 0x101 per channel); IPX_GRAY_SRC=0: the YCbCr
-        // source with the stride-0 row of 128s as both chroma planes (the same bytes, with the chroma arithmetic)
-        b.ratio = env_int("IPX_GRAY_SRC", 1) ? IPX_GRAY : IPX_YCBCR_420;
-        const int rc = run_dev_ycbcr(ctx, s, pl, n, &b, true, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride, wm_out,
-                                     wm_frame_stride);
-        if (rc <= 0) return rc;      // 1: not a shape the planar kernel takes
-    }
-    const size_t fs = align256((size_t)sw * sh * 4);
-    uint8_t *rgba = nullptr;
-    IPX_HIP(hipMallocAsync((void **)&rgba, fs * n, s));
-    hipError_t e = launch_gray_expand(rgba, fs, gray, stride, frame_stride, sw, sh, n, s);
-    int rc = IPX_OK;
-    if (e != hipSuccess) { set_error("gray expansion failed: %s", hipGetErrorString(e)); rc = IPX_ERR_HIP; }
-    if (!rc) rc = ipx_plan_run_dev(ctx, s, pl, n, rgba, sw * 4, fs, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride, wm_out, wm_frame_stride);
-    (void)hipFreeAsync(rgba, s);
-    return rc;
+    // scaleX_Gray / drawGray read a pixel as (y, y, y, 0xff), tmp alpha 1.  A YCbCr pixel with Cb = Cr = 128 converts to exactly that in both of the
+    // reference's conversions -- color.YCbCrToRGB: (y*0x10101) >> 16 = y; color.YCbCr.RGBA: (y*0x10101) >> 8 = y*0x101 = color.Gray.RGBA -- and
+    // scaleX_YCbCr4xx writes the same tmp alpha, so the batch runs as 4:4:4 planes with a stride-0 row of 128s as both chroma planes.
+    if ((size_t)pl->p.sw + 8 > ipx_ctx::kFlatChromaBytes) { set_error("ipx_plan_run_dev_gray: frames wider than %zu pixels", ipx_ctx::kFlatChromaBytes - 8); return IPX_ERR_UNSUPPORTED; }
+    DevSrc d;
+    d.kind = IPX_SRC_YCBCR; d.pix = gray; d.stride = stride; d.cb = d.cr = ctx->flat_chroma;
+    d.cstride = 0; d.ratio = IPX_YCBCR_444; d.w = pl->p.sw; d.h = pl->p.sh;
+    d.nframes = n; d.frame_stride = frame_stride; d.c_frame_stride = 0;
+    return run_dev_any(ctx, stream ? (hipStream_t)stream : ctx->stream, pl, n, d, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride,
+                       wm_out, wm_frame_stride);
 }
 IPX_CATCH_STATUS
 

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ipx_internal.h"
+#include "ipx_ks.h"
 
 using namespace ipx;
 
@@ -55,6 +56,9 @@ struct ipx_ctx {
     // (ipx_plan_acquire: the per-operator seam, the pool): no hipMalloc / hipFree in the steady state
     std::mutex plan_mu;
     std::map<std::string, std::pair<ipx_glyphset *, ipx_plan *>> plan_cache;
+    // axes of the kernel scaler in HBM by (destination extent, source extent), for the per-operation seam (ks_axis_get)
+    std::mutex ks_mu;
+    std::map<std::pair<int, int>, std::pair<uint8_t *, KsAxisDev>> ks_axes;
     static constexpr size_t kFlatChromaBytes = (size_t)64 << 10;
 };
 
@@ -85,34 +89,19 @@ struct PlanScale {
     bool on = false;
     int dw = 0, dh = 0;
     Rect sr{0, 0, 0, 0};
-    AxisTap *xt = nullptr, *yt = nullptr;
-    int dyadic_shift = -1;
-    int kx = -1, ky = -1;   // dyadic bits per axis (dyadic_shift = kx + ky), -1 = not dyadic
-    uint32_t imul = 0;      // the packed-integer lerp (ScaleOut::imul): set when the axes qualify
-};
-
-// One tiling of the source frame and the device tables that depend on it (per scaled output k)
-struct PlanGeom {
-    bool ok = false;
-    int band_rows = 0, blk_cols = 0, nbands = 0, ncolblk = 0;
-    int nx_out[2] = {0, 0}; // per output: ceil(widest column block / 256)
-    int most_rows = 0;      // most destination rows any band owns, over the scaled outputs
-    int *row_begin[2] = {nullptr, nullptr}, *col_begin[2] = {nullptr, nullptr};
-    uint32_t *yrow[2] = {nullptr, nullptr};     // dh + 1 entries of {ctl, yw} (ScaleOut::yrow), when imul is set
-    uint32_t *yrow16[2] = {nullptr, nullptr};   // dh + 1 entries of {ctl, y0', y1', 0} (ScaleOut::yrow16), when kx and ky <= 8
+    KsAxis hx, hy;          // newDistrib of the two axes, as built on the host (the fused kernel's tables are cut from these)
+    KsAxisDev ax[2]{};      // the same in the plan's blob: [0] horizontal, [1] vertical
 };
 
 struct ipx_plan {
     ipx_plan_params p{};
     ipx_plan_info info{};
-    bool fused = false;
-    PlanGeom g;           // tiles of one dword per pixel (RGBA and NRGBA sources)
-    PlanGeom conv;        // tiles of converted taps, two dwords per pixel (YCbCr sources); conv.ok = false: that kernel is not used
     PlanScale sc[2];      // 0 = resize, 1 = thumbnail
+    KsFusedPlan fused;    // tiling and tables of the one-pass kernel (ipx_ks_fused.hip); fused.ok = false: per-output kernels
+    size_t fused_off = 0; // where those tables start in the blob
     uint8_t *blob = nullptr;
     ClippedGlyphs glyphs;
     mutable std::mutex mu;
-    mutable ipx_plan *thumb_only = nullptr;   // RGBA sub-plan for YCbCr batches (thumbnail of the converted frame)
     ipx_glyphset *owned_gs = nullptr;         // a glyph set that lives and dies with this plan (ipx_plan_acquire)
 };
 

@@ -1,6 +1,6 @@
 """HIP path vs the CPU oracle, through the C ABI (include/ipx.h).  Bit-exact everywhere: the
-kernels restate the same float64 / uint32 arithmetic (the +-1 LSB allowance of the north star for
-the bilinear taps is not needed and not used).
+kernels do the kernel scaler's float64 operations in the reference's order with contraction off, and the
+uint32 composite as it is (the +-1 LSB allowance of the north star for the scaler is not needed and not used).
 
 PARITY UNPINNED against the Go reference itself: see oracle/ipx_oracle.h.
 """
@@ -73,9 +73,9 @@ def test_golden_glyphs(ctx):
 
 SCALE_GEOMS = [
     # sw, sh, dw, dh, sr, dr, op, opaque, nonzero dst
-    (1920, 1080, 1024, 768, None, None, 0, True, False),    # BASELINE resize, dyadic scales
+    (1920, 1080, 1024, 768, None, None, 0, True, False),    # BASELINE resize: 3-4 x 2-3 taps
     (1920, 1080, 1024, 576, None, None, 0, True, False),    # product default (keep_aspect)
-    (1920, 1080, 200, 200, (420, 0, 1500, 1080), None, 0, True, False),  # thumbnail: x5.4
+    (1920, 1080, 200, 200, (420, 0, 1500, 1080), None, 0, True, False),  # thumbnail: x5.4, 11 x 11 taps
     (640, 480, 1024, 768, None, None, 0, True, False),      # upscale x1.6
     (854, 480, 1024, 575, None, None, 0, False, False),     # odd width, translucent
     (333, 500, 511, 768, None, None, 1, False, False),
@@ -84,8 +84,10 @@ SCALE_GEOMS = [
     (97, 61, 40, 40, (5, 7, 90, 55), (3, 2, 36, 39), 0, False, True),
     (97, 61, 40, 40, None, (-7, -5, 50, 47), 1, False, True),  # dr clipped by dst
     (2, 2, 9, 7, None, None, 0, False, False),
-    (1, 5, 4, 9, None, None, 0, False, False),              # 1-wide source: both taps clamp
-    (64, 64, 64, 64, None, None, 0, False, True),           # equal size => Copy (drawCopyOver)
+    (1, 5, 4, 9, None, None, 0, False, False),              # 1-wide source: a single tap per column
+    (64, 64, 64, 64, None, None, 0, False, True),           # equal size: one tap of weight 1 per axis, Over a used frame
+    (3840, 2160, 200, 200, (840, 0, 3000, 2160), None, 0, True, False),   # 4K thumbnail: x10.8, 22-23 taps per axis
+    (200, 150, 1024, 768, None, None, 0, False, False),     # upscale x5.12: ten destination rows per source row
 ]
 
 
@@ -125,20 +127,21 @@ def test_draw_and_glyphs_vs_oracle(ctx):
             np.testing.assert_array_equal(got, want)
 
 
-# ---- the fused batched path (band kernel) vs the oracle -----------------------------------------------
+# ---- the batched path (one-pass kernel, per-output fallback) vs the oracle -----------------------------------------------
 
 PLAN_CASES = [
     # sw, sh, n, resize, thumbnail, env
     (1920, 1080, 2, (1024, 768, False), (200, True), {}),
     (1920, 1080, 1, (1024, 768, True), (200, True), {}),
-    (1920, 1080, 1, (1024, 768, True), (200, False), {"IPX_BLK_COLS": "512"}),
+    (1920, 1080, 1, (1024, 768, True), (200, False), {"IPX_KS_STRIPS": "4"}),
     (640, 480, 3, (1024, 768, True), (200, True), {}),
     (854, 480, 2, (1024, 768, True), (200, True), {}),                  # rows not 16-byte aligned
-    (1080, 1920, 1, (1024, 768, True), (200, True), {"IPX_BAND_ROWS": "5"}),
+    (1080, 1920, 1, (1024, 768, True), (200, True), {"IPX_KS_SPLIT_ROWS": "37"}),
     (3840, 2160, 1, (1024, 768, False), (200, True), {}),
-    (333, 500, 2, (1024, 768, True), (64, True), {"IPX_BLK_COLS": "64", "IPX_BAND_ROWS": "3"}),
-    (200, 200, 1, (200, 200, False), (200, True), {}),                  # scale 1: reference takes Copy
-    (1280, 720, 2, (100, 30, False), (200, False), {"IPX_BAND_ROWS": "16"}),
+    (332, 500, 2, (1024, 768, True), (64, True), {"IPX_KS_STRIPS": "5", "IPX_KS_SPLIT_ROWS": "13"}),
+    (333, 500, 2, (1024, 768, True), (64, True), {}),                   # odd width: per-output kernels
+    (200, 200, 1, (200, 200, False), (200, True), {}),                  # scale 1: one tap of weight 1 per axis
+    (1280, 720, 2, (100, 30, False), (200, False), {"IPX_KS_SPLIT": "0"}),
     (37, 23, 2, (64, 64, True), (10, True), {}),
     (7680, 4320, 1, (1024, 768, True), (200, True), {}),
 ]
@@ -186,29 +189,26 @@ def test_plan_subsets_and_unfused(ctx, monkeypatch):
     gs.close()
 
 
-PATH_ENVS = [{"IPX_PIPE": "0"},                                  # one workgroup per item (band_kernel)
-             {"IPX_NO_DYADIC": "1"},                             # float64 lerp everywhere
-             {"IPX_NO_DYADIC": "1", "IPX_PIPE": "0"},
-             {"IPX_PIPE_WGS": "1"},                              # one persistent workgroup per CU
-             {"IPX_BLK_COLS": "256"},                            # many column blocks (x taps change)
-             {"IPX_BLK_COLS": "1000", "IPX_BAND_ROWS": "16"},    # the 17-row single-column-group tile shape
-             {"IPX_PIPE_NT": "256"},                             # 256-thread workgroups on wide tiles (two chunks per thread)
-             {"IPX_PIPE_NT": "256", "IPX_NO_DYADIC": "1"},
-             {"IPX_PIPE_ORDER": "0"},                            # one contiguous run of items per workgroup
-             {"IPX_PIPE_ORDER": "0", "IPX_BLK_COLS": "256"},
-             {"IPX_PIPE_ORDER": "1", "IPX_BLK_COLS": "256"}]     # grid-interleaved order over several column blocks
+PATH_ENVS = [{"IPX_FUSED": "0"},                                 # per-output kernels (ks_generic_kernel), no one-pass kernel
+             {"IPX_KS_SPEC": "0"},                               # the general four-channel kernel alone, no speculative opaque pass
+             {"IPX_KS_SPLIT": "0"},                              # one segment per frame even for a small batch
+             {"IPX_KS_SPLIT": "1", "IPX_KS_SPLIT_ROWS": "50"},   # many short segments: every destination row near a seam re-stages its rows
+             {"IPX_KS_STRIPS": "3"},                             # several column strips (the thumbnail's columns sit in the middle ones)
+             {"IPX_KS_STRIPS": "7", "IPX_KS_SPEC": "0"},
+             {"IPX_KS_STRIPS": "2", "IPX_KS_SPLIT": "0"}]
 
 
 @pytest.mark.parametrize("env", PATH_ENVS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_every_kernel_path_is_bit_exact(ctx, env, monkeypatch):
-    """The shipped default is the persistent pipelined kernel with the exact fp32 lerp on dyadic
-    axes; the fallbacks (one workgroup per item, float64 lerp, other tile shapes) must give the same
-    bytes."""
+    """The shipped default is the one-pass kernel with the speculative opaque pass; the per-output kernels, the general
+    kernel and other tilings (strips, segments) must give the same bytes.  Frame 1 of every batch is translucent, so the
+    speculative pass gives it up and the general kernel redoes its items."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for sw, sh, n, resize in ((1920, 1080, 3, (1024, 768, False)), (1280, 720, 2, (1024, 768, True)),
                               (854, 480, 2, (1024, 768, True))):
         frames = rgba_frames(n, sw, sh, seed=sw)
+        frames[1] = rgba_frames(1, sw, sh, seed=sw + 1, opaque=False)[0]
         glyphs = text_glyphs(sw, sh)
         gs = ctx.glyphset(glyphs, DEFAULT_COL)
         plan = ctx.plan(sw, sh, resize=resize, thumbnail=(200, True), watermark=gs)
@@ -222,23 +222,25 @@ def test_every_kernel_path_is_bit_exact(ctx, env, monkeypatch):
 
 
 def test_random_geometries_vs_oracle(ctx, monkeypatch):
-    """Seeded sweep over frame sizes (odd widths included), operator parameters and tile shapes: the
-    ownership tables (which block produces which destination row / column) and both lerps must agree
-    with the oracle on every byte."""
+    """Seeded sweep over frame sizes (odd widths included), operator parameters (down- and upscales, crop and non-crop
+    thumbnails) and tilings: the ownership tables (which strip owns a destination column, which segment a destination row),
+    the row tables and both kernels must agree with the oracle on every byte."""
     rng = np.random.default_rng(20261004)
     for trial in range(36):
         sw = int(rng.choice([rng.integers(2, 90), rng.integers(90, 700), 4 * rng.integers(60, 500)]))
         sh = int(rng.choice([rng.integers(2, 60), rng.integers(60, 500)]))
         resize = (int(rng.integers(1, 1300)), int(rng.integers(1, 900)), bool(rng.integers(0, 2)))
         thumb = (int(rng.integers(1, 300)), bool(rng.integers(0, 2)))
-        for k in ("IPX_BLK_COLS", "IPX_BAND_ROWS", "IPX_PIPE"):
+        for k in ("IPX_KS_STRIPS", "IPX_KS_SPLIT_ROWS", "IPX_KS_SPLIT", "IPX_KS_SPEC"):
             monkeypatch.delenv(k, raising=False)
         if rng.random() < 0.5:
-            monkeypatch.setenv("IPX_BLK_COLS", str(int(rng.choice([8, 64, 252, 1000, 2044]))))
+            monkeypatch.setenv("IPX_KS_STRIPS", str(int(rng.choice([1, 2, 3, 5, 9]))))
         if rng.random() < 0.5:
-            monkeypatch.setenv("IPX_BAND_ROWS", str(int(rng.choice([1, 2, 5, 8, 16]))))
+            monkeypatch.setenv("IPX_KS_SPLIT_ROWS", str(int(rng.choice([4, 9, 17, 64, 200]))))
+        if rng.random() < 0.5:
+            monkeypatch.setenv("IPX_KS_SPLIT", str(int(rng.integers(0, 2))))
         if rng.random() < 0.25:
-            monkeypatch.setenv("IPX_PIPE", "0")
+            monkeypatch.setenv("IPX_KS_SPEC", "0")
         n = int(rng.integers(1, 4))
         frames = rgba_frames(n, sw, sh, seed=trial, opaque=bool(rng.integers(0, 2)))
         glyphs = text_glyphs(sw, sh, n=5, width_px=min(60, sw), height_px=min(20, sh))
@@ -250,7 +252,7 @@ def test_random_geometries_vs_oracle(ctx, monkeypatch):
             for k in ("resize", "thumbnail", "watermark"):
                 if k in got:
                     np.testing.assert_array_equal(got[k][i], want[k], err_msg="trial %d %s %dx%d resize=%s thumb=%s env=%s" % (
-                        trial, k, sw, sh, resize, thumb, {e: os.environ.get(e) for e in ("IPX_BLK_COLS", "IPX_BAND_ROWS", "IPX_PIPE")}))
+                        trial, k, sw, sh, resize, thumb, {e: os.environ.get(e) for e in ("IPX_KS_STRIPS", "IPX_KS_SPLIT_ROWS", "IPX_KS_SPLIT", "IPX_KS_SPEC")}))
         plan.close()
         gs.close()
 
