@@ -16,7 +16,7 @@ HEADERS = ["ipx_internal.h", "ipx_runtime_internal.h", "ipx_device.h", "ipx_ks.h
 # -ffp-contract=off: the kernel scaler must round every float64 product before the add, as the
 # reference's GOAMD64=v1 build does (no FMA); the kernels also carry `#pragma clang fp contract(off)`.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",
-         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"] + os.environ.get("IPX_CXXFLAGS", "").split()   # e.g. -DIPX_DIAG=1: phase stamps
 
 
 def hipcc():

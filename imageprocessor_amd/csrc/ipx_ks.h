@@ -116,6 +116,7 @@ struct KsFusedArgs {
     const KsStrip *strips; const KsSeg *segs;
     int nout; KsFusedOut o[2];
     int lds_w[2], lds_rows;    // byte offsets in LDS: weight tables, staged row entries (the tile is at 0)
+    unsigned long long *stamps; // diagnostic build (-DIPX_DIAG=1) only: per-phase cycle sums over all waves, else NULL
     int *redo;                 // speculative (opaque) kernel: one int per item, 1 = the item met a pixel with alpha != 0xff and was
                                // abandoned; general kernel: only items with redo[item] != 0 run (NULL: all)
 };

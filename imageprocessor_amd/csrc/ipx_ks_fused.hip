@@ -34,6 +34,16 @@
 namespace ipx {
 namespace {
 
+#ifndef IPX_DIAG
+#define IPX_DIAG 0
+#endif
+#if IPX_DIAG
+#define KS_DIAG_ARGS , tsum, tlast
+#define KS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tsum[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define KS_DIAG_ARGS
+#define KS_STAMP(i) do { } while (0)
+#endif
 constexpr int kOOB = 0x7fffffff;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -64,44 +74,72 @@ struct KsCol {                 // one destination column of a lane
 
 // scaleX on the B rows of the tile for one column, then scaleY's accumulation and, where a destination row completes, its store
 template <int NCH, int NACC, int B, bool CROP>
-__device__ __forceinline__ void ks_column(const uint8_t *lds, KsCol<NCH, NACC> &c, int ntap, int wstride, int pitch, const uint8_t *rows,
-                                          __amdgpu_buffer_rsrc_t ors, int ostride)
+__device__ __forceinline__ void ks_column(const uint8_t *lds, const uint8_t *tile, KsCol<NCH, NACC> &c, int ntap, int wstride, int pitch,
+                                          const uint8_t *rows, __amdgpu_buffer_rsrc_t ors, int ostride
+#if IPX_DIAG
+                                          , unsigned long long *tsum, unsigned long long &tlast
+#endif
+                                          )
 {
     double acc[B][NCH];
 #pragma unroll
     for (int r = 0; r < B; r++)
 #pragma unroll
         for (int k = 0; k < NCH; k++) acc[r][k] = 0.0;
-    const uint8_t *tap = lds + c.xb;
+    const uint8_t *tap = tile + c.xb;
     const uint8_t *wp = lds + c.wofs;
-    for (int t = 0; t < ntap; t++) {
-        const double w = *(const double *)wp;
+    // two taps per iteration: their ten LDS reads are in flight together
+    auto one_tap = [&](uint32_t px, double w, int r) {
+        acc[r][0] += ks_chan<0, CROP>(px) * w;
+        if (NCH > 1) acc[r][1 % NCH] += ks_chan<1, CROP>(px) * w;
+        if (NCH > 2) acc[r][2 % NCH] += ks_chan<2, CROP>(px) * w;
+        if (NCH > 3) acc[r][3 % NCH] += ks_chan<3, CROP>(px) * w;
+    };
+    int t = 0;
+    for (; t + 2 <= ntap; t += 2) {
+        const double w0 = *(const double *)wp, w1 = *(const double *)(wp + wstride);
+        uint32_t p0[B], p1[B];
 #pragma unroll
-        for (int r = 0; r < B; r++) {
-            const uint32_t px = *(const uint32_t *)(tap + r * pitch);
-            acc[r][0] += ks_chan<0, CROP>(px) * w;
-            if (NCH > 1) acc[r][1 % NCH] += ks_chan<1, CROP>(px) * w;
-            if (NCH > 2) acc[r][2 % NCH] += ks_chan<2, CROP>(px) * w;
-            if (NCH > 3) acc[r][3 % NCH] += ks_chan<3, CROP>(px) * w;
-        }
-        tap += 4;
-        wp += wstride;
+        for (int r = 0; r < B; r++) { p0[r] = *(const uint32_t *)(tap + r * pitch); p1[r] = *(const uint32_t *)(tap + r * pitch + 4); }
+#pragma unroll
+        for (int r = 0; r < B; r++) one_tap(p0[r], w0, r);
+#pragma unroll
+        for (int r = 0; r < B; r++) one_tap(p1[r], w1, r);     // (a column's taps in source order, row by row)
+        tap += 8;
+        wp += 2 * wstride;
     }
+    if (t < ntap) {
+        const double w0 = *(const double *)wp;
+        uint32_t p0[B];
+#pragma unroll
+        for (int r = 0; r < B; r++) p0[r] = *(const uint32_t *)(tap + r * pitch);
+#pragma unroll
+        for (int r = 0; r < B; r++) one_tap(p0[r], w0, r);
+    }
+    KS_STAMP(4);                                         // scaleX of the group's rows for this column
     typedef KsRowT<NACC> Row;
+    // the group's row entries in one batch of LDS reads (read one by one where they are used, every read was a round trip of its own)
+    double rw[B][NACC], ritw[B][NACC];
+    int remit[B][NACC];
 #pragma unroll
     for (int r = 0; r < B; r++) {
         const Row *row = (const Row *)(rows + r * sizeof(Row));
+#pragma unroll
+        for (int p = 0; p < NACC; p++) { rw[r][p] = row->w[p]; ritw[r][p] = row->itw[p]; remit[r][p] = row->emit[p]; }
+    }
+#pragma unroll
+    for (int r = 0; r < B; r++) {
         double tmp[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; k++) tmp[k] = acc[r][k] * c.itwf;
 #pragma unroll
         for (int p = 0; p < NACC; p++) {
-            const double w = row->w[p];
+            const double w = rw[r][p];
 #pragma unroll
             for (int k = 0; k < NCH; k++) c.q[p][k] += tmp[k] * w;     // w = 0 for an accumulator this row does not feed: x + 0 == x
-            const int dy = __builtin_amdgcn_readfirstlane(row->emit[p]);
+            const int dy = __builtin_amdgcn_readfirstlane(remit[r][p]);
             if (dy >= 0) {                                             // wave-uniform
-                const double s = row->itw[p];
+                const double s = ritw[r][p];
                 uint32_t px;
                 if (NCH == 4) {
                     double pa = c.q[p][3 % NCH];
@@ -164,11 +202,15 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     else if (a.nout > 1 && wv < a.o[0].waves + a.o[1].waves) { role = 1; wk = wv - a.o[0].waves; }
     role = __builtin_amdgcn_readfirstlane(role);
     wk = __builtin_amdgcn_readfirstlane(wk);
+    // the waves of the output with the longer tap loop are the critical path of every group: they go first when several waves of a
+    // SIMD are ready, the others fill the gaps
+    if (a.nout > 1 && role >= 0 && a.o[role].ntap * a.o[role].cpl > a.o[1 - role].ntap * a.o[1 - role].cpl) __builtin_amdgcn_s_setprio(2);
     KsCol<NCH, NACC> col[kKsMaxCpl];
     __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000);
     int ntap = 0, wstride = 0, ostride = 0, cpl = 0;
     bool crop = false;
     const uint8_t *rows_lds = lds + a.lds_rows;
+    const int tile_bytes = B * pitch, rows_bytes = 2 * B * (int)sizeof(Row);   // the tile and the row entries are double-buffered
     if (role >= 0) {
         const KsFusedOut &o = a.o[role];
         ors = __builtin_amdgcn_make_buffer_rsrc((void *)(o.out + (size_t)frame * o.frame_stride), 0, o.obytes, 0x00020000);
@@ -212,41 +254,58 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     };
     issue(0);
     bool bad = false;
+#if IPX_DIAG
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     for (int g = 0; g < ngroups; g++) {
+#if IPX_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        KS_STAMP(0);                                     // waiting for the group's staged loads
+#endif
         const int y0 = sg.ys + g * B;
         // ---- registers -> LDS tile and watermark frame ----
 #pragma unroll
         for (int i = 0; i < kKsMaxStage; i++) {
             if (s_row[i] < 0) continue;
             const u32x4 v = stage[i];
-            *(u32x4 *)(lds + s_lds[i]) = v;
+            *(u32x4 *)(lds + (g & 1) * tile_bytes + s_lds[i]) = v;
             const int y = y0 + s_row[i];
             const bool live = y < sg.r1;
             if (OPQ && live) bad |= ((v.x & v.y & v.z & v.w) >> 24) != 0xffu;
             if (a.wm && live && y >= sg.r0) __builtin_amdgcn_raw_buffer_store_b128(v, wrs, s_wm[i], y0 * a.wm_stride, 0);
         }
-        if (rstage) ((uint32_t *)(lds + a.lds_rows))[rk * B * RW + ri] = rstg;
+        if (rstage) ((uint32_t *)(lds + a.lds_rows + (g & 1) * rows_bytes))[rk * B * RW + ri] = rstg;
+        KS_STAMP(1);                                     // registers -> LDS, watermark stores
         if (OPQ) {
             if (__syncthreads_or(bad)) {                 // not an opaque frame: the general kernel redoes the item
                 if (tid == 0) a.redo[blockIdx.x] = 1;
                 return;
             }
         } else __syncthreads();
+        KS_STAMP(2);                                     // barrier
         if (g + 1 < ngroups) issue(g + 1);
+        KS_STAMP(3);                                     // issuing the next group's loads
         // ---- scaleX on the tile, scaleY's sums, finished destination rows ----
+        // (one barrier per group: a wave that writes buffer g & 1 two groups on has passed the barrier of group g + 1, which every wave
+        // reaches only after its arithmetic on group g)
         if (role >= 0) {
+            const uint8_t *tile = lds + (g & 1) * tile_bytes, *rws = rows_lds + (g & 1) * rows_bytes;
             if (crop) {
 #pragma unroll
                 for (int j = 0; j < kKsMaxCpl; j++)
-                    if (j < cpl) ks_column<NCH, NACC, B, true>(lds, col[j], ntap, wstride, pitch, rows_lds, ors, ostride);
+                    if (j < cpl) ks_column<NCH, NACC, B, true>(lds, tile, col[j], ntap, wstride, pitch, rws, ors, ostride KS_DIAG_ARGS);
             } else {
 #pragma unroll
                 for (int j = 0; j < kKsMaxCpl; j++)
-                    if (j < cpl) ks_column<NCH, NACC, B, false>(lds, col[j], ntap, wstride, pitch, rows_lds, ors, ostride);
+                    if (j < cpl) ks_column<NCH, NACC, B, false>(lds, tile, col[j], ntap, wstride, pitch, rws, ors, ostride KS_DIAG_ARGS);
             }
         }
-        __syncthreads();                                 // everyone is done with the tile before the next group overwrites it
+        KS_STAMP(5);                                     // scaleY's sums and finished rows
     }
+#if IPX_DIAG
+    if (a.stamps && lane == 0)
+        for (int i = 0; i < 6; i++) atomicAdd(&a.stamps[(role < 0 ? 2 : role) * 8 + i], tsum[i]);
+#endif
     if (OPQ && tid == 0) a.redo[blockIdx.x] = 0;
 }
 

@@ -255,14 +255,14 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
             if (chunks <= kKsMaxStage * kKsMaxThreads) nthreads = ((chunks + kKsMaxStage - 1) / kKsMaxStage + 63) & ~63;
             else continue;
         }
-        size_t lds = (size_t)B * pitch;
+        size_t lds = 2 * (size_t)B * pitch;                        // the tile is double-buffered
         int lds_w[2] = {0, 0};
         for (int k = 0; k < 2; k++) {
             lds_w[k] = (int)lds;
             if (sc[k]) lds += (size_t)sc[k]->hx->ntap * wcols[k] * sizeof(double);
         }
         const int lds_rows = (int)lds;
-        lds += 2 * (size_t)B * row_bytes;
+        lds += 2 * 2 * (size_t)B * row_bytes + 64;                 // two buffers of row entries for two outputs (+ slack: the tap loop reads one tap ahead)
         if (lds > lds_budget) continue;
 
         // ---- accepted: lay the tables out ----

@@ -1078,9 +1078,32 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
         const int max_items = n * pl->fused.nstrips * std::max(pl->fused.whole.nseg, pl->fused.split.nseg);
         if (env_int("IPX_KS_SPEC", 1)) IPX_HIP(hipMallocAsync((void **)&redo, (size_t)max_items * sizeof(int), s));
         a.redo = redo;
+#if IPX_DIAG
+        static unsigned long long *stamp_buf = nullptr;   // IPX_STAMPS=1: phase stamps, never in a timed run
+        if (env_int("IPX_STAMPS", 0)) {
+            if (!stamp_buf) IPX_HIP(hipMalloc((void **)&stamp_buf, 24 * sizeof(unsigned long long)));
+            IPX_HIP(hipMemsetAsync(stamp_buf, 0, 24 * sizeof(unsigned long long), s));
+            a.stamps = stamp_buf;
+        }
+#endif
         bool matched = false;
         hipError_t e = launch_ks_fused(pl->fused, a, ctx->cus, s, &matched);
         if (redo) (void)hipFreeAsync(redo, s);
+#if IPX_DIAG
+        if (a.stamps && matched) {
+            unsigned long long h[24];
+            IPX_HIP(hipMemcpyAsync(h, a.stamps, sizeof h, hipMemcpyDeviceToHost, s));
+            IPX_HIP(hipStreamSynchronize(s));
+            const char *who[3] = {"resize waves", "thumbnail waves", "idle waves"};
+            for (int r = 0; r < 3; r++) {
+                double tot = 0;
+                for (int i = 0; i < 6; i++) tot += (double)h[r * 8 + i];
+                if (tot > 0)
+                    fprintf(stderr, "[ipx stamps] %-16s share of wave time: wait-loads %.1f%%  drain %.1f%%  barrier %.1f%%  issue %.1f%%  scaleX %.1f%%  scaleY %.1f%%  (%.3g cycles)\n", who[r],
+                            100 * h[r * 8] / tot, 100 * h[r * 8 + 1] / tot, 100 * h[r * 8 + 2] / tot, 100 * h[r * 8 + 3] / tot, 100 * h[r * 8 + 4] / tot, 100 * h[r * 8 + 5] / tot, tot);
+            }
+        }
+#endif
         if (e != hipSuccess) { set_error("one-pass kernel launch failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
         if (matched) {
             IPX_HIP(composite_text(pl, wm, wm_frame_stride, n, s));
