@@ -116,6 +116,8 @@ struct KsFusedArgs {
     const KsStrip *strips; const KsSeg *segs;
     int nout; KsFusedOut o[2];
     int lds_w[2], lds_rows;    // byte offsets in LDS: weight tables, staged row entries (the tile is at 0)
+    uint8_t wave_role[16];     // per wave: output index << 4 | index among that output's waves; 0xff = no role (stages pixels only).  The roles
+                               // are interleaved so that the waves of one output spread over the SIMDs however the hardware deals waves out
     unsigned long long *stamps; // diagnostic build (-DIPX_DIAG=1) only: per-phase cycle sums over all waves, else NULL
     int *redo;                 // speculative (opaque) kernel: one int per item, 1 = the item met a pixel with alpha != 0xff and was
                                // abandoned; general kernel: only items with redo[item] != 0 run (NULL: all)

@@ -45,6 +45,11 @@ namespace {
 #define KS_STAMP(i) do { } while (0)
 #endif
 constexpr int kOOB = 0x7fffffff;
+
+// Workgroup barrier for LDS traffic only.  __syncthreads() also waits for every global store the wave has in flight (vmcnt(0)): here
+// that was the round trip of the watermark and destination-row stores at every group, a fifth of the run.  Nothing in this kernel
+// communicates between waves through global memory, so LDS visibility (lgkmcnt) is all the barrier has to order.
+__device__ __forceinline__ void ks_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t ks_ftou8(double f)   // uint8(ftou(f) >> 8)
@@ -198,8 +203,10 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
 
     // ---- this lane's destination columns ----
     int role = -1, wk = 0;
-    if (a.nout > 0 && wv < a.o[0].waves) { role = 0; wk = wv; }
-    else if (a.nout > 1 && wv < a.o[0].waves + a.o[1].waves) { role = 1; wk = wv - a.o[0].waves; }
+    {
+        const int rb = a.wave_role[wv & 15];
+        if (rb != 0xff) { role = rb >> 4; wk = rb & 15; }
+    }
     role = __builtin_amdgcn_readfirstlane(role);
     wk = __builtin_amdgcn_readfirstlane(wk);
     // the waves of the output with the longer tap loop are the critical path of every group: they go first when several waves of a
@@ -276,12 +283,12 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
         }
         if (rstage) ((uint32_t *)(lds + a.lds_rows + (g & 1) * rows_bytes))[rk * B * RW + ri] = rstg;
         KS_STAMP(1);                                     // registers -> LDS, watermark stores
-        if (OPQ) {
-            if (__syncthreads_or(bad)) {                 // not an opaque frame: the general kernel redoes the item
+        if (OPQ && g == 0) {
+            if (__syncthreads_or(bad)) {                 // not an opaque frame (seen in the first rows already): the general kernel redoes the item
                 if (tid == 0) a.redo[blockIdx.x] = 1;
                 return;
             }
-        } else __syncthreads();
+        } else ks_barrier();
         KS_STAMP(2);                                     // barrier
         if (g + 1 < ngroups) issue(g + 1);
         KS_STAMP(3);                                     // issuing the next group's loads
@@ -306,7 +313,10 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     if (a.stamps && lane == 0)
         for (int i = 0; i < 6; i++) atomicAdd(&a.stamps[(role < 0 ? 2 : role) * 8 + i], tsum[i]);
 #endif
-    if (OPQ && tid == 0) a.redo[blockIdx.x] = 0;
+    if (OPQ) {                                           // any pixel with alpha != 0xff in the rest of the item: redo it as well
+        const int any = __syncthreads_or(bad);
+        if (tid == 0) a.redo[blockIdx.x] = any;
+    }
 }
 
 template <int NCH, int NACC, bool OPQ>
@@ -347,6 +357,18 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, int cus, hipStr
         o.wx = po.wx; o.itwf = po.itwf; o.xlo = po.xlo; o.colb = po.colb;
         o.rows = g.rows[k]; o.rowoff = g.rowoff[k];
         a.lds_w[i] = p.lds_w[k];
+    }
+    // deal the roles out: the waves of the output with fewer waves are spread evenly among the others
+    {
+        for (int w = 0; w < 16; w++) a.wave_role[w] = 0xff;
+        const int n0 = a.nout > 0 ? a.o[0].waves : 0, n1 = a.nout > 1 ? a.o[1].waves : 0, n = n0 + n1;
+        int i0 = 0, i1 = 0;
+        for (int w = 0; w < n && w < 16; w++) {
+            // output 1 takes slot w when its share of the slots so far falls behind
+            const bool one = i1 < n1 && (i0 >= n0 || (long long)(i1 + 1) * n <= (long long)(w + 1) * n1);
+            if (one) a.wave_role[w] = (uint8_t)(1 << 4 | i1++);
+            else a.wave_role[w] = (uint8_t)(0 << 4 | i0++);
+        }
     }
     const long long nitems = (long long)a.nframes * p.nstrips * g.nseg;
     if (nitems > 0x7fffffffLL) return hipSuccess;
