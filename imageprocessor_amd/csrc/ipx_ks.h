@@ -98,6 +98,7 @@ struct KsFusedOut {
     uint8_t *out; size_t frame_stride; int ostride, obytes;   // destination frames (tightly packed rows)
     int dw, dh, sr_x0, sr_y0;
     int kind;                  // tap kind of the source pixels for this output (IPX_SRC_* / *_CROP)
+    int mode, aone;            // filled by the launcher from `kind`: the tap mode on this source type's tile; tmp alpha = 1 (Gray, YCbCr)
     int pk;                    // which output of the plan this is (0 resize, 1 thumbnail); the launcher fills everything below from it
     int ntap;                  // horizontal taps per destination column, padded with zero weights
     int waves, cpl;            // wave roles: `waves` waves of 64 lanes, `cpl` columns per lane
@@ -110,9 +111,11 @@ struct KsFusedOut {
     const int32_t *rowoff;     // [nseg] first entry of each segment
 };
 struct KsFusedArgs {
-    const uint8_t *src; size_t src_fs; int sstride, sw, sh;
+    const uint8_t *src; size_t src_fs; int sstride, sw, sh;   // pixels, or the luma plane
+    int src_kind;              // IPX_SRC_*: how `src` is laid out
+    const uint8_t *cb, *cr; int cstride, ratio; size_t c_fs;   // IPX_SRC_YCBCR: the chroma planes (cstride 0: a Gray frame)
     uint8_t *wm; size_t wm_fs; int wm_stride;
-    int nframes, nstrips, nseg, nthreads, pitch;
+    int nframes, nstrips, nseg, nthreads, pitch, dbuf;
     const KsStrip *strips; const KsSeg *segs;
     int nout; KsFusedOut o[2];
     int lds_w[2], lds_rows;    // byte offsets in LDS: weight tables, staged row entries (the tile is at 0)
@@ -126,7 +129,7 @@ struct KsFusedArgs {
 struct KsFusedGeom { int nseg = 0; const KsSeg *segs = nullptr; const void *rows[2] = {nullptr, nullptr}; const int32_t *rowoff[2] = {nullptr, nullptr}; };
 struct KsFusedPlan {
     bool ok = false;
-    int nacc = 2, rows = 4, pitch = 0, nstrips = 0, nthreads = 0, nstg = 0;
+    int nacc = 2, rows = 4, pitch = 0, nstrips = 0, nthreads = 0, nstg = 0, dbuf = 0;   // dbuf: two tile buffers fit in LDS (one barrier per group)
     int lds_w[2] = {0, 0}, lds_rows = 0, lds_bytes = 0;
     const KsStrip *strips = nullptr;
     struct Out { int ntap = 0, waves = 0, cpl = 0, wcols = 0; const double *wx = nullptr, *itwf = nullptr; const int32_t *xlo = nullptr, *colb = nullptr; } o[2];
@@ -143,7 +146,7 @@ constexpr int kKsMaxCpl = 2;
 struct KsFusedIn { int dw, dh, sr_x0, sr_y0; const KsAxis *hx, *hy; };
 bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, int px_bytes, std::vector<uint8_t> *blob, KsFusedPlan *out);
 void ks_fused_rebase(KsFusedPlan *p, const uint8_t *dev_blob);
-// kinds[k]: the tap kind per output.  *matched = false: nothing launched (shape, alignment or kind the kernel is not built for)
+// *matched = false: nothing launched (shape, alignment or kind the kernel is not built for)
 hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, int cus, hipStream_t s, bool *matched);
 
 }  // namespace ipx

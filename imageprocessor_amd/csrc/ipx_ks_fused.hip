@@ -23,6 +23,7 @@
 // alpha, term by term), so the clamp never fires and the stored alpha is 0xff: the alpha channel costs nothing.  The kernel checks
 // the assumption on every pixel it stages; an item that meets alpha != 0xff gives up and is redone by the NCH = 4 kernel (`redo`).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "ipx_ks.h"
@@ -59,13 +60,110 @@ __device__ __forceinline__ uint32_t ks_ftou8(double f)   // uint8(ftou(f) >> 8)
     return (uint32_t)i >> 8;
 }
 
-// channel C of the tap as the 16-bit value scaleX_RGBA weights, as float64.  CROP: the crop copy's `if pr > pa { pr = pa }` first.
-template <int C, bool CROP>
-__device__ __forceinline__ double ks_chan(uint32_t px)
+// ---- source types: how four pixels of a tile row come from HBM, go to LDS (as the 16-bit values scaleX weights) and to the watermark frame ----
+enum { KS_RGBA = 0, KS_NRGBA = 1, KS_YCC = 2, KS_GRAY = 3, KS_TAP64 = 4 };
+// bytes per pixel of the LDS tile: RGBA keeps the packed bytes (a tap is byte * 0x101), the converting types keep four 16-bit taps,
+// Gray one (y * 0x101)
+template <int SRC> struct KsPx { static constexpr int bytes = SRC == KS_RGBA ? 4 : SRC == KS_GRAY ? 2 : 8; };
+// tap modes of an output (KsFusedOut::kind folded per source type)
+enum { KS_TAP_PLAIN = 0,   // the value in the tile
+       KS_TAP_CLAMP = 1,   // RGBA tile: min(c, a) -- the crop copy's clamp of a colour above its alpha
+       KS_TAP_TOP = 2,     // 16-bit tile: (v >> 8) * 0x101 -- the crop copy's 8-bit pixel widened again
+       KS_TAP_MINTOP = 3 };// 16-bit tile: (min(c, a) >> 8) * 0x101 (RGBA64 may hold a colour above its alpha)
+
+struct KsStageRegs { uint32_t v[4]; };
+
+// color.YCbCr.RGBA as scaleX_YCbCr4xx inlines it, for one pixel with the chroma terms of its sample: 16-bit values, clamped
+__device__ __forceinline__ void ks_ycc16(uint32_t yb, int rt, int gt, int bt, uint32_t &r, uint32_t &g, uint32_t &b)
 {
-    if (!CROP || C == 3) return widen<C>(px);
-    const uint32_t c = (px >> (8 * C)) & 0xffu, al = px >> 24;
-    return (double)(min(c, al) * 0x101u);
+    const int yy1 = (int)(yb * 0x10101u);
+    r = (uint32_t)min(max((yy1 + rt) >> 8, 0), 0xffff);
+    g = (uint32_t)min(max((yy1 + gt) >> 8, 0), 0xffff);
+    b = (uint32_t)min(max((yy1 + bt) >> 8, 0), 0xffff);
+}
+
+// converts the staged registers of one chunk (four pixels) into LDS taps at `dst` and the four RGBA8 pixels draw.Draw would write
+template <int SRC>
+__device__ __forceinline__ u32x4 ks_convert(const KsStageRegs &s, uint8_t *dst, int hs)
+{
+    u32x4 px;
+    if (SRC == KS_RGBA) {
+        px.x = s.v[0]; px.y = s.v[1]; px.z = s.v[2]; px.w = s.v[3];
+        *(u32x4 *)dst = px;
+    } else if (SRC == KS_GRAY) {
+        const uint32_t y4 = s.v[0];
+        uint32_t lo = __builtin_amdgcn_perm(0u, y4, 0x01010000u), hi = __builtin_amdgcn_perm(0u, y4, 0x03030202u);   // y * 0x101 per pixel
+        *(uint2 *)dst = make_uint2(lo, hi);
+        px.x = __builtin_amdgcn_perm(0u, y4, 0x0d000000u); px.y = __builtin_amdgcn_perm(0u, y4, 0x0d010101u);       // (y, y, y, 0xff)
+        px.z = __builtin_amdgcn_perm(0u, y4, 0x0d020202u); px.w = __builtin_amdgcn_perm(0u, y4, 0x0d030303u);
+    } else if (SRC == KS_TAP64) {
+        // (two 16-byte loads per chunk: v[] holds the first half here, the caller passes the second through `hs`-less overload)
+        px = u32x4{0, 0, 0, 0};
+    } else if (SRC == KS_NRGBA) {
+        uint32_t t[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t p = s.v[i], a16 = (p >> 24) * 0x101u;   // scaleX_NRGBA: c * a16 / 0xff
+            const uint32_t r = (p & 0xffu) * a16 / 0xffu, g = ((p >> 8) & 0xffu) * a16 / 0xffu, b = ((p >> 16) & 0xffu) * a16 / 0xffu;
+            t[2 * i] = r | g << 16; t[2 * i + 1] = b | a16 << 16;
+        }
+        *(u32x4 *)dst = u32x4{t[0], t[1], t[2], t[3]};
+        *(u32x4 *)(dst + 16) = u32x4{t[4], t[5], t[6], t[7]};
+        px.x = __builtin_amdgcn_perm(t[1], t[0], 0x07050301u); px.y = __builtin_amdgcn_perm(t[3], t[2], 0x07050301u);   // drawNRGBASrc: the top bytes
+        px.z = __builtin_amdgcn_perm(t[5], t[4], 0x07050301u); px.w = __builtin_amdgcn_perm(t[7], t[6], 0x07050301u);
+    } else {   // KS_YCC: v[0] = four luma bytes, v[1] / v[2] = the Cb / Cr bytes of their samples (two when hs, else four)
+        uint32_t t[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ci = hs ? i >> 1 : i;
+            const int cb1 = (int)((s.v[1] >> (8 * ci)) & 0xffu) - 128, cr1 = (int)((s.v[2] >> (8 * ci)) & 0xffu) - 128;
+            uint32_t r, g, b;
+            ks_ycc16((s.v[0] >> (8 * i)) & 0xffu, 91881 * cr1, -22554 * cb1 - 46802 * cr1, 116130 * cb1, r, g, b);
+            t[2 * i] = r | g << 16; t[2 * i + 1] = b | 0xffff0000u;
+        }
+        *(u32x4 *)dst = u32x4{t[0], t[1], t[2], t[3]};
+        *(u32x4 *)(dst + 16) = u32x4{t[4], t[5], t[6], t[7]};
+        px.x = __builtin_amdgcn_perm(t[1], t[0], 0x07050301u); px.y = __builtin_amdgcn_perm(t[3], t[2], 0x07050301u);   // DrawYCbCr: the top bytes
+        px.z = __builtin_amdgcn_perm(t[5], t[4], 0x07050301u); px.w = __builtin_amdgcn_perm(t[7], t[6], 0x07050301u);
+    }
+    return px;
+}
+
+// the 16-bit values of one tap as float64, NCH channels (1: gray, 3: colours of an opaque source, 4: colours and alpha)
+template <int SRC, int NCH, int MODE>
+__device__ __forceinline__ void ks_fetch(const uint8_t *p, double (&v)[NCH])
+{
+    if (SRC == KS_RGBA) {
+        const uint32_t px = *(const uint32_t *)p;
+        if (MODE == KS_TAP_CLAMP && NCH == 4) {
+            const uint32_t al = px >> 24;
+            v[0] = (double)(min(px & 0xffu, al) * 0x101u);
+            v[1 % NCH] = (double)(min((px >> 8) & 0xffu, al) * 0x101u);
+            v[2 % NCH] = (double)(min((px >> 16) & 0xffu, al) * 0x101u);
+            v[3 % NCH] = (double)(al * 0x101u);
+        } else {
+            v[0] = widen<0>(px);
+            if (NCH > 1) v[1 % NCH] = widen<1>(px);
+            if (NCH > 2) v[2 % NCH] = widen<2>(px);
+            if (NCH > 3) v[3 % NCH] = widen<3>(px);
+        }
+    } else if (SRC == KS_GRAY) {
+        v[0] = (double)(uint32_t) * (const uint16_t *)p;
+    } else {
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < NCH; k++) c[k] = *(const uint16_t *)(p + 2 * k);
+        if (MODE == KS_TAP_MINTOP && NCH == 4) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) c[k] = min(c[k], c[3]);
+        }
+        if (MODE == KS_TAP_TOP || MODE == KS_TAP_MINTOP) {
+#pragma unroll
+            for (int k = 0; k < NCH; k++) c[k] = __builtin_amdgcn_perm(0u, c[k], 0x0c0c0101u);   // (v >> 8) * 0x101
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; k++) v[k] = (double)c[k];
+    }
 }
 
 template <int NCH, int NACC>
@@ -77,8 +175,9 @@ struct KsCol {                 // one destination column of a lane
     int ooff;                  // byte offset of the column in a destination row; kOOB = the lane has no such column
 };
 
-// scaleX on the B rows of the tile for one column, then scaleY's accumulation and, where a destination row completes, its store
-template <int NCH, int NACC, int B, bool CROP>
+// scaleX on the B rows of the tile for one column, then scaleY's accumulation and, where a destination row completes, its store.
+// AONE: the source type's scaleX writes tmp alpha = 1 (Gray, YCbCr): scaleY's alpha sum is the row's `ones`, and colours are clamped to it.
+template <int SRC, int NCH, int NACC, int B, int MODE, bool AONE>
 __device__ __forceinline__ void ks_column(const uint8_t *lds, const uint8_t *tile, KsCol<NCH, NACC> &c, int ntap, int wstride, int pitch,
                                           const uint8_t *rows, __amdgpu_buffer_rsrc_t ors, int ostride
 #if IPX_DIAG
@@ -86,6 +185,7 @@ __device__ __forceinline__ void ks_column(const uint8_t *lds, const uint8_t *til
 #endif
                                           )
 {
+    constexpr int PXB = KsPx<SRC>::bytes;
     double acc[B][NCH];
 #pragma unroll
     for (int r = 0; r < B; r++)
@@ -93,44 +193,41 @@ __device__ __forceinline__ void ks_column(const uint8_t *lds, const uint8_t *til
         for (int k = 0; k < NCH; k++) acc[r][k] = 0.0;
     const uint8_t *tap = tile + c.xb;
     const uint8_t *wp = lds + c.wofs;
-    // two taps per iteration: their ten LDS reads are in flight together
-    auto one_tap = [&](uint32_t px, double w, int r) {
-        acc[r][0] += ks_chan<0, CROP>(px) * w;
-        if (NCH > 1) acc[r][1 % NCH] += ks_chan<1, CROP>(px) * w;
-        if (NCH > 2) acc[r][2 % NCH] += ks_chan<2, CROP>(px) * w;
-        if (NCH > 3) acc[r][3 % NCH] += ks_chan<3, CROP>(px) * w;
+    // two taps per iteration: their LDS reads are in flight together.  A column's taps are added in source order, row by row.
+    auto one_tap = [&](const uint8_t *p, double w, int r) {
+        double v[NCH];
+        ks_fetch<SRC, NCH, MODE>(p, v);
+#pragma unroll
+        for (int k = 0; k < NCH; k++) acc[r][k] += v[k] * w;
     };
     int t = 0;
     for (; t + 2 <= ntap; t += 2) {
         const double w0 = *(const double *)wp, w1 = *(const double *)(wp + wstride);
-        uint32_t p0[B], p1[B];
 #pragma unroll
-        for (int r = 0; r < B; r++) { p0[r] = *(const uint32_t *)(tap + r * pitch); p1[r] = *(const uint32_t *)(tap + r * pitch + 4); }
+        for (int r = 0; r < B; r++) one_tap(tap + r * pitch, w0, r);
 #pragma unroll
-        for (int r = 0; r < B; r++) one_tap(p0[r], w0, r);
-#pragma unroll
-        for (int r = 0; r < B; r++) one_tap(p1[r], w1, r);     // (a column's taps in source order, row by row)
-        tap += 8;
+        for (int r = 0; r < B; r++) one_tap(tap + r * pitch + PXB, w1, r);
+        tap += 2 * PXB;
         wp += 2 * wstride;
     }
     if (t < ntap) {
         const double w0 = *(const double *)wp;
-        uint32_t p0[B];
 #pragma unroll
-        for (int r = 0; r < B; r++) p0[r] = *(const uint32_t *)(tap + r * pitch);
-#pragma unroll
-        for (int r = 0; r < B; r++) one_tap(p0[r], w0, r);
+        for (int r = 0; r < B; r++) one_tap(tap + r * pitch, w0, r);
     }
     KS_STAMP(4);                                         // scaleX of the group's rows for this column
     typedef KsRowT<NACC> Row;
     // the group's row entries in one batch of LDS reads (read one by one where they are used, every read was a round trip of its own)
-    double rw[B][NACC], ritw[B][NACC];
+    double rw[B][NACC], ritw[B][NACC], rone[B][NACC];
     int remit[B][NACC];
 #pragma unroll
     for (int r = 0; r < B; r++) {
         const Row *row = (const Row *)(rows + r * sizeof(Row));
 #pragma unroll
-        for (int p = 0; p < NACC; p++) { rw[r][p] = row->w[p]; ritw[r][p] = row->itw[p]; remit[r][p] = row->emit[p]; }
+        for (int p = 0; p < NACC; p++) {
+            rw[r][p] = row->w[p]; ritw[r][p] = row->itw[p]; remit[r][p] = row->emit[p];
+            if (AONE) rone[r][p] = row->ones[p];
+        }
     }
 #pragma unroll
     for (int r = 0; r < B; r++) {
@@ -153,7 +250,20 @@ __device__ __forceinline__ void ks_column(const uint8_t *lds, const uint8_t *til
                     if (pg > pa) pg = pa;
                     if (pb > pa) pb = pa;
                     px = ks_ftou8(pr * s) | ks_ftou8(pg * s) << 8 | ks_ftou8(pb * s) << 16 | ks_ftou8(pa * s) << 24;
+                } else if (AONE) {
+                    const double pa = rone[r][p];                      // what scaleY sums from a column of tmp alphas that are all 1
+                    double pr = c.q[p][0], pg = c.q[p][1 % NCH], pb = c.q[p][2 % NCH];
+                    if (pr > pa) pr = pa;
+                    if (NCH == 1) px = ks_ftou8(pr * s) * 0x010101u | ks_ftou8(pa * s) << 24;
+                    else {
+                        if (pg > pa) pg = pa;
+                        if (pb > pa) pb = pa;
+                        px = ks_ftou8(pr * s) | ks_ftou8(pg * s) << 8 | ks_ftou8(pb * s) << 16 | ks_ftou8(pa * s) << 24;
+                    }
+                } else if (NCH == 1) {
+                    px = ks_ftou8(c.q[p][0] * s) * 0x010101u | 0xff000000u;   // an opaque gray frame: three equal colour sums, alpha 0xff
                 } else {
+                    // an opaque frame: no colour sum can exceed the alpha sum (rounding is monotonic), alpha is 0xff
                     px = ks_ftou8(c.q[p][0] * s) | ks_ftou8(c.q[p][1 % NCH] * s) << 8 | ks_ftou8(c.q[p][2 % NCH] * s) << 16 | 0xff000000u;
                 }
                 __builtin_amdgcn_raw_buffer_store_b32(px, ors, c.ooff, dy * ostride, 0);
@@ -164,10 +274,13 @@ __device__ __forceinline__ void ks_column(const uint8_t *lds, const uint8_t *til
     }
 }
 
-template <int NCH, int NACC, int B, bool OPQ>
+template <int SRC, int NCH, int NACC, int B, bool OPQ>
 __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
 {
+    constexpr int CPLM = NACC == 2 ? kKsMaxCpl : 1;   // columns per lane: four accumulators per column leave registers for one (ks_fused_plan knows)
     extern __shared__ __align__(16) uint8_t lds[];
+    constexpr int PXB = KsPx<SRC>::bytes;
+    constexpr int CHB = 4 * PXB;                      // LDS bytes of a chunk (four pixels)
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int item = (int)blockIdx.x;
     if (!OPQ && a.redo && !a.redo[item]) return;
@@ -176,25 +289,33 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     const int strip = item % a.nstrips, frame = item / a.nstrips;
     const KsStrip st = a.strips[strip];
     const KsSeg sg = a.segs[seg];
-    const int pitch = a.pitch, CH = pitch >> 4;
+    const int pitch = a.pitch, CH = pitch / CHB;
     typedef KsRowT<NACC> Row;
     constexpr int RW = (int)(sizeof(Row) / 4);       // dwords per row entry
+    constexpr int SPX = SRC == KS_RGBA || SRC == KS_NRGBA ? 4 : SRC == KS_TAP64 ? 8 : 1;   // source bytes per pixel (luma plane for YCbCr / Gray)
+    const int hs = SRC == KS_YCC && (a.ratio == IPX_YCBCR_422 || a.ratio == IPX_YCBCR_420), vs = SRC == KS_YCC && (a.ratio == IPX_YCBCR_420 || a.ratio == IPX_YCBCR_440);
 
     const uint8_t *sframe = a.src + (size_t)frame * a.src_fs;
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)sframe, 0, (a.sh - 1) * a.sstride + a.sw * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void *)sframe, 0, (a.sh - 1) * a.sstride + a.sw * SPX, 0x00020000);
+    const int chh = vs ? (a.sh + 1) / 2 : a.sh, cww = hs ? (a.sw + 1) / 2 : a.sw;
+    const __amdgpu_buffer_rsrc_t cbrs = __builtin_amdgcn_make_buffer_rsrc((void *)(SRC == KS_YCC ? a.cb + (size_t)frame * a.c_fs : nullptr), 0,
+                                                                         SRC == KS_YCC ? (chh - 1) * a.cstride + cww : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t crrs = __builtin_amdgcn_make_buffer_rsrc((void *)(SRC == KS_YCC ? a.cr + (size_t)frame * a.c_fs : nullptr), 0,
+                                                                         SRC == KS_YCC ? (chh - 1) * a.cstride + cww : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.wm ? a.wm + (size_t)frame * a.wm_fs : nullptr), 0,
                                                                         a.wm ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);
 
-    // ---- what this thread stages per group: up to kKsMaxStage 16-byte chunks of the tile, and one dword of the row entries ----
-    int s_lds[kKsMaxStage], s_src[kKsMaxStage], s_wm[kKsMaxStage], s_row[kKsMaxStage];   // (the frame width is a multiple of 4: whole chunks)
+    // ---- what this thread stages per group: up to kKsMaxStage chunks of four pixels, and one dword of the row entries ----
+    int s_lds[kKsMaxStage], s_src[kKsMaxStage], s_wm[kKsMaxStage], s_row[kKsMaxStage], s_cx[kKsMaxStage];
 #pragma unroll
     for (int i = 0; i < kKsMaxStage; i++) {
         const int q = tid + i * a.nthreads;
         const int row = q / CH, ch = q - row * CH, x = st.t0 + ch * 4;
-        const bool in = q < B * CH && x < a.sw;
+        const bool in = q < B * CH && x < a.sw;          // (the frame width is a multiple of 4: whole chunks)
         s_row[i] = in ? row : -1;
-        s_lds[i] = row * pitch + ch * 16;
-        s_src[i] = in ? row * a.sstride + x * 4 : kOOB;
+        s_lds[i] = row * pitch + ch * CHB;
+        s_src[i] = in ? row * a.sstride + x * SPX : kOOB;
+        s_cx[i] = in ? (hs ? x >> 1 : x) : kOOB;         // chroma byte offset within its row
         s_wm[i] = in && x >= st.c0 && x < st.c1 ? row * a.wm_stride + x * 4 : kOOB; // owned columns only (c0 and c1 are multiples of 4)
     }
     const int rk = tid / (B * RW), ri = tid - rk * (B * RW);                         // row entries: dword ri of output rk's B entries
@@ -209,20 +330,18 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     }
     role = __builtin_amdgcn_readfirstlane(role);
     wk = __builtin_amdgcn_readfirstlane(wk);
-    // the waves of the output with the longer tap loop are the critical path of every group: they go first when several waves of a
-    // SIMD are ready, the others fill the gaps
-    if (a.nout > 1 && role >= 0 && a.o[role].ntap * a.o[role].cpl > a.o[1 - role].ntap * a.o[1 - role].cpl) __builtin_amdgcn_s_setprio(2);
-    KsCol<NCH, NACC> col[kKsMaxCpl];
+    KsCol<NCH, NACC> col[CPLM];
     __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000);
-    int ntap = 0, wstride = 0, ostride = 0, cpl = 0;
-    bool crop = false;
+    int ntap = 0, wstride = 0, ostride = 0, cpl = 0, mode = KS_TAP_PLAIN;
+    bool aone = false;
     const uint8_t *rows_lds = lds + a.lds_rows;
-    const int tile_bytes = B * pitch, rows_bytes = 2 * B * (int)sizeof(Row);   // the tile and the row entries are double-buffered
+    const int dbuf = a.dbuf;
+    const int tile_bytes = B * pitch, rows_bytes = 2 * B * (int)sizeof(Row);   // a second tile and a second set of row entries when dbuf
     if (role >= 0) {
         const KsFusedOut &o = a.o[role];
         ors = __builtin_amdgcn_make_buffer_rsrc((void *)(o.out + (size_t)frame * o.frame_stride), 0, o.obytes, 0x00020000);
         ntap = o.ntap; wstride = o.wcols * 8; ostride = o.ostride; cpl = o.cpl;
-        crop = o.kind == IPX_SRC_RGBA_CROP;
+        mode = o.mode; aone = o.aone != 0;
         rows_lds += role * B * (int)sizeof(Row);
         const int cb = o.colb[strip], ce = o.colb[strip + 1];
         // the strip's weight table -> LDS (every wave of the role copies a share)
@@ -233,7 +352,7 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
             for (int i = wk * 64 + lane; i < n; i += o.waves * 64) wdst[i] = wsrc[i];
         }
 #pragma unroll
-        for (int j = 0; j < kKsMaxCpl; j++) {
+        for (int j = 0; j < CPLM; j++) {
             const int slot = wk * 64 + lane + j * 64 * o.waves, dx = cb + slot;
             const bool has = j < o.cpl && dx < ce;
 #pragma unroll
@@ -241,21 +360,44 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
 #pragma unroll
                 for (int k = 0; k < NCH; k++) col[j].q[p][k] = 0.0;
             col[j].itwf = has ? o.itwf[dx] : 0.0;
-            col[j].xb = has ? (o.sr_x0 + o.xlo[dx] - st.t0) * 4 : 0;
+            col[j].xb = has ? (o.sr_x0 + o.xlo[dx] - st.t0) * PXB : 0;
             col[j].wofs = a.lds_w[role] + (has ? slot : 0) * 8;
             col[j].ooff = has ? dx * 4 : kOOB;
         }
     }
 
     const int ngroups = (sg.r1 - sg.ys + B - 1) / B;
-    u32x4 stage[kKsMaxStage];
+    KsStageRegs stage[kKsMaxStage];
+    uint32_t stage2[SRC == KS_TAP64 ? kKsMaxStage : 1][4];   // the second 16 bytes of a chunk of 8-byte pixels
     uint32_t rstg = 0;
     auto issue = [&](int g) {
         const int y0 = sg.ys + g * B;
 #pragma unroll
         for (int i = 0; i < kKsMaxStage; i++) {
             const bool ok = s_row[i] >= 0 && y0 + s_row[i] < sg.r1;
-            stage[i] = __builtin_amdgcn_raw_buffer_load_b128(srs, ok ? s_src[i] : kOOB, y0 * a.sstride, 0);
+            const int off = ok ? s_src[i] : kOOB;
+            if (SRC == KS_RGBA || SRC == KS_NRGBA || SRC == KS_TAP64) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srs, off, y0 * a.sstride, 0);
+                stage[i].v[0] = v.x; stage[i].v[1] = v.y; stage[i].v[2] = v.z; stage[i].v[3] = v.w;
+                if (SRC == KS_TAP64) {
+                    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(srs, ok ? s_src[i] + 16 : kOOB, y0 * a.sstride, 0);
+                    stage2[SRC == KS_TAP64 ? i : 0][0] = u.x; stage2[SRC == KS_TAP64 ? i : 0][1] = u.y;
+                    stage2[SRC == KS_TAP64 ? i : 0][2] = u.z; stage2[SRC == KS_TAP64 ? i : 0][3] = u.w;
+                }
+            } else {
+                stage[i].v[0] = __builtin_amdgcn_raw_buffer_load_b32(srs, off, y0 * a.sstride, 0);     // four luma bytes
+                if (SRC == KS_YCC) {
+                    const int cy = vs ? (y0 + s_row[i]) >> 1 : y0 + s_row[i];
+                    const int coff = ok ? cy * a.cstride + s_cx[i] : kOOB;
+                    if (hs) {
+                        stage[i].v[1] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(cbrs, coff, 0, 0);
+                        stage[i].v[2] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(crrs, coff, 0, 0);
+                    } else {
+                        stage[i].v[1] = __builtin_amdgcn_raw_buffer_load_b32(cbrs, coff, 0, 0);
+                        stage[i].v[2] = __builtin_amdgcn_raw_buffer_load_b32(crrs, coff, 0, 0);
+                    }
+                }
+            }
         }
         if (rstage) rstg = rsrc[(size_t)g * B * RW];
     };
@@ -269,19 +411,26 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         KS_STAMP(0);                                     // waiting for the group's staged loads
 #endif
-        const int y0 = sg.ys + g * B;
-        // ---- registers -> LDS tile and watermark frame ----
+        const int y0 = sg.ys + g * B, buf = dbuf ? g & 1 : 0;
+        // ---- registers -> taps in the LDS tile, pixels in the watermark frame ----
 #pragma unroll
         for (int i = 0; i < kKsMaxStage; i++) {
             if (s_row[i] < 0) continue;
-            const u32x4 v = stage[i];
-            *(u32x4 *)(lds + (g & 1) * tile_bytes + s_lds[i]) = v;
+            uint8_t *dst = lds + buf * tile_bytes + s_lds[i];
+            u32x4 v;
+            if (SRC == KS_TAP64) {
+                const uint32_t *s0 = stage[i].v, *s1 = stage2[SRC == KS_TAP64 ? i : 0];
+                *(u32x4 *)dst = u32x4{s0[0], s0[1], s0[2], s0[3]};
+                *(u32x4 *)(dst + 16) = u32x4{s1[0], s1[1], s1[2], s1[3]};
+                v.x = __builtin_amdgcn_perm(s0[1], s0[0], 0x07050301u); v.y = __builtin_amdgcn_perm(s0[3], s0[2], 0x07050301u);   // drawRGBA with Src: the top bytes
+                v.z = __builtin_amdgcn_perm(s1[1], s1[0], 0x07050301u); v.w = __builtin_amdgcn_perm(s1[3], s1[2], 0x07050301u);
+            } else v = ks_convert<SRC>(stage[i], dst, hs);
             const int y = y0 + s_row[i];
             const bool live = y < sg.r1;
             if (OPQ && live) bad |= ((v.x & v.y & v.z & v.w) >> 24) != 0xffu;
             if (a.wm && live && y >= sg.r0) __builtin_amdgcn_raw_buffer_store_b128(v, wrs, s_wm[i], y0 * a.wm_stride, 0);
         }
-        if (rstage) ((uint32_t *)(lds + a.lds_rows + (g & 1) * rows_bytes))[rk * B * RW + ri] = rstg;
+        if (rstage) ((uint32_t *)(lds + a.lds_rows + buf * rows_bytes))[rk * B * RW + ri] = rstg;
         KS_STAMP(1);                                     // registers -> LDS, watermark stores
         if (OPQ && g == 0) {
             if (__syncthreads_or(bad)) {                 // not an opaque frame (seen in the first rows already): the general kernel redoes the item
@@ -293,21 +442,33 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
         if (g + 1 < ngroups) issue(g + 1);
         KS_STAMP(3);                                     // issuing the next group's loads
         // ---- scaleX on the tile, scaleY's sums, finished destination rows ----
-        // (one barrier per group: a wave that writes buffer g & 1 two groups on has passed the barrier of group g + 1, which every wave
-        // reaches only after its arithmetic on group g)
         if (role >= 0) {
-            const uint8_t *tile = lds + (g & 1) * tile_bytes, *rws = rows_lds + (g & 1) * rows_bytes;
-            if (crop) {
-#pragma unroll
-                for (int j = 0; j < kKsMaxCpl; j++)
-                    if (j < cpl) ks_column<NCH, NACC, B, true>(lds, tile, col[j], ntap, wstride, pitch, rws, ors, ostride KS_DIAG_ARGS);
+            const uint8_t *tile = lds + buf * tile_bytes, *rws = rows_lds + buf * rows_bytes;
+#define KS_COLS(MODE, AONE)                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < CPLM; j++)                                                                                 \
+        if (j < cpl) ks_column<SRC, NCH, NACC, B, MODE, AONE>(lds, tile, col[j], ntap, wstride, pitch, rws, ors, ostride KS_DIAG_ARGS)
+            if (SRC == KS_RGBA) {
+                if (NCH == 4 && mode == KS_TAP_CLAMP) { KS_COLS(KS_TAP_CLAMP, false); }
+                else { KS_COLS(KS_TAP_PLAIN, false); }
+            } else if (SRC == KS_GRAY) {
+                if (aone) { KS_COLS(KS_TAP_PLAIN, true); }
+                else { KS_COLS(KS_TAP_PLAIN, false); }
+            } else if (SRC == KS_YCC) {
+                if (aone) { KS_COLS(KS_TAP_PLAIN, true); }
+                else { KS_COLS(KS_TAP_TOP, false); }
+            } else if (SRC == KS_NRGBA) {
+                if (mode == KS_TAP_TOP) { KS_COLS(KS_TAP_TOP, false); }
+                else { KS_COLS(KS_TAP_PLAIN, false); }
             } else {
-#pragma unroll
-                for (int j = 0; j < kKsMaxCpl; j++)
-                    if (j < cpl) ks_column<NCH, NACC, B, false>(lds, tile, col[j], ntap, wstride, pitch, rws, ors, ostride KS_DIAG_ARGS);
+                if (mode == KS_TAP_MINTOP) { KS_COLS(KS_TAP_MINTOP, false); }
+                else { KS_COLS(KS_TAP_PLAIN, false); }
             }
+#undef KS_COLS
         }
         KS_STAMP(5);                                     // scaleY's sums and finished rows
+        // one tile buffer: everyone is done with it before the next group overwrites it.  Two: a wave that writes buffer g & 1 two groups
+        // on has passed the barrier of group g + 1, which every wave reaches only after its arithmetic on group g
+        if (!dbuf) ks_barrier();
     }
 #if IPX_DIAG
     if (a.stamps && lane == 0)
@@ -319,15 +480,21 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     }
 }
 
-template <int NCH, int NACC, bool OPQ>
+template <int SRC, int NCH, int NACC, bool OPQ>
 hipError_t launch_one(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hipStream_t s)
 {
     static KernelLaunchCache cache;
-    auto fn = ks_fused_kernel<NCH, NACC, kKsRows, OPQ>;
+    auto fn = ks_fused_kernel<SRC, NCH, NACC, kKsRows, OPQ>;
     hipError_t e = cache.prepare((const void *)fn, p.nthreads, (size_t)p.lds_bytes, nullptr);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, dim3(nitems), dim3(p.nthreads), (size_t)p.lds_bytes, s, a);
     return hipGetLastError();
+}
+
+template <int SRC, int NCH>
+hipError_t launch_src(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hipStream_t s)
+{
+    return p.nacc == 2 ? launch_one<SRC, NCH, 2, false>(p, a, nitems, s) : launch_one<SRC, NCH, 4, false>(p, a, nitems, s);
 }
 
 }  // namespace
@@ -336,17 +503,44 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, int cus, hipStr
 {
     *matched = false;
     if (!p.ok || a.nframes <= 0) return hipSuccess;
-    if (a.sw & 3) return hipSuccess;                               // whole 16-byte chunks only
-    // frames are addressed dword-wise through buffer descriptors
+    if (a.sw & 3) return hipSuccess;                               // whole chunks of four pixels only
+    // frames are addressed through buffer descriptors with aligned dword (chroma: word) loads
     if ((((uintptr_t)a.src) | (uintptr_t)a.sstride | a.src_fs) & 3) return hipSuccess;
     if (a.wm && ((((uintptr_t)a.wm) | (uintptr_t)a.wm_stride | a.wm_fs) & 3)) return hipSuccess;
-    for (int k = 0; k < a.nout; k++)
-        if (a.o[k].kind != IPX_SRC_RGBA && a.o[k].kind != IPX_SRC_RGBA_CROP) return hipSuccess;
+    int src = KS_RGBA;
+    switch (a.src_kind) {
+    case IPX_SRC_RGBA: src = KS_RGBA; break;
+    case IPX_SRC_NRGBA: src = KS_NRGBA; break;
+    case IPX_SRC_TAP64: src = KS_TAP64; break;
+    case IPX_SRC_YCBCR: {
+        src = a.cstride == 0 ? KS_GRAY : KS_YCC;                  // a stride-0 chroma row of 128s: a Gray frame (ipx_plan_run_dev_gray)
+        if (src == KS_YCC) {
+            const bool hs = a.ratio == IPX_YCBCR_422 || a.ratio == IPX_YCBCR_420;
+            const uintptr_t al = hs ? 1 : 3;
+            if ((((uintptr_t)a.cb) | (uintptr_t)a.cr | (uintptr_t)a.cstride | a.c_fs) & al) return hipSuccess;
+        }
+        break;
+    }
+    default: return hipSuccess;
+    }
+    for (int i = 0; i < a.nout; i++) {                             // the tap kind of each output as a mode of this source type's tile
+        KsFusedOut &o = a.o[i];
+        o.aone = 0; o.mode = KS_TAP_PLAIN;
+        switch (o.kind) {
+        case IPX_SRC_RGBA: case IPX_SRC_NRGBA: case IPX_SRC_TAP64: break;
+        case IPX_SRC_YCBCR: o.aone = 1; break;
+        case IPX_SRC_RGBA_CROP: o.mode = KS_TAP_CLAMP; break;
+        case IPX_SRC_NRGBA_CROP: o.mode = KS_TAP_TOP; break;
+        case IPX_SRC_YCBCR_CROP: o.mode = src == KS_GRAY ? KS_TAP_PLAIN : KS_TAP_TOP; break;   // gray: (y * 0x101 >> 8) * 0x101 is y * 0x101 again
+        case IPX_SRC_TAP64_CROP: o.mode = KS_TAP_MINTOP; break;
+        default: return hipSuccess;
+        }
+    }
     // large batches: one segment per frame (no row is staged twice); small ones: enough items to fill the chip
     const char *ev = getenv("IPX_KS_SPLIT");                       // test knob: 1 = always the split segmentation, 0 = never
     const bool whole = ev && *ev ? atoi(ev) == 0 : (long long)a.nframes * p.nstrips >= 2LL * cus;
     const KsFusedGeom &g = whole || p.split.nseg <= 1 ? p.whole : p.split;
-    a.nstrips = p.nstrips; a.nseg = g.nseg; a.nthreads = p.nthreads; a.pitch = p.pitch;
+    a.nstrips = p.nstrips; a.nseg = g.nseg; a.nthreads = p.nthreads; a.pitch = p.pitch; a.dbuf = p.dbuf;
     a.strips = p.strips; a.segs = g.segs;
     a.lds_rows = p.lds_rows;
     for (int i = 0; i < a.nout; i++) {                             // a.o[i].pk: which of the plan's outputs this is
@@ -373,19 +567,22 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, int cus, hipStr
     const long long nitems = (long long)a.nframes * p.nstrips * g.nseg;
     if (nitems > 0x7fffffffLL) return hipSuccess;
     *matched = true;
-    hipError_t e;
-    const bool spec = a.redo != nullptr;        // the caller provides the redo flags when it wants the speculative opaque pass first
-    if (p.nacc == 2) {
-        if (spec) {
-            e = launch_one<3, 2, true>(p, a, (int)nitems, s);
-            if (e == hipSuccess) e = launch_one<4, 2, false>(p, a, (int)nitems, s);
-        } else e = launch_one<4, 2, false>(p, a, (int)nitems, s);
-    } else {
-        if (spec) {
-            e = launch_one<3, 4, true>(p, a, (int)nitems, s);
-            if (e == hipSuccess) e = launch_one<4, 4, false>(p, a, (int)nitems, s);
-        } else e = launch_one<4, 4, false>(p, a, (int)nitems, s);
+    const int n = (int)nitems;
+    if (getenv("IPX_KS_DEBUG"))
+        fprintf(stderr, "[ipx ks] src %d nacc %d frames %d strips %d segs %d threads %d pitch %d dbuf %d lds %d | out0 ntap %d waves %d cpl %d wcols %d | out1 ntap %d waves %d cpl %d wcols %d\n", src, p.nacc,
+                a.nframes, a.nstrips, a.nseg, a.nthreads, a.pitch, a.dbuf, p.lds_bytes, a.o[0].ntap, a.o[0].waves, a.o[0].cpl, a.o[0].wcols, a.nout > 1 ? a.o[1].ntap : 0,
+                a.nout > 1 ? a.o[1].waves : 0, a.nout > 1 ? a.o[1].cpl : 0, a.nout > 1 ? a.o[1].wcols : 0);
+    switch (src) {
+    case KS_NRGBA: a.redo = nullptr; return launch_src<KS_NRGBA, 4>(p, a, n, s);
+    case KS_TAP64: a.redo = nullptr; return launch_src<KS_TAP64, 4>(p, a, n, s);
+    case KS_YCC: a.redo = nullptr; return launch_src<KS_YCC, 3>(p, a, n, s);
+    case KS_GRAY: a.redo = nullptr; return launch_src<KS_GRAY, 1>(p, a, n, s);
+    default: break;
     }
+    if (!a.redo) return launch_src<KS_RGBA, 4>(p, a, n, s);        // the general kernel alone
+    // the speculative opaque pass first; the general kernel then redoes the items that met a pixel with alpha != 0xff
+    hipError_t e = p.nacc == 2 ? launch_one<KS_RGBA, 3, 2, true>(p, a, n, s) : launch_one<KS_RGBA, 3, 4, true>(p, a, n, s);
+    if (e == hipSuccess) e = launch_src<KS_RGBA, 4>(p, a, n, s);
     return e;
 }
 

@@ -237,7 +237,7 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
                     if (!sc[k] || wcols[k] <= 0) { ok = ok && W[k] == 0; continue; }
                     if (W[k] <= 0) { ok = false; continue; }
                     cpl[k] = (wcols[k] + 64 * W[k] - 1) / (64 * W[k]);
-                    if (cpl[k] > kKsMaxCpl) ok = false;
+                    if (cpl[k] > (P.nacc == 2 ? kKsMaxCpl : 1)) ok = false;   // four accumulators per column: one column per lane
                 }
                 if (!ok) continue;
                 double simd[4] = {0, 0, 0, 0};
@@ -246,27 +246,34 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
                 if (T < bestT) { bestT = T; bestW[0] = W[0]; bestW[1] = W[1]; bestcpl[0] = cpl[0]; bestcpl[1] = cpl[1]; }
             }
         }
-        int nthreads = 64 * (bestW[0] + bestW[1]);
-        if (nthreads == 0) nthreads = 256;                         // no scaled output: the watermark copy alone
-        else if (bestT >= 1e299) continue;                         // too many columns per strip for kKsMaxWaves waves
+        const bool any_cols = (sc[0] && wcols[0] > 0) || (sc[1] && wcols[1] > 0);
+        if (any_cols && bestT >= 1e299) continue;                  // too many columns per strip for kKsMaxWaves waves: more strips
+        int nthreads = any_cols ? 64 * (bestW[0] + bestW[1]) : 256;   // no scaled output: the watermark copy alone
         nthreads = std::max(nthreads, 256);
-        const int chunks = B * (pitch / 16);
+        const int chunks = B * (pitch / (4 * px_bytes));          // chunks of four pixels
         if (chunks > kKsMaxStage * nthreads) {
             if (chunks <= kKsMaxStage * kKsMaxThreads) nthreads = ((chunks + kKsMaxStage - 1) / kKsMaxStage + 63) & ~63;
             else continue;
         }
-        size_t lds = 2 * (size_t)B * pitch;                        // the tile is double-buffered
+        // two tile buffers if they fit (one barrier per group), else one
+        size_t rest = 0;
         int lds_w[2] = {0, 0};
+        for (int k = 0; k < 2; k++)
+            if (sc[k]) rest += (size_t)sc[k]->hx->ntap * wcols[k] * sizeof(double);
+        rest += 2 * 2 * (size_t)B * row_bytes + 64;                // two buffers of row entries for two outputs (+ slack)
+        int dbuf = 1;
+        if (2 * (size_t)B * pitch + rest > lds_budget) dbuf = 0;
+        if ((size_t)(dbuf + 1) * B * pitch + rest > lds_budget) continue;
+        size_t lds = (size_t)(dbuf + 1) * B * pitch;
         for (int k = 0; k < 2; k++) {
             lds_w[k] = (int)lds;
             if (sc[k]) lds += (size_t)sc[k]->hx->ntap * wcols[k] * sizeof(double);
         }
         const int lds_rows = (int)lds;
-        lds += 2 * 2 * (size_t)B * row_bytes + 64;                 // two buffers of row entries for two outputs (+ slack: the tap loop reads one tap ahead)
-        if (lds > lds_budget) continue;
+        lds += 2 * 2 * (size_t)B * row_bytes + 64;
 
         // ---- accepted: lay the tables out ----
-        P.nstrips = ns; P.pitch = pitch; P.nthreads = nthreads;
+        P.nstrips = ns; P.pitch = pitch; P.nthreads = nthreads; P.dbuf = dbuf;
         P.nstg = (chunks + nthreads - 1) / nthreads;
         P.lds_w[0] = lds_w[0]; P.lds_w[1] = lds_w[1]; P.lds_rows = lds_rows; P.lds_bytes = (int)lds;
         P.strips = as_off<KsStrip>(blob_put(blob, strips.data(), strips.size() * sizeof(KsStrip)));

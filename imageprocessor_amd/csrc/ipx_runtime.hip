@@ -916,12 +916,15 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
         const PlanScale &sk = pl->sc[k];
         fin[k].dw = sk.dw; fin[k].dh = sk.dh; fin[k].sr_x0 = sk.sr.x0; fin[k].sr_y0 = sk.sr.y0; fin[k].hx = &sk.hx; fin[k].hy = &sk.hy;
     }
+    size_t fused_off[3] = {0, 0, 0};
     if (!env_int("IPX_NO_FUSE", 0)) {
-        std::vector<uint8_t> fblob;
-        if (ks_fused_plan(sw, sh, have[0] ? &fin[0] : nullptr, have[1] ? &fin[1] : nullptr, 4, &fblob, &pl->fused)) {
-            const size_t off = put(fblob.size());
-            memcpy(blob.data() + off, fblob.data(), fblob.size());
-            pl->fused_off = off;
+        const int px_bytes[3] = {4, 8, 2};
+        for (int f = 0; f < 3; f++) {
+            std::vector<uint8_t> fblob;
+            if (ks_fused_plan(sw, sh, have[0] ? &fin[0] : nullptr, have[1] ? &fin[1] : nullptr, px_bytes[f], &fblob, &pl->fused[f])) {
+                fused_off[f] = put(fblob.size());
+                memcpy(blob.data() + fused_off[f], fblob.data(), fblob.size());
+            }
         }
     }
     if (!blob.empty()) {
@@ -936,7 +939,8 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
             ks_axis_pack(pl->sc[k].hx, blob.data() + axoff[k][0], pl->blob + axoff[k][0], &pl->sc[k].ax[0]);
             ks_axis_pack(pl->sc[k].hy, blob.data() + axoff[k][1], pl->blob + axoff[k][1], &pl->sc[k].ax[1]);
         }
-        if (pl->fused.ok) ks_fused_rebase(&pl->fused, pl->blob + pl->fused_off);
+        for (int f = 0; f < 3; f++)
+            if (pl->fused[f].ok) ks_fused_rebase(&pl->fused[f], pl->blob + fused_off[f]);
         e = hipMemcpy(pl->blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             set_error("plan table upload failed: %s", hipGetErrorString(e));
@@ -1060,9 +1064,12 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
     if (!wm && !outs[0] && !outs[1]) return IPX_OK;
     int kinds[2] = {src.kind, pl->p.crop_to_fit ? ks_crop_kind(src.kind) : src.kind};
 
-    if (pl->fused.ok && src.kind == IPX_SRC_RGBA && env_int("IPX_FUSED", 1)) {
+    const bool gray = src.kind == IPX_SRC_YCBCR && src.cstride == 0;
+    const KsFusedPlan &fp = pl->fused[src.kind == IPX_SRC_RGBA ? 0 : gray ? 2 : 1];
+    if (fp.ok && env_int("IPX_FUSED", 1)) {
         KsFusedArgs a{};
         a.src = src.pix; a.src_fs = src.frame_stride; a.sstride = src.stride; a.sw = sw; a.sh = sh;
+        a.src_kind = src.kind; a.cb = src.cb; a.cr = src.cr; a.cstride = src.cstride; a.ratio = src.ratio; a.c_fs = src.c_frame_stride;
         a.wm = wm; a.wm_fs = wm_frame_stride; a.wm_stride = sw * 4;
         a.nframes = n;
         for (int k = 0; k < 2; k++) {
@@ -1073,10 +1080,10 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
             o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
             o.kind = kinds[k]; o.pk = k;
         }
-        // the speculative opaque pass first (IPX_KS_SPEC=0: the general kernel alone): one flag per item
+        // RGBA frames: the speculative opaque pass first (IPX_KS_SPEC=0: the general kernel alone), one flag per item
         int *redo = nullptr;
-        const int max_items = n * pl->fused.nstrips * std::max(pl->fused.whole.nseg, pl->fused.split.nseg);
-        if (env_int("IPX_KS_SPEC", 1)) IPX_HIP(hipMallocAsync((void **)&redo, (size_t)max_items * sizeof(int), s));
+        const int max_items = n * fp.nstrips * std::max(fp.whole.nseg, fp.split.nseg);
+        if (src.kind == IPX_SRC_RGBA && env_int("IPX_KS_SPEC", 1)) IPX_HIP(hipMallocAsync((void **)&redo, (size_t)max_items * sizeof(int), s));
         a.redo = redo;
 #if IPX_DIAG
         static unsigned long long *stamp_buf = nullptr;   // IPX_STAMPS=1: phase stamps, never in a timed run
@@ -1087,7 +1094,7 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
         }
 #endif
         bool matched = false;
-        hipError_t e = launch_ks_fused(pl->fused, a, ctx->cus, s, &matched);
+        hipError_t e = launch_ks_fused(fp, a, ctx->cus, s, &matched);
         if (redo) (void)hipFreeAsync(redo, s);
 #if IPX_DIAG
         if (a.stamps && matched) {

@@ -97,8 +97,9 @@ struct ipx_plan {
     ipx_plan_params p{};
     ipx_plan_info info{};
     PlanScale sc[2];      // 0 = resize, 1 = thumbnail
-    KsFusedPlan fused;    // tiling and tables of the one-pass kernel (ipx_ks_fused.hip); fused.ok = false: per-output kernels
-    size_t fused_off = 0; // where those tables start in the blob
+    // tilings and tables of the one-pass kernel (ipx_ks_fused.hip) per LDS tile format -- [0] packed RGBA8 pixels (4 bytes), [1] four 16-bit
+    // taps per pixel (8: NRGBA, YCbCr, deep sources), [2] one 16-bit tap (2: Gray); .ok = false: per-output kernels for that format
+    KsFusedPlan fused[3];
     uint8_t *blob = nullptr;
     ClippedGlyphs glyphs;
     mutable std::mutex mu;

@@ -133,9 +133,11 @@ def _expect_ycbcr_ops(y, cb, cr, ratio, resize, thumb, glyphs, col):
                                   (2560, 1440, 1, 2, (1024, 768, True), (200, True)),      # two column blocks
                                   (1920, 1080, 1, 2, (3840, 2160, False), (200, True))],   # upscale: falls back (too many columns)
                          ids=lambda c: "%dx%d r%d" % (c[0], c[1], c[3]))
-@pytest.mark.parametrize("fused", ["1", "0"], ids=["fused", "three-kernel"])
+@pytest.mark.parametrize("fused", ["1", "0", "split"], ids=["one-pass", "per-output", "one-pass-split-strips"])
 def test_ycbcr_batch_plan(ctx, case, fused, monkeypatch):
-    monkeypatch.setenv("IPX_YCC_FUSED", fused)
+    monkeypatch.setenv("IPX_FUSED", "0" if fused == "0" else "1")
+    if fused == "split":
+        monkeypatch.setenv("IPX_KS_STRIPS", "3"); monkeypatch.setenv("IPX_KS_SPLIT", "1"); monkeypatch.setenv("IPX_KS_SPLIT_ROWS", "23")
     from helpers import DEFAULT_COL, text_glyphs
     w, h, n, ratio, resize, thumb = case
     planes = [_rand_ycbcr(w, h, ratio, 50 + i) for i in range(n)]
@@ -164,15 +166,16 @@ def test_ycbcr_batch_plan(ctx, case, fused, monkeypatch):
 @pytest.mark.parametrize("case", [(640, 360, 3, (1024, 768, True), (200, True)), (333, 251, 2, (200, 100, False), (64, False)),
                                   (200, 200, 2, (200, 200, False), (100, True)), (1920, 1080, 2, (1024, 768, False), (200, False)),
                                   (1280, 720, 2, (500, 333, False), (200, True))], ids=lambda c: "%dx%d" % (c[0], c[1]))
-@pytest.mark.parametrize("fused", ["conv", "per-tap", "0"], ids=["fused-converted-tile", "fused-per-tap", "three-kernels"])
+@pytest.mark.parametrize("fused", ["conv", "split", "0"], ids=["one-pass", "one-pass-split-strips", "per-output"])
 def test_nrgba_batch_plan(ctx, case, fused, monkeypatch):
     """ipx_plan_run_dev_nrgba: a batch of *image.NRGBA frames (PNGs with alpha), per operator as the reference's helpers treat the
     type: 16-bit premultiplied taps for resizeImage, drawNRGBA* first for the crop thumbnail and the watermark.  The converted-tile
     kernel (every source pixel premultiplied once, ipx_band_conv.hip), the per-tap kernel it falls back to (ipx_band_nrgba.hip; both
     need widths that are multiples of 4) and the three-kernel path."""
     from helpers import DEFAULT_COL, text_glyphs
-    monkeypatch.setenv("IPX_NRGBA_FUSED", "0" if fused == "0" else "1")
-    monkeypatch.setenv("IPX_NRGBA_CONV", "1" if fused == "conv" else "0")
+    monkeypatch.setenv("IPX_FUSED", "0" if fused == "0" else "1")
+    if fused == "split":
+        monkeypatch.setenv("IPX_KS_STRIPS", "2"); monkeypatch.setenv("IPX_KS_SPLIT", "1"); monkeypatch.setenv("IPX_KS_SPLIT_ROWS", "31")
     w, h, n, resize, thumb = case
     rng = np.random.default_rng(w)
     frames = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)          # non-premultiplied: colour may exceed alpha
