@@ -150,16 +150,19 @@ __device__ __forceinline__ void ks_fetch(const uint8_t *p, double (&v)[NCH])
     } else if (SRC == KS_GRAY) {
         v[0] = (double)(uint32_t) * (const uint16_t *)p;
     } else {
+        // one 8-byte LDS read per tap (three 16-bit reads per tap loaded the LDS pipe more than the two extractions cost the VALU)
+        const uint2 t = *(const uint2 *)p;
         uint32_t c[4];
+        if (MODE == KS_TAP_TOP) {                          // (v >> 8) * 0x101 straight from the packed halves
+            c[0] = __builtin_amdgcn_perm(0u, t.x, 0x0c0c0101u); c[1] = __builtin_amdgcn_perm(0u, t.x, 0x0c0c0303u);
+            c[2] = __builtin_amdgcn_perm(0u, t.y, 0x0c0c0101u); c[3] = __builtin_amdgcn_perm(0u, t.y, 0x0c0c0303u);
+        } else {
+            c[0] = t.x & 0xffffu; c[1] = t.x >> 16; c[2] = t.y & 0xffffu; c[3] = t.y >> 16;
+            if (MODE == KS_TAP_MINTOP) {
 #pragma unroll
-        for (int k = 0; k < NCH; k++) c[k] = *(const uint16_t *)(p + 2 * k);
-        if (MODE == KS_TAP_MINTOP && NCH == 4) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) c[k] = min(c[k], c[3]);
-        }
-        if (MODE == KS_TAP_TOP || MODE == KS_TAP_MINTOP) {
-#pragma unroll
-            for (int k = 0; k < NCH; k++) c[k] = __builtin_amdgcn_perm(0u, c[k], 0x0c0c0101u);   // (v >> 8) * 0x101
+                for (int k = 0; k < 3; k++) c[k] = __builtin_amdgcn_perm(0u, min(c[k], c[3]), 0x0c0c0101u);
+                c[3] = __builtin_amdgcn_perm(0u, c[3], 0x0c0c0101u);
+            }
         }
 #pragma unroll
         for (int k = 0; k < NCH; k++) v[k] = (double)c[k];
@@ -485,8 +488,10 @@ hipError_t launch_one(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hi
 {
     static KernelLaunchCache cache;
     auto fn = ks_fused_kernel<SRC, NCH, NACC, kKsRows, OPQ>;
-    hipError_t e = cache.prepare((const void *)fn, p.nthreads, (size_t)p.lds_bytes, nullptr);
+    int resident = 0;
+    hipError_t e = cache.prepare((const void *)fn, p.nthreads, (size_t)p.lds_bytes, getenv("IPX_KS_DEBUG") ? &resident : nullptr);
     if (e != hipSuccess) return e;
+    if (resident) fprintf(stderr, "[ipx ks] %d workgroups of %d threads with %d bytes of LDS resident per CU\n", resident, p.nthreads, p.lds_bytes);
     hipLaunchKernelGGL(fn, dim3(nitems), dim3(p.nthreads), (size_t)p.lds_bytes, s, a);
     return hipGetLastError();
 }

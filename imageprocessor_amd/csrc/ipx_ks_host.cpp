@@ -210,12 +210,30 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
                 while (c < ns && d < sc[k]->dw && sc[k]->sr_x0 + hx.lo[d] < strips[c].c0) d++;
                 colb[k][c] = c == ns ? sc[k]->dw : d;
             }
+        }
+        // Whole waves: the output with the most columns gets strip boundaries at multiples of 64 columns (a strip of 513 columns costs
+        // a ninth wave for one column).  Its columns next to a boundary may then tap outside the strip's own source columns: the tile
+        // grows to hold them (t0 below c0), the watermark stores stay with [c0, c1).
+        {
+            const int pk = sc[0] && (!sc[1] || sc[0]->dw >= sc[1]->dw) ? 0 : 1;
+            if (sc[pk] && ns > 1)
+                for (int c = 1; c < ns; c++) {
+                    int target = (colb[pk][c] + 32) / 64 * 64;
+                    target = std::max(target, colb[pk][c - 1]);
+                    colb[pk][c] = std::min(target, sc[pk]->dw);
+                }
+        }
+        for (int k = 0; k < 2; k++) {
+            if (!sc[k]) continue;
+            const KsAxis &hx = *sc[k]->hx;
             for (int c = 0; c < ns; c++) {
                 const int n = colb[k][c + 1] - colb[k][c];
                 wcols[k] = std::max(wcols[k], n);
                 if (n > 0) {
-                    const int lastcol = colb[k][c + 1] - 1;
-                    strips[c].tw = std::max(strips[c].tw, sc[k]->sr_x0 + hx.lo[lastcol] + hx.ntap - strips[c].t0);   // padded taps stay in the tile
+                    const int first = sc[k]->sr_x0 + hx.lo[colb[k][c]], last = sc[k]->sr_x0 + hx.lo[colb[k][c + 1] - 1] + hx.ntap;   // padded taps stay in the tile
+                    const int t1 = std::max(strips[c].t0 + strips[c].tw, last);
+                    strips[c].t0 = std::min(strips[c].t0, first & ~3);
+                    strips[c].tw = t1 - strips[c].t0;
                 }
             }
         }

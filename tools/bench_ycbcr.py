@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the decoded-JPEG batch path (ipx_plan_run_dev_ycbcr): n x 1920x1080 4:2:0 frames resident in HBM -> resize 1024x576 +
-thumbnail 200 + watermark through the fused planar kernel band_conv_kernel; IPX_YCC_FUSED=0 times the earlier
-three-kernel path instead."""
+thumbnail 200 + watermark through the one-pass kernel ks_fused_kernel<KS_YCC>; IPX_FUSED=0 times the per-output
+kernels instead."""
 import os
 import sys
 
