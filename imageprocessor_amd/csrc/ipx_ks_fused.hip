@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "ipx_ks.h"
 
@@ -130,11 +131,15 @@ __device__ __forceinline__ u32x4 ks_convert(const KsStageRegs &s, uint8_t *dst, 
 }
 
 // the 16-bit values of one tap as float64, NCH channels (1: gray, 3: colours of an opaque source, 4: colours and alpha)
+// what one tap is in LDS: the packed pixel (RGBA), one 16-bit value (Gray), four 16-bit values
+template <int SRC> struct KsTapRaw { typedef uint2 type; };
+template <> struct KsTapRaw<KS_RGBA> { typedef uint32_t type; };
+template <> struct KsTapRaw<KS_GRAY> { typedef uint16_t type; };
 template <int SRC, int NCH, int MODE>
-__device__ __forceinline__ void ks_fetch(const uint8_t *p, double (&v)[NCH])
+__device__ __forceinline__ void ks_fetch(typename KsTapRaw<SRC>::type raw, double (&v)[NCH])
 {
-    if (SRC == KS_RGBA) {
-        const uint32_t px = *(const uint32_t *)p;
+    if constexpr (SRC == KS_RGBA) {
+        const uint32_t px = raw;
         if (MODE == KS_TAP_CLAMP && NCH == 4) {
             const uint32_t al = px >> 24;
             v[0] = (double)(min(px & 0xffu, al) * 0x101u);
@@ -147,11 +152,11 @@ __device__ __forceinline__ void ks_fetch(const uint8_t *p, double (&v)[NCH])
             if (NCH > 2) v[2 % NCH] = widen<2>(px);
             if (NCH > 3) v[3 % NCH] = widen<3>(px);
         }
-    } else if (SRC == KS_GRAY) {
-        v[0] = (double)(uint32_t) * (const uint16_t *)p;
+    } else if constexpr (SRC == KS_GRAY) {
+        v[0] = (double)(uint32_t)raw;
     } else {
         // one 8-byte LDS read per tap (three 16-bit reads per tap loaded the LDS pipe more than the two extractions cost the VALU)
-        const uint2 t = *(const uint2 *)p;
+        const uint2 t = raw;
         uint32_t c[4];
         if (MODE == KS_TAP_TOP) {                          // (v >> 8) * 0x101 straight from the packed halves
             c[0] = __builtin_amdgcn_perm(0u, t.x, 0x0c0c0101u); c[1] = __builtin_amdgcn_perm(0u, t.x, 0x0c0c0303u);
@@ -196,28 +201,38 @@ __device__ __forceinline__ void ks_column(const uint8_t *lds, const uint8_t *til
         for (int k = 0; k < NCH; k++) acc[r][k] = 0.0;
     const uint8_t *tap = tile + c.xb;
     const uint8_t *wp = lds + c.wofs;
-    // two taps per iteration: their LDS reads are in flight together.  A column's taps are added in source order, row by row.
-    auto one_tap = [&](const uint8_t *p, double w, int r) {
+    // Two taps per iteration.  Their LDS reads are issued together and kept together (sched_barrier: left alone, the scheduler spreads
+    // them between the arithmetic of the previous row, each followed by a wait of its own).  A column's taps are added in source order.
+    typedef typename KsTapRaw<SRC>::type Raw;
+    auto one_tap = [&](Raw raw, double w, int r) {
         double v[NCH];
-        ks_fetch<SRC, NCH, MODE>(p, v);
+        ks_fetch<SRC, NCH, MODE>(raw, v);
 #pragma unroll
         for (int k = 0; k < NCH; k++) acc[r][k] += v[k] * w;
     };
+    auto taps = [&](auto nt) {                           // nt taps: all their LDS reads first, then the arithmetic tap by tap
+        constexpr int NT = decltype(nt)::value;
+        double w[NT];
+        Raw px[NT][B];
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            w[i] = *(const double *)(wp + i * wstride);
+#pragma unroll
+            for (int r = 0; r < B; r++) px[i][r] = *(const Raw *)(tap + r * pitch + i * PXB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int r = 0; r < B; r++) one_tap(px[i][r], w[i], r);
+        tap += NT * PXB;
+        wp += NT * wstride;
+    };
     int t = 0;
-    for (; t + 2 <= ntap; t += 2) {
-        const double w0 = *(const double *)wp, w1 = *(const double *)(wp + wstride);
-#pragma unroll
-        for (int r = 0; r < B; r++) one_tap(tap + r * pitch, w0, r);
-#pragma unroll
-        for (int r = 0; r < B; r++) one_tap(tap + r * pitch + PXB, w1, r);
-        tap += 2 * PXB;
-        wp += 2 * wstride;
-    }
-    if (t < ntap) {
-        const double w0 = *(const double *)wp;
-#pragma unroll
-        for (int r = 0; r < B; r++) one_tap(tap + r * pitch, w0, r);
-    }
+    constexpr int TU = SRC == KS_RGBA || SRC == KS_GRAY ? 4 : 2;   // (8-byte taps: two at a time keep the registers)
+    for (; t + TU <= ntap; t += TU) taps(std::integral_constant<int, TU>());
+    if (TU > 2 && t + 2 <= ntap) { taps(std::integral_constant<int, 2>()); t += 2; }
+    if (t < ntap) taps(std::integral_constant<int, 1>());
     KS_STAMP(4);                                         // scaleX of the group's rows for this column
     typedef KsRowT<NACC> Row;
     // the group's row entries in one batch of LDS reads (read one by one where they are used, every read was a round trip of its own)
