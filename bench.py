@@ -431,17 +431,22 @@ def main():
         L.ipx_event_destroy(ctx.handle, e1)
     frames_done, elapsed = shard.aggregate(F * K, elapsed)   # frames summed over ranks, time = max over ranks
 
-    if args.check and rank == 0:
+    # Every run checks what it timed: frames 0, P - 1 and F - 1 of the last buffer set (slot i holds pool frame i % P) against the CPU
+    # oracle, every byte of every output.  The oracle is the checker here, never the thing measured.  --check adds P more slots.
+    checked = None
+    if rank == 0:
         import oracle
-        want = oracle.process(pool[0], resize=resize or (1, 1, False), thumb=thumb or (1, False), glyphs=glyphs, col=DEFAULT_COL,
-                              want=[k for k, b in (("resize", res), ("thumbnail", th), ("watermark", wm)) if b])
-        if res:
-            assert np.array_equal(res.download((info.resize_h, info.resize_w, 4)), want["resize"])
-        if th:
-            assert np.array_equal(th.download((info.thumb_h, info.thumb_w, 4)), want["thumbnail"])
-        if wm:
-            assert np.array_equal(wm.download((sh, sw, 4)), want["watermark"])
-        print("check ok", file=sys.stderr)
+        s_, r_, t_, w_ = sets[(turn[0] - 1) % nsets]
+        slots = sorted({0, min(P, F) - 1, F - 1} | (set(range(min(P, F), min(2 * P, F))) if args.check else set()))
+        rstride, tstride = info.resize_bytes + pad, info.thumb_bytes + pad
+        for slot in slots:
+            want = oracle.process(pool[slot % P], resize=resize or (1, 1, False), thumb=thumb or (1, False), glyphs=glyphs, col=DEFAULT_COL,
+                                  want=[k for k, b in (("resize", r_), ("thumbnail", t_), ("watermark", w_)) if b])
+            for key, buf, stride, shape in (("resize", r_, rstride, (info.resize_h, info.resize_w, 4)), ("thumbnail", t_, tstride, (info.thumb_h, info.thumb_w, 4)),
+                                            ("watermark", w_, info.wm_bytes, (sh, sw, 4))):
+                if buf and not np.array_equal(buf.download(shape, offset=slot * stride), want[key]):
+                    raise SystemExit("bench.py: %s of slot %d differs from the oracle" % (key, slot))
+        checked = True
 
     if rank == 0 and os.environ.get("IPX_BENCH_TRACE"):
         print("launch_ms:", " ".join("%.3f" % m for m in launch_ms), file=sys.stderr)
@@ -484,10 +489,13 @@ def main():
                 "wm": "watermark only (copy + 16 glyphs)", "thumb": "thumbnail 200 crop only",
                 "resize-wm": "resize 1024x768 + watermark"}[args.workload]),
                 "frames_per_gpu": F, "sharding": "independent frames, round-robin by rank, no collective",
-                "arithmetic": "u8 pixels; taps interpolated in f64 (exact fp32 on dyadic axes), composite in u32"},
+                "arithmetic": "u8 pixels; x/image's kernel scaler in f64 (every product rounded before it is added, as the reference's amd64 build), composite in u32"},
+            "checked": checked,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "band_pipe_kernel", "algorithmic_bytes_per_launch": alg,
+                         "kernel": "ks_fused_kernel<RGBA, 3 channels> (speculative opaque pass; the 4-channel kernel redoes items that meet alpha != 0xff)",
+                         "in_practice": "float64 VALU issue: v_cvt_f64_u32 / v_mul_f64 / v_add_f64 at 16 lanes per clock and SIMD (DESIGN.md 4.1); HBM traffic stays the algorithmic minimum",
+                         "algorithmic_bytes_per_launch": alg,
                          "avg_launch_ms": round(avg_ms, 4), "traffic_source": traffic_src,
                          "buffer_sets": nsets,
                          "avg_launch_ms_by_set": [round(sum(launch_ms[i::nsets]) / len(launch_ms[i::nsets]), 4) for i in range(nsets)],

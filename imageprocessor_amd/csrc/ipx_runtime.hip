@@ -408,7 +408,13 @@ IPX_CATCH_STATUS
 int ipx_memcpy_d2d(ipx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes) try
 {
     IPX_ENTER(ctx);
-    if (bytes) IPX_HIP(hipMemcpy(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice));
+    // A device-to-device hipMemcpy returns before the copy has run, and the null stream it runs on does not order against the
+    // context's non-blocking streams: a launch queued right after it could read the destination half copied (a 1024-slot test batch
+    // tiled with this call did, once).  Queue it on the context's stream and wait: done on return, like the two host copies.
+    if (bytes) {
+        IPX_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        IPX_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return IPX_OK;
 }
 IPX_CATCH_STATUS

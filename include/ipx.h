@@ -104,10 +104,12 @@ void *ipx_host_alloc(ipx_ctx *ctx, size_t bytes);
 int ipx_host_free(ipx_ctx *ctx, void *p);
 void *ipx_dev_alloc(ipx_ctx *ctx, size_t bytes);
 int ipx_dev_free(ipx_ctx *ctx, void *p);
+/* The three copies are complete when they return (the device-to-device one runs on the context's stream and waits for it). */
 int ipx_memcpy_h2d(ipx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int ipx_memcpy_d2h(ipx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int ipx_memcpy_d2d(ipx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
-/* A plain streaming copy (grid-stride kernel, 16 bytes per lane; dst, src and bytes multiples of 16), asynchronous on `stream`.  Not
+/* A plain streaming copy (every workgroup copies a contiguous region of its own, 16 bytes per lane; dst, src and bytes multiples of 16),
+ * asynchronous on `stream`.  Not
  * part of the path: bench.py times it on the box it runs on, because the streaming ceiling the band kernels are held against differs
  * from box to box and with where buffers land. */
 int ipx_stream_copy(ipx_ctx *ctx, void *stream, void *dst_dev, const void *src_dev, size_t bytes);

@@ -322,6 +322,111 @@ def test_full_size_batch_properties(ctx):
         b.free()
 
 
+# ---- the headline shapes of BASELINE.json, each on the path the bench times -------------------------------
+
+@pytest.mark.parametrize("resize", [(1024, 768, False), (1024, 768, True)], ids=["1024x768", "keep_aspect-1024x576"])
+@pytest.mark.parametrize("env", [{}, {"IPX_FUSED": "0"}, {"IPX_KS_SPEC": "0"}, {"IPX_KS_SPLIT": "0"}],
+                         ids=["default", "per-output", "general-kernel", "one-segment"])
+def test_config2_resize_only_1080p_plan(ctx, resize, env, monkeypatch):
+    """BASELINE config 2: a resize-only plan on 1920x1080 frames through the batched path (resize.go:61-75,121-125)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 3
+    frames = rgba_frames(n, 1920, 1080, seed=0xC2)
+    plan = ctx.plan(1920, 1080, resize=resize, thumbnail=None, watermark=None)
+    assert (plan.info.resize_w, plan.info.resize_h) == ((1024, 768) if not resize[2] else (1024, 576))
+    src = ctx.alloc(frames.nbytes).upload(frames)
+    out = ctx.alloc(n * plan.info.resize_bytes)
+    plan.run_dev(n, src.ptr, out.ptr, None, None)
+    ctx.sync()
+    got = out.download((n, plan.info.resize_h, plan.info.resize_w, 4))
+    for i in range(n):
+        np.testing.assert_array_equal(got[i], oracle.process(frames[i], resize=resize, want=("resize",))["resize"], err_msg="frame %d" % i)
+    for b in (src, out):
+        b.free()
+    plan.close()
+
+
+@pytest.mark.parametrize("workload", ["full", "resize"])
+def test_bench_batch_shape_1024_frames(ctx, workload):
+    """The batch bench.py times (BASELINE configs 2 and 3): 1024 slots of 1920x1080, 32 seeded frames tiled over them, one launch.  The 32
+    distinct frames are compared with the oracle, and every other slot with the slot that holds the same frame: every workgroup of
+    the launch, wherever it ran and whatever its neighbours were, produced the bytes of its frame."""
+    F, P, sw, sh = 1024, 32, 1920, 1080
+    pool = rgba_frames(P, sw, sh, seed=0xB3)
+    glyphs = text_glyphs(sw, sh)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    full = workload == "full"
+    plan = ctx.plan(sw, sh, resize=(1024, 768, False), thumbnail=(200, True) if full else None, watermark=gs if full else None)
+    info = plan.info
+    assert info.algorithmic_bytes == (19894528 if full else 11440128)        # SURVEY.md 8(d)
+    fbytes = sw * sh * 4
+    src = ctx.alloc(F * fbytes).upload(pool)
+    for i in range(P, F, P):
+        ctx.copy_d2d(src.ptr + i * fbytes, src.ptr, P * fbytes)
+    outs = {"resize": ((info.resize_h, info.resize_w, 4), info.resize_bytes)}
+    if full:
+        outs["thumbnail"] = ((info.thumb_h, info.thumb_w, 4), info.thumb_bytes)
+        outs["watermark"] = ((sh, sw, 4), info.wm_bytes)
+    bufs = {k: ctx.alloc(F * nb) for k, (_, nb) in outs.items()}
+    plan.run_dev(F, src.ptr, bufs["resize"].ptr, bufs["thumbnail"].ptr if full else None, bufs["watermark"].ptr if full else None)
+    ctx.sync()
+    for k, (shape, nb) in outs.items():
+        first = bufs[k].download((P,) + shape)
+        for i in range(P):
+            want = oracle.process(pool[i], resize=(1024, 768, False), thumb=(200, True), glyphs=glyphs if full else (), col=DEFAULT_COL, want=(k,))[k]
+            np.testing.assert_array_equal(first[i], want, err_msg="%s of pool frame %d" % (k, i))
+        for j in range(1, F // P):
+            chunk = bufs[k].download((P,) + shape, offset=j * P * nb)
+            assert np.array_equal(chunk, first), "%s: slots %d..%d differ from slots 0..%d" % (k, j * P, j * P + P - 1, P - 1)
+    for b in [src] + list(bufs.values()):
+        b.free()
+    plan.close()
+    gs.close()
+
+
+def test_config4_4k_batch(ctx):
+    """BASELINE config 4's per-GPU shape: a batch of 3840x2160 frames through the full pipeline (64 slots, 8 distinct frames): properties
+    on every slot, four frames against the oracle."""
+    F, P, sw, sh = 64, 8, 3840, 2160
+    pool = rgba_frames(P, sw, sh, seed=0x4C)
+    pool[0][...] = 91
+    pool[0][..., 3] = 255
+    glyphs = text_glyphs(sw, sh)
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(sw, sh, resize=(1024, 768, False), thumbnail=(200, True), watermark=gs)
+    info = plan.info
+    assert info.algorithmic_bytes == 69660928                                 # SURVEY.md 8(d)
+    fbytes = sw * sh * 4
+    src = ctx.alloc(F * fbytes).upload(pool)
+    for i in range(P, F, P):
+        ctx.copy_d2d(src.ptr + i * fbytes, src.ptr, P * fbytes)
+    res, th, wm = ctx.alloc(F * info.resize_bytes), ctx.alloc(F * info.thumb_bytes), ctx.alloc(F * info.wm_bytes)
+    plan.run_dev(F, src.ptr, res.ptr, th.ptr, wm.ptr)
+    ctx.sync()
+    r = res.download((F, 768, 1024, 4))
+    t = th.download((F, 200, 200, 4))
+    assert (r[0, ..., :3] == 91).all() and (t[0, ..., :3] == 91).all()          # a constant frame scales to the constant (K1)
+    assert (r[..., 3] == 255).all() and (t[..., 3] == 255).all()                # opaque in, opaque out
+    for j in range(1, F // P):                                                  # a slot equals the slot that holds the same frame
+        assert np.array_equal(r[j * P:(j + 1) * P], r[:P]) and np.array_equal(t[j * P:(j + 1) * P], t[:P])
+    box = np.zeros((sh, sw), bool)
+    for g in glyphs:
+        x0, y0, x1, y1 = g["dr"]
+        box[max(y0, 0):y1, max(x0, 0):x1] = True
+    for slot in (0, 5, 26, F - 1):
+        w = wm.download((sh, sw, 4), offset=slot * info.wm_bytes)
+        assert (w[~box] == pool[slot % P][~box]).all()                          # the watermark frame is the source outside the glyph boxes
+        want = oracle.process(pool[slot % P], resize=(1024, 768, False), thumb=(200, True), glyphs=glyphs, col=DEFAULT_COL)
+        np.testing.assert_array_equal(r[slot], want["resize"])
+        np.testing.assert_array_equal(t[slot], want["thumbnail"])
+        np.testing.assert_array_equal(w, want["watermark"])
+    for b in (src, res, th, wm):
+        b.free()
+    plan.close()
+    gs.close()
+
+
 def test_concurrent_callers(ctx):
     """worker.go:90-96: several goroutines share one processor; lanes=2 forces waiting."""
     import threading
