@@ -212,8 +212,10 @@ int dev_composite(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, size
 // =============================================================================================
 extern "C" {
 
+static void prepare_hip_env();
 int ipx_device_count(void) try
 {
+    prepare_hip_env();
     clear_error();
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -222,11 +224,29 @@ int ipx_device_count(void) try
 }
 IPX_CATCH_STATUS
 
+// ROCclr maps HIP streams onto a fixed number of hardware queues per device (GPU_MAX_HW_QUEUES, 4 by default) and reads the variable
+// when the runtime initialises.  A context opens its own stream and five lane streams: with four queues the high-priority lane that
+// serves single-frame calls shared a queue with a batch lane in about one context of ten, and its calls then waited for the batch
+// (tools/seam_hunt.py).  So before the first HIP call of the process the variable is set -- unless the operator has set it -- to hold
+// every stream of a default context on a queue of its own.
+static void prepare_hip_env()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (!getenv("GPU_MAX_HW_QUEUES")) {
+            char v[16];
+            snprintf(v, sizeof v, "%d", std::max(8, env_int("IPX_LANES", 5) + 3));
+            setenv("GPU_MAX_HW_QUEUES", v, 0);
+        }
+    });
+}
+
 int ipx_create(const ipx_config *cfg, ipx_ctx **out) try
 {
     clear_error();
     if (!out) { set_error("ipx_create: null out"); return IPX_ERR_INVALID; }
     *out = nullptr;
+    prepare_hip_env();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();
@@ -251,15 +271,16 @@ int ipx_create(const ipx_config *cfg, ipx_ctx **out) try
     c->lane_bytes = cfg && cfg->lane_bytes ? cfg->lane_bytes : (size_t)64 << 20;
     c->host_cache_limit = (size_t)std::max(0, env_int("IPX_HOST_CACHE_MB", 8192)) << 20;
     c->lanes.resize(lanes);
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    // the last lane is the one a batch leaves free: single-frame calls land on it, ahead of the batch's queued work.  Its stream is
+    // created first: streams take hardware queues in the order they are made
+    hipError_t e = hipSuccess;
+    if (c->lanes.size() >= 3) e = hipStreamCreateWithPriority(&c->lanes.back().stream, hipStreamNonBlocking, prio_hi);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (size_t i = 0; i < c->lanes.size(); i++) {
         Lane &l = c->lanes[i];
-        // the last lane is the one a batch leaves free: single-frame calls land on it, ahead of the batch's queued work
-        if (e == hipSuccess)
-            e = i + 1 == c->lanes.size() && c->lanes.size() >= 3 ? hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_hi)
-                                                                 : hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
+        if (e == hipSuccess && !l.stream) e = hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&l.flag, sizeof(int));
     }
     if (e == hipSuccess) {

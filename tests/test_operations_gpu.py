@@ -242,11 +242,12 @@ def test_single_image_calls_are_served_while_a_batch_runs(ipx, ops, font):
     device) and ONE staging lane, and a host batch leaves one lane free: single calls finish while the batch is still running,
     and both produce the oracle's bytes.
 
-    The latency bound is tried on up to three fresh contexts: about one context in ten still sees its single calls wait on the GPU for
-    the batch beside them (the high-priority lane's stream then shares a hardware queue with a batch lane -- HIP's stream -> queue
-    assignment, not visible at this level; tools/seam_hunt.py).  The other cause this test found -- small pageable copies blocking the
-    ENQUEUEING thread behind other streams' work in three contexts of ten -- is gone: such calls go through a pinned bounce buffer
-    (run_host_packed).  The bytes are checked on every attempt."""
+    Round 2 retried the latency bound on up to three contexts: about one context in ten had its single calls wait for the batch.  The
+    cause was the order in which the context made its streams: ROCclr hands streams to hardware queues in creation order, and the
+    high-priority lane, made last, came to share a queue with a batch lane.  It is made first now (and GPU_MAX_HW_QUEUES is raised to
+    one queue per stream of a context before the runtime starts, ipx_create): 32 contexts of 32 served their single calls in 3 - 9 ms
+    beside a 115 ms batch (tools/seam_hunt.py), so the bound is asserted on the first context.  The other cause this test found -- small
+    pageable copies blocking the ENQUEUEING thread behind other streams' work -- went away with the pinned bounce buffer (run_host_packed)."""
     import threading
     import time
     task = _task([{"Type": "thumbnail", "Parameters": {"size": 200.0, "crop_to_fit": True}},
@@ -257,8 +258,8 @@ def test_single_image_calls_are_served_while_a_batch_runs(ipx, ops, font):
     batch_frames = rgba_frames(4, w, h, seed=5)
     want = oracle.process(batch_frames[1], resize=(1024, 768, True), thumb=(200, True))
     tried = []
-    for attempt in range(3):
-        with ipx.Context(device=0) as c:        # default lanes: three for a batch's pipeline, one left for single calls
+    for attempt in range(1):
+        with ipx.Context(device=0) as c:        # default lanes: four for a batch's pipeline, one left for single calls
             ip = ops.ImageProcessor(c, font)
             for _ in range(3):                  # first call builds the plan; the later ones come from the cache
                 res, err = ip.Process(task, SRC, "jpeg")
