@@ -993,7 +993,10 @@ void ipx_plan_destroy(ipx_ctx *ctx, ipx_plan *plan)
 // The per-operator entries (ipx_*_process, ipx_processor_process) and the pool describe their operators per call; building a glyph set
 // and a plan per call cost three hipMalloc / hipFree pairs, each of which waits for every stream of the device.  The context keeps
 // plans (with their glyph sets) by content instead: operator parameters, colour, and every glyph's rectangle and mask bytes.
-static constexpr size_t kMaxCachedPlans = 256;
+// The cache holds at most IPX_PLAN_CACHE_MAX (256) plans; a new content then takes the place of the plan that was handed out longest
+// ago and that no call holds (a worker fed arbitrary upload sizes would otherwise fill the cache with sizes it never sees again, and
+// sizes that become frequent later could not enter).
+static size_t max_cached_plans() { return (size_t)std::max(1, env_int("IPX_PLAN_CACHE_MAX", 256)); }
 
 static int ops_key(const ipx_pool_ops &in, std::string *key)
 {
@@ -1022,7 +1025,11 @@ int ipx_plan_acquire(ipx_ctx *ctx, const ipx_pool_ops *ops, ipx_plan **plan, int
     std::lock_guard<std::mutex> lk(ctx->plan_mu);      // (a miss builds under the lock: two callers with the same new content build once)
     const bool use_cache = env_int("IPX_PLAN_CACHE", 1) != 0;     // 0: a plan per call, as before the cache existed (tools/bench_seam.py)
     auto it = ctx->plan_cache.find(key);
-    if (use_cache && it != ctx->plan_cache.end()) { *plan = it->second.second; *cached = 1; return IPX_OK; }
+    if (use_cache && it != ctx->plan_cache.end()) {
+        *plan = it->second.second; *cached = 1;
+        (*plan)->cache_refs++; (*plan)->cache_stamp = ++ctx->plan_clock;
+        return IPX_OK;
+    }
     ipx_glyphset *gs = nullptr;
     if (ops->do_watermark && ops->n_glyphs > 0) {
         rc = ipx_glyphset_create(ctx, ops->glyphs, ops->n_glyphs, ops->col, &gs);
@@ -1038,7 +1045,21 @@ int ipx_plan_acquire(ipx_ctx *ctx, const ipx_pool_ops *ops, ipx_plan **plan, int
     rc = ipx_plan_create(ctx, &pp, &pl);
     if (rc) { if (gs) ipx_glyphset_destroy(ctx, gs); return rc; }
     pl->owned_gs = gs;
-    if (use_cache && ctx->plan_cache.size() < kMaxCachedPlans) { ctx->plan_cache.emplace(std::move(key), std::make_pair(gs, pl)); *cached = 1; }
+    if (use_cache && ctx->plan_cache.size() >= max_cached_plans()) {   // make room: the least recently used plan nobody holds
+        auto victim = ctx->plan_cache.end();
+        for (auto i2 = ctx->plan_cache.begin(); i2 != ctx->plan_cache.end(); ++i2)
+            if (i2->second.second->cache_refs == 0 && (victim == ctx->plan_cache.end() || i2->second.second->cache_stamp < victim->second.second->cache_stamp))
+                victim = i2;
+        if (victim != ctx->plan_cache.end()) {
+            ipx_plan_destroy(ctx, victim->second.second);               // (hipFree waits for the launches that still read its tables)
+            ctx->plan_cache.erase(victim);
+        }
+    }
+    if (use_cache && ctx->plan_cache.size() < max_cached_plans()) {
+        pl->cache_refs = 1; pl->cache_stamp = ++ctx->plan_clock;
+        ctx->plan_cache.emplace(std::move(key), std::make_pair(gs, pl));
+        *cached = 1;
+    }
     *plan = pl;
     return IPX_OK;
 }
@@ -1046,7 +1067,11 @@ IPX_CATCH_STATUS
 
 void ipx_plan_release(ipx_ctx *ctx, ipx_plan *plan, int cached)
 {
-    if (plan && !cached) ipx_plan_destroy(ctx, plan);   // a plan the full cache did not take lives for one call
+    if (!plan) return;
+    if (!cached) { ipx_plan_destroy(ctx, plan); return; }   // a plan the cache did not take (every cached plan was in use) lives for one call
+    if (!ctx) return;
+    std::lock_guard<std::mutex> lk(ctx->plan_mu);
+    if (plan->cache_refs > 0) plan->cache_refs--;
 }
 
 int ipx_plan_query(const ipx_plan *plan, ipx_plan_info *info) try

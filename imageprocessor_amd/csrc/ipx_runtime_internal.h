@@ -56,6 +56,7 @@ struct ipx_ctx {
     // (ipx_plan_acquire: the per-operator seam, the pool): no hipMalloc / hipFree in the steady state
     std::mutex plan_mu;
     std::map<std::string, std::pair<ipx_glyphset *, ipx_plan *>> plan_cache;
+    uint64_t plan_clock = 0;
     // axes of the kernel scaler in HBM by (destination extent, source extent), for the per-operation seam (ks_axis_get)
     std::mutex ks_mu;
     std::map<std::pair<int, int>, std::pair<uint8_t *, KsAxisDev>> ks_axes;
@@ -104,6 +105,9 @@ struct ipx_plan {
     ClippedGlyphs glyphs;
     mutable std::mutex mu;
     ipx_glyphset *owned_gs = nullptr;         // a glyph set that lives and dies with this plan (ipx_plan_acquire)
+    // a plan of the context's cache (guarded by ipx_ctx::plan_mu): calls holding it, and when it was last handed out
+    int cache_refs = 0;
+    uint64_t cache_stamp = 0;
 };
 
 inline int env_int(const char *name, int dflt)

@@ -517,8 +517,9 @@ typedef struct {
 
 /* A plan (and its uploaded glyph set) from the context's cache, keyed by content: what the per-operator entries and the pool use,
  * so that describing the operators per call costs no hipMalloc / hipFree in the steady state (each of those waits for every stream
- * of the device).  *cached = 1: the context owns the plan (valid until ipx_destroy); 0: the cache was full and the plan is the
- * caller's for this call.  Either way hand it back with ipx_plan_release. */
+ * of the device).  *cached = 1: the context owns the plan, and it stays valid at least until the caller hands it back; 0: every plan
+ * of the full cache was in use and this one is the caller's for this call.  Either way hand it back with ipx_plan_release.  The
+ * cache holds IPX_PLAN_CACHE_MAX (256) plans and replaces the least recently used one nobody holds. */
 int ipx_plan_acquire(ipx_ctx *ctx, const ipx_pool_ops *ops, ipx_plan **plan, int *cached);
 void ipx_plan_release(ipx_ctx *ctx, ipx_plan *plan, int cached);
 

@@ -317,3 +317,44 @@ def test_fused_failure_falls_back_to_the_sequential_order(ctx, ops):
                    "failed to draw watermark text: rasteriser failed")
     assert list(res["ProcessedPaths"]) == ["resize"] and res["Status"] == "failed"
     np.testing.assert_array_equal(res["Outputs"]["resize"][0], oracle.scale_bilinear(SRC, 64, 36))
+
+
+def test_plan_cache_replaces_the_least_recently_used_plan(ipx, monkeypatch):
+    """ipx_plan_acquire (what every per-operator call and the pool go through): a worker fed arbitrary upload sizes must not fill the
+    cache with sizes it never sees again.  With room for 8 plans: 20 different sizes go in, a size used a moment ago is still there, the
+    oldest is gone, and a plan some call still holds is never the victim."""
+    import ctypes as C
+    from imageprocessor_amd import _lib
+    monkeypatch.setenv("IPX_PLAN_CACHE_MAX", "8")
+    L = ipx.lib()
+    with ipx.Context(device=0) as c:
+        def acquire(w):
+            ops_ = _lib.PoolOps(sw=w, sh=40, do_resize=1, resize_w=16, resize_h=16, keep_aspect=0, do_thumbnail=0, thumb_size=0, crop_to_fit=0,
+                                do_watermark=0, glyphs=None, n_glyphs=0)
+            plan, cached = C.c_void_p(), C.c_int()
+            assert L.ipx_plan_acquire(c.handle, C.byref(ops_), C.byref(plan), C.byref(cached)) == 0
+            return plan.value, cached.value
+        held, _ = acquire(1000)                            # kept by "a call in flight" through everything below
+        seen = {}
+        for w in range(100, 120):
+            p, cached = acquire(w)
+            assert cached == 1
+            seen[w] = p
+            L.ipx_plan_release(c.handle, p, cached)
+        p, cached = acquire(119)                           # the most recent one: a hit, the same plan
+        assert cached == 1 and p == seen[119]
+        L.ipx_plan_release(c.handle, p, cached)
+        p, cached = acquire(1000)                          # never evicted while held
+        assert cached == 1 and p == held
+        L.ipx_plan_release(c.handle, p, cached)
+        L.ipx_plan_release(c.handle, held, 1)
+        # the oldest sizes were replaced: asking for one builds a new plan that works
+        frames = rgba_frames(1, 100, 40, seed=3)
+        p, cached = acquire(100)
+        assert cached == 1
+        out = np.zeros((1, 16, 16, 4), np.uint8)
+        src_d, out_d = c.alloc(frames.nbytes).upload(frames), c.alloc(out.nbytes)
+        assert L.ipx_plan_run_dev(c.handle, None, p, 1, src_d.ptr, 400, frames.nbytes, out_d.ptr, out.nbytes, None, 0, None, 0) == 0
+        c.sync()
+        np.testing.assert_array_equal(out_d.download((16, 16, 4)), oracle.scale_bilinear(frames[0], 16, 16))
+        L.ipx_plan_release(c.handle, p, cached)
