@@ -38,6 +38,10 @@ struct Huff {
     uint8_t vals[256];
 };
 
+// Known divergence on DAMAGED tables (parity unpinned there): Go's processDHT fills an 8-bit first-level table with `base := uint8(code << (7 - i))`,
+// so the codes of an over-subscribed length wrap around modulo 256 and later codes overwrite earlier entries; here such codes are left out of
+// the (9-bit) first level and only match through the per-length ranges.  A valid table (Kraft sum <= 1) decodes the same either way; a file
+// whose DHT is over-full can decode to different garbage than Go's before both fail.  tools/fuzz_corrupt.py (26 000 files) has not produced one.
 void huff_build(Huff &h, const uint8_t counts[16], const uint8_t *vals, int total)
 {
     h.ncodes = total;
@@ -293,7 +297,7 @@ struct Decoder {
                                 const int t = br.huff(hf[0][td[i]]);
                                 if (br.err) break;
                                 if (t > 16) { fail(IPX_ERR_UNSUPPORTED); return; }     // "excessive DC component"
-                                dc[k] += br.receive_extend(t);
+                                dc[k] = (int32_t)((uint32_t)dc[k] + (uint32_t)br.receive_extend(t));   // Go's int32 wraps; a signed overflow here would be undefined
                                 put(b[0], (int32_t)((uint32_t)dc[k] << al));
                             }
                             if (zig <= ze && eobrun > 0) eobrun--;
@@ -390,8 +394,8 @@ struct Decoder {
                     if (ctq[c] > 3) return fail(IPX_ERR_INVALID);
                     int hh = s[7 + 3 * c] >> 4, vv = s[7 + 3 * c] & 15;
                     if (hh < 1 || hh > 4 || vv < 1 || vv > 4) return fail(IPX_ERR_INVALID);
+                    if (ncomp == 1) hh = vv = 1;      // reader.go normalises a one-component file first: its factors, 3 included, mean nothing
                     if (hh == 3 || vv == 3) return fail(IPX_ERR_UNSUPPORTED);
-                    if (ncomp == 1) hh = vv = 1;
                     ch[c] = hh; cv[c] = vv;
                 }
                 if (ncomp == 3 && (ch[1] != 1 || cv[1] != 1 || ch[2] != 1 || cv[2] != 1 || ch[0] > 2 || cv[0] > 2)) return fail(IPX_ERR_UNSUPPORTED);

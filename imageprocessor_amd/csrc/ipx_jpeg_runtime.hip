@@ -9,6 +9,7 @@
 #include <thread>
 
 #include "ipx_runtime_internal.h"
+#include "ipx_threads.h"
 
 // ---- jpeg.Encode: the entries that touch the device (tables / entropy coder: ipx_jpeg_host.cpp) ----------
 
@@ -65,19 +66,12 @@ static int jpeg_batch_host_entropy(ipx_ctx *ctx, Lane &lane, const int16_t *dcoe
     if (e != hipSuccess) { (void)hipHostFree(host); set_error("coefficient download failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
     JpegTables t;
     jpeg_tables(quality, &t);
-    const int nt = std::max(1, std::min((int)std::thread::hardware_concurrency(), n));
     std::vector<std::vector<uint8_t>> streams(n);
-    std::atomic<int> next{0};
-    auto work = [&] {
-        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1))
-            jpeg_write_stream(host + (per / sizeof(int16_t)) * (size_t)i, w, h, t, &streams[i]);
-    };
     std::atomic<int> failed{IPX_OK};
-    auto guarded = [&] { const int rc = guarded_status(work, nullptr); if (rc) failed = rc; };
-    std::vector<std::thread> pool;
-    for (int i = 1; i < nt; i++) pool.emplace_back(guarded);
-    guarded();
-    for (auto &th : pool) th.join();
+    HostPool::instance().parallel_for(n, 16, [&](int i) {
+        const int rc = guarded_status([&] { jpeg_write_stream(host + (per / sizeof(int16_t)) * (size_t)i, w, h, t, &streams[i]); }, nullptr);
+        if (rc) failed = rc;
+    });
     (void)hipHostFree(host);
     if (failed) { set_error("entropy coding on the host failed (out of memory)"); return failed; }
     size_t total = 0;
@@ -338,10 +332,7 @@ static int run_host_jpeg_impl(ipx_ctx *ctx, const ipx_plan *pl, int n, const uin
         std::lock_guard<std::mutex> lk(res_mu);
         if (status == IPX_OK) { status = rc; err_text = text; }
     };
-    std::vector<std::thread> pool;
-    for (int i = 1; i < nl; i++) pool.emplace_back(guarded, lanes[i]);
-    guarded(lanes[0]);
-    for (auto &t : pool) t.join();
+    HostPool::instance().parallel_for(nl, nl, [&](int i) { guarded(lanes[i]); });   // one host thread per lane (they block on their streams)
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         for (auto *l : lanes) l->busy = false;
@@ -458,29 +449,18 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     // host preparation runs on a few threads: parsing is trivial, but finding the RSTn markers and packing the scans walk
     // every compressed byte (0.3 GB for a thousand 1080p files)
     std::atomic<int> prep_failed{IPX_OK};     // an exception inside a preparation thread (allocation): checked after each parallel_for
-    auto parallel_for = [&](int count, const std::function<void(int)> &fn) {
-        const int nt = std::max(1, std::min({count / 8, (int)std::thread::hardware_concurrency(), 16}));
-        std::atomic<int> next{0};
-        auto work = [&] {
-            const int rc = guarded_status([&] { for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); }, nullptr);
+    // (the process-wide pool of ipx_threads.h: sized from the CPUs this process may use, no thread started per call)
+    auto parallel_for = [&](int count, const std::function<void(int)> &fn) {            // light items: a thread per eight of them
+        HostPool::instance().parallel_for(count, std::max(1, std::min(count / 8, 16)), [&](int i) {
+            const int rc = guarded_status([&] { fn(i); }, nullptr);
             if (rc) prep_failed = rc;
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
+        });
     };
     auto parallel_for_each = [&](int count, const std::function<void(int)> &fn) {      // heavy items (a file's scans): a thread each, up to 16
-        const int nt = std::max(1, std::min({count, (int)std::thread::hardware_concurrency(), 16}));
-        std::atomic<int> next{0};
-        auto work = [&] {
-            const int rc = guarded_status([&] { for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); }, nullptr);
+        HostPool::instance().parallel_for(count, 16, [&](int i) {
+            const int rc = guarded_status([&] { fn(i); }, nullptr);
             if (rc) prep_failed = rc;
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
+        });
     };
     // pieces of a scan: the whole scan, or one per restart interval.  Inside entropy-coded data 0xff is followed by 0x00 or by a
     // marker, so every 0xff 0xd0..0xd7 pair is an RSTn.
@@ -655,24 +635,23 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     t_alloc = dms();
     uint8_t *hblob = (uint8_t *)ipx_host_alloc(ctx, blob_bytes + 16);
     if (!hblob) { ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
-    // the host-decoded files of the batch: scans walked on the preparation threads into slots of one pinned block
+    // the host-decoded files of the batch (progressive, several scans): their scans are walked on the preparation threads, further
+    // down, in groups of kHostGroup files through a pinned block of two groups -- one uploads while the next decodes.  (One block for
+    // all of them was 6.3 MB per 1080p file, 1.6 GB for a part of 256 progressive files, per part and per feeder of a pool.)
     int nhost = 0;
     for (int i = 0; i < n; i++) if (valid[i] && info[i].host_scans) hslot[i] = nhost++;
     int16_t *hpin = nullptr;
-    const size_t hcoef_words = (size_t)a.nblk * 64;
+    const size_t hcoef_words = (size_t)a.nblk * 64, hslot_words = hcoef_words + a.nblk;
+    const int kHostGroup = std::max(1, env_int("IPX_JPEG_HOST_GROUP", 16));
+    std::vector<int> hfiles;
+    for (int i = 0; i < n; i++) if (hslot[i] >= 0) hfiles.push_back(i);
     if (nhost) {
-        hpin = (int16_t *)ipx_host_alloc(ctx, (size_t)nhost * (hcoef_words + a.nblk) * sizeof(int16_t));
-        if (!hpin) { (void)ipx_host_free(ctx, hblob); ipx_jpeg_planes_free(ctx, own.release()); return IPX_ERR_NOMEM; }
-        std::vector<int> hfiles;
-        for (int i = 0; i < n; i++) if (hslot[i] >= 0) hfiles.push_back(i);
-        parallel_for_each(nhost, [&](int j) {
-            const int i = hfiles[j];
-            bool prog = false;
-            JpegDecInfo full;
-            const int rc = jpeg_host_decode(jpegs[i].data, jpegs[i].len, &full, hpin + (size_t)j * hcoef_words, hpin + (size_t)nhost * hcoef_words + (size_t)j * a.nblk,
-                                            (size_t)a.nblk, tabs[i].qnat, &prog);
-            if (rc != IPX_OK) { status[i] = rc; valid[i] = 0; }
-        });
+        hpin = (int16_t *)ipx_host_alloc(ctx, (size_t)2 * std::min(nhost, kHostGroup) * hslot_words * sizeof(int16_t));
+        if (!hpin) {   // no pinned memory for them: these files stay on the caller's CPU path, the rest of the batch goes on
+            for (int i : hfiles) { status[i] = IPX_ERR_UNSUPPORTED; valid[i] = 0; }
+            hfiles.clear();
+            clear_error();
+        }
     }
     t_pin = dms();
     parallel_for(n, [&](int i) { if (valid[i] && !info[i].host_scans) memcpy(hblob + blob_off[i], jpegs[i].data + info[i].scan_off, info[i].scan_len); });
@@ -680,20 +659,52 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     t_pack = dms();
     e = hipMemcpyAsync(d_blob, hblob, blob_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_img, items.data(), sizeof(JpegDecImage) * items.size(), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_valid, valid.data(), (size_t)n, hipMemcpyHostToDevice, s);
     pl.valid = d_valid;
     a.nitems = (int)items.size();
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tabs.data(), sizeof(JpegDecTables) * n, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_coefs, 0, (size_t)n * a.nblk * 128, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, sizeof(int) * n, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_dcs, 0, (size_t)n * a.nblk * 2, s);
     a.blob = d_blob; a.img = d_img; a.tab = d_tab; a.coefs = d_coefs; a.status = d_status; a.dcs = d_dcs;
-    for (int i = 0; i < n && e == hipSuccess; i++) {       // host-decoded files: their coefficients go into their slots (after the memsets, same stream)
-        if (!valid[i] || hslot[i] < 0) continue;
-        const size_t j = (size_t)hslot[i];
-        e = hipMemcpyAsync(d_coefs + (size_t)i * hcoef_words, hpin + j * hcoef_words, hcoef_words * 2, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_dcs + (size_t)i * a.nblk, hpin + (size_t)nhost * hcoef_words + j * a.nblk, (size_t)a.nblk * 2, hipMemcpyHostToDevice, s);
+    // host-decoded files: group by group, scans walked on the pool's threads into one half of the pinned block, coefficients copied into
+    // their slots (after the memsets, same stream) while the next group decodes into the other half
+    {
+        hipEvent_t hev[2] = {nullptr, nullptr};
+        bool hused[2] = {false, false};
+        for (int g0 = 0, gi = 0; g0 < (int)hfiles.size() && e == hipSuccess; g0 += kHostGroup, gi++) {
+            const int half = gi & 1, cnt = std::min(kHostGroup, (int)hfiles.size() - g0);
+            int16_t *base = hpin + (size_t)half * std::min(nhost, kHostGroup) * hslot_words;
+            if (hused[half]) e = hipEventSynchronize(hev[half]);          // the copies of two groups ago have left this half
+            if (e != hipSuccess) break;
+            parallel_for_each(cnt, [&](int j) {
+                const int i = hfiles[g0 + j];
+                bool prog = false;
+                JpegDecInfo full;
+                const int rc = jpeg_host_decode(jpegs[i].data, jpegs[i].len, &full, base + (size_t)j * hslot_words, base + (size_t)j * hslot_words + hcoef_words,
+                                                (size_t)a.nblk, tabs[i].qnat, &prog);
+                if (rc != IPX_OK) { status[i] = rc; valid[i] = 0; }
+            });
+            if (prep_failed) break;
+            for (int j = 0; j < cnt && e == hipSuccess; j++) {
+                const int i = hfiles[g0 + j];
+                if (!valid[i]) continue;
+                e = hipMemcpyAsync(d_coefs + (size_t)i * hcoef_words, base + (size_t)j * hslot_words, hcoef_words * 2, hipMemcpyHostToDevice, s);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_dcs + (size_t)i * a.nblk, base + (size_t)j * hslot_words + hcoef_words, (size_t)a.nblk * 2, hipMemcpyHostToDevice, s);
+            }
+            if (e == hipSuccess && !hev[half]) e = hipEventCreateWithFlags(&hev[half], hipEventDisableTiming);
+            if (e == hipSuccess) { e = hipEventRecord(hev[half], s); hused[half] = true; }
+        }
+        for (hipEvent_t ev : hev) if (ev) (void)hipEventDestroy(ev);
+        if (prep_failed) {
+            (void)hipStreamSynchronize(s);
+            (void)ipx_host_free(ctx, hblob); if (hpin) (void)ipx_host_free(ctx, hpin); ipx_jpeg_planes_free(ctx, own.release());
+            set_error("jpeg decode: host preparation failed");
+            return prep_failed;
+        }
     }
+    // (which files are decodable is final only now: a host-decoded file may have failed in its scans; and the host decoder fills the
+    // quantisation tables of its files)
+    if (e == hipSuccess) e = hipMemcpyAsync(d_valid, valid.data(), (size_t)n, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tabs.data(), sizeof(JpegDecTables) * n, hipMemcpyHostToDevice, s);
     int ref_gpu = -1;                                        // the first image the Huffman kernels decode: the one whose tables a shared-table launch carries
     for (int i = 0; i < n && ref_gpu < 0; i++) if (valid[i] && !info[i].host_scans) ref_gpu = i;
     a.first_valid = ref_gpu >= 0 ? ref_gpu : ref;
@@ -925,10 +936,7 @@ int ipx_plan_run_jpeg_jpeg(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_by
         if (rcs[k]) errs[k] = ipx_last_error();
     };
     auto guarded = [&](int k) { const int rc = guarded_status([&] { work(k); }, &errs[k]); if (rc) rcs[k] = rc; };
-    std::vector<std::thread> pool;
-    for (int k = 1; k < parts; k++) pool.emplace_back(guarded, k);
-    guarded(0);
-    for (auto &t : pool) t.join();
+    HostPool::instance().parallel_for(parts, parts, [&](int k) { guarded(k); });      // one host thread per part (each drives a lane)
     std::unique_ptr<ipx_jpeg_result> all(new ipx_jpeg_result);
     int rc = IPX_OK;
     for (int k = 0; k < parts; k++) {
