@@ -1,118 +1,88 @@
 package ipx
 
+/*
+#include <stdlib.h>
+#include "ipx.h"
+*/
+import "C"
+
 import (
-	"context"
-	"sync"
-	"time"
+	"unsafe"
 )
 
-// Task is what processMessage (internal/worker/worker.go:165-234) has in hand after fileRepo.GetOriginal: the object bytes, the frame size
-// read from the JPEG header (image.DecodeConfig) and the operators of domain.ProcessingTask.
-type Task struct {
-	ID     string
-	File   []byte
-	W, H   int
-	Ops    Ops
-	Result chan TaskResult // receives exactly one value
+// Batcher is the micro-batcher of the library (ipx_batcher_*, include/ipx.h): the goroutines of internal/worker/worker.go:112-149 pull ONE
+// message each from a channel of concurrency*2 (:88); every one of them hands its file over with Process and blocks until ITS objects are
+// back.  Grouping by frame size and operator content, the size / timer flush and the per-file status live below the ABI (and are tested
+// there: tests/test_batcher_gpu.py, tools/sanitize/batcher_host_test.cpp under ThreadSanitizer) -- round 2's Go-side batching is gone.
+// At-least-once semantics are unchanged: processMessage (worker.go:165-234) commits its message only after Process returned and
+// fileRepo.SaveProcessed stored the objects.
+type Batcher struct {
+	c *C.ipx_batcher
+	p *Pool
 }
 
-// TaskResult carries the three objects (nil for operators the task did not ask for) or the reason the CPU path has to run.
-type TaskResult struct {
+// NewBatcher: maxBatch files per job (0 = 256), maxWaitMicros how long the first file of a group waits for company (0 = 2000),
+// quality = domain.DefaultJPEGQuality (task.go:57; 0 = 85).
+func NewBatcher(p *Pool, maxBatch, maxWaitMicros, quality int) (*Batcher, error) {
+	cfg := C.ipx_batcher_config{max_batch: C.int32_t(maxBatch), max_wait_us: C.int32_t(maxWaitMicros), quality: C.int32_t(quality)}
+	var b *C.ipx_batcher
+	if err := call(func() C.int { return C.ipx_batcher_create(p.c, &cfg, &b) }); err != nil {
+		return nil, err
+	}
+	return &Batcher{b, p}, nil
+}
+
+// Close flushes what is pending and waits for it.
+func (b *Batcher) Close() { C.ipx_batcher_destroy(b.c); b.c = nil }
+
+// Objects are the three streams of one message (nil for operators its task did not ask for).  They are views into blocks the library
+// owns: copy or store them (fileRepo.SaveProcessed, image_processor.go:76), then call Release.
+type Objects struct {
 	Resize, Thumbnail, Watermark []byte
-	Err                          error // IsUnsupported(Err): run the reference's own image.Decode path for this message
 	release                      func()
 }
 
-// Release returns the pinned blocks the objects live in; call it after fileRepo.SaveProcessed (image_processor.go:76).
-func (r *TaskResult) Release() {
-	if r.release != nil {
-		r.release()
+func (o *Objects) Release() {
+	if o.release != nil {
+		o.release()
+		o.release = nil
 	}
 }
 
-// Batcher micro-batches the messages the worker's goroutines pull from Kafka (worker.go:112-149) by frame size and operator set and
-// runs each batch as one JPEG job of the pool: image.Decode, every operator and jpeg.Encode on the GPUs, at-least-once semantics
-// unchanged (a message is committed by its goroutine only after its TaskResult arrived and the objects were saved).
-type Batcher struct {
-	Pool     *Pool
-	MaxBatch int           // files per job (256 is a good start: a part of ipx_plan_run_jpeg_jpeg)
-	MaxWait  time.Duration // how long the first message of a batch may wait for company (a few milliseconds)
-	Quality  int           // domain.DefaultJPEGQuality = 85 (task.go:57)
-
-	mu      sync.Mutex
-	pending map[batchKey][]*Task
-	timers  map[batchKey]*time.Timer
+// Process is the drop-in for (*ImageProcessor).Process on the JPEG path (image_processor.go:39-102): the object bytes GetOriginal
+// returned (worker.go:177-186), the frame size from the file's header (image.DecodeConfig) and the operators of the task.  It blocks
+// until the file's batch has run.  IsUnsupported(err): this file is not one the GPU path decodes (progressive CMYK, 4:1:1, ...) -- run the
+// reference's own image.Decode path for this message; its neighbours in the batch are not affected.
+func (b *Batcher) Process(file []byte, w, h int, o Ops) (*Objects, error) {
+	ops, free := b.p.ops(w, h, o)
+	defer free() // copied by ipx_batcher_submit
+	cfile := C.CBytes(file)
+	defer C.free(cfile) // read until ipx_batcher_wait has returned
+	fb := C.ipx_bytes{data: (*C.uint8_t)(cfile), len: C.size_t(len(file))}
+	var t C.ipx_batch_ticket
+	if err := call(func() C.int { return C.ipx_batcher_submit(b.c, &fb, &ops, &t) }); err != nil {
+		return nil, err
+	}
+	var res C.ipx_batch_result
+	if err := call(func() C.int { return C.ipx_batcher_wait(b.c, t, &res) }); err != nil {
+		C.ipx_batcher_release(b.c, t)
+		return nil, err
+	}
+	if Status(res.status) != OK {
+		C.ipx_batcher_release(b.c, t)
+		return nil, &Error{Status(res.status), "file not decodable on the GPU path"}
+	}
+	return &Objects{Resize: view(res.resize), Thumbnail: view(res.thumb), Watermark: view(res.wm),
+		release: func() { C.ipx_batcher_release(b.c, t) }}, nil
 }
 
-type batchKey struct {
-	w, h int
-	ops  string // a fingerprint of the operator parameters and the rasterised text
+// Stats: how the files were grouped so far.
+type BatcherStats struct{ Files, Batches, BySize, ByTimer, Largest, Pending int64 }
+
+func (b *Batcher) Stats() BatcherStats {
+	var s C.ipx_batcher_stats
+	C.ipx_batcher_get_stats(b.c, &s)
+	return BatcherStats{int64(s.files), int64(s.batches), int64(s.flushed_by_size), int64(s.flushed_by_timer), int64(s.largest_batch), int64(s.pending_files)}
 }
 
-// Submit hands one message over; the caller then waits on t.Result.
-func (b *Batcher) Submit(ctx context.Context, t *Task, opsFingerprint string) {
-	k := batchKey{t.W, t.H, opsFingerprint}
-	b.mu.Lock()
-	if b.pending == nil {
-		b.pending, b.timers = map[batchKey][]*Task{}, map[batchKey]*time.Timer{}
-	}
-	b.pending[k] = append(b.pending[k], t)
-	full := len(b.pending[k]) >= b.MaxBatch
-	if len(b.pending[k]) == 1 && !full {
-		b.timers[k] = time.AfterFunc(b.MaxWait, func() { b.flush(k) })
-	}
-	b.mu.Unlock()
-	if full {
-		b.flush(k)
-	}
-}
-
-func (b *Batcher) flush(k batchKey) {
-	b.mu.Lock()
-	batch := b.pending[k]
-	delete(b.pending, k)
-	if t := b.timers[k]; t != nil {
-		t.Stop()
-		delete(b.timers, k)
-	}
-	b.mu.Unlock()
-	if len(batch) == 0 {
-		return
-	}
-	files := make([][]byte, len(batch))
-	for i, t := range batch {
-		files[i] = t.File
-	}
-	job, err := b.Pool.SubmitJPEG(k.w, k.h, batch[0].Ops, files, b.Quality)
-	if err == nil {
-		err = job.Wait()
-	}
-	if err != nil { // the whole batch failed (e.g. a frame size beyond the GPU path): every message takes the CPU path
-		for _, t := range batch {
-			t.Result <- TaskResult{Err: err}
-		}
-		if job != nil {
-			job.Release()
-		}
-		return
-	}
-	var once sync.Once
-	left := int32(len(batch))
-	var lmu sync.Mutex
-	release := func() { // the blocks are shared by the batch: free them when the last message has saved its objects
-		lmu.Lock()
-		left--
-		last := left == 0
-		lmu.Unlock()
-		if last {
-			once.Do(job.Release)
-		}
-	}
-	for i, t := range batch {
-		if st := job.FileStatus(i); st != OK {
-			t.Result <- TaskResult{Err: &Error{st, "file not decodable on the GPU path"}, release: release}
-			continue
-		}
-		t.Result <- TaskResult{Resize: job.Resize(i), Thumbnail: job.Thumbnail(i), Watermark: job.Watermark(i), release: release}
-	}
-}
+var _ = unsafe.Pointer(nil)

@@ -800,3 +800,56 @@ def jpeg_quant_tables(quality):
     out = (C.c_uint8 * 128)()
     _check(lib().ipx_jpeg_quant_tables(int(quality), out))
     return np.frombuffer(out, np.uint8).reshape(2, 64).copy()
+
+
+class Batcher:
+    """Micro-batching of single uploads (ipx_batcher_*): what the goroutines of internal/worker/worker.go:112-149 would call, one file each.
+
+    submit(file bytes, frame size, operators) -> ticket; wait(ticket) -> (status, {operator: bytes | None}); the ticket is released by wait."""
+
+    def __init__(self, pool, max_batch=0, max_wait_us=0, quality=0):
+        self.pool = pool
+        cfg = _lib.BatcherConfig(max_batch, max_wait_us, quality)
+        h = C.c_void_p()
+        _check(lib().ipx_batcher_create(pool.handle, C.byref(cfg), C.byref(h)))
+        self.handle = h.value
+        self._keep = {}
+        self._mu = __import__("threading").Lock()
+
+    def close(self):
+        if self.handle:
+            lib().ipx_batcher_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def submit(self, data, sw, sh, resize=None, thumbnail=None, glyphs=None, col=(255, 255, 255, 127), watermark=False):
+        ops_, keep = Pool._ops(sw, sh, resize, thumbnail, glyphs, col, watermark)
+        buf = C.create_string_buffer(bytes(data), len(data))
+        fb = _lib.Bytes(C.cast(buf, C.c_void_p), len(data))
+        t = C.c_uint64()
+        _check(lib().ipx_batcher_submit(self.handle, C.byref(fb), C.byref(ops_), C.byref(t)))
+        with self._mu:
+            self._keep[t.value] = buf          # the file's bytes stay where they are until the ticket is released
+        return t.value
+
+    def wait(self, ticket):
+        res = _lib.BatchResult()
+        try:
+            _check(lib().ipx_batcher_wait(self.handle, ticket, C.byref(res)))
+            out = {k: (C.string_at(getattr(res, f).data, getattr(res, f).len) if getattr(res, f).data else None)
+                   for k, f in (("resize", "resize"), ("thumbnail", "thumb"), ("watermark", "wm"))}
+            return res.status, out
+        finally:
+            lib().ipx_batcher_release(self.handle, ticket)
+            with self._mu:
+                self._keep.pop(ticket, None)
+
+    def stats(self):
+        st = _lib.BatcherStats()
+        _check(lib().ipx_batcher_get_stats(self.handle, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in st._fields_}

@@ -107,6 +107,18 @@ class Job(C.Structure):
                 ("status", C.POINTER(C.c_int32))]
 
 
+class BatcherConfig(C.Structure):
+    _fields_ = [("max_batch", C.c_int32), ("max_wait_us", C.c_int32), ("quality", C.c_int32)]
+
+
+class BatchResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("resize", Bytes), ("thumb", Bytes), ("wm", Bytes)]
+
+
+class BatcherStats(C.Structure):
+    _fields_ = [(k, C.c_longlong) for k in ("files", "batches", "flushed_by_size", "flushed_by_timer", "largest_batch", "pending_files")]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _Z = C.c_size_t
@@ -215,6 +227,12 @@ SIGNATURES = {
     "ipx_pool_run_host": (_I, [_P, C.POINTER(Job), _I]),
     "ipx_plan_acquire": (_I, [_P, C.POINTER(PoolOps), C.POINTER(_P), C.POINTER(_I)]),
     "ipx_plan_release": (None, [_P, _P, _I]),
+    "ipx_batcher_create": (_I, [_P, C.POINTER(BatcherConfig), C.POINTER(_P)]),
+    "ipx_batcher_destroy": (None, [_P]),
+    "ipx_batcher_submit": (_I, [_P, C.POINTER(Bytes), C.POINTER(PoolOps), C.POINTER(C.c_uint64)]),
+    "ipx_batcher_wait": (_I, [_P, C.c_uint64, C.POINTER(BatchResult)]),
+    "ipx_batcher_release": (_I, [_P, C.c_uint64]),
+    "ipx_batcher_get_stats": (_I, [_P, C.POINTER(BatcherStats)]),
 }
 
 _lib = None

@@ -552,6 +552,41 @@ int ipx_job_release(ipx_pool *pool, ipx_ticket ticket);                         
 /* Synchronous convenience for pixel jobs: submit them all (mixed sizes welcome: the queue runs the largest first), wait, release. */
 int ipx_pool_run_host(ipx_pool *pool, const ipx_job *jobs, int n_jobs);
 
+/* ---- micro-batching of single uploads ---------------------------------------------------------------------------------------
+ * The reference pulls ONE message per goroutine (internal/worker/worker.go:112-149) from a channel of concurrency * 2 (:88); what
+ * turns those single files into GPU batches has to sit between the goroutines and the pool, and it sits here, below the ABI, so that
+ * its policy is the library's (and tested) rather than every binding's.  ipx_batcher_submit takes ONE uploaded JPEG file with the
+ * operators of its task (ops->sw x ops->sh = the frame size from the file's header, image.DecodeConfig) and returns a ticket at once;
+ * files are grouped by frame size and operator content (parameters, colour, every glyph's rectangle and mask bytes); a group goes to the
+ * pool as one IPX_JOB_JPEG when it holds max_batch files or when its first file has waited max_wait_us.  ipx_batcher_wait blocks until
+ * the ticket's group is done and fills the file's own result: status IPX_OK and three streams (NULL for operators the task did not ask
+ * for), or IPX_ERR_UNSUPPORTED / IPX_ERR_INVALID for a file the GPU path does not decode -- its neighbours are not affected, the worker
+ * runs its own image.Decode path for that message.  The streams live in blocks shared by the group: ipx_batcher_release hands a file's
+ * share back (call it after fileRepo.SaveProcessed, image_processor.go:76), the blocks go with the group's last file.  At-least-once
+ * delivery is unchanged: a goroutine commits its message only after its own ticket came back and its objects were saved.
+ * cgo rule: the file bytes must stay valid (C-allocated for Go) until ipx_batcher_wait or ipx_batcher_release has returned for the
+ * ticket; the operator description and its glyph masks are copied at submit.  Every entry is thread-safe. */
+typedef struct ipx_batcher ipx_batcher;
+typedef struct {
+    int32_t max_batch;      /* files per job; 0 = 256 (a part of ipx_plan_run_jpeg_jpeg) */
+    int32_t max_wait_us;    /* how long the first file of a group may wait for company; 0 = 2000 */
+    int32_t quality;        /* jpeg.Options.Quality of the outputs; 0 = 85 (domain.DefaultJPEGQuality, task.go:57) */
+} ipx_batcher_config;
+typedef uint64_t ipx_batch_ticket;
+typedef struct {
+    int32_t status;               /* of this file: IPX_OK, or why the worker has to decode it itself */
+    ipx_bytes resize, thumb, wm;  /* valid until ipx_batcher_release(ticket) */
+} ipx_batch_result;
+typedef struct {
+    long long files, batches, flushed_by_size, flushed_by_timer, largest_batch, pending_files;
+} ipx_batcher_stats;
+int ipx_batcher_create(ipx_pool *pool, const ipx_batcher_config *cfg, ipx_batcher **out);
+void ipx_batcher_destroy(ipx_batcher *b);     /* flushes what is pending, waits for it, frees what was not released */
+int ipx_batcher_submit(ipx_batcher *b, const ipx_bytes *file, const ipx_pool_ops *ops, ipx_batch_ticket *ticket);
+int ipx_batcher_wait(ipx_batcher *b, ipx_batch_ticket ticket, ipx_batch_result *res);
+int ipx_batcher_release(ipx_batcher *b, ipx_batch_ticket ticket);
+int ipx_batcher_get_stats(ipx_batcher *b, ipx_batcher_stats *out);
+
 #ifdef __cplusplus
 }
 #endif
