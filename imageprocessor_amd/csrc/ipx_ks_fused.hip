@@ -292,7 +292,7 @@ __device__ __forceinline__ void ks_column(const uint8_t *lds, const uint8_t *til
     }
 }
 
-template <int SRC, int NCH, int NACC, int B, bool OPQ>
+template <int SRC, int NCH, int NACC, int B, bool OPQ, bool RAG>
 __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
 {
     constexpr int CPLM = NACC == 2 ? kKsMaxCpl : 1;   // columns per lane: four accumulators per column leave registers for one (ks_fused_plan knows)
@@ -324,16 +324,18 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
                                                                         a.wm ? (a.sh - 1) * a.wm_stride + a.sw * 4 : 0, 0x00020000);
 
     // ---- what this thread stages per group: up to kKsMaxStage chunks of four pixels, and one dword of the row entries ----
-    int s_lds[kKsMaxStage], s_src[kKsMaxStage], s_wm[kKsMaxStage], s_row[kKsMaxStage], s_cx[kKsMaxStage];
+    int s_lds[kKsMaxStage], s_src[kKsMaxStage], s_wm[kKsMaxStage], s_row[kKsMaxStage], s_cx[kKsMaxStage], s_np[kKsMaxStage];
+    constexpr bool ragged = RAG && (SRC == KS_RGBA || SRC == KS_NRGBA);   // the frame's last chunk of a row holds fewer than four pixels (a.sw & 3)
 #pragma unroll
     for (int i = 0; i < kKsMaxStage; i++) {
         const int q = tid + i * a.nthreads;
         const int row = q / CH, ch = q - row * CH, x = st.t0 + ch * 4;
-        const bool in = q < B * CH && x < a.sw;          // (the frame width is a multiple of 4: whole chunks)
+        const bool in = q < B * CH && x < a.sw;
         s_row[i] = in ? row : -1;
         s_lds[i] = row * pitch + ch * CHB;
         s_src[i] = in ? row * a.sstride + x * SPX : kOOB;
         s_cx[i] = in ? (hs ? x >> 1 : x) : kOOB;         // chroma byte offset within its row
+        s_np[i] = !ragged ? 4 : in ? min(4, a.sw - x) : 0;   // pixels of the chunk inside the frame
         s_wm[i] = in && x >= st.c0 && x < st.c1 ? row * a.wm_stride + x * 4 : kOOB; // owned columns only (c0 and c1 are multiples of 4)
     }
     const int rk = tid / (B * RW), ri = tid - rk * (B * RW);                         // row entries: dword ri of output rk's B entries
@@ -395,7 +397,13 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
             const bool ok = s_row[i] >= 0 && y0 + s_row[i] < sg.r1;
             const int off = ok ? s_src[i] : kOOB;
             if (SRC == KS_RGBA || SRC == KS_NRGBA || SRC == KS_TAP64) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srs, off, y0 * a.sstride, 0);
+                u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srs, ragged && s_np[i] < 4 ? kOOB : off, y0 * a.sstride, 0);
+                if (ragged) {   // (uniform) the short chunk pixel by pixel: a 16-byte load would read past the row, and past the frame in its last row
+                    const int np = ok ? s_np[i] : 4;
+                    v.x |= __builtin_amdgcn_raw_buffer_load_b32(srs, np < 4 ? off : kOOB, y0 * a.sstride, 0);
+                    v.y |= __builtin_amdgcn_raw_buffer_load_b32(srs, np == 2 || np == 3 ? off + 4 : kOOB, y0 * a.sstride, 0);
+                    v.z |= __builtin_amdgcn_raw_buffer_load_b32(srs, np == 3 ? off + 8 : kOOB, y0 * a.sstride, 0);
+                }
                 stage[i].v[0] = v.x; stage[i].v[1] = v.y; stage[i].v[2] = v.z; stage[i].v[3] = v.w;
                 if (SRC == KS_TAP64) {
                     const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(srs, ok ? s_src[i] + 16 : kOOB, y0 * a.sstride, 0);
@@ -445,8 +453,21 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
             } else v = ks_convert<SRC>(stage[i], dst, hs);
             const int y = y0 + s_row[i];
             const bool live = y < sg.r1;
-            if (OPQ && live) bad |= ((v.x & v.y & v.z & v.w) >> 24) != 0xffu;
-            if (a.wm && live && y >= sg.r0) __builtin_amdgcn_raw_buffer_store_b128(v, wrs, s_wm[i], y0 * a.wm_stride, 0);
+            if (OPQ && live) {
+                uint32_t m = v.x & v.y & v.z & v.w;
+                if (ragged && s_np[i] < 4) m = v.x & (s_np[i] > 1 ? v.y : ~0u) & (s_np[i] > 2 ? v.z : ~0u);
+                bad |= (m >> 24) != 0xffu;
+            }
+            if (a.wm && live && y >= sg.r0) {
+                if (!ragged) __builtin_amdgcn_raw_buffer_store_b128(v, wrs, s_wm[i], y0 * a.wm_stride, 0);
+                else {
+                    const int np = s_np[i], wo = s_wm[i];
+                    __builtin_amdgcn_raw_buffer_store_b128(v, wrs, np == 4 ? wo : kOOB, y0 * a.wm_stride, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(v.x, wrs, np < 4 ? wo : kOOB, y0 * a.wm_stride, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(v.y, wrs, (np == 2 || np == 3) && wo != kOOB ? wo + 4 : kOOB, y0 * a.wm_stride, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(v.z, wrs, np == 3 && wo != kOOB ? wo + 8 : kOOB, y0 * a.wm_stride, 0);
+                }
+            }
         }
         if (rstage) ((uint32_t *)(lds + a.lds_rows + buf * rows_bytes))[rk * B * RW + ri] = rstg;
         KS_STAMP(1);                                     // registers -> LDS, watermark stores
@@ -498,17 +519,26 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     }
 }
 
-template <int SRC, int NCH, int NACC, bool OPQ>
-hipError_t launch_one(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hipStream_t s)
+template <int SRC, int NCH, int NACC, bool OPQ, bool RAG>
+hipError_t launch_rag(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hipStream_t s)
 {
     static KernelLaunchCache cache;
-    auto fn = ks_fused_kernel<SRC, NCH, NACC, kKsRows, OPQ>;
+    auto fn = ks_fused_kernel<SRC, NCH, NACC, kKsRows, OPQ, RAG>;
     int resident = 0;
     hipError_t e = cache.prepare((const void *)fn, p.nthreads, (size_t)p.lds_bytes, getenv("IPX_KS_DEBUG") ? &resident : nullptr);
     if (e != hipSuccess) return e;
     if (resident) fprintf(stderr, "[ipx ks] %d workgroups of %d threads with %d bytes of LDS resident per CU\n", resident, p.nthreads, p.lds_bytes);
     hipLaunchKernelGGL(fn, dim3(nitems), dim3(p.nthreads), (size_t)p.lds_bytes, s, a);
     return hipGetLastError();
+}
+
+template <int SRC, int NCH, int NACC, bool OPQ>
+hipError_t launch_one(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hipStream_t s)
+{
+    if constexpr (SRC == KS_RGBA || SRC == KS_NRGBA) {
+        if (a.sw & 3) return launch_rag<SRC, NCH, NACC, OPQ, true>(p, a, nitems, s);
+    }
+    return launch_rag<SRC, NCH, NACC, OPQ, false>(p, a, nitems, s);
 }
 
 template <int SRC, int NCH>
@@ -523,7 +553,6 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, int cus, hipStr
 {
     *matched = false;
     if (!p.ok || a.nframes <= 0) return hipSuccess;
-    if (a.sw & 3) return hipSuccess;                               // whole chunks of four pixels only
     // frames are addressed through buffer descriptors with aligned dword (chroma: word) loads
     if ((((uintptr_t)a.src) | (uintptr_t)a.sstride | a.src_fs) & 3) return hipSuccess;
     if (a.wm && ((((uintptr_t)a.wm) | (uintptr_t)a.wm_stride | a.wm_fs) & 3)) return hipSuccess;
@@ -543,6 +572,7 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, int cus, hipStr
     }
     default: return hipSuccess;
     }
+    if ((a.sw & 3) && src != KS_RGBA && src != KS_NRGBA) return hipSuccess;   // ragged rows: only where a pixel is a dword
     for (int i = 0; i < a.nout; i++) {                             // the tap kind of each output as a mode of this source type's tile
         KsFusedOut &o = a.o[i];
         o.aone = 0; o.mode = KS_TAP_PLAIN;

@@ -192,7 +192,10 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
     const char *ev = getenv("IPX_KS_STRIPS");
     const int first_strips = ev && atoi(ev) > 0 ? std::min(atoi(ev), 64) : 1;
     ev = getenv("IPX_KS_SPLIT_ROWS");
-    const int split_rows = ev && atoi(ev) > 0 ? atoi(ev) : kKsSplitRows;
+    // a segment re-stages the rows its first destination rows reach back to (as many as the vertical tap count): keep that a small share
+    int ytaps = 1;
+    for (int k = 0; k < 2; k++) if (sc[k]) ytaps = std::max(ytaps, sc[k]->hy->ntap);
+    const int split_rows = ev && atoi(ev) > 0 ? atoi(ev) : std::max(kKsSplitRows, 6 * ytaps);
     for (int nstrips = first_strips; nstrips <= 64; nstrips++) {
         const int wc = std::max(4, (((sw + nstrips - 1) / nstrips) + 3) & ~3);
         const int ns = (sw + wc - 1) / wc;
@@ -260,7 +263,9 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
                 if (!ok) continue;
                 double simd[4] = {0, 0, 0, 0};
                 for (int i = 0; i < nw; i++) { const int k = i < W[0] ? 0 : 1; simd[i & 3] += cpl[k] * percol[k]; }
-                const double T = std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3])) + 1e-3 * nw;
+                // (a workgroup whose waves do not divide by the four SIMDs loads them unevenly, and two such workgroups on a CU stack
+                // their surplus on the same SIMDs: measured 30 % slower with 6 waves than with 12)
+                const double T = (std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3])) + 1e-3 * nw) * (nw % 4 ? 1.25 : 1.0);
                 if (T < bestT) { bestT = T; bestW[0] = W[0]; bestW[1] = W[1]; bestcpl[0] = cpl[0]; bestcpl[1] = cpl[1]; }
             }
         }
