@@ -44,7 +44,7 @@ func (p *Plan) RunHostPaletted(n int, index, palettes, resizeOut, thumbOut, wmOu
 	})
 }
 
-// Deep is one of the image types that reach x/image's generic scale_RGBA_Image_* and image/draw's drawRGBA / drawCMYK.
+// Deep is one of the image types that reach x/image's generic scaleX_Image and image/draw's drawRGBA / drawCMYK.
 type Deep int
 
 const (

@@ -127,14 +127,15 @@ int ipx_stream_destroy(ipx_ctx *ctx, void *stream);
 /* ---- per-operation seam, host pointers, synchronous ------------------------------------------
  * Each call stages through a pinned lane, runs the HIP kernel and copies the result back. */
 
-/* xdraw.BiLinear.Scale(dst, dr, src, sr, op, nil) for *image.RGBA <- *image.RGBA:
- * resizeImage (resize.go:121-125) and both Scale calls of cropAndResize (thumbnail.go:128-131).
+/* xdraw.BiLinear.Scale(dst, dr, src, sr, op, nil) for *image.RGBA <- *image.RGBA -- BiLinear is x/image's tent Kernel run through its
+ * two-pass float64 kernel scaler (newDistrib, scaleX_RGBA, scaleY_RGBA_{Src,Over}), NOT the 2x2-tap ApproxBiLinear:
+ * resizeImage (resize.go:121-125) and both Scale calls of cropAndResize (thumbnail.go:128-131; equal sizes are not simplified to a Copy).
  * dst is read as well as written when op = IPX_OP_OVER.  sr must lie inside the source
  * (IPX_ERR_UNSUPPORTED otherwise: the reference would leave its typed fast path). */
 int ipx_scale_bilinear_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
                              const uint8_t *src, int sw, int sh, int sstride, ipx_rect sr, int op);
 /* draw.Draw / draw.DrawMask with a nil mask, *image.RGBA <- *image.RGBA: the full-frame copy of
- * addTextWatermark (watermark.go:90-92) and the equal-size Scale of thumbnail.go:128-130. */
+ * addTextWatermark (watermark.go:90-92). */
 int ipx_draw_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r,
                    const uint8_t *src, int sw, int sh, int sstride, int spx, int spy, int op);
 /* freetype.Context.DrawString's compositing (watermark.go:151): draw.DrawMask(dst, dr,
@@ -146,9 +147,9 @@ int ipx_composite_glyphs_rgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int d
 /* ---- source-type variants of the same helpers ---------------------------------
  * image.Decode hands the reference *image.NRGBA for PNGs with alpha and *image.YCbCr for JPEGs
  * (image_processor.go:47); resizeImage / cropAndResize / draw.Draw take them as they are.  These
- * entries do the same on the GPU: per-tap conversion inside the interpolator exactly as x/image/draw
- * does it (scale_RGBA_NRGBA_*, scale_RGBA_YCbCr4xx_Src), and image/draw's drawNRGBA{Src,Over} /
- * imageutil.DrawYCbCr for copies (the watermark's draw.Draw and the thumbnail's crop copy). */
+ * entries do the same on the GPU: per-tap conversion inside the kernel scaler exactly as x/image/draw
+ * does it (scaleX_NRGBA, scaleX_YCbCr4xx), and image/draw's drawNRGBA{Src,Over} /
+ * imageutil.DrawYCbCr for copies (the watermark's draw.Draw). */
 int ipx_scale_bilinear_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect dr,
                               const uint8_t *src, int sw, int sh, int sstride, ipx_rect sr, int op);
 int ipx_draw_nrgba8(ipx_ctx *ctx, uint8_t *dst, int dw, int dh, int dstride, ipx_rect r,
@@ -243,14 +244,14 @@ int ipx_plan_run_dev_ycbcr(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int
                            uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                            size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
 /* A batch of *image.NRGBA frames (PNGs with alpha): like the YCbCr batch, per operator as the reference's helpers treat the
- * type -- resize and the non-crop thumbnail interpolate 16-bit premultiplied taps (scale_RGBA_NRGBA_*), the crop thumbnail and
- * the watermark premultiply to RGBA8 first (drawNRGBAOver onto a zeroed frame / drawNRGBASrc).  One fused pass (band_nrgba_kernel) for
+ * type -- resize and the non-crop thumbnail weight 16-bit premultiplied taps (scaleX_NRGBA), the crop thumbnail scales its 8-bit
+ * crop copy and the watermark premultiplies to RGBA8 (drawNRGBASrc).  One pass (ks_fused_kernel) for
  * 16-byte aligned frames whose width is a multiple of 4, three kernels otherwise; the same bytes either way. */
 int ipx_plan_run_dev_nrgba(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const uint8_t *src, int sstride,
                            size_t src_frame_stride, uint8_t *resize_out, size_t resize_frame_stride, uint8_t *thumb_out,
                            size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
 /* A batch of *image.Gray frames (one-component JPEGs, grey PNGs): image/draw's drawGray and x/image's
- * scale_RGBA_Gray_Src both read a source pixel as (y, y, y, 0xff).  A YCbCr pixel with Cb = Cr = 128 converts to exactly that in both of
+ * scaleX_Gray both read a source pixel as (y, y, y, 0xff).  A YCbCr pixel with Cb = Cr = 128 converts to exactly that in both of
  * the reference's conversions, so the batch takes the planar pass with a constant chroma row (1 byte per pixel read); shapes that kernel
  * does not take are expanded to RGBA8 in HBM and take the RGBA pass.  The outputs are bit for bit the reference's either way. */
 int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const uint8_t *gray, int stride,
@@ -259,9 +260,9 @@ int ipx_plan_run_dev_gray(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int 
 /* A batch of *image.Paletted frames (what image.Decode returns for GIF uploads and palette PNGs, image_processor.go:47): one index
  * byte per pixel plus, per frame, 256 palette entries of 4 bytes (R, G, B, A), non-premultiplied, unused entries zero; palettes of
  * frame i at palettes + i*1024, in device memory, 4-byte aligned.  No routine of x/image or image/draw specialises on this type: the
- * generic ones (scale_RGBA_Image_*, drawRGBA) read Palette[i].RGBA() per tap.  For every entry the GIF and PNG decoders produce --
+ * generic ones (scaleX_Image, drawRGBA) read Palette[i].RGBA() per tap.  For every entry the GIF and PNG decoders produce --
  * opaque color.RGBA, the zero colour for a GIF's transparent index, color.NRGBA for a PNG's tRNS -- that is exactly the
- * premultiplication scale_RGBA_NRGBA_* / drawNRGBA* apply to (R, G, B, A), so the frames are expanded to NRGBA8 in HBM and take
+ * premultiplication scaleX_NRGBA / drawNRGBA* apply to (R, G, B, A), so the frames are expanded to NRGBA8 in HBM and take
  * ipx_plan_run_dev_nrgba; outputs are bit for bit the generic routines' (tests/test_sources_gpu.py against an oracle of those). */
 int ipx_plan_run_dev_paletted(ipx_ctx *ctx, void *stream, const ipx_plan *plan, int n, const uint8_t *index, int stride,
                               size_t frame_stride, const uint8_t *palettes, uint8_t *resize_out, size_t resize_frame_stride,
@@ -279,7 +280,7 @@ int ipx_plan_run_host_paletted(ipx_ctx *ctx, const ipx_plan *plan, int n, const 
                                size_t thumb_frame_stride, uint8_t *wm_out, size_t wm_frame_stride);
 /* The remaining image types image.Decode returns (image_processor.go:47) -- *image.NRGBA64, *image.RGBA64, *image.Gray16 from 16-bit
  * PNGs, *image.CMYK from four-component JPEGs ("deep" sources; SURVEY.md 8(f) N2 tail).  resizeImage (resize.go:121-125) takes them
- * through x/image's generic scale_RGBA_Image_{Src,Over}, which reads every tap as src.At(x, y).RGBA() at full 16-bit precision; the
+ * through x/image's generic scaleX_Image, which reads every tap as src.At(x, y).RGBA() at full 16-bit precision; the
  * crop copy (thumbnail.go:128-130) and draw.Draw (watermark.go:92) go through image/draw's drawRGBA (drawCMYK for CMYK) and keep the
  * top byte of the same value.  `src` is Go's Pix for the type: big-endian 16-bit channels R G B A (8 bytes per pixel; NRGBA64 not
  * premultiplied, RGBA64 premultiplied), big-endian Y (2 bytes), or C M Y K bytes (4); rows `sstride` bytes apart, 2-byte aligned
