@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random geometries through the fused band kernels (RGBA, NRGBA, Gray via flat chroma, Paletted, YCbCr at every subsampling ratio) and their fallbacks, against the
+"""Random geometries through the one-pass kernel scaler (RGBA, NRGBA, Gray, Paletted, YCbCr at every subsampling ratio, the deep types), random tilings of it and the per-output kernels, against the
 oracle's routines for the type: frame sizes (mostly multiples of 4: the fused kernels' domain), resize / thumbnail parameters, tile shapes.
 usage: tools/fuzz_sources.py [trials] [seed]"""
 import os
@@ -63,14 +63,19 @@ for trial in range(trials):
     _, tw0, th0 = oracle.thumb_geometry(w, h, *thumb)
     if nw < 1 or nh < 1 or tw0 < 1 or th0 < 1 or max(nw, nh, tw0, th0) > 65535:      # (beyond 65535 pixels a side: IPX_ERR_UNSUPPORTED by design)
         continue
-    for k in ("IPX_BLK_COLS", "IPX_BAND_ROWS", "IPX_CONV_BLK_COLS", "IPX_DEEP_DIRECT"):
+    knobs = ("IPX_KS_STRIPS", "IPX_KS_SPLIT_ROWS", "IPX_KS_SPLIT", "IPX_KS_SPEC", "IPX_FUSED")
+    for k in knobs:
         os.environ.pop(k, None)
     if rng.random() < 0.4:
-        os.environ["IPX_BLK_COLS"] = str(int(rng.choice([8, 64, 252, 1000, 2044])))
+        os.environ["IPX_KS_STRIPS"] = str(int(rng.choice([1, 2, 3, 5, 9])))          # tilings of the one-pass kernel (read when the plan is made)
     if rng.random() < 0.4:
-        os.environ["IPX_CONV_BLK_COLS"] = str(int(rng.choice([8, 64, 252, 508, 1020])))      # the converted-tile kernel's own tiling
-    if rng.random() < 0.3:
-        os.environ["IPX_BAND_ROWS"] = str(int(rng.choice([2, 4, 8])))
+        os.environ["IPX_KS_SPLIT_ROWS"] = str(int(rng.choice([4, 9, 17, 64, 200])))
+    if rng.random() < 0.5:
+        os.environ["IPX_KS_SPLIT"] = str(int(rng.integers(0, 2)))                     # one segment per frame / many
+    if rng.random() < 0.2:
+        os.environ["IPX_KS_SPEC"] = "0"                                               # the general four-channel kernel alone
+    if rng.random() < 0.1:
+        os.environ["IPX_FUSED"] = "0"                                                 # per-output kernels
     kind = ["nrgba", "gray", "paletted", "ycbcr", "rgba", "deep"][trial % 6]
     n = int(rng.integers(1, 4))
     glyphs = text_glyphs(w, h, n=5, width_px=min(60, w), height_px=min(20, h))
@@ -78,8 +83,6 @@ for trial in range(trials):
     plan = ctx.plan(w, h, resize=resize, thumbnail=thumb, watermark=gs)
     if kind == "deep":
         dk = int(rng.integers(0, 4))
-        if rng.random() < 0.3:
-            os.environ["IPX_DEEP_DIRECT"] = "0"                 # through the frames of taps
         if dk == oracle.DEEP_GRAY16:
             vals = rng.integers(0, 65536, (n, h, w), dtype=np.uint16)
         elif dk == oracle.DEEP_CMYK:
@@ -105,7 +108,8 @@ for trial in range(trials):
         srcs = [frames[i] for i in range(n)]
     elif kind == "rgba":
         frames = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)
-        frames[..., :3] = np.minimum(frames[..., :3], frames[..., 3:])      # premultiplied, as image.RGBA holds it
+        if rng.random() < 0.7:
+            frames[..., :3] = np.minimum(frames[..., :3], frames[..., 3:])      # premultiplied, as image.RGBA holds it (else: colours above alpha, clamped by the crop copy)
         if rng.random() < 0.5:
             frames[..., 3] = 255
         got = plan.run_host(frames)
@@ -129,7 +133,7 @@ for trial in range(trials):
             if key in got and not np.array_equal(got[key][i], wv):
                 bad += 1
                 print("MISMATCH trial", trial, kind, key, "frame", i, "%dx%d" % (w, h), "resize", resize, "thumb", thumb,
-                      {e: os.environ.get(e) for e in ("IPX_BLK_COLS", "IPX_BAND_ROWS")}, flush=True)
+                      {e: os.environ.get(e) for e in knobs}, flush=True)
                 break
     plan.close()
     gs.close()
