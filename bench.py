@@ -301,6 +301,8 @@ def e2e_legs(ipx, device, n, sw, sh, resize, reps, lanes=5):
     up = sw * sh * 4
     down = i.resize_bytes + i.thumb_bytes + i.wm_bytes
     legs = {}
+    # what the link gives pinned copies on this box, with the byte mix of a pixels-to-pixels call (8.3 MB up : 11.6 MB down per frame)
+    link = ctx.link_probe(64 * up, 64 * down, 3)
 
     def leg(name, call, up_b, down_b, note):
         call()     # warm: lane buffers, pinned blocks
@@ -312,8 +314,14 @@ def e2e_legs(ipx, device, n, sw, sh, resize, reps, lanes=5):
             ms.append((time.perf_counter() - t0) * 1e3)
         mean = sum(ms) / len(ms)
         d = down_b(res) if callable(down_b) else down_b
+        h2d, d2h = n * up_b / (mean * 1e-3) / 1e9, n * d / (mean * 1e-3) / 1e9
+        # the least time the link needs for the call's bytes (each direction alone at its rate, both together at their summed rate when
+        # they run side by side) over the time the call took: 1.0 = the call costs what its copies alone cost on this box
+        t_link = max(n * up_b / (link["up"] * 1e9), n * d / (link["down"] * 1e9),
+                     n * (up_b + d) / ((link["up_while_down"] + link["down_while_up"]) * 1e9))
+        frac = t_link / (mean * 1e-3)
         legs[name] = {"images_per_s": round(n / (mean * 1e-3), 1), "ms_per_call": [round(v, 2) for v in ms], "frames_per_call": n,
-                      "h2d_GBps": round(n * up_b / (mean * 1e-3) / 1e9, 2), "d2h_GBps": round(n * d / (mean * 1e-3) / 1e9, 2),
+                      "h2d_GBps": round(h2d, 2), "d2h_GBps": round(d2h, 2), "frac_of_link": round(frac, 3),
                       "bytes_up_per_image": int(up_b), "bytes_down_per_image": int(d), "what": note}
         return res
 
@@ -337,7 +345,51 @@ def e2e_legs(ipx, device, n, sw, sh, resize, reps, lanes=5):
     plan.close()
     gs.close()
     ctx.close()
-    return {"workload": "%d x %dx%d per call, photograph-like frames, %d lanes, pinned host memory" % (n, sw, sh, lanes), "legs": legs}
+    legs["pool_pixels_to_pixels"] = pool_leg(ipx, n, sw, sh, resize, reps, pool)
+    return {"workload": "%d x %dx%d per call, photograph-like frames, %d lanes, pinned host memory" % (n, sw, sh, lanes),
+            "link_GBps": dict(link, what="ipx_link_probe: 64 frames' worth of pinned memory up (8.3 MB each) and down (11.6 MB each), alone and at once, best of 3; copies in 32 MiB pieces, one stream per direction; at once = the better of copy engine / kernel stores for the way down"),
+            "legs": legs}
+
+
+def pool_leg(ipx, n, sw, sh, resize, reps, frames4):
+    """The product's own multi-device path: ONE process, ipx_pool_create over every visible device, the batch as one pixel job per device
+    through the job API (what a Go worker binds; on an 8-GPU node this leg is the 8-GPU run).  Frames and outputs in pinned memory next
+    to each slot's GPU."""
+    from helpers import DEFAULT_COL, text_glyphs
+    ndev = max(1, ipx.device_count())
+    glyphs = text_glyphs(sw, sh)
+    with ipx.Pool(devices=tuple(range(ndev))) as pool:
+        per = (n + ndev - 1) // ndev
+        jobs, keep = [], []
+        tmp = ipx.Context(device=0)
+        info = tmp.plan(sw, sh, resize=resize, thumbnail=(200, True), watermark=True).info
+        rb, tb = (info.resize_h, info.resize_w, 4), (info.thumb_h, info.thumb_w, 4)
+        tmp.close()
+        for d in range(ndev):
+            src = pool.host_alloc(d, (per, sh, sw, 4))
+            for k in range(per):
+                src[k] = frames4[k % 4]
+            outs = (pool.host_alloc(d, (per,) + rb), pool.host_alloc(d, (per,) + tb), pool.host_alloc(d, (per, sh, sw, 4)))
+            keep.append((src,) + outs)
+            jobs.append(dict(frames=src, resize=resize, thumbnail=(200, True), glyphs=glyphs, col=DEFAULT_COL, out=dict(resize=outs[0], thumbnail=outs[1], watermark=outs[2])))
+        def run():
+            tickets = [pool.submit(j["frames"], resize=j["resize"], thumbnail=j["thumbnail"], glyphs=j["glyphs"], col=j["col"], out=j["out"]) for j in jobs]
+            for t in tickets:
+                t.wait()
+        run()                                                 # warm: plans, glyph sets, lane buffers
+        before = [pool.frames_done(sl) for sl in range(pool.slots())]
+        ms = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            run()
+            ms.append((time.perf_counter() - t0) * 1e3)
+        done = [pool.frames_done(sl) - b for sl, b in zip(range(pool.slots()), before)]
+        for arrs in keep:
+            for a in arrs:
+                pool.host_free(a)
+    mean = sum(ms) / len(ms)
+    return {"images_per_s": round(per * ndev / (mean * 1e-3), 1), "ms_per_call": [round(v, 2) for v in ms], "frames_per_call": per * ndev, "devices": ndev,
+            "frames_done_per_slot": done, "what": "ipx_pool_* / ipx_job_submit + ipx_job_wait: one process, one context per visible device, one largest-first queue; RGBA8 frames in, the three RGBA8 outputs back"}
 
 
 def main():

@@ -441,6 +441,12 @@ class Context:
     def copy_d2d(self, dst_ptr, src_ptr, nbytes):
         _check(lib().ipx_memcpy_d2d(self.handle, dst_ptr, src_ptr, nbytes))
 
+    def link_probe(self, up_bytes, down_bytes, reps=3):
+        """-> {"up", "down", "up_while_down", "down_while_up"} in GB/s: what pinned copies get from the host link on this box"""
+        out = (C.c_double * 4)()
+        _check(lib().ipx_link_probe(self.handle, int(up_bytes), int(down_bytes), int(reps), C.byref(out)))
+        return {"up": round(out[0], 2), "down": round(out[1], 2), "up_while_down": round(out[2], 2), "down_while_up": round(out[3], 2)}
+
     def stream_copy(self, dst_ptr, src_ptr, nbytes, stream=None):
         """A plain streaming copy kernel: what this box's HBM gives a copy (bench.py's copy_ceiling)."""
         _check(lib().ipx_stream_copy(self.handle, stream, dst_ptr, src_ptr, nbytes))

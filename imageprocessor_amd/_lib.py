@@ -227,6 +227,7 @@ SIGNATURES = {
     "ipx_pool_run_host": (_I, [_P, C.POINTER(Job), _I]),
     "ipx_plan_acquire": (_I, [_P, C.POINTER(PoolOps), C.POINTER(_P), C.POINTER(_I)]),
     "ipx_plan_release": (None, [_P, _P, _I]),
+    "ipx_link_probe": (_I, [_P, _Z, _Z, _I, C.POINTER(C.c_double * 4)]),
     "ipx_batcher_create": (_I, [_P, C.POINTER(BatcherConfig), C.POINTER(_P)]),
     "ipx_batcher_destroy": (None, [_P]),
     "ipx_batcher_submit": (_I, [_P, C.POINTER(Bytes), C.POINTER(PoolOps), C.POINTER(C.c_uint64)]),

@@ -61,6 +61,10 @@ struct ChunkLess {   // the most expensive chunk first; submission order among e
 struct Slot {
     int device = 0;
     ipx_ctx *ctx = nullptr;
+    // every feeder of the slot uploads on this one stream: one copy engine at a time per direction is what the host link moves most
+    // with (tools/link_streams.py: 1 stream up + 1 down 96 GB/s summed, 3 + 3 74); made by the slot's first feeder
+    std::mutex up_mu;
+    hipStream_t up_stream = nullptr;
 };
 
 }  // namespace
@@ -79,38 +83,6 @@ struct ipx_pool {
 };
 
 namespace {
-
-// CPUs local to a device's PCIe root, intersected with what the process may use.  Best effort: nothing happens if sysfs says nothing.
-void bind_near_device(int device)
-{
-    if (env_int("IPX_POOL_NUMA", 1) == 0) return;
-    char bus[32] = {0};
-    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
-    for (char *c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);
-    char path[128];
-    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
-    FILE *f = fopen(path, "r");
-    if (!f) return;
-    char line[4096] = {0};
-    const bool ok = fgets(line, sizeof line, f) != nullptr;
-    fclose(f);
-    if (!ok) return;
-    cpu_set_t allowed, want;
-    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
-    CPU_ZERO(&want);
-    for (char *p = line; *p;) {            // "0-31,64-95"
-        char *e = nullptr;
-        long a = strtol(p, &e, 10);
-        if (e == p) break;
-        long b = a;
-        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
-        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
-            if (CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &want);
-        p = *e == ',' ? e + 1 : e;
-        if (*e != ',') break;
-    }
-    if (CPU_COUNT(&want) > 0) (void)sched_setaffinity(0, sizeof want, &want);
-}
 
 // bytes per pixel of a pixel job's frames; 0 for a kind that is none
 int pixel_job_bpp(int kind)
@@ -160,6 +132,7 @@ int copy_ops(const ipx_pool_ops &in, PoolOps *out)
 
 struct Feeder {
     hipStream_t stream = nullptr;
+    hipEvent_t uploaded = nullptr;
     uint8_t *dev = nullptr;
     size_t dev_bytes = 0;
 };
@@ -185,26 +158,48 @@ int run_pixel_chunk(Slot &s, Feeder &f, const JobState &j, ipx_plan *plan, int i
     const size_t fsrc = align256((size_t)sw * sh * bpp);
     const size_t fres = q.resize_out ? align256(info.resize_bytes) : 0, fth = q.thumb_out ? align256(info.thumb_bytes) : 0;
     const size_t fwm = q.wm_out ? align256(info.wm_bytes) : 0;
-    rc = feeder_reserve(f, (fsrc + fres + fth + fwm) * (size_t)m + 256);
+    // outputs in pinned memory are written by the kernels themselves, over the link (run_host_packed in ipx_runtime.hip has the why)
+    uint8_t *vres = nullptr, *vth = nullptr, *vwm = nullptr;
+    bool direct = env_int("IPX_HOST_DIRECT", 1) != 0;
+    if (direct && fres) direct = (vres = pinned_device_view(q.resize_out + (size_t)i0 * q.resize_frame_stride, q.resize_frame_stride * (m - 1) + info.resize_bytes)) != nullptr;
+    if (direct && fth) direct = (vth = pinned_device_view(q.thumb_out + (size_t)i0 * q.thumb_frame_stride, q.thumb_frame_stride * (m - 1) + info.thumb_bytes)) != nullptr;
+    if (direct && fwm) direct = (vwm = pinned_device_view(q.wm_out + (size_t)i0 * q.wm_frame_stride, q.wm_frame_stride * (m - 1) + info.wm_bytes)) != nullptr;
+    rc = feeder_reserve(f, (fsrc + (direct ? 0 : fres + fth + fwm)) * (size_t)m + 256);
     if (rc) return rc;
     uint8_t *dsrc = f.dev, *dres = fres ? dsrc + fsrc * m : nullptr, *dth = fth ? dsrc + (fsrc + fres) * m : nullptr;
     uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * m : nullptr;
+    size_t sres = fres, sth = fth, swm = fwm;
+    if (direct) {
+        dres = vres; sres = q.resize_frame_stride;
+        dth = vth; sth = q.thumb_frame_stride;
+        dwm = vwm; swm = q.wm_frame_stride;
+    }
     hipError_t e = hipSuccess;
-    for (int i = 0; i < m && e == hipSuccess; i++)
+    // direct outputs: the upload goes on the slot's shared stream and the feeder's own stream (kernels) waits for it
+    const hipStream_t up = direct && s.up_stream && f.uploaded ? s.up_stream : f.stream;
+    if (q.sstride == sw * bpp)
+        for (int i = 0; i < m && e == hipSuccess; i++)
+            e = hipMemcpyAsync(dsrc + fsrc * i, q.src + (size_t)(i0 + i) * q.src_frame_stride, (size_t)sw * sh * bpp, hipMemcpyHostToDevice, up);
+    else for (int i = 0; i < m && e == hipSuccess; i++)
         e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * bpp, q.src + (size_t)(i0 + i) * q.src_frame_stride, q.sstride, (size_t)sw * bpp, sh,
-                             hipMemcpyHostToDevice, f.stream);
+                             hipMemcpyHostToDevice, up);
+    if (e == hipSuccess && up != f.stream) {
+        e = hipEventRecord(f.uploaded, up);
+        if (e == hipSuccess) e = hipStreamWaitEvent(f.stream, f.uploaded, 0);
+    }
+    if (e != hipSuccess && up != f.stream) (void)hipStreamSynchronize(up);
     if (e != hipSuccess) { (void)hipStreamSynchronize(f.stream); set_error("pool: upload failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
     switch (q.kind) {
-    case IPX_JOB_RGBA8: rc = ipx_plan_run_dev(s.ctx, f.stream, plan, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm); break;
-    case IPX_JOB_NRGBA8: rc = ipx_plan_run_dev_nrgba(s.ctx, f.stream, plan, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm); break;
-    case IPX_JOB_GRAY8: rc = ipx_plan_run_dev_gray(s.ctx, f.stream, plan, m, dsrc, sw, fsrc, dres, fres, dth, fth, dwm, fwm); break;
+    case IPX_JOB_RGBA8: rc = ipx_plan_run_dev(s.ctx, f.stream, plan, m, dsrc, sw * 4, fsrc, dres, sres, dth, sth, dwm, swm); break;
+    case IPX_JOB_NRGBA8: rc = ipx_plan_run_dev_nrgba(s.ctx, f.stream, plan, m, dsrc, sw * 4, fsrc, dres, sres, dth, sth, dwm, swm); break;
+    case IPX_JOB_GRAY8: rc = ipx_plan_run_dev_gray(s.ctx, f.stream, plan, m, dsrc, sw, fsrc, dres, sres, dth, sth, dwm, swm); break;
     default:
         rc = ipx_plan_run_dev_deep(s.ctx, f.stream, plan, m, q.kind == IPX_JOB_NRGBA64 ? IPX_DEEP_NRGBA64 : q.kind == IPX_JOB_RGBA64 ? IPX_DEEP_RGBA64 :
-                                   q.kind == IPX_JOB_GRAY16 ? IPX_DEEP_GRAY16 : IPX_DEEP_CMYK, dsrc, sw * bpp, fsrc, dres, fres, dth, fth, dwm, fwm);
+                                   q.kind == IPX_JOB_GRAY16 ? IPX_DEEP_GRAY16 : IPX_DEEP_CMYK, dsrc, sw * bpp, fsrc, dres, sres, dth, sth, dwm, swm);
         break;
     }
     if (rc) { (void)hipStreamSynchronize(f.stream); return rc; }
-    for (int i = 0; i < m && e == hipSuccess; i++) {
+    for (int i = 0; i < m && e == hipSuccess && !direct; i++) {
         if (dres && info.resize_bytes) e = hipMemcpyAsync(q.resize_out + (size_t)(i0 + i) * q.resize_frame_stride, dres + fres * i, info.resize_bytes, hipMemcpyDeviceToHost, f.stream);
         if (e == hipSuccess && dth && info.thumb_bytes) e = hipMemcpyAsync(q.thumb_out + (size_t)(i0 + i) * q.thumb_frame_stride, dth + fth * i, info.thumb_bytes, hipMemcpyDeviceToHost, f.stream);
         if (e == hipSuccess && dwm && info.wm_bytes) e = hipMemcpyAsync(q.wm_out + (size_t)(i0 + i) * q.wm_frame_stride, dwm + fwm * i, info.wm_bytes, hipMemcpyDeviceToHost, f.stream);
@@ -247,6 +242,11 @@ void feeder_main(ipx_pool *pool, int slot_index)
     bind_near_device(s.device);
     Feeder f;
     if (hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); f.stream = nullptr; }
+    if (hipEventCreateWithFlags(&f.uploaded, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); f.uploaded = nullptr; }
+    {
+        std::lock_guard<std::mutex> lk(s.up_mu);
+        if (!s.up_stream && hipStreamCreateWithFlags(&s.up_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); s.up_stream = nullptr; }
+    }
     for (;;) {
         Chunk c;
         {
@@ -273,6 +273,7 @@ void feeder_main(ipx_pool *pool, int slot_index)
     }
     if (f.dev) (void)hipFree(f.dev);
     if (f.stream) { (void)hipStreamSynchronize(f.stream); (void)hipStreamDestroy(f.stream); }
+    if (f.uploaded) (void)hipEventDestroy(f.uploaded);
 }
 
 int job_check(const ipx_job *job)
@@ -338,7 +339,10 @@ void ipx_pool_destroy(ipx_pool *pool)
     for (auto &t : pool->feeders) t.join();      // feeders drain the queue before they leave
     for (auto &kv : pool->jobs)
         for (size_t i = 0; i < kv.second->results.size(); i++) ipx_jpeg_result_free(kv.second->result_ctx[i], kv.second->results[i]);
-    for (auto &s : pool->slots) ipx_destroy(s->ctx);     // (with the plans its cache holds)
+    for (auto &s : pool->slots) {
+        if (s->up_stream) { (void)hipSetDevice(s->device); (void)hipStreamSynchronize(s->up_stream); (void)hipStreamDestroy(s->up_stream); }
+        ipx_destroy(s->ctx);     // (with the plans its cache holds)
+    }
     delete pool;
 }
 
@@ -356,14 +360,10 @@ void *ipx_pool_host_alloc(ipx_pool *pool, int slot, size_t bytes) try
     Slot &s = *pool->slots[slot];
     void *p = nullptr;
     std::string text;
-    std::thread t([&] {      // allocate and first-touch on a thread bound next to the slot's GPU
-        (void)hipSetDevice(s.device);
-        bind_near_device(s.device);
-        p = ipx_host_alloc(s.ctx, bytes);
-        if (p) memset(p, 0, bytes);
-        else text = ipx_last_error();
-    });
-    t.join();
+    // (ipx_host_alloc itself pins fresh blocks on a thread bound next to the context's GPU)
+    p = ipx_host_alloc(s.ctx, bytes);
+    if (p) memset(p, 0, bytes);
+    else text = ipx_last_error();
     if (!p) set_error("%s", text.c_str());
     return p;
 }

@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -314,6 +315,7 @@ void ipx_destroy(ipx_ctx *c)
         if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
         if (l.dev) (void)hipFree(l.dev);
         if (l.pin) (void)hipHostFree(l.pin);
+        for (auto &ev : l.ev) if (ev) (void)hipEventDestroy(ev);
         if (l.dec) (void)hipFree(l.dec);
         if (l.flag) (void)hipFree(l.flag);
     }
@@ -344,10 +346,22 @@ void *ipx_host_alloc(ipx_ctx *ctx, size_t bytes)
             return p;
         }
     }
-    (void)hipSetDevice(ctx->device);
     void *p = nullptr;
     if (getenv("IPX_DEBUG")) fprintf(stderr, "[ipx] pinning %zu MiB (cache holds %zu MiB in %zu blocks)\n", want >> 20, ctx->host_cached >> 20, ctx->host_free_blocks.size());
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    // A fresh block is pinned on a thread bound to the CPUs next to the context's GPU (sysfs local_cpulist), so that its pages land on
+    // that NUMA node: measured on the driver's two-socket box, copies from and to such blocks move 80 GB/s both directions summed against
+    // 57 GB/s for blocks pinned wherever the calling thread happened to run (bench.py's pool leg against its context leg, round 3).
+    // Rare: freed blocks are cached (below).  IPX_POOL_NUMA=0 switches the binding off.
+    hipError_t e = hipSuccess;
+    {
+        std::thread t([&] {
+            (void)hipSetDevice(ctx->device);
+            bind_near_device(ctx->device);
+            e = hipHostMalloc(&p, want, hipHostMallocDefault);
+            if (e == hipSuccess && env_int("IPX_HOST_TOUCH", 1)) memset(p, 0, want);     // first touch, where the pages are to live
+        });
+        t.join();
+    }
     if (e != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); return nullptr; }
     std::lock_guard<std::mutex> lk(ctx->host_mu);
     ctx->host_size[p] = want;
@@ -445,6 +459,79 @@ int ipx_stream_copy(ipx_ctx *ctx, void *stream, void *dst_dev, const void *src_d
     IPX_ENTER(ctx);
     if (((uintptr_t)dst_dev | (uintptr_t)src_dev | bytes) & 15) { set_error("ipx_stream_copy: pointers and size must be multiples of 16"); return IPX_ERR_INVALID; }
     if (bytes) IPX_HIP(launch_stream_copy(dst_dev, src_dev, bytes, stream ? (hipStream_t)stream : ctx->stream));
+    return IPX_OK;
+}
+IPX_CATCH_STATUS
+
+// What the host link gives pinned copies on this box, in this process: one direction alone, and both at once with the byte mix of a
+// call (bench.py holds the PCIe-inclusive legs against it).  Not part of the path.
+}  // extern "C"
+namespace {
+__global__ void link_store_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+extern "C" {
+
+int ipx_link_probe(ipx_ctx *ctx, size_t up_bytes, size_t down_bytes, int reps, double out_gbps[4]) try
+{
+    IPX_ENTER(ctx);
+    if (!out_gbps || !up_bytes || !down_bytes || (down_bytes & 15) || reps < 1) { set_error("ipx_link_probe: bad argument"); return IPX_ERR_INVALID; }
+    uint8_t *hu = (uint8_t *)ipx_host_alloc(ctx, up_bytes), *hd = (uint8_t *)ipx_host_alloc(ctx, down_bytes);
+    uint8_t *du = nullptr, *dd = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hu && hd ? hipSuccess : hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMalloc((void **)&du, up_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&dd, down_bytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) { memset(hu, 1, up_bytes); e = hipMemset(dd, 2, down_bytes); }
+    uint8_t *hd_dev = e == hipSuccess ? pinned_device_view(hd, down_bytes) : nullptr;
+    const size_t piece = (size_t)std::max(1, env_int("IPX_PROBE_CHUNK_MB", 32)) << 20;
+    // down_by_kernel: the download as a kernel's stores into the pinned block (how run_host_packed delivers outputs) instead of a copy
+    auto timed = [&](bool up, bool down, bool down_by_kernel, double *gb_up, double *gb_down) {
+        double best = 1e30;
+        for (int r = 0; r < reps + 1 && e == hipSuccess; r++) {           // (the first repetition warms the path)
+            const auto t0 = std::chrono::steady_clock::now();
+            if (down && down_by_kernel) {
+                hipLaunchKernelGGL(link_store_kernel, dim3(512), dim3(256), 0, s2, (uint4 *)hd_dev, (const uint4 *)dd, down_bytes / 16);
+                e = hipGetLastError();
+            }
+            // copies go in pieces, enqueued alternately: the runtime picks a copy engine per stream when the stream's first copy is
+            // enqueued, the lowest one idle at that moment, and two large copies enqueued together land on the same engine
+            for (size_t o = 0; e == hipSuccess && (o < up_bytes || o < down_bytes); o += piece) {
+                if (up && o < up_bytes) e = hipMemcpyAsync(du + o, hu + o, std::min(piece, up_bytes - o), hipMemcpyHostToDevice, s1);
+                if (down && !down_by_kernel && o < down_bytes && e == hipSuccess) e = hipMemcpyAsync(hd + o, dd + o, std::min(piece, down_bytes - o), hipMemcpyDeviceToHost, s2);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s1);
+            if (e == hipSuccess) e = hipStreamSynchronize(s2);
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (r > 0) best = std::min(best, sec);
+        }
+        if (gb_up) *gb_up = up ? up_bytes / best / 1e9 : 0;
+        if (gb_down) *gb_down = down ? down_bytes / best / 1e9 : 0;
+    };
+    if (e == hipSuccess) timed(true, false, false, &out_gbps[0], nullptr);
+    if (e == hipSuccess) timed(false, true, false, nullptr, &out_gbps[1]);
+    if (e == hipSuccess) timed(true, true, false, &out_gbps[2], &out_gbps[3]);
+    if (e == hipSuccess && hd_dev) {        // both at once, the better of the two ways down
+        double u = 0, d = 0;
+        timed(true, true, true, &u, &d);
+        if (u + d > out_gbps[2] + out_gbps[3]) { out_gbps[2] = u; out_gbps[3] = d; }
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (s1) (void)hipStreamDestroy(s1);
+    if (s2) (void)hipStreamDestroy(s2);
+    if (du) (void)hipFree(du);
+    if (dd) (void)hipFree(dd);
+    if (hu) (void)ipx_host_free(ctx, hu);
+    if (hd) (void)ipx_host_free(ctx, hd);
+    if (e != hipSuccess) { set_error("ipx_link_probe: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? IPX_ERR_NOMEM : IPX_ERR_HIP; }
     return IPX_OK;
 }
 IPX_CATCH_STATUS
@@ -1279,52 +1366,99 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
             bounce = l.pin != nullptr;
         }
     }
+    // The host link moves both directions at once only when uploads and downloads sit on streams of their own AND go in pieces: the
+    // runtime picks a copy engine per hipMemcpyAsync, and two large copies enqueued together share one (tools/link_streams.py,
+    // ipx_link_probe: 2 x 512 MiB as single copies 28.7 + 28.7 GB/s, in 32 MiB pieces 47.9 + 47.9).  So the call is a three-stage
+    // pipeline over the lanes it took: every upload on the first lane's stream, every kernel on the third's, every download on the
+    // second's, the lanes' scratch buffers as the slots chunks rotate through, events between the stages.
+    const size_t piece = (size_t)std::max(1, env_int("IPX_COPY_PIECE_MB", 32)) << 20;
+    auto copy_pieces = [&](uint8_t *dst, const uint8_t *from, size_t bytes, hipMemcpyKind k, hipStream_t st) {
+        hipError_t r = hipSuccess;
+        for (size_t o = 0; o < bytes && r == hipSuccess; o += piece) r = hipMemcpyAsync(dst + o, from + o, std::min(piece, bytes - o), k, st);
+        return r;
+    };
     auto d2h = [&](uint8_t *host, size_t host_stride, const uint8_t *dev, size_t dev_stride, size_t bytes, int i0, int m,
                    hipStream_t st) {
         if (!dev || !bytes) return hipSuccess;
-        if (host_stride == dev_stride)  // tight on both sides: one copy for the chunk
-            return hipMemcpyAsync(host + (size_t)i0 * host_stride, dev, dev_stride * (m - 1) + bytes, hipMemcpyDeviceToHost, st);
+        if (host_stride == dev_stride)  // tight on both sides: the chunk as one run of bytes
+            return copy_pieces(host + (size_t)i0 * host_stride, dev, dev_stride * (m - 1) + bytes, hipMemcpyDeviceToHost, st);
         hipError_t r = hipSuccess;
         for (int i = 0; i < m && r == hipSuccess; i++)
             r = hipMemcpyAsync(host + (size_t)(i0 + i) * host_stride, dev + dev_stride * i, bytes, hipMemcpyDeviceToHost, st);
         return r;
     };
+    // Outputs in pinned memory (hipHostMalloc / hipHostRegister: mapped into the device's address space) are written by the kernels
+    // themselves, over the link, instead of into the lane's scratch and from there by a copy engine: uploads are then the only copies
+    // in flight, so the two directions cannot land on one engine, and a chunk has two stages instead of three.
+    uint8_t *vres = nullptr, *vth = nullptr, *vwm = nullptr;
+    bool direct = !bounce && env_int("IPX_HOST_DIRECT", 1) != 0;
+    if (direct && resize_out) direct = (vres = pinned_device_view(resize_out, resize_frame_stride * (n - 1) + pl->info.resize_bytes)) != nullptr;
+    if (direct && thumb_out) direct = (vth = pinned_device_view(thumb_out, thumb_frame_stride * (n - 1) + pl->info.thumb_bytes)) != nullptr;
+    if (direct && wm_out) direct = (vwm = pinned_device_view(wm_out, wm_frame_stride * (n - 1) + pl->info.wm_bytes)) != nullptr;
+    const size_t S = lanes.size();
+    const hipStream_t s_up = lanes[0]->stream, s_down = lanes[S > 1 ? 1 : 0]->stream, s_run = lanes[S > 2 ? 2 : 0]->stream;
+    const bool staged = S > 1 && env_int("IPX_HOST_STAGED", 1) != 0;
+    if (staged)
+        for (auto *l : lanes)
+            for (auto &ev : l->ev)
+                if (!ev && e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     for (int i0 = 0, c = 0; !rc && e == hipSuccess && i0 < n; i0 += chunk, c++) {
-        Lane &l = *lanes[c % lanes.size()];
+        Lane &l = *lanes[c % S];
+        const hipStream_t up = staged ? s_up : l.stream, run = staged ? s_run : l.stream, down = staged ? s_down : l.stream;
         const int m = std::min(chunk, n - i0);
         uint8_t *dsrc = (uint8_t *)(((uintptr_t)l.dev + 255) & ~(uintptr_t)255);
         uint8_t *dres = fres ? dsrc + fsrc * chunk : nullptr;
         uint8_t *dth = fth ? dsrc + (fsrc + fres) * chunk : nullptr;
         uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * chunk : nullptr;
         uint8_t *dpal = fpal ? dsrc + (fsrc + fres + fth + fwm) * chunk : nullptr;
-        // the lane's stream serialises reuse of its scratch: chunk c waits for chunk c - lanes
+        size_t sres = fres, sth = fth, swm = fwm;
+        if (direct) {
+            dres = fres ? vres + (size_t)i0 * resize_frame_stride : nullptr; sres = resize_frame_stride;
+            dth = fth ? vth + (size_t)i0 * thumb_frame_stride : nullptr; sth = thumb_frame_stride;
+            dwm = fwm ? vwm + (size_t)i0 * wm_frame_stride : nullptr; swm = wm_frame_stride;
+        }
+        // reuse of a lane's scratch: chunk c waits until chunk c - S has been downloaded (stream order when one stream does it all)
+        if (staged && c >= (int)S) e = hipStreamWaitEvent(up, l.ev[2], 0);
+        if (e != hipSuccess) break;
         if (bounce) {
             for (int y = 0; y < sh; y++) memcpy(l.pin + (size_t)y * sw * bpp, src + (size_t)y * sstride, (size_t)sw * bpp);
-            e = hipMemcpyAsync(dsrc, l.pin, (size_t)sw * sh * bpp, hipMemcpyHostToDevice, l.stream);
+            e = hipMemcpyAsync(dsrc, l.pin, (size_t)sw * sh * bpp, hipMemcpyHostToDevice, up);
         } else if (src_tight) {
-            e = hipMemcpyAsync(dsrc, src + (size_t)i0 * src_frame_stride, fsrc * m, hipMemcpyHostToDevice, l.stream);
+            e = copy_pieces(dsrc, src + (size_t)i0 * src_frame_stride, fsrc * m, hipMemcpyHostToDevice, up);
         } else {
             for (int i = 0; i < m && e == hipSuccess; i++)
                 e = hipMemcpy2DAsync(dsrc + fsrc * i, (size_t)sw * bpp, src + (size_t)(i0 + i) * src_frame_stride, sstride,
-                                     (size_t)sw * bpp, sh, hipMemcpyHostToDevice, l.stream);
+                                     (size_t)sw * bpp, sh, hipMemcpyHostToDevice, up);
         }
-        if (e == hipSuccess && dpal) e = hipMemcpyAsync(dpal, palettes + (size_t)i0 * 1024, (size_t)m * 1024, hipMemcpyHostToDevice, l.stream);
+        if (e == hipSuccess && dpal) e = hipMemcpyAsync(dpal, palettes + (size_t)i0 * 1024, (size_t)m * 1024, hipMemcpyHostToDevice, up);
+        if (e == hipSuccess && staged) e = hipEventRecord(l.ev[0], up);
+        if (e == hipSuccess && staged) e = hipStreamWaitEvent(run, l.ev[0], 0);
         if (e != hipSuccess) break;
         switch (kind) {
-        case IPX_SRC_RGBA: rc = ipx_plan_run_dev(ctx, l.stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm); break;
-        case IPX_SRC_NRGBA: rc = ipx_plan_run_dev_nrgba(ctx, l.stream, pl, m, dsrc, sw * 4, fsrc, dres, fres, dth, fth, dwm, fwm); break;
-        case IPX_GRAY: rc = ipx_plan_run_dev_gray(ctx, l.stream, pl, m, dsrc, sw, fsrc, dres, fres, dth, fth, dwm, fwm); break;
-        case kPalettedKind: rc = ipx_plan_run_dev_paletted(ctx, l.stream, pl, m, dsrc, sw, fsrc, dpal, dres, fres, dth, fth, dwm, fwm); break;
-        default: rc = ipx_plan_run_dev_deep(ctx, l.stream, pl, m, kind - kDeepKind, dsrc, sw * bpp, fsrc, dres, fres, dth, fth, dwm, fwm); break;
+        case IPX_SRC_RGBA: rc = ipx_plan_run_dev(ctx, run, pl, m, dsrc, sw * 4, fsrc, dres, sres, dth, sth, dwm, swm); break;
+        case IPX_SRC_NRGBA: rc = ipx_plan_run_dev_nrgba(ctx, run, pl, m, dsrc, sw * 4, fsrc, dres, sres, dth, sth, dwm, swm); break;
+        case IPX_GRAY: rc = ipx_plan_run_dev_gray(ctx, run, pl, m, dsrc, sw, fsrc, dres, sres, dth, sth, dwm, swm); break;
+        case kPalettedKind: rc = ipx_plan_run_dev_paletted(ctx, run, pl, m, dsrc, sw, fsrc, dpal, dres, sres, dth, sth, dwm, swm); break;
+        default: rc = ipx_plan_run_dev_deep(ctx, run, pl, m, kind - kDeepKind, dsrc, sw * bpp, fsrc, dres, sres, dth, sth, dwm, swm); break;
         }
         if (rc) break;
-        if (bounce) {          // one copy of the three outputs (they follow the source in the lane's scratch), handed out after the sync below
-            if (fres + fth + fwm) e = hipMemcpyAsync(l.pin + fsrc, dsrc + fsrc, fres + fth + fwm, hipMemcpyDeviceToHost, l.stream);
+        if (direct) {          // the outputs are where they belong when the kernels have finished
+            if (staged) e = hipEventRecord(l.ev[2], run);
             continue;
         }
-        e = d2h(resize_out, resize_frame_stride, dres, fres, pl->info.resize_bytes, i0, m, l.stream);
-        if (e == hipSuccess) e = d2h(thumb_out, thumb_frame_stride, dth, fth, pl->info.thumb_bytes, i0, m, l.stream);
-        if (e == hipSuccess) e = d2h(wm_out, wm_frame_stride, dwm, fwm, pl->info.wm_bytes, i0, m, l.stream);
+        if (staged) {
+            e = hipEventRecord(l.ev[1], run);
+            if (e == hipSuccess) e = hipStreamWaitEvent(down, l.ev[1], 0);
+            if (e != hipSuccess) break;
+        }
+        if (bounce) {          // one copy of the three outputs (they follow the source in the lane's scratch), handed out after the sync below
+            if (fres + fth + fwm) e = hipMemcpyAsync(l.pin + fsrc, dsrc + fsrc, fres + fth + fwm, hipMemcpyDeviceToHost, down);
+            continue;
+        }
+        e = d2h(resize_out, resize_frame_stride, dres, fres, pl->info.resize_bytes, i0, m, down);
+        if (e == hipSuccess) e = d2h(thumb_out, thumb_frame_stride, dth, fth, pl->info.thumb_bytes, i0, m, down);
+        if (e == hipSuccess) e = d2h(wm_out, wm_frame_stride, dwm, fwm, pl->info.wm_bytes, i0, m, down);
+        if (e == hipSuccess && staged) e = hipEventRecord(l.ev[2], down);
     }
     const double t_enq = trace ? ms_since(t_in) : 0;
     for (auto *l : lanes) {

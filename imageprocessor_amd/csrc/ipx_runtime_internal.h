@@ -2,7 +2,11 @@
 // translation unit that implements ABI entries needs (ipx_runtime.hip, ipx_jpeg_runtime.hip).  Not part of the ABI.
 #pragma once
 
+#include <sched.h>
+
 #include <algorithm>
+#include <cctype>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +32,7 @@ struct Lane {
     size_t dec_bytes = 0;
     uint8_t *pin = nullptr;   // pinned bounce buffer for small single-frame calls on pageable memory (run_host_packed)
     size_t pin_bytes = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // of the chunk in this lane's scratch: uploaded, computed, downloaded (run_host_packed)
     bool busy = false;
 };
 
@@ -205,6 +210,50 @@ template <class F> inline int guarded_status(F &&fn, std::string *text) noexcept
         if (text) { try { *text = ipx_last_error(); } catch (...) { } }
         return rc;
     }
+}
+
+// CPUs local to a device's PCIe root, intersected with what the process may use.  Best effort: nothing happens if sysfs says nothing.
+inline void bind_near_device(int device)
+{
+    if (env_int("IPX_POOL_NUMA", 1) == 0) return;
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char *c = bus; *c; c++) *c = (char)tolower((unsigned char)*c);
+    char path[128];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    char line[4096] = {0};
+    const bool ok = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!ok) return;
+    cpu_set_t allowed, want;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    CPU_ZERO(&want);
+    for (char *p = line; *p;) {            // "0-31,64-95"
+        char *e = nullptr;
+        long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &want);
+        p = *e == ',' ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    if (CPU_COUNT(&want) > 0) (void)sched_setaffinity(0, sizeof want, &want);
+}
+
+
+// The device's view of `span` bytes of host memory a kernel may write: non-null when the range is pinned and mapped (hipHostMalloc,
+// hipHostRegister), null for pageable memory.  Kernels then write outputs over the link themselves (run_host_packed, the pool's chunks).
+inline uint8_t *pinned_device_view(uint8_t *host, size_t span)
+{
+    if (!host || !span) return nullptr;
+    hipPointerAttribute_t at, last;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess || at.type != hipMemoryTypeHost || !at.devicePointer) { (void)hipGetLastError(); return nullptr; }
+    if (hipPointerGetAttributes(&last, host + span - 1) != hipSuccess || last.type != hipMemoryTypeHost) { (void)hipGetLastError(); return nullptr; }   // a registered range may end before the batch does
+    return (uint8_t *)at.devicePointer;
 }
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }

@@ -113,6 +113,11 @@ int ipx_memcpy_d2d(ipx_ctx *ctx, void *dst_dev, const void *src_dev, size_t byte
  * part of the path: bench.py times it on the box it runs on, because the streaming ceiling the band kernels are held against differs
  * from box to box and with where buffers land. */
 int ipx_stream_copy(ipx_ctx *ctx, void *stream, void *dst_dev, const void *src_dev, size_t bytes);
+/* What the host link gives pinned memory on this box: out_gbps = {up alone, down alone, up while down runs, down while up runs}, best of
+ * `reps` transfers of up_bytes / down_bytes (down_bytes a multiple of 16).  Copies go in 32 MiB pieces on one stream per direction; the
+ * both-at-once pair is the better of two ways down -- a copy engine, or a kernel storing into the pinned block (how the host entries
+ * deliver their outputs).  Not part of the path: bench.py holds its PCIe-inclusive legs against it (`frac_of_link`). */
+int ipx_link_probe(ipx_ctx *ctx, size_t up_bytes, size_t down_bytes, int reps, double out_gbps[4]);
 /* Blocks until the device is idle (every stream). */
 int ipx_device_sync(ipx_ctx *ctx);
 /* Blocks until everything queued on `stream` (a hipStream_t, NULL = the context's stream) is done. */
