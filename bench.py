@@ -569,6 +569,11 @@ def main():
                 for b in bs:
                     if b:
                         b.free()
+            # the timed region's context goes first: a process holds ONE context or pool per device in production, and a second idle
+            # one costs the pool leg 12 % (its streams share the device's hardware queues)
+            plan.close()
+            ctx.close()
+            plan = ctx = None
             out["e2e"] = e2e_legs(ipx, local_rank % max(1, ipx.device_count()), args.e2e_frames, sw, sh, resize, args.e2e_reps)
         else:
             out["e2e"] = None
@@ -577,8 +582,9 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
-    plan.close()
-    ctx.close()
+    if ctx is not None:
+        plan.close()
+        ctx.close()
 
 
 if __name__ == "__main__":

@@ -518,10 +518,12 @@ int ipx_link_probe(ipx_ctx *ctx, size_t up_bytes, size_t down_bytes, int reps, d
     if (e == hipSuccess) timed(true, false, false, &out_gbps[0], nullptr);
     if (e == hipSuccess) timed(false, true, false, nullptr, &out_gbps[1]);
     if (e == hipSuccess) timed(true, true, false, &out_gbps[2], &out_gbps[3]);
-    if (e == hipSuccess && hd_dev) {        // both at once, the better of the two ways down
+    if (e == hipSuccess && hd_dev) {        // the better of the two ways down, alone and beside the upload
         double u = 0, d = 0;
-        timed(true, true, true, &u, &d);
-        if (u + d > out_gbps[2] + out_gbps[3]) { out_gbps[2] = u; out_gbps[3] = d; }
+        timed(false, true, true, nullptr, &d);
+        out_gbps[1] = std::max(out_gbps[1], d);
+        if (e == hipSuccess) timed(true, true, true, &u, &d);
+        if (e == hipSuccess && u + d > out_gbps[2] + out_gbps[3]) { out_gbps[2] = u; out_gbps[3] = d; }
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
