@@ -91,7 +91,8 @@ struct KsSeg { int ys, r0, r1; };         // rows [ys, r1) are streamed; rows [r
 // What one source row does to scaleY's running sums of one output.  A destination row dy keeps its sums in accumulator dy % NACC (at
 // most NACC destination rows are fed by one source row); w = 0: that accumulator gets nothing from this row; emit >= 0: this was the
 // last row of destination row `emit` -- finish it (times itw, clamp to the alpha `ones` for sources whose tmp alpha is 1) and clear.
-template <int NACC> struct KsRowT { double w[NACC], itw[NACC], ones[NACC]; int32_t emit[NACC], pad[NACC]; };
+// wf: the weight of the float pass (ipx_ks_fused.hip, "the float pass"): float(w * invTotalWeight of the destination row).
+template <int NACC> struct KsRowT { double w[NACC], itw[NACC], ones[NACC]; int32_t emit[NACC]; float wf[NACC]; };
 static_assert(sizeof(KsRowT<2>) == 64 && sizeof(KsRowT<4>) == 128, "row entries are copied dword-wise");
 
 struct KsFusedOut {
@@ -104,6 +105,8 @@ struct KsFusedOut {
     int waves, cpl;            // wave roles: `waves` waves of 64 lanes, `cpl` columns per lane
     int wcols;                 // columns per tap row of the LDS weight table (most destination columns any strip owns)
     const double *wx;          // [strip][ntap][wcols] horizontal weights
+    const float *wxf;          // the float pass: float(w * invTotalWeightFFFF * 0xffff [* 0x101 where the tile holds bytes]), same layout
+    float feps;                // the float pass: a channel whose value / 256 has a fraction within feps of 0 or 1 is not decided
     const double *itwf;        // [dw] invTotalWeightFFFF
     const int32_t *xlo;        // [dw] first tap, relative to the source rectangle
     const int32_t *colb;       // [nstrips + 1] first destination column owned by each strip
@@ -118,21 +121,26 @@ struct KsFusedArgs {
     int nframes, nstrips, nseg, nthreads, pitch, dbuf;
     const KsStrip *strips; const KsSeg *segs;
     int nout; KsFusedOut o[2];
-    int lds_w[2], lds_rows;    // byte offsets in LDS: weight tables, staged row entries (the tile is at 0)
+    int lds_w[2], lds_rows, lds_open;   // byte offsets in LDS: weight tables, staged row entries, the float pass's undecided pixels (the tile is at 0)
     uint8_t wave_role[16];     // per wave: output index << 4 | index among that output's waves; 0xff = no role (stages pixels only).  The roles
                                // are interleaved so that the waves of one output spread over the SIMDs however the hardware deals waves out
     unsigned long long *stamps; // diagnostic build (-DIPX_DIAG=1) only: per-phase cycle sums over all waves, else NULL
-    int *redo;                 // speculative (opaque) kernel: one int per item, 1 = the item met a pixel with alpha != 0xff and was
-                               // abandoned; general kernel: only items with redo[item] != 0 run (NULL: all)
+    int *redo;                 // speculative kernels (opaque, float): one int per item, 1 = the item met a pixel with alpha != 0xff or
+                               // overflowed the frame's list and is to be redone; general kernel: only items with redo[item] != 0 run (NULL: all)
+    uint2 *fix; int *fix_count; int fix_cap;   // the float pass: per frame a list of (output << 31 | dy, dx) of the pixels it could not
+                               // decide, fix_cap entries each, and how many were appended
 };
+// what the exact per-pixel pass after the float pass needs per output: the axes in HBM (NULL list: no float pass)
+struct KsFix { uint2 *list = nullptr; int *count = nullptr; int cap = 0; KsAxisDev ax[2], ay[2]; };
 // one segmentation of the frame's rows and the row tables cut for it
 struct KsFusedGeom { int nseg = 0; const KsSeg *segs = nullptr; const void *rows[2] = {nullptr, nullptr}; const int32_t *rowoff[2] = {nullptr, nullptr}; };
 struct KsFusedPlan {
     bool ok = false;
     int nacc = 2, rows = 4, pitch = 0, nstrips = 0, nthreads = 0, nstg = 0, dbuf = 0;   // dbuf: two tile buffers fit in LDS (one barrier per group)
-    int lds_w[2] = {0, 0}, lds_rows = 0, lds_bytes = 0;
+    int lds_w[2] = {0, 0}, lds_rows = 0, lds_open = 0, lds_bytes = 0;
     const KsStrip *strips = nullptr;
-    struct Out { int ntap = 0, waves = 0, cpl = 0, wcols = 0; const double *wx = nullptr, *itwf = nullptr; const int32_t *xlo = nullptr, *colb = nullptr; } o[2];
+    struct Out { int ntap = 0, waves = 0, cpl = 0, wcols = 0; const double *wx = nullptr, *itwf = nullptr; const int32_t *xlo = nullptr, *colb = nullptr;
+                 const float *wxf = nullptr; float feps = 0; } o[2];
     KsFusedGeom whole, split;   // one segment per frame (large batches) / segments of about kKsSplitRows rows (small ones)
 };
 constexpr int kKsSplitRows = 96;
@@ -141,12 +149,16 @@ constexpr int kKsMaxStage = 3;    // 16-byte chunks a thread stages per group
 constexpr int kKsMaxWaves = 12;   // waves per workgroup (768 threads: three waves per SIMD, 168 registers each)
 constexpr int kKsMaxThreads = 64 * kKsMaxWaves;
 constexpr int kKsMaxCpl = 2;
+constexpr int kKsOpenPerWave = 128;   // the float pass: undecided pixels a wave collects in LDS before they go to the frame's list
 // cuts the frame into strips and segments, assigns wave roles and lays every table out in `blob` (appended, 16-byte aligned offsets;
 // the pointers in *out are OFFSETS into the blob until ks_fused_rebase adds the device address).  sc[k] = nullptr: output absent.
 struct KsFusedIn { int dw, dh, sr_x0, sr_y0; const KsAxis *hx, *hy; };
 bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, int px_bytes, std::vector<uint8_t> *blob, KsFusedPlan *out);
 void ks_fused_rebase(KsFusedPlan *p, const uint8_t *dev_blob);
 // *matched = false: nothing launched (shape, alignment or kind the kernel is not built for)
-hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, int cus, hipStream_t s, bool *matched);
+// fix: lists for the float pass (RGBA with `redo`, YCbCr, Gray sources), or NULL: float64 throughout
+hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fix, int cus, hipStream_t s, bool *matched);
+// the exact pass over the float pass's lists: every listed pixel of output `k` (described by `g`, one frame per blockIdx.y) recomputed
+hipError_t launch_ks_fix(const KsGenArgs &g, const uint2 *list, const int *count, int cap, int k, hipStream_t s);
 
 }  // namespace ipx

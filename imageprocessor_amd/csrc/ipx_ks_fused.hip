@@ -22,6 +22,16 @@
 // are data-independent, no colour can exceed alpha (rounding is monotonic: each product and each partial sum of a colour is <= the one of
 // alpha, term by term), so the clamp never fires and the stored alpha is 0xff: the alpha channel costs nothing.  The kernel checks
 // the assumption on every pixel it stages; an item that meets alpha != 0xff gives up and is redone by the NCH = 4 kernel (`redo`).
+//
+// The float pass (FAST = true; RGBA frames taken as opaque, YCbCr, Gray).  The float64 arithmetic above is what bounds the kernel, and a
+// byte of output needs almost none of it: the same sums in float -- taps are exact in float, one fused multiply-add per term, both
+// normalisations folded into the weights -- land within (nx + ny + 3) / 256 sixteen-bit units of the reference's value (derivation at
+// ks_float_eps, ipx_ks_host.cpp), and the byte is floor((V + 0.5) / 256): unless V + 0.5 lies that close to a multiple of 256, the
+// float result IS the reference's byte.  The pass checks exactly that for every channel it stores (the fraction of t / 256 against
+// feps); a pixel with a channel it cannot decide -- about one in a thousand -- goes on its frame's list, and ks_fix_kernel recomputes
+// the listed pixels in float64, operation by operation as the reference does.  A frame whose list is full hands the item to the
+// float64 kernel through `redo`, like an item that is not opaque.  Results are the reference's bits either way; IPX_KS_FAST=0 runs
+// float64 throughout.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -174,10 +184,35 @@ __device__ __forceinline__ void ks_fetch(typename KsTapRaw<SRC>::type raw, doubl
     }
 }
 
-template <int NCH, int NACC>
+// the same tap as float (the float pass); an RGBA tile's bytes stay bytes -- the weights carry the 0x101
+template <int SRC, int NCH, int MODE>
+__device__ __forceinline__ void ks_fetchf(typename KsTapRaw<SRC>::type raw, float (&v)[NCH])
+{
+    if constexpr (SRC == KS_RGBA) {
+        v[0] = (float)(raw & 0xffu);                                   // v_cvt_f32_ubyte0 .. 3
+        if (NCH > 1) v[1 % NCH] = (float)((raw >> 8) & 0xffu);
+        if (NCH > 2) v[2 % NCH] = (float)((raw >> 16) & 0xffu);
+        if (NCH > 3) v[3 % NCH] = (float)(raw >> 24);
+    } else if constexpr (SRC == KS_GRAY) {
+        v[0] = (float)(uint32_t)raw;
+    } else {
+        const uint2 t = raw;
+        uint32_t c[4];
+        if (MODE == KS_TAP_TOP) {
+            c[0] = __builtin_amdgcn_perm(0u, t.x, 0x0c0c0101u); c[1] = __builtin_amdgcn_perm(0u, t.x, 0x0c0c0303u);
+            c[2] = __builtin_amdgcn_perm(0u, t.y, 0x0c0c0101u); c[3] = 0;
+        } else {
+            c[0] = t.x & 0xffffu; c[1] = t.x >> 16; c[2] = t.y & 0xffffu; c[3] = t.y >> 16;
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; k++) v[k] = (float)c[k];
+    }
+}
+
+template <int NCH, int NACC, class T = double>
 struct KsCol {                 // one destination column of a lane
-    double q[NACC][NCH];       // scaleY's running sums
-    double itwf;               // invTotalWeightFFFF of the column
+    T q[NACC][NCH];            // scaleY's running sums
+    double itwf;               // invTotalWeightFFFF of the column (float64 kernels)
     int xb;                    // LDS byte offset of the column's first tap within a tile row
     int wofs;                  // LDS byte offset of the column's first weight
     int ooff;                  // byte offset of the column in a destination row; kOOB = the lane has no such column
@@ -292,16 +327,127 @@ __device__ __forceinline__ void ks_column(const uint8_t *lds, const uint8_t *til
     }
 }
 
-template <int SRC, int NCH, int NACC, int B, bool OPQ, bool RAG>
+// The pixels a wave of the float pass could not decide wait in LDS (kKsOpenPerWave per wave) and go to the frame's list in HBM a batch
+// at a time: the append needs the list's old count back, and a wave that waits for an atomic's return waits for every load it has in
+// flight as well -- the next group's pixels.  One such wait per hundred pixels, not one per pixel.
+struct KsOpen {
+    uint2 *wave;               // this wave's entries in LDS
+    int n;                     // how many (wave-uniform)
+    uint2 *list; int *count; int cap;   // the frame's list in HBM
+    bool full;                 // the list had no room for an entry of this lane
+};
+__device__ __forceinline__ void ks_open_flush(KsOpen &o)
+{
+    if (o.n == 0) return;                                              // wave-uniform
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    int base = 0;
+    if (lane == 0) base = atomicAdd(o.count, o.n);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int i = lane; i < o.n; i += 64) {
+        if (base + i < o.cap) o.list[base + i] = o.wave[i];
+        else o.full = true;
+    }
+    o.n = 0;
+}
+
+// The float pass's column: the same walk with float sums.
+template <int SRC, int NCH, int NACC, int B, int MODE>
+__device__ __forceinline__ void ks_column_fast(const uint8_t *lds, const uint8_t *tile, KsCol<NCH, NACC, float> &c, int ntap, int wstride, int pitch,
+                                               const uint8_t *rows, __amdgpu_buffer_rsrc_t ors, int ostride, float feps, uint32_t okey, KsOpen &op)
+{
+    constexpr int PXB = KsPx<SRC>::bytes;
+    float acc[B][NCH];
+#pragma unroll
+    for (int r = 0; r < B; r++)
+#pragma unroll
+        for (int k = 0; k < NCH; k++) acc[r][k] = 0.f;
+    const uint8_t *tap = tile + c.xb;
+    const uint8_t *wp = lds + c.wofs;
+    typedef typename KsTapRaw<SRC>::type Raw;
+    auto taps = [&](auto nt) {
+        constexpr int NT = decltype(nt)::value;
+        float w[NT];
+        Raw px[NT][B];
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            w[i] = *(const float *)(wp + i * wstride);
+#pragma unroll
+            for (int r = 0; r < B; r++) px[i][r] = *(const Raw *)(tap + r * pitch + i * PXB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int r = 0; r < B; r++) {
+                float v[NCH];
+                ks_fetchf<SRC, NCH, MODE>(px[i][r], v);
+#pragma unroll
+                for (int k = 0; k < NCH; k++) acc[r][k] = __builtin_fmaf(v[k], w[i], acc[r][k]);
+            }
+        tap += NT * PXB;
+        wp += NT * wstride;
+    };
+    int t = 0;
+    constexpr int TU = SRC == KS_RGBA || SRC == KS_GRAY ? 4 : 2;
+    for (; t + TU <= ntap; t += TU) taps(std::integral_constant<int, TU>());
+    if (TU > 2 && t + 2 <= ntap) { taps(std::integral_constant<int, 2>()); t += 2; }
+    if (t < ntap) taps(std::integral_constant<int, 1>());
+    typedef KsRowT<NACC> Row;
+    float rw[B][NACC];
+    int remit[B][NACC];
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        const Row *row = (const Row *)(rows + r * sizeof(Row));
+#pragma unroll
+        for (int p = 0; p < NACC; p++) { rw[r][p] = row->wf[p]; remit[r][p] = row->emit[p]; }
+    }
+    const float hi = 1.0f - feps;
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+#pragma unroll
+        for (int p = 0; p < NACC; p++) {
+            const float w = rw[r][p];
+#pragma unroll
+            for (int k = 0; k < NCH; k++) c.q[p][k] = __builtin_fmaf(acc[r][k], w, c.q[p][k]);
+            const int dy = __builtin_amdgcn_readfirstlane(remit[r][p]);
+            if (dy >= 0) {                                             // wave-uniform
+                uint32_t b[NCH];
+                bool open = false;                                     // a channel too close to a multiple of 256 to call
+#pragma unroll
+                for (int k = 0; k < NCH; k++) {
+                    const float u = (c.q[p][k] + 0.5f) * (1.0f / 256.0f);
+                    const float fr = __builtin_amdgcn_fractf(u);
+                    open |= fr < feps || fr > hi;
+                    b[k] = min((uint32_t)u, 255u);
+                    c.q[p][k] = 0.f;
+                }
+                const uint32_t px = NCH == 1 ? b[0] * 0x010101u | 0xff000000u : b[0] | b[1 % NCH] << 8 | b[2 % NCH] << 16 | 0xff000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(px, ors, c.ooff, dy * ostride, 0);
+                open = open && c.ooff != kOOB;
+                const unsigned long long m = __ballot(open);
+                if (m) {                                               // wave-uniform; about one store in fifteen
+                    const int k = __popcll(m);
+                    if (op.n + k > kKsOpenPerWave) ks_open_flush(op);
+                    const int slot = op.n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // open lanes below this one
+                    if (open) op.wave[slot] = make_uint2(okey | (uint32_t)dy, (uint32_t)c.ooff >> 2);
+                    op.n += k;
+                }
+            }
+        }
+    }
+}
+
+template <int SRC, int NCH, int NACC, int B, bool OPQ, bool RAG, bool FAST>
 __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
 {
+    typedef std::conditional_t<FAST, float, double> Sum;
     constexpr int CPLM = NACC == 2 ? kKsMaxCpl : 1;   // columns per lane: four accumulators per column leave registers for one (ks_fused_plan knows)
     extern __shared__ __align__(16) uint8_t lds[];
     constexpr int PXB = KsPx<SRC>::bytes;
     constexpr int CHB = 4 * PXB;                      // LDS bytes of a chunk (four pixels)
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int item = (int)blockIdx.x;
-    if (!OPQ && a.redo && !a.redo[item]) return;
+    if (!OPQ && !FAST && a.redo && !a.redo[item]) return;
     const int seg = item % a.nseg;
     item /= a.nseg;
     const int strip = item % a.nstrips, frame = item / a.nstrips;
@@ -350,9 +496,10 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     }
     role = __builtin_amdgcn_readfirstlane(role);
     wk = __builtin_amdgcn_readfirstlane(wk);
-    KsCol<NCH, NACC> col[CPLM];
+    KsCol<NCH, NACC, Sum> col[CPLM];
     __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000);
     int ntap = 0, wstride = 0, ostride = 0, cpl = 0, mode = KS_TAP_PLAIN;
+    float feps = 0.f;
     bool aone = false;
     const uint8_t *rows_lds = lds + a.lds_rows;
     const int dbuf = a.dbuf;
@@ -360,16 +507,22 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     if (role >= 0) {
         const KsFusedOut &o = a.o[role];
         ors = __builtin_amdgcn_make_buffer_rsrc((void *)(o.out + (size_t)frame * o.frame_stride), 0, o.obytes, 0x00020000);
-        ntap = o.ntap; wstride = o.wcols * 8; ostride = o.ostride; cpl = o.cpl;
+        ntap = o.ntap; wstride = o.wcols * (FAST ? 4 : 8); ostride = o.ostride; cpl = o.cpl; feps = o.feps;
         mode = o.mode; aone = o.aone != 0;
         rows_lds += role * B * (int)sizeof(Row);
         const int cb = o.colb[strip], ce = o.colb[strip + 1];
         // the strip's weight table -> LDS (every wave of the role copies a share)
         {
-            const double *wsrc = o.wx + (size_t)strip * o.ntap * o.wcols;
-            double *wdst = (double *)(lds + a.lds_w[role]);
             const int n = o.ntap * o.wcols;
-            for (int i = wk * 64 + lane; i < n; i += o.waves * 64) wdst[i] = wsrc[i];
+            if (FAST) {
+                const float *wsrc = o.wxf + (size_t)strip * o.ntap * o.wcols;
+                float *wdst = (float *)(lds + a.lds_w[role]);
+                for (int i = wk * 64 + lane; i < n; i += o.waves * 64) wdst[i] = wsrc[i];
+            } else {
+                const double *wsrc = o.wx + (size_t)strip * o.ntap * o.wcols;
+                double *wdst = (double *)(lds + a.lds_w[role]);
+                for (int i = wk * 64 + lane; i < n; i += o.waves * 64) wdst[i] = wsrc[i];
+            }
         }
 #pragma unroll
         for (int j = 0; j < CPLM; j++) {
@@ -378,10 +531,10 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
 #pragma unroll
             for (int p = 0; p < NACC; p++)
 #pragma unroll
-                for (int k = 0; k < NCH; k++) col[j].q[p][k] = 0.0;
+                for (int k = 0; k < NCH; k++) col[j].q[p][k] = 0;
             col[j].itwf = has ? o.itwf[dx] : 0.0;
             col[j].xb = has ? (o.sr_x0 + o.xlo[dx] - st.t0) * PXB : 0;
-            col[j].wofs = a.lds_w[role] + (has ? slot : 0) * 8;
+            col[j].wofs = a.lds_w[role] + (has ? slot : 0) * (FAST ? 4 : 8);
             col[j].ooff = has ? dx * 4 : kOOB;
         }
     }
@@ -429,6 +582,14 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     };
     issue(0);
     bool bad = false;
+    KsOpen open;
+    uint32_t okey = 0;
+    if (FAST) {
+        open.wave = (uint2 *)(lds + a.lds_open) + wv * kKsOpenPerWave;
+        open.n = 0; open.full = false;
+        open.list = a.fix + (size_t)frame * a.fix_cap; open.count = a.fix_count + frame; open.cap = a.fix_cap;
+        okey = role >= 0 ? (uint32_t)a.o[role].pk << 31 : 0u;
+    }
 #if IPX_DIAG
     unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
@@ -486,7 +647,16 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
 #define KS_COLS(MODE, AONE)                                                                                                              \
     _Pragma("unroll") for (int j = 0; j < CPLM; j++)                                                                                 \
         if (j < cpl) ks_column<SRC, NCH, NACC, B, MODE, AONE>(lds, tile, col[j], ntap, wstride, pitch, rws, ors, ostride KS_DIAG_ARGS)
-            if (SRC == KS_RGBA) {
+#define KS_COLSF(MODE)                                                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < CPLM; j++)                                                                                 \
+        if (j < cpl) ks_column_fast<SRC, NCH, NACC, B, MODE>(lds, tile, col[j], ntap, wstride, pitch, rws, ors, ostride, feps, okey, open)
+            if constexpr (FAST) {
+                // (the alpha of these sources never reaches the sums: opaque RGBA, YCbCr and Gray store 0xff)
+                if constexpr (SRC == KS_YCC) {
+                    if (!aone) { KS_COLSF(KS_TAP_TOP); }
+                    else { KS_COLSF(KS_TAP_PLAIN); }
+                } else { KS_COLSF(KS_TAP_PLAIN); }
+            } else if (SRC == KS_RGBA) {
                 if (NCH == 4 && mode == KS_TAP_CLAMP) { KS_COLS(KS_TAP_CLAMP, false); }
                 else { KS_COLS(KS_TAP_PLAIN, false); }
             } else if (SRC == KS_GRAY) {
@@ -503,6 +673,7 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
                 else { KS_COLS(KS_TAP_PLAIN, false); }
             }
 #undef KS_COLS
+#undef KS_COLSF
         }
         KS_STAMP(5);                                     // scaleY's sums and finished rows
         // one tile buffer: everyone is done with it before the next group overwrites it.  Two: a wave that writes buffer g & 1 two groups
@@ -513,17 +684,21 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     if (a.stamps && lane == 0)
         for (int i = 0; i < 6; i++) atomicAdd(&a.stamps[(role < 0 ? 2 : role) * 8 + i], tsum[i]);
 #endif
-    if (OPQ) {                                           // any pixel with alpha != 0xff in the rest of the item: redo it as well
+    if (FAST) {
+        ks_open_flush(open);
+        bad |= open.full;
+    }
+    if (OPQ || FAST) {                                   // any pixel with alpha != 0xff in the rest of the item, or a full list: redo it as well
         const int any = __syncthreads_or(bad);
         if (tid == 0) a.redo[blockIdx.x] = any;
     }
 }
 
-template <int SRC, int NCH, int NACC, bool OPQ, bool RAG>
+template <int SRC, int NCH, int NACC, bool OPQ, bool RAG, bool FAST>
 hipError_t launch_rag(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hipStream_t s)
 {
     static KernelLaunchCache cache;
-    auto fn = ks_fused_kernel<SRC, NCH, NACC, kKsRows, OPQ, RAG>;
+    auto fn = ks_fused_kernel<SRC, NCH, NACC, kKsRows, OPQ, RAG, FAST>;
     int resident = 0;
     hipError_t e = cache.prepare((const void *)fn, p.nthreads, (size_t)p.lds_bytes, getenv("IPX_KS_DEBUG") ? &resident : nullptr);
     if (e != hipSuccess) return e;
@@ -532,13 +707,13 @@ hipError_t launch_rag(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hi
     return hipGetLastError();
 }
 
-template <int SRC, int NCH, int NACC, bool OPQ>
+template <int SRC, int NCH, int NACC, bool OPQ, bool FAST = false>
 hipError_t launch_one(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hipStream_t s)
 {
     if constexpr (SRC == KS_RGBA || SRC == KS_NRGBA) {
-        if (a.sw & 3) return launch_rag<SRC, NCH, NACC, OPQ, true>(p, a, nitems, s);
+        if (a.sw & 3) return launch_rag<SRC, NCH, NACC, OPQ, true, FAST>(p, a, nitems, s);
     }
-    return launch_rag<SRC, NCH, NACC, OPQ, false>(p, a, nitems, s);
+    return launch_rag<SRC, NCH, NACC, OPQ, false, FAST>(p, a, nitems, s);
 }
 
 template <int SRC, int NCH>
@@ -549,7 +724,7 @@ hipError_t launch_src(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hi
 
 }  // namespace
 
-hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, int cus, hipStream_t s, bool *matched)
+hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fix, int cus, hipStream_t s, bool *matched)
 {
     *matched = false;
     if (!p.ok || a.nframes <= 0) return hipSuccess;
@@ -592,13 +767,13 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, int cus, hipStr
     const KsFusedGeom &g = whole || p.split.nseg <= 1 ? p.whole : p.split;
     a.nstrips = p.nstrips; a.nseg = g.nseg; a.nthreads = p.nthreads; a.pitch = p.pitch; a.dbuf = p.dbuf;
     a.strips = p.strips; a.segs = g.segs;
-    a.lds_rows = p.lds_rows;
+    a.lds_rows = p.lds_rows; a.lds_open = p.lds_open;
     for (int i = 0; i < a.nout; i++) {                             // a.o[i].pk: which of the plan's outputs this is
         const int k = a.o[i].pk;
         const KsFusedPlan::Out &po = p.o[k];
         KsFusedOut &o = a.o[i];
         o.ntap = po.ntap; o.waves = po.waves; o.cpl = po.cpl; o.wcols = po.wcols;
-        o.wx = po.wx; o.itwf = po.itwf; o.xlo = po.xlo; o.colb = po.colb;
+        o.wx = po.wx; o.itwf = po.itwf; o.xlo = po.xlo; o.colb = po.colb; o.wxf = po.wxf; o.feps = po.feps;
         o.rows = g.rows[k]; o.rowoff = g.rowoff[k];
         a.lds_w[i] = p.lds_w[k];
     }
@@ -622,16 +797,49 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, int cus, hipStr
         fprintf(stderr, "[ipx ks] src %d nacc %d frames %d strips %d segs %d threads %d pitch %d dbuf %d lds %d | out0 ntap %d waves %d cpl %d wcols %d | out1 ntap %d waves %d cpl %d wcols %d\n", src, p.nacc,
                 a.nframes, a.nstrips, a.nseg, a.nthreads, a.pitch, a.dbuf, p.lds_bytes, a.o[0].ntap, a.o[0].waves, a.o[0].cpl, a.o[0].wcols, a.nout > 1 ? a.o[1].ntap : 0,
                 a.nout > 1 ? a.o[1].waves : 0, a.nout > 1 ? a.o[1].cpl : 0, a.nout > 1 ? a.o[1].wcols : 0);
+    // the float pass where the source type has one and the caller brought lists: float kernel, the listed pixels in float64, then the
+    // float64 kernel on the items the float kernel gave up
+    const bool fast = fix && fix->list && a.redo && (src == KS_RGBA || src == KS_YCC || src == KS_GRAY);
+    a.fix = fast ? fix->list : nullptr; a.fix_count = fast ? fix->count : nullptr; a.fix_cap = fast ? fix->cap : 0;
+    auto exact_listed = [&]() {
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < a.nout && e == hipSuccess; i++) {
+            const KsFusedOut &o = a.o[i];
+            KsGenArgs g{};
+            g.dst = o.out; g.dstride = o.ostride; g.dst_fs = o.frame_stride;
+            g.adr_x1 = o.dw; g.adr_y1 = o.dh; g.sr_x0 = o.sr_x0; g.sr_y0 = o.sr_y0;
+            g.ax = fix->ax[o.pk]; g.ay = fix->ay[o.pk]; g.op = IPX_OP_SRC; g.kind = o.kind;
+            g.src = a.src; g.sstride = a.sstride; g.src_fs = a.src_fs;
+            g.cb = a.cb; g.cr = a.cr; g.cstride = a.cstride; g.ratio = a.ratio; g.c_fs = a.c_fs;
+            g.nframes = a.nframes;
+            e = launch_ks_fix(g, fix->list, fix->count, fix->cap, o.pk, s);
+        }
+        return e;
+    };
+    hipError_t e = hipSuccess;
     switch (src) {
     case KS_NRGBA: a.redo = nullptr; return launch_src<KS_NRGBA, 4>(p, a, n, s);
     case KS_TAP64: a.redo = nullptr; return launch_src<KS_TAP64, 4>(p, a, n, s);
-    case KS_YCC: a.redo = nullptr; return launch_src<KS_YCC, 3>(p, a, n, s);
-    case KS_GRAY: a.redo = nullptr; return launch_src<KS_GRAY, 1>(p, a, n, s);
+    case KS_YCC:
+        if (!fast) { a.redo = nullptr; return launch_src<KS_YCC, 3>(p, a, n, s); }
+        e = p.nacc == 2 ? launch_one<KS_YCC, 3, 2, false, true>(p, a, n, s) : launch_one<KS_YCC, 3, 4, false, true>(p, a, n, s);
+        if (e == hipSuccess) e = exact_listed();
+        if (e == hipSuccess) e = launch_src<KS_YCC, 3>(p, a, n, s);
+        return e;
+    case KS_GRAY:
+        if (!fast) { a.redo = nullptr; return launch_src<KS_GRAY, 1>(p, a, n, s); }
+        e = p.nacc == 2 ? launch_one<KS_GRAY, 1, 2, false, true>(p, a, n, s) : launch_one<KS_GRAY, 1, 4, false, true>(p, a, n, s);
+        if (e == hipSuccess) e = exact_listed();
+        if (e == hipSuccess) e = launch_src<KS_GRAY, 1>(p, a, n, s);
+        return e;
     default: break;
     }
     if (!a.redo) return launch_src<KS_RGBA, 4>(p, a, n, s);        // the general kernel alone
     // the speculative opaque pass first; the general kernel then redoes the items that met a pixel with alpha != 0xff
-    hipError_t e = p.nacc == 2 ? launch_one<KS_RGBA, 3, 2, true>(p, a, n, s) : launch_one<KS_RGBA, 3, 4, true>(p, a, n, s);
+    if (fast) {
+        e = p.nacc == 2 ? launch_one<KS_RGBA, 3, 2, true, true>(p, a, n, s) : launch_one<KS_RGBA, 3, 4, true, true>(p, a, n, s);
+        if (e == hipSuccess) e = exact_listed();
+    } else e = p.nacc == 2 ? launch_one<KS_RGBA, 3, 2, true>(p, a, n, s) : launch_one<KS_RGBA, 3, 4, true>(p, a, n, s);
     if (e == hipSuccess) e = launch_src<KS_RGBA, 4>(p, a, n, s);
     return e;
 }

@@ -8,6 +8,8 @@
 // vertical sum in source-row order; clamp to alpha; times invTotalWeight; ftou) -- and no float64 image ever goes to HBM.  The price
 // is that a tmp value is computed by every destination row that uses it (two for a downscale).  Bound: FP64 VALU and L2 gathers; this
 // is not the throughput path.
+#include <algorithm>
+
 #include "ipx_ks.h"
 
 #pragma clang fp contract(off)
@@ -66,16 +68,10 @@ __device__ __forceinline__ uint32_t ks_ftou(double f)   // impl.go ftou
     return i > 0xffff ? 0xffffu : (i > 0 ? (uint32_t)i : 0u);
 }
 
+// one destination pixel (dx, dy relative to dr.Min) of the frame `a` points at
 template <int KIND>
-__global__ __launch_bounds__(256) void ks_generic_kernel(KsGenArgs a)
+__device__ __forceinline__ void ks_pixel(const KsGenArgs &a, int dx, int dy)
 {
-    a.dst += blockIdx.z * a.dst_fs;      // frame of a batch (all zero for a single frame)
-    a.src += blockIdx.z * a.src_fs;
-    if (KIND == IPX_SRC_YCBCR || KIND == IPX_SRC_YCBCR_CROP) { a.cb += blockIdx.z * a.c_fs; a.cr += blockIdx.z * a.c_fs; }
-    const int dx = a.adr_x0 + (int)(blockIdx.x * 64 + threadIdx.x);
-    const int dy = a.adr_y0 + (int)(blockIdx.y * 4 + threadIdx.y);
-    if (dx >= a.adr_x1 || dy >= a.adr_y1) return;
-
     const int xlo = a.ax.lo[dx], xn = a.ax.cnt[dx], ylo = a.ay.lo[dy], yn = a.ay.cnt[dy];
     const double *wx = a.ax.w + (size_t)dx * a.ax.ntap, *wy = a.ay.w + (size_t)dy * a.ay.ntap;
     const double xs = a.ax.itwffff[dx], ys = a.ay.itw[dy];
@@ -109,6 +105,80 @@ __global__ __launch_bounds__(256) void ks_generic_kernel(KsGenArgs a)
     *d = op == IPX_OP_SRC ? pack_src(pr0, pg0, pb0, pa0) : blend_over(*d, pr0, pg0, pb0, pa0);   // scaleY_RGBA_Src / _Over
 }
 
+template <int KIND>
+__global__ __launch_bounds__(256) void ks_generic_kernel(KsGenArgs a)
+{
+    a.dst += blockIdx.z * a.dst_fs;      // frame of a batch (all zero for a single frame)
+    a.src += blockIdx.z * a.src_fs;
+    if (KIND == IPX_SRC_YCBCR || KIND == IPX_SRC_YCBCR_CROP) { a.cb += blockIdx.z * a.c_fs; a.cr += blockIdx.z * a.c_fs; }
+    const int dx = a.adr_x0 + (int)(blockIdx.x * 64 + threadIdx.x);
+    const int dy = a.adr_y0 + (int)(blockIdx.y * 4 + threadIdx.y);
+    if (dx >= a.adr_x1 || dy >= a.adr_y1) return;
+    ks_pixel<KIND>(a, dx, dy);
+}
+
+// The exact pass behind the one-pass kernel's float pass (ipx_ks_fused.hip): per frame (blockIdx.y) a list of the pixels whose byte the
+// float sums could not decide; the ones of output `k` are recomputed here, in float64 and in the reference's order.
+// R lanes per pixel (R = 8, 16 or 64, at least the vertical tap count where that is at most 64): lane j of a pixel's group walks source
+// row j from left to right -- scaleX's sum for tmp[row][dx], in source-column order -- and the group's values are then added in
+// source-row order, one after the other as scaleY does, in every lane of the group (the first one stores).  A thread per pixel would
+// walk nx * ny taps one after the other: 1936 dependent steps for an 8K frame's thumbnail, 0.7 ms for a batch of two frames.
+template <int KIND>
+__global__ __launch_bounds__(256) void ks_fix_kernel(KsGenArgs a, const uint2 *list, const int *count, int cap, int k, int R)
+{
+    const int frame = (int)blockIdx.y, n = min(count[frame], cap);
+    a.dst += frame * a.dst_fs;
+    a.src += frame * a.src_fs;
+    if (KIND == IPX_SRC_YCBCR || KIND == IPX_SRC_YCBCR_CROP) { a.cb += frame * a.c_fs; a.cr += frame * a.c_fs; }
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+    const int per_wave = 64 / R, sub = lane / R, sl = lane - sub * R, per_block = 4 * per_wave;
+    constexpr bool alpha_one = KIND == IPX_SRC_YCBCR;
+    for (int i0 = (int)blockIdx.x * per_block; i0 < n; i0 += (int)gridDim.x * per_block) {
+        const int i = i0 + wv * per_wave + sub;
+        bool live = i < n;
+        const uint2 e = live ? list[(size_t)frame * cap + i] : make_uint2(0u, 0u);
+        const int dy = (int)(e.x & 0x7fffffffu), dx = (int)e.y;
+        live = live && (int)(e.x >> 31) == k && dx < a.adr_x1 && dy < a.adr_y1;
+        const int xlo = live ? a.ax.lo[dx] : 0, xn = live ? a.ax.cnt[dx] : 0, ylo = live ? a.ay.lo[dy] : 0, yn = live ? a.ay.cnt[dy] : 0;
+        const double *wx = a.ax.w + (size_t)(live ? dx : 0) * a.ax.ntap, *wy = a.ay.w + (size_t)(live ? dy : 0) * a.ay.ntap;
+        const double xs = live ? a.ax.itwffff[dx] : 0.0;
+        double qr = 0, qg = 0, qb = 0, qa = 0;
+        for (int jb = 0; __any(jb < yn); jb += R) {                      // (wave-uniform) R source rows at a time, top to bottom
+            const int j = jb + sl;
+            double pr = 0, pg = 0, pb = 0, pa = 0;
+            if (j < yn)
+                for (int t = 0; t < xn; t++) {
+                    const Tap4 tp = ks_tap<KIND>(a, a.sr_x0 + xlo + t, a.sr_y0 + ylo + j);
+                    const double w = wx[t];
+                    pr += (double)tp.r * w;
+                    pg += (double)tp.g * w;
+                    pb += (double)tp.b * w;
+                    if (!alpha_one) pa += (double)tp.a * w;
+                }
+            const double tr = pr * xs, tg = pg * xs, tb = pb * xs, ta = alpha_one ? 1.0 : pa * xs;
+            for (int jj = 0; jj < R; jj++) {                              // every lane of the group adds the group's rows in order
+                const int from = sub * R + jj;
+                const double vr = __shfl(tr, from), vg = __shfl(tg, from), vb = __shfl(tb, from), va = __shfl(ta, from);
+                if (jb + jj < yn) {
+                    const double w = wy[jb + jj];
+                    qr += vr * w;
+                    qg += vg * w;
+                    qb += vb * w;
+                    qa += va * w;
+                }
+            }
+        }
+        if (live && sl == 0) {
+            const double ys = a.ay.itw[dy];
+            if (qr > qa) qr = qa;
+            if (qg > qa) qg = qa;
+            if (qb > qa) qb = qa;
+            const uint32_t pr0 = ks_ftou(qr * ys), pg0 = ks_ftou(qg * ys), pb0 = ks_ftou(qb * ys), pa0 = ks_ftou(qa * ys);
+            *(uint32_t *)(a.dst + (size_t)(a.dr_y0 + dy) * a.dstride + (size_t)(a.dr_x0 + dx) * 4) = pack_src(pr0, pg0, pb0, pa0);
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_ks_generic(const KsGenArgs &a, hipStream_t s)
@@ -125,6 +195,24 @@ hipError_t launch_ks_generic(const KsGenArgs &a, hipStream_t s)
     case IPX_SRC_YCBCR_CROP: hipLaunchKernelGGL(ks_generic_kernel<IPX_SRC_YCBCR_CROP>, grid, block, 0, s, a); break;
     case IPX_SRC_TAP64_CROP: hipLaunchKernelGGL(ks_generic_kernel<IPX_SRC_TAP64_CROP>, grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL(ks_generic_kernel<IPX_SRC_RGBA>, grid, block, 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_ks_fix(const KsGenArgs &a, const uint2 *list, const int *count, int cap, int k, hipStream_t s)
+{
+    if (a.nframes <= 0 || cap <= 0) return hipSuccess;
+    const int R = a.ay.ntap <= 8 ? 8 : a.ay.ntap <= 16 ? 16 : 64;
+    // a few blocks per frame walk its list (a photograph leaves about a thousandth of its pixels there, the list holds forty times that)
+    // (more of them when the batch is small: about a thousand blocks in all)
+    const int per_block = 4 * (64 / R), most = (cap + per_block - 1) / per_block;
+    dim3 block(256), grid(std::max(1, std::min(most, std::max(8, 1024 / a.nframes))), a.nframes);
+    switch (a.kind) {
+    case IPX_SRC_YCBCR: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_YCBCR>, grid, block, 0, s, a, list, count, cap, k, R); break;
+    case IPX_SRC_YCBCR_CROP: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_YCBCR_CROP>, grid, block, 0, s, a, list, count, cap, k, R); break;
+    case IPX_SRC_RGBA_CROP: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_RGBA_CROP>, grid, block, 0, s, a, list, count, cap, k, R); break;
+    case IPX_SRC_RGBA: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_RGBA>, grid, block, 0, s, a, list, count, cap, k, R); break;
+    default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

@@ -99,6 +99,20 @@ void ks_axis_pack(const KsAxis &a, uint8_t *h, const uint8_t *d, KsAxisDev *out)
 // =====================================================================================================================================
 namespace ipx {
 
+// The float pass's margin (ipx_ks_fused.hip, "the float pass"), as a fraction of 256 sixteen-bit units.
+// Reference, in real numbers: X_i = sum_j tap_ij a_j (a = horizontal weights over their total), V = sum_i X_i b_i, result
+// min(floor(V + 0.5), 0xffff) >> 8 = floor((V + 0.5) / 256) capped at 255; its float64 evaluation is within 1e-6 units of that for any
+// tap count below 10^4.  The float pass evaluates the same sums with taps exact in float (at most 16 bits), weights a' = fl(a), b' = fl(b)
+// (relative error u = 2^-24 each) and one fused multiply-add per term: every partial sum is at most 65537, so every rounding is at most
+// u * 65537 < 2^-8 (1 + 2e-5) units.
+//   |X'_i - X_i| <= nx roundings + 65535 u for the weights                      <= (nx + 1) 2^-8 (1 + 3e-5)
+//   |V' - V|     <= ny roundings + the X errors (sum b' <= 1 + u) + 65535 u     <= (nx + ny + 2) 2^-8 (1 + 4e-5)
+//   t = fl(V' + 0.5): one more rounding                                          <= (nx + ny + 3) 2^-8 (1 + 4e-5)
+// t / 256 and its fraction are exact.  So when that fraction is at least feps = (nx + ny + 4) 2^-16 away from 0 and from 1 (one spare
+// 2^-8 for the factors and the reference's own rounding), floor(t / 256) IS the reference's byte; a channel that is not goes on the
+// frame's list and is recomputed in float64, operation by operation as the reference does it (ks_fix_kernel).
+float ks_float_eps(int nx, int ny) { return std::nextafter((float)((nx + ny + 4) * (1.0 / 65536.0)), 1.0f); }
+
 namespace {
 
 size_t blob_put(std::vector<uint8_t> *blob, const void *src, size_t bytes)
@@ -135,7 +149,7 @@ void build_rows(const KsFusedIn &o, const std::vector<KsSeg> &segs, int B, std::
         const int n = ((sg.r1 - sg.ys + B - 1) / B) * B;
         std::vector<KsRowT<NACC>> e(n);
         for (auto &r : e)
-            for (int p = 0; p < NACC; p++) { r.w[p] = 0; r.itw[p] = 0; r.ones[p] = 0; r.emit[p] = -1; r.pad[p] = 0; }
+            for (int p = 0; p < NACC; p++) { r.w[p] = 0; r.itw[p] = 0; r.ones[p] = 0; r.emit[p] = -1; r.wf[p] = 0; }
         // destination rows owned by this segment: their LAST source row lies in [r0, r1)
         while (d0 < o.dh && o.sr_y0 + hy.lo[d0] + hy.cnt[d0] - 1 < sg.r0) d0++;
         for (int d = d0; d < o.dh && o.sr_y0 + hy.lo[d] + hy.cnt[d] - 1 < sg.r1; d++) {
@@ -143,6 +157,7 @@ void build_rows(const KsFusedIn &o, const std::vector<KsSeg> &segs, int B, std::
             for (int k = 0; k < hy.cnt[d]; k++) {
                 const int y = o.sr_y0 + hy.lo[d] + k - sg.ys;   // >= 0 by the choice of ys
                 e[y].w[p] = hy.w[(size_t)d * hy.ntap + k];
+                e[y].wf[p] = (float)(hy.w[(size_t)d * hy.ntap + k] * hy.itw[d]);
                 if (k == hy.cnt[d] - 1) { e[y].emit[p] = d; e[y].itw[p] = hy.itw[d]; e[y].ones[p] = hy.ones[d]; }
             }
         }
@@ -284,6 +299,7 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
         for (int k = 0; k < 2; k++)
             if (sc[k]) rest += (size_t)sc[k]->hx->ntap * wcols[k] * sizeof(double);
         rest += 2 * 2 * (size_t)B * row_bytes + 64;                // two buffers of row entries for two outputs (+ slack)
+        rest += (size_t)kKsMaxWaves * kKsOpenPerWave * sizeof(uint2);   // the float pass's undecided pixels, per wave
         int dbuf = 1;
         if (2 * (size_t)B * pitch + rest > lds_budget) dbuf = 0;
         if ((size_t)(dbuf + 1) * B * pitch + rest > lds_budget) continue;
@@ -294,11 +310,14 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
         }
         const int lds_rows = (int)lds;
         lds += 2 * 2 * (size_t)B * row_bytes + 64;
+        lds = (lds + 15) & ~(size_t)15;
+        const int lds_open = (int)lds;
+        lds += (size_t)kKsMaxWaves * kKsOpenPerWave * sizeof(uint2);
 
         // ---- accepted: lay the tables out ----
         P.nstrips = ns; P.pitch = pitch; P.nthreads = nthreads; P.dbuf = dbuf;
         P.nstg = (chunks + nthreads - 1) / nthreads;
-        P.lds_w[0] = lds_w[0]; P.lds_w[1] = lds_w[1]; P.lds_rows = lds_rows; P.lds_bytes = (int)lds;
+        P.lds_w[0] = lds_w[0]; P.lds_w[1] = lds_w[1]; P.lds_rows = lds_rows; P.lds_open = lds_open; P.lds_bytes = (int)lds;
         P.strips = as_off<KsStrip>(blob_put(blob, strips.data(), strips.size() * sizeof(KsStrip)));
         for (int k = 0; k < 2; k++) {
             if (!sc[k]) continue;
@@ -311,6 +330,15 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
                     for (int t = 0; t < hx.ntap; t++)
                         wx[((size_t)c * hx.ntap + t) * wcols[k] + i] = hx.w[(size_t)(colb[k][c] + i) * hx.ntap + t];
             o.wx = as_off<double>(blob_put(blob, wx.data(), wx.size() * sizeof(double)));
+            // the float pass: weights with both normalisations folded in, in the unit of the 16-bit result (a byte tile's taps are bytes)
+            std::vector<float> wxf(wx.size(), 0.f);
+            const double unit = px_bytes == 4 ? 65535.0 * 257.0 : 65535.0;
+            for (int c = 0; c < ns; c++)
+                for (int i = 0; i < colb[k][c + 1] - colb[k][c]; i++)
+                    for (int t = 0; t < hx.ntap; t++)
+                        wxf[((size_t)c * hx.ntap + t) * wcols[k] + i] = (float)(hx.w[(size_t)(colb[k][c] + i) * hx.ntap + t] * hx.itwffff[colb[k][c] + i] * unit);
+            o.wxf = as_off<float>(blob_put(blob, wxf.data(), wxf.size() * sizeof(float)));
+            o.feps = ks_float_eps(hx.ntap, sc[k]->hy->ntap);
             o.itwf = as_off<double>(blob_put(blob, hx.itwffff.data(), hx.itwffff.size() * sizeof(double)));
             o.xlo = as_off<int32_t>(blob_put(blob, hx.lo.data(), hx.lo.size() * sizeof(int32_t)));
             o.colb = as_off<int32_t>(blob_put(blob, colb[k].data(), colb[k].size() * sizeof(int32_t)));
@@ -348,7 +376,7 @@ void ks_fused_rebase(KsFusedPlan *p, const uint8_t *d)
     fix(p->strips);
     for (int k = 0; k < 2; k++) {
         if (!p->o[k].wx) continue;                // output absent (offset 0 is the strips table, never an output's)
-        fix(p->o[k].wx); fix(p->o[k].itwf); fix(p->o[k].xlo); fix(p->o[k].colb);
+        fix(p->o[k].wx); fix(p->o[k].itwf); fix(p->o[k].xlo); fix(p->o[k].colb); fix(p->o[k].wxf);
     }
     for (KsFusedGeom *g : {&p->whole, &p->split}) {
         fix(g->segs);

@@ -1221,10 +1221,34 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
             o.dw = ps.dw; o.dh = ps.dh; o.sr_x0 = ps.sr.x0; o.sr_y0 = ps.sr.y0;
             o.kind = kinds[k]; o.pk = k;
         }
-        // RGBA frames: the speculative opaque pass first (IPX_KS_SPEC=0: the general kernel alone), one flag per item
+        // RGBA frames: the speculative opaque pass first (IPX_KS_SPEC=0: the general kernel alone), one flag per item.  RGBA, YCbCr and
+        // Gray frames: the float pass (IPX_KS_FAST=0: float64 throughout) with a list per frame for the pixels it cannot decide --
+        // 1 / 24 of the output pixels each, thirty times what photographs put there; a frame that fills its list is redone in float64.
+        // One stream-ordered block: [flags][counts][lists].
         int *redo = nullptr;
+        KsFix fixv, *fix = nullptr;
         const int max_items = n * fp.nstrips * std::max(fp.whole.nseg, fp.split.nseg);
-        if (src.kind == IPX_SRC_RGBA && env_int("IPX_KS_SPEC", 1)) IPX_HIP(hipMallocAsync((void **)&redo, (size_t)max_items * sizeof(int), s));
+        const bool spec = src.kind == IPX_SRC_RGBA && env_int("IPX_KS_SPEC", 1);
+        // (the float pass costs three more launches and a memset, about 0.1 ms: batches under 100 megapixels of source -- 48 frames
+        // of 1080p, 3 of 8K -- stay with float64; IPX_KS_FAST=2 takes it whatever the size)
+        const int fast_env = env_int("IPX_KS_FAST", 1);
+        const bool fast = (spec || src.kind == IPX_SRC_YCBCR) && fast_env && (fast_env > 1 || (double)n * sw * sh >= 100e6);
+        if (spec || fast) {
+            size_t px = 0;
+            for (int k = 0; k < 2; k++) if (outs[k]) px += (size_t)pl->sc[k].dw * pl->sc[k].dh;
+            const int cap_env = env_int("IPX_KS_FIX_CAP", 0);     // test knob: tiny lists, so that frames fill them
+            const int cap = !fast ? 0 : cap_env > 0 ? cap_env : (int)std::min<size_t>(std::max<size_t>(px / 24, 1024), (size_t)1 << 20);
+            const size_t flags = align256((size_t)max_items * sizeof(int)), counts = fast ? align256((size_t)n * sizeof(int)) : 0;
+            IPX_HIP(hipMallocAsync((void **)&redo, flags + counts + (size_t)n * cap * sizeof(uint2), s));
+            if (fast) {
+                fixv.count = (int *)((uint8_t *)redo + flags);
+                fixv.list = (uint2 *)((uint8_t *)redo + flags + counts);
+                fixv.cap = cap;
+                for (int k = 0; k < 2; k++) { fixv.ax[k] = pl->sc[k].ax[0]; fixv.ay[k] = pl->sc[k].ax[1]; }
+                IPX_HIP(hipMemsetAsync(fixv.count, 0, (size_t)n * sizeof(int), s));
+                fix = &fixv;
+            }
+        }
         a.redo = redo;
 #if IPX_DIAG
         static unsigned long long *stamp_buf = nullptr;   // IPX_STAMPS=1: phase stamps, never in a timed run
@@ -1235,7 +1259,7 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
         }
 #endif
         bool matched = false;
-        hipError_t e = launch_ks_fused(fp, a, ctx->cus, s, &matched);
+        hipError_t e = launch_ks_fused(fp, a, fix, ctx->cus, s, &matched);
         if (redo) (void)hipFreeAsync(redo, s);
 #if IPX_DIAG
         if (a.stamps && matched) {

@@ -190,6 +190,10 @@ def test_plan_subsets_and_unfused(ctx, monkeypatch):
 
 
 PATH_ENVS = [{"IPX_FUSED": "0"},                                 # per-output kernels (ks_generic_kernel), no one-pass kernel
+             {"IPX_KS_FAST": "0"},                               # float64 throughout: no float pass
+             {"IPX_KS_FAST": "0", "IPX_KS_STRIPS": "3"},
+             {"IPX_KS_FIX_CAP": "7"},                            # the float pass with lists of 7 pixels: frames fill them, their items are redone in float64
+             {"IPX_KS_FIX_CAP": "300", "IPX_KS_SPLIT": "1", "IPX_KS_SPLIT_ROWS": "50"},   # some items fit their frame's list, some do not
              {"IPX_KS_SPEC": "0"},                               # the general four-channel kernel alone, no speculative opaque pass
              {"IPX_KS_SPLIT": "0"},                              # one segment per frame even for a small batch
              {"IPX_KS_SPLIT": "1", "IPX_KS_SPLIT_ROWS": "50"},   # many short segments: every destination row near a seam re-stages its rows
@@ -200,8 +204,8 @@ PATH_ENVS = [{"IPX_FUSED": "0"},                                 # per-output ke
 
 @pytest.mark.parametrize("env", PATH_ENVS, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_every_kernel_path_is_bit_exact(ctx, env, monkeypatch):
-    """The shipped default is the one-pass kernel with the speculative opaque pass; the per-output kernels, the general
-    kernel and other tilings (strips, segments) must give the same bytes.  Frame 1 of every batch is translucent, so the
+    """The shipped default is the one-pass kernel with the float pass on frames taken as opaque; float64 throughout, the
+    per-output kernels, the general kernel and other tilings (strips, segments) must give the same bytes.  Frame 1 of every batch is translucent, so the
     speculative pass gives it up and the general kernel redoes its items."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -231,8 +235,9 @@ def test_random_geometries_vs_oracle(ctx, monkeypatch):
         sh = int(rng.choice([rng.integers(2, 60), rng.integers(60, 500)]))
         resize = (int(rng.integers(1, 1300)), int(rng.integers(1, 900)), bool(rng.integers(0, 2)))
         thumb = (int(rng.integers(1, 300)), bool(rng.integers(0, 2)))
-        for k in ("IPX_KS_STRIPS", "IPX_KS_SPLIT_ROWS", "IPX_KS_SPLIT", "IPX_KS_SPEC"):
+        for k in ("IPX_KS_STRIPS", "IPX_KS_SPLIT_ROWS", "IPX_KS_SPLIT", "IPX_KS_SPEC", "IPX_KS_FIX_CAP"):
             monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("IPX_KS_FAST", "2")                      # the float pass whatever the batch size (conftest.py)
         if rng.random() < 0.5:
             monkeypatch.setenv("IPX_KS_STRIPS", str(int(rng.choice([1, 2, 3, 5, 9]))))
         if rng.random() < 0.5:
@@ -241,6 +246,11 @@ def test_random_geometries_vs_oracle(ctx, monkeypatch):
             monkeypatch.setenv("IPX_KS_SPLIT", str(int(rng.integers(0, 2))))
         if rng.random() < 0.25:
             monkeypatch.setenv("IPX_KS_SPEC", "0")
+        pick = rng.random()
+        if pick < 0.25:
+            monkeypatch.setenv("IPX_KS_FAST", "0")
+        elif pick < 0.5:
+            monkeypatch.setenv("IPX_KS_FIX_CAP", str(int(rng.choice([1, 5, 40, 400]))))
         n = int(rng.integers(1, 4))
         frames = rgba_frames(n, sw, sh, seed=trial, opaque=bool(rng.integers(0, 2)))
         glyphs = text_glyphs(sw, sh, n=5, width_px=min(60, sw), height_px=min(20, sh))
@@ -252,7 +262,7 @@ def test_random_geometries_vs_oracle(ctx, monkeypatch):
             for k in ("resize", "thumbnail", "watermark"):
                 if k in got:
                     np.testing.assert_array_equal(got[k][i], want[k], err_msg="trial %d %s %dx%d resize=%s thumb=%s env=%s" % (
-                        trial, k, sw, sh, resize, thumb, {e: os.environ.get(e) for e in ("IPX_KS_STRIPS", "IPX_KS_SPLIT_ROWS", "IPX_KS_SPLIT", "IPX_KS_SPEC")}))
+                        trial, k, sw, sh, resize, thumb, {e: os.environ.get(e) for e in ("IPX_KS_STRIPS", "IPX_KS_SPLIT_ROWS", "IPX_KS_SPLIT", "IPX_KS_SPEC", "IPX_KS_FAST", "IPX_KS_FIX_CAP")}))
         plan.close()
         gs.close()
 
@@ -325,8 +335,8 @@ def test_full_size_batch_properties(ctx):
 # ---- the headline shapes of BASELINE.json, each on the path the bench times -------------------------------
 
 @pytest.mark.parametrize("resize", [(1024, 768, False), (1024, 768, True)], ids=["1024x768", "keep_aspect-1024x576"])
-@pytest.mark.parametrize("env", [{}, {"IPX_FUSED": "0"}, {"IPX_KS_SPEC": "0"}, {"IPX_KS_SPLIT": "0"}],
-                         ids=["default", "per-output", "general-kernel", "one-segment"])
+@pytest.mark.parametrize("env", [{}, {"IPX_FUSED": "0"}, {"IPX_KS_SPEC": "0"}, {"IPX_KS_SPLIT": "0"}, {"IPX_KS_FAST": "0"}],
+                         ids=["default", "per-output", "general-kernel", "one-segment", "float64"])
 def test_config2_resize_only_1080p_plan(ctx, resize, env, monkeypatch):
     """BASELINE config 2: a resize-only plan on 1920x1080 frames through the batched path (resize.go:61-75,121-125)."""
     for k, v in env.items():
@@ -494,3 +504,31 @@ def test_mixed_entries_from_many_threads(ctx):
     plan.close()
     gs.close()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("env", [{}, {"IPX_KS_FIX_CAP": "64"}, {"IPX_KS_FAST": "0"}], ids=["float-pass", "float-pass-short-lists", "float64"])
+def test_values_exactly_on_a_rounding_boundary(ctx, env, monkeypatch):
+    """The float pass (ipx_ks_fused.hip) decides a byte from float sums only when the value is provably clear of a multiple of 256 and
+    leaves the rest to float64 (ks_fix_kernel).  Exact 2:1 and 4:1 downscales make the hardest case plentiful: the weights are
+    multiples of 1/8 (1/32) per axis, so sum(tap * weight) + 0.5 lands EXACTLY on a multiple of 256 for about one value in 3000 of a
+    random frame -- there the byte is whatever the reference's float64 roundings make of it.  All of them must come out as the
+    oracle's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    frames = rgba_frames(2, 1920, 1080, seed=0xB0DA)
+    plan = ctx.plan(1920, 1080, resize=(960, 540, False), thumbnail=(270, True), watermark=None)
+    got = plan.run_host(frames)
+    on_boundary = 0
+    for i in range(2):
+        want = oracle.process(frames[i], resize=(960, 540, False), thumb=(270, True), want=("resize", "thumbnail"))
+        for k in ("resize", "thumbnail"):
+            np.testing.assert_array_equal(got[k][i], want[k], err_msg="%s frame %d %s" % (k, i, env))
+        # how many values of the 2:1 output sit exactly on a boundary (integer arithmetic: weights (1, 3, 3, 1) / 8 per axis)
+        f = frames[i][..., :3].astype(np.int64)
+        wy = np.array([1, 3, 3, 1])
+        rows = sum(wy[k] * np.pad(f, ((1, 1), (0, 0), (0, 0)), mode="edge")[k:k + 1080:2] for k in range(4))[:540]
+        cols = sum(wy[k] * np.pad(rows, ((0, 0), (1, 1), (0, 0)), mode="edge")[:, k:k + 1920:2] for k in range(4))[:, :960]
+        inner = cols[1:-1, 1:-1]                                     # (edge rows and columns have their own, renormalised weights)
+        on_boundary += int(np.count_nonzero((257 * inner + 32) % (256 * 64) == 0))
+    assert on_boundary > 100, on_boundary                            # the case is really there
+    plan.close()

@@ -133,11 +133,15 @@ def _expect_ycbcr_ops(y, cb, cr, ratio, resize, thumb, glyphs, col):
                                   (2560, 1440, 1, 2, (1024, 768, True), (200, True)),      # two column blocks
                                   (1920, 1080, 1, 2, (3840, 2160, False), (200, True))],   # upscale: falls back (too many columns)
                          ids=lambda c: "%dx%d r%d" % (c[0], c[1], c[3]))
-@pytest.mark.parametrize("fused", ["1", "0", "split"], ids=["one-pass", "per-output", "one-pass-split-strips"])
+@pytest.mark.parametrize("fused", ["1", "0", "split", "f64", "cap"], ids=["one-pass", "per-output", "one-pass-split-strips", "one-pass-float64", "one-pass-short-lists"])
 def test_ycbcr_batch_plan(ctx, case, fused, monkeypatch):
     monkeypatch.setenv("IPX_FUSED", "0" if fused == "0" else "1")
     if fused == "split":
         monkeypatch.setenv("IPX_KS_STRIPS", "3"); monkeypatch.setenv("IPX_KS_SPLIT", "1"); monkeypatch.setenv("IPX_KS_SPLIT_ROWS", "23")
+    if fused == "f64":
+        monkeypatch.setenv("IPX_KS_FAST", "0")          # no float pass
+    if fused == "cap":
+        monkeypatch.setenv("IPX_KS_FIX_CAP", "9")       # the float pass's lists fill up: the frames' items are redone in float64
     from helpers import DEFAULT_COL, text_glyphs
     w, h, n, ratio, resize, thumb = case
     planes = [_rand_ycbcr(w, h, ratio, 50 + i) for i in range(n)]
