@@ -202,8 +202,9 @@ struct JpegParArgs {
     const uint8_t *blob; const JpegDecTables *tab; const JpegParImage *img;
     uint8_t *ublob;                        // the scans without stuffing, same offsets as blob, zero filled
     int nimg, max_nsub, bpm, ybl, nblk;
-    int stage_rows;                        // 1: the workgroup's sub-sequences are staged in LDS (64 KiB, two waves per CU); 0: read through L1 / L2
-    uint32_t *stuffed;                     // [nimg][max_nsub] stuffed zeros before each 1 KiB chunk (after the scan)
+    int stage_rows;                        // 1: the workgroup's sub-sequences are staged in LDS (64 KiB, two waves per CU; 1 KiB sub-sequences only); 0: read through L1 / L2
+    int sub;                               // bytes of scan per sub-sequence: 128, 256, 512 or 1024 (jpeg_par_sub_bytes(): the largest)
+    uint32_t *stuffed;                     // [nimg][max_nsub] stuffed zeros before each sub-sequence's chunk (after the scan)
     uint32_t *scan_end, *ulen;             // per image: first marker in the stuffed scan; bytes of the unstuffed scan
     unsigned long long *entry, *exit_a, *exit_b;
     unsigned long long *ck_state; uint32_t *ck_ends;   // per sub-sequence, jpeg_par_checkpoints() each: state and block ends at the checkpoints

@@ -31,7 +31,7 @@ namespace ipx {
 
 namespace {
 
-constexpr int kSub = 1024;            // bytes of scan per sub-sequence
+constexpr int kSub = 1024;            // bytes of scan per sub-sequence at most (JpegParArgs::sub: 256 and 512 for small batches)
 constexpr int kRow = kSub + 4;        // LDS bytes per staged sub-sequence
 constexpr uint32_t kEnd = 0xffffffffu;
 
@@ -206,9 +206,9 @@ __device__ __forceinline__ Tables stage(uint8_t *lds, const JpegParArgs &a, cons
     if (lane < 32) bd[lane] = (&tab->bound[0][0])[lane];
     uint8_t *rows = tb + 4096;
     const uint8_t *scan = a.ublob + im.scan_off;           // unstuffed copy: same offsets as the packed scans, zero padded
-    const uint32_t base = (uint32_t)first_sub * kSub;
+    const uint32_t base = (uint32_t)first_sub * (uint32_t)a.sub;
     const uint32_t cap = (im.scan_len + 15u) & ~15u;       // the unstuffed scan is no longer than the stuffed one
-    const uint32_t avail = a.stage_rows == 1 && cap > base ? min(cap - base, (uint32_t)(64 * kSub + 16)) : 0u;
+    const uint32_t avail = a.stage_rows == 1 && a.sub == kSub && cap > base ? min(cap - base, (uint32_t)(64 * kSub + 16)) : 0u;
     for (uint32_t ch = lane; ch < (avail >> 4); ch += 64) {
         const uint4 v = *(const uint4 *)(scan + base + ch * 16);
         const uint32_t i = ch * 16;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void par_count_kernel(JpegParArgs a)
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= (int)im.nsub) return;
     const uint8_t *scan = a.blob + im.scan_off;
-    const uint32_t b0 = (uint32_t)t * kSub, b1 = min(b0 + kSub, im.scan_len);
+    const uint32_t b0 = (uint32_t)t * (uint32_t)a.sub, b1 = min(b0 + (uint32_t)a.sub, im.scan_len);
     uint32_t n = 0, first_marker = 0xffffffffu;
     uint32_t prev = b0 > 0 ? scan[b0 - 1] : 0u;
     for (uint32_t j = b0; j < b1; j += 16) {                 // scans start 16-byte aligned (and are padded), chunks are multiples of 16
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void par_unstuff_kernel(JpegParArgs a)
     const uint8_t *scan = a.blob + im.scan_off;
     uint8_t *dst = a.ublob + im.scan_off;
     const uint32_t end = min(a.scan_end[blockIdx.y], im.scan_len);
-    const uint32_t b0 = (uint32_t)t * kSub, b1 = min(b0 + kSub, end);
+    const uint32_t b0 = (uint32_t)t * (uint32_t)a.sub, b1 = min(b0 + (uint32_t)a.sub, end);
     uint32_t o = b0 - a.stuffed[im.sub_off + t];
     uint32_t prev = b0 > 0 ? scan[b0 - 1] : 0u;
     // whole input words (chunks start 4-byte aligned) through a small byte queue; output words are stored whole only when
@@ -311,7 +311,11 @@ __global__ __launch_bounds__(256) void par_unstuff_kernel(JpegParArgs a)
     if (b0 < end && b1 == end) a.ulen[blockIdx.y] = o;       // the chunk that holds the last byte of the scan
 }
 
-// steps 1 and 2.  round 0: speculative; round >= 1: re-decode where the entry changed
+// steps 1 and 2.  round 0: speculative; round >= 1: re-decode where the entry changed.
+// A round >= 1 is a fixed point WITHIN the wave first: lane t takes lane t - 1's exit of this very pass (a shuffle) and decodes again
+// while any entry in the wave still changes; only the first lane of a wave depends on what another wave left in the round before.  With
+// 256-byte sub-sequences a stream needs several of them to fall into step, and one host round per sub-sequence (a launch and a wait
+// each) was most of a small batch's decode: 5 rounds for 8 files, 2 now.
 __global__ __launch_bounds__(64) void par_sync_kernel(JpegParArgs a, int round)
 {
     extern __shared__ uint4 lds_raw[];
@@ -320,66 +324,87 @@ __global__ __launch_bounds__(64) void par_sync_kernel(JpegParArgs a, int round)
     if (first >= (int)im.nsub) return;
     Reader r;
     const Tables T = stage((uint8_t *)lds_raw, a, im, blockIdx.y, lane, first, r);
-    if (t >= (int)im.nsub) return;
-    const size_t s = im.sub_off + t;
+    const bool live = t < (int)im.nsub;
+    const size_t s = im.sub_off + (live ? t : 0);
     const unsigned long long *exit_prev = round & 1 ? a.exit_a : a.exit_b;
     unsigned long long *exit_next = round & 1 ? a.exit_b : a.exit_a;
-    const uint32_t ustart = (uint32_t)t * kSub * 8u, uend = min(ustart + kSub * 8u, r.ubits);
-    unsigned long long entry;
-    if (round == 0) entry = ustart < r.ubits ? pack_state(ustart, 0, 0) : pack_state(kEnd, 0, 0);   // t == 0: the truth; t > 0: a guess
-    else if (t == 0) { exit_next[s] = exit_prev[s]; return; }
-    else {
-        entry = exit_prev[s - 1];
-        if (entry == a.entry[s]) { exit_next[s] = exit_prev[s]; return; }
-        atomicAdd(a.changed, 1u);
-    }
-    a.entry[s] = entry;
-    const uint32_t p = (uint32_t)entry;
-    uint32_t ends = 0;
-    unsigned long long out;
-    // Checkpoints: the decoder state at the first symbol boundary at or after ustart + ck_bits(k).  A re-decode (round >= 1) that
-    // arrives at a checkpoint in the state the previous decode of this sub-sequence had there decodes the rest exactly as before:
-    // it stops, keeps the old exit and adds the old block-end count of the remainder.  Streams re-synchronise within a few hundred
-    // bits as a rule, so round 1 costs a fraction of round 0.
+    const uint32_t ustart = (uint32_t)t * (uint32_t)a.sub * 8u, uend = min(ustart + (uint32_t)a.sub * 8u, r.ubits);
     unsigned long long *ck = a.ck_state + s * kCk;
     uint32_t *cke = a.ck_ends + s * kCk;
-    int k = 0;
-    if (p == kEnd || p >= uend) out = p >= r.ubits ? pack_state(kEnd, 0, 0) : entry;   // nothing of this sub-sequence is left to decode
-    else {
-        const uint32_t old_total = a.ends[s];
-        r.seek(p);
-        NoSink sink;
-        int c = (int)(entry >> 32) & 0xff, z = (int)(entry >> 40) & 0xff;
-        bool ended = false;
-        out = entry;
-        for (; k < kCk; k++) {
-            const uint32_t limit = ustart + ck_bits(k);
-            if (limit >= uend) break;                               // the remaining checkpoints lie beyond this sub-sequence
-            if (p >= limit) { ck[k] = kNoState; continue; }         // entered beyond it: not on this trajectory
-            uint32_t e1;
-            out = run(r, T, Slots::of(im), a.bpm, a.ybl, c, z, limit, sink, &e1);
-            ends += e1;
-            if ((uint32_t)out == kEnd) { ended = true; break; }
-            if (round > 0 && ck[k] == out) {
-                const uint32_t old_at = cke[k], shift = ends - old_at;
-                cke[k] = ends;
-                for (int j = k + 1; j < kCk; j++) cke[j] += shift;
-                exit_next[s] = exit_prev[s];
-                a.ends[s] = ends + (old_total - old_at);
-                return;
+
+    // one decode of this lane's sub-sequence from `entry`; again = there was an earlier decode whose checkpoints may end this one early.
+    // Checkpoints: the decoder state at the first symbol boundary at or after ustart + ck_bits(k).  A re-decode that arrives at a
+    // checkpoint in the state the previous decode of this sub-sequence had there decodes the rest exactly as before: it stops, keeps
+    // the old exit and adds the old block-end count of the remainder.  Streams re-synchronise within a few hundred bits as a rule, so a
+    // re-decode costs a fraction of the first one.
+    auto decode = [&](unsigned long long entry, bool again, unsigned long long old_exit, uint32_t old_total, uint32_t *total) -> unsigned long long {
+        const uint32_t p = (uint32_t)entry;
+        uint32_t ends = 0;
+        unsigned long long out;
+        int k = 0;
+        if (p == kEnd || p >= uend) out = p >= r.ubits ? pack_state(kEnd, 0, 0) : entry;   // nothing of this sub-sequence is left to decode
+        else {
+            r.seek(p);
+            NoSink sink;
+            int c = (int)(entry >> 32) & 0xff, z = (int)(entry >> 40) & 0xff;
+            bool ended = false;
+            out = entry;
+            for (; k < kCk; k++) {
+                const uint32_t limit = ustart + ck_bits(k);
+                if (limit >= uend) break;                               // the remaining checkpoints lie beyond this sub-sequence
+                if (p >= limit) { ck[k] = kNoState; continue; }         // entered beyond it: not on this trajectory
+                uint32_t e1;
+                out = run(r, T, Slots::of(im), a.bpm, a.ybl, c, z, limit, sink, &e1);
+                ends += e1;
+                if ((uint32_t)out == kEnd) { ended = true; break; }
+                if (again && ck[k] == out) {
+                    const uint32_t old_at = cke[k], shift = ends - old_at;
+                    cke[k] = ends;
+                    for (int j = k + 1; j < kCk; j++) cke[j] += shift;
+                    *total = ends + (old_total - old_at);
+                    return old_exit;
+                }
+                ck[k] = out; cke[k] = ends;
+                c = (int)(out >> 32) & 0xff; z = (int)(out >> 40) & 0xff;
             }
-            ck[k] = out; cke[k] = ends;
-            c = (int)(out >> 32) & 0xff; z = (int)(out >> 40) & 0xff;
+            if (!ended) {
+                uint32_t e1;
+                out = run(r, T, Slots::of(im), a.bpm, a.ybl, c, z, uend, sink, &e1);
+                ends += e1;
+            }
         }
-        if (!ended) {
-            uint32_t e1;
-            out = run(r, T, Slots::of(im), a.bpm, a.ybl, c, z, uend, sink, &e1);
-            ends += e1;
+        for (int j = k; j < kCk; j++) ck[j] = kNoState;                 // checkpoints this decode did not reach
+        *total = ends;
+        return out;
+    };
+
+    if (round == 0) {
+        if (!live) return;
+        const unsigned long long entry = ustart < r.ubits ? pack_state(ustart, 0, 0) : pack_state(kEnd, 0, 0);   // t == 0: the truth; t > 0: a guess
+        a.entry[s] = entry;
+        uint32_t total = 0;
+        exit_next[s] = decode(entry, false, 0, 0, &total);
+        a.ends[s] = total;
+        return;
+    }
+    unsigned long long entry = live ? a.entry[s] : 0, mine = live ? exit_prev[s] : 0;
+    uint32_t total = live ? a.ends[s] : 0;
+    const unsigned long long left = live && t > 0 && lane == 0 ? exit_prev[s - 1] : 0;     // what the wave before left in the round before
+    bool any_change = false;
+    for (int pass = 0; pass < 64; pass++) {                                               // (an entry moves at most one lane per pass)
+        const unsigned long long up = __shfl_up(mine, 1);
+        const unsigned long long want = lane == 0 ? left : up;
+        const bool changed = live && t > 0 && want != entry;
+        if (!__any(changed)) break;
+        if (changed) {
+            entry = want;
+            any_change = true;
+            mine = decode(entry, true, mine, total, &total);
         }
     }
-    for (int j = k; j < kCk; j++) ck[j] = kNoState;                 // checkpoints this decode did not reach
-    exit_next[s] = out;
-    a.ends[s] = ends;
+    if (!live) return;
+    if (any_change) { atomicAdd(a.changed, 1u); a.entry[s] = entry; a.ends[s] = total; }
+    exit_next[s] = mine;
 }
 
 struct CoefSink {
@@ -411,7 +436,7 @@ __global__ __launch_bounds__(64) void par_write_kernel(JpegParArgs a)
     const size_t s = im.sub_off + t;
     const unsigned long long entry = a.entry[s];
     const uint32_t p = (uint32_t)entry;
-    const uint32_t uend = min(((uint32_t)t + 1) * kSub * 8u, r.ubits);
+    const uint32_t uend = min(((uint32_t)t + 1) * (uint32_t)a.sub * 8u, r.ubits);
     if (p == kEnd || p >= uend) return;
     CoefSink sink{a.coefs + (size_t)im.img * a.nblk * 64, a.dcs + (size_t)im.img * a.nblk, T.unz, a.ends[(size_t)blockIdx.y * a.max_nsub + t], (uint32_t)a.nblk, a.status + im.img};
     sink.drop = a.stage_rows == 2;

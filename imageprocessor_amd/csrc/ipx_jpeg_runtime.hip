@@ -117,99 +117,139 @@ IPX_CATCH_STATUS
 
 }  // extern "C"
 
-static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const uint8_t *src, int w, int h, int stride, size_t frame_stride,
-                            int n, int quality, uint8_t **blob, size_t *offs, size_t *lens)
+// jpeg.Encode of up to three sets of n frames (the three operators' outputs of one batch) with THREE waits for the device in all: every
+// set's transform + symbol sizing, one read-back of the sizes; every set's bit packing + 0xff count, one read-back; every set's byte
+// stuffing into one block, one download.  (One set after the other, as rounds 1 and 2 ran it, is nine waits: 5.5 ms for a batch of 8.)
+struct JpegEncSet { int16_t *dcoefs; const uint8_t *src; int w, h, stride; size_t frame_stride; size_t *offs, *lens; };   // offs / lens: [n], into *blob
+static int jpeg_encode_sets(ipx_ctx *ctx, hipStream_t s, const JpegEncSet *sets, int K, int n, int quality, uint8_t **blob)
 {
-    const size_t per = ipx_jpeg_coef_count(w, h) * sizeof(int16_t);
+    *blob = nullptr;
+    if (K <= 0 || K > 3 || n <= 0) return IPX_OK;
     const bool trace = env_int("IPX_DEBUG_J2J", 0) != 0;
     const auto te0 = std::chrono::steady_clock::now();
     auto ems = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count(); };
     double t_q1 = 0, t_s1 = 0, t_q2 = 0, t_s2 = 0, t_q3 = 0;
 
-    // ---- entropy coding on the GPU: size, scan, place, stuff (ipx_jpeg_entropy.hip); two small read-backs ----
-    const int nblk = (int)(per / 128);
+    // ---- entropy coding on the GPU: size, scan, place, stuff (ipx_jpeg_entropy.hip) ----
     JpegTables t;
     jpeg_tables(quality, &t);
-    std::vector<uint8_t> hdr;
-    jpeg_write_header(w, h, t, &hdr);
     uint32_t packed[1024];
     jpeg_huff_packed(packed);
     AsyncFree mem{s, {}};
-    uint32_t *d_tab, *d_len, *d_tot, *d_ubytes, *d_ff, *d_fftot;
-    unsigned long long *d_ubase, *d_obase;
-    uint8_t *d_hdr, *d_ustream = nullptr, *d_ostream = nullptr;
+    uint32_t *d_tab;
     IPX_HIP(mem.get(&d_tab, sizeof packed));
-    IPX_HIP(mem.get(&d_len, (size_t)n * nblk * 4));
-    IPX_HIP(mem.get(&d_tot, (size_t)n * 4));
-    IPX_HIP(mem.get(&d_ubytes, (size_t)n * 4));
-    IPX_HIP(mem.get(&d_fftot, (size_t)n * 4));
-    IPX_HIP(mem.get(&d_ubase, (size_t)n * 8));
-    IPX_HIP(mem.get(&d_obase, (size_t)n * 8));
-    IPX_HIP(mem.get(&d_hdr, hdr.size()));
     IPX_HIP(hipMemcpyAsync(d_tab, packed, sizeof packed, hipMemcpyHostToDevice, s));
-    IPX_HIP(hipMemcpyAsync(d_hdr, hdr.data(), hdr.size(), hipMemcpyHostToDevice, s));
-    if (env_int("IPX_JPEG_FUSED_LEN", 1)) {
-        // the transform kernel sizes the AC symbols of every block while it has the block in LDS; a small kernel adds the DC symbols
-        int16_t *d_dcq;
-        IPX_HIP(mem.get(&d_dcq, (size_t)n * nblk * 2));
-        int rc = fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, dcoefs, d_tab, d_len, d_dcq);
-        if (rc) return rc;
-        IPX_HIP(launch_jpeg_dclen(d_dcq, nblk, n, d_tab, d_len, s));
-    } else {
-        int rc = fdct_rgba8(ctx, s, src, w, h, stride, frame_stride, n, quality, dcoefs, nullptr, nullptr, nullptr);
-        if (rc) return rc;
-        IPX_HIP(launch_jpeg_len(dcoefs, nblk, n, d_tab, d_len, s));     // the earlier separate pass over the coefficients
+    struct Dev {
+        int nblk = 0, max_chunks = 0;
+        std::vector<uint8_t> hdr;
+        uint32_t *d_len = nullptr, *d_ubytes = nullptr, *d_ff = nullptr;
+        unsigned long long *d_ubase = nullptr, *d_obase = nullptr;
+        uint8_t *d_hdr = nullptr;
+    } dv[3];
+    uint32_t *d_tot, *d_fftot;                    // [K][n]
+    IPX_HIP(mem.get(&d_tot, (size_t)K * n * 4));
+    IPX_HIP(mem.get(&d_fftot, (size_t)K * n * 4));
+    for (int k = 0; k < K; k++) {
+        const JpegEncSet &o = sets[k];
+        Dev &d = dv[k];
+        d.nblk = (int)(ipx_jpeg_coef_count(o.w, o.h) * sizeof(int16_t) / 128);
+        jpeg_write_header(o.w, o.h, t, &d.hdr);
+        IPX_HIP(mem.get(&d.d_len, (size_t)n * d.nblk * 4));
+        IPX_HIP(mem.get(&d.d_ubytes, (size_t)n * 4));
+        IPX_HIP(mem.get(&d.d_ubase, (size_t)n * 8));
+        IPX_HIP(mem.get(&d.d_obase, (size_t)n * 8));
+        IPX_HIP(mem.get(&d.d_hdr, d.hdr.size()));
+        IPX_HIP(hipMemcpyAsync(d.d_hdr, d.hdr.data(), d.hdr.size(), hipMemcpyHostToDevice, s));
+        if (env_int("IPX_JPEG_FUSED_LEN", 1)) {
+            // the transform kernel sizes the AC symbols of every block while it has the block in LDS; a small kernel adds the DC symbols
+            int16_t *d_dcq;
+            IPX_HIP(mem.get(&d_dcq, (size_t)n * d.nblk * 2));
+            int rc = fdct_rgba8(ctx, s, o.src, o.w, o.h, o.stride, o.frame_stride, n, quality, o.dcoefs, d_tab, d.d_len, d_dcq);
+            if (rc) return rc;
+            IPX_HIP(launch_jpeg_dclen(d_dcq, d.nblk, n, d_tab, d.d_len, s));
+        } else {
+            int rc = fdct_rgba8(ctx, s, o.src, o.w, o.h, o.stride, o.frame_stride, n, quality, o.dcoefs, nullptr, nullptr, nullptr);
+            if (rc) return rc;
+            IPX_HIP(launch_jpeg_len(o.dcoefs, d.nblk, n, d_tab, d.d_len, s));     // the earlier separate pass over the coefficients
+        }
+        IPX_HIP(launch_scan(d.d_len, d.nblk, n, d_tot + (size_t)k * n, s));
     }
-    IPX_HIP(launch_scan(d_len, nblk, n, d_tot, s));
-    std::vector<uint32_t> tot(n), ubytes(n), ff(n);
-    IPX_HIP(hipMemcpyAsync(tot.data(), d_tot, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    std::vector<uint32_t> tot((size_t)K * n), ubytes((size_t)K * n), ff((size_t)K * n);
+    IPX_HIP(hipMemcpyAsync(tot.data(), d_tot, (size_t)K * n * 4, hipMemcpyDeviceToHost, s));
     t_q1 = ems();
     IPX_HIP(hipStreamSynchronize(s));
     t_s1 = ems();
-    std::vector<unsigned long long> ubase(n), obase(n);
+    std::vector<unsigned long long> ubase((size_t)K * n), obase((size_t)K * n);
     unsigned long long utotal = 0;
-    uint32_t umax = 0;
-    for (int i = 0; i < n; i++) {
-        ubytes[i] = (tot[i] + 7) / 8;
-        ubase[i] = utotal;
-        utotal += align256((size_t)ubytes[i] + 8);
-        umax = std::max(umax, ubytes[i]);
-    }
     const int chunk = jpeg_chunk_bytes();
-    const int max_chunks = (int)((umax + chunk - 1) / chunk);
+    size_t ff_words = 0;
+    for (int k = 0; k < K; k++) {
+        uint32_t umax = 0;
+        for (int i = 0; i < n; i++) {
+            const size_t j = (size_t)k * n + i;
+            ubytes[j] = (tot[j] + 7) / 8;
+            ubase[j] = utotal;
+            utotal += align256((size_t)ubytes[j] + 8);
+            umax = std::max(umax, ubytes[j]);
+        }
+        dv[k].max_chunks = (int)((umax + chunk - 1) / chunk);
+        ff_words += (size_t)n * dv[k].max_chunks;
+    }
+    uint8_t *d_ustream = nullptr, *d_ostream = nullptr;
+    uint32_t *d_ffall = nullptr;
     IPX_HIP(mem.get(&d_ustream, (size_t)utotal));
-    IPX_HIP(mem.get(&d_ff, (size_t)n * max_chunks * 4));
+    IPX_HIP(mem.get(&d_ffall, std::max<size_t>(ff_words, 1) * 4));
     IPX_HIP(hipMemsetAsync(d_ustream, 0, (size_t)utotal, s));
-    IPX_HIP(hipMemcpyAsync(d_ubase, ubase.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
-    IPX_HIP(hipMemcpyAsync(d_ubytes, ubytes.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    IPX_HIP(launch_jpeg_bits(dcoefs, nblk, n, d_tab, d_len, d_tot, d_ubase, d_ustream, s));
-    IPX_HIP(launch_jpeg_ffcount(d_ustream, d_ubase, d_ubytes, max_chunks, n, d_ff, s));
-    IPX_HIP(launch_scan(d_ff, max_chunks, n, d_fftot, s));
-    IPX_HIP(hipMemcpyAsync(ff.data(), d_fftot, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    {
+        size_t at = 0;
+        for (int k = 0; k < K; k++) {
+            Dev &d = dv[k];
+            d.d_ff = d_ffall + at;
+            at += (size_t)n * d.max_chunks;
+            IPX_HIP(hipMemcpyAsync(d.d_ubase, ubase.data() + (size_t)k * n, (size_t)n * 8, hipMemcpyHostToDevice, s));
+            IPX_HIP(hipMemcpyAsync(d.d_ubytes, ubytes.data() + (size_t)k * n, (size_t)n * 4, hipMemcpyHostToDevice, s));
+            IPX_HIP(launch_jpeg_bits(sets[k].dcoefs, d.nblk, n, d_tab, d.d_len, d_tot + (size_t)k * n, d.d_ubase, d_ustream, s));
+            IPX_HIP(launch_jpeg_ffcount(d_ustream, d.d_ubase, d.d_ubytes, d.max_chunks, n, d.d_ff, s));
+            IPX_HIP(launch_scan(d.d_ff, d.max_chunks, n, d_fftot + (size_t)k * n, s));
+        }
+    }
+    IPX_HIP(hipMemcpyAsync(ff.data(), d_fftot, (size_t)K * n * 4, hipMemcpyDeviceToHost, s));
     t_q2 = ems();
     IPX_HIP(hipStreamSynchronize(s));
     t_s2 = ems();
     unsigned long long ototal = 0;
-    for (int i = 0; i < n; i++) {
-        lens[i] = hdr.size() + ubytes[i] + ff[i] + 2;
-        obase[i] = ototal;
-        offs[i] = (size_t)ototal;
-        ototal += (lens[i] + 15) & ~(size_t)15;
-    }
+    for (int k = 0; k < K; k++)
+        for (int i = 0; i < n; i++) {
+            const size_t j = (size_t)k * n + i;
+            sets[k].lens[i] = dv[k].hdr.size() + ubytes[j] + ff[j] + 2;
+            obase[j] = ototal;
+            sets[k].offs[i] = (size_t)ototal;
+            ototal += (sets[k].lens[i] + 15) & ~(size_t)15;
+        }
     IPX_HIP(mem.get(&d_ostream, (size_t)ototal));
-    IPX_HIP(hipMemcpyAsync(d_obase, obase.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
-    IPX_HIP(launch_jpeg_stuff(d_ustream, d_ubase, d_ubytes, max_chunks, n, d_ff, d_hdr, (int)hdr.size(), d_obase, d_ostream, s));
+    for (int k = 0; k < K; k++) {
+        Dev &d = dv[k];
+        IPX_HIP(hipMemcpyAsync(d.d_obase, obase.data() + (size_t)k * n, (size_t)n * 8, hipMemcpyHostToDevice, s));
+        IPX_HIP(launch_jpeg_stuff(d_ustream, d.d_ubase, d.d_ubytes, d.max_chunks, n, d.d_ff, d.d_hdr, (int)d.hdr.size(), d.d_obase, d_ostream, s));
+    }
     uint8_t *host = (uint8_t *)ipx_host_alloc(ctx, (size_t)ototal ? (size_t)ototal : 1);   // pinned: the download runs at link speed
-    if (!host) return IPX_ERR_NOMEM;
+    if (!host) { (void)hipStreamSynchronize(s); return IPX_ERR_NOMEM; }
     hipError_t e = hipMemcpyAsync(host, d_ostream, (size_t)ototal, hipMemcpyDeviceToHost, s);
     t_q3 = ems();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    { const hipError_t e2 = hipStreamSynchronize(s); if (e == hipSuccess) e = e2; }          // (ubase / obase are read by the queued copies until here)
     if (trace)
-        fprintf(stderr, "[ipx] encode of %d x %dx%d: sized (queued %.2f ms, done %.2f), packed (queued %.2f, done %.2f), stream of %.1f MB queued %.2f, down at %.2f\n",
-                n, w, h, t_q1, t_s1, t_q2, t_s2, (double)ototal / 1e6, t_q3, ems());
+        fprintf(stderr, "[ipx] encode of %d sets x %d frames: sized (queued %.2f ms, done %.2f), packed (queued %.2f, done %.2f), streams of %.1f MB queued %.2f, down at %.2f\n",
+                K, n, t_q1, t_s1, t_q2, t_s2, (double)ototal / 1e6, t_q3, ems());
     if (e != hipSuccess) { (void)ipx_host_free(ctx, host); set_error("stream download failed: %s", hipGetErrorString(e)); return IPX_ERR_HIP; }
     *blob = host;
     return IPX_OK;
+}
+
+static int jpeg_encode_core(ipx_ctx *ctx, hipStream_t s, int16_t *dcoefs, const uint8_t *src, int w, int h, int stride, size_t frame_stride,
+                            int n, int quality, uint8_t **blob, size_t *offs, size_t *lens)
+{
+    const JpegEncSet one{dcoefs, src, w, h, stride, frame_stride, offs, lens};
+    return jpeg_encode_sets(ctx, s, &one, 1, n, quality, blob);
 }
 
 // ---- host frames in, JPEG streams out: the worker's whole GPU leg ----------------------------------------
@@ -243,9 +283,9 @@ static int run_host_jpeg_impl(ipx_ctx *ctx, const ipx_plan *pl, int n, const uin
     const size_t cres = fres ? ipx_jpeg_coef_count(pl->info.resize_w, pl->info.resize_h) * 2 : 0;
     const size_t cth = fth ? ipx_jpeg_coef_count(pl->info.thumb_w, pl->info.thumb_h) * 2 : 0;
     const size_t cwm = fwm ? ipx_jpeg_coef_count(sw, sh) * 2 : 0;
-    const size_t ccoef = align256(std::max(cres, std::max(cth, cwm)));
-    const size_t per_frame = fsrc + fres + fth + fwm + ccoef;
-    // every lane runs its own host thread: upload, operators, three encodes (each with two small read-backs) --
+    const size_t ccoef[3] = {align256(cres), align256(cth), align256(cwm)};     // a coefficient buffer per output (jpeg_encode_sets)
+    const size_t per_frame = fsrc + fres + fth + fwm + ccoef[0] + ccoef[1] + ccoef[2];
+    // every lane runs its own host thread: upload, operators, the three encodes together (two small read-backs) --
     // the threads block independently, so copies and kernels of different chunks overlap
     std::vector<Lane *> lanes;
     {
@@ -266,14 +306,14 @@ static int run_host_jpeg_impl(ipx_ctx *ctx, const ipx_plan *pl, int n, const uin
     auto worker = [&](Lane *l) {
         if (hipSetDevice(ctx->device) != hipSuccess) { status = IPX_ERR_HIP; return; }
         int rc = lane_reserve(*l, per_frame * chunk + 256);
-        std::vector<size_t> offs(chunk), lens(chunk);
+        std::vector<size_t> offs(3 * (size_t)chunk), lens(3 * (size_t)chunk);
         for (int c = next.fetch_add(1); !rc && c < nchunks && status == IPX_OK; c = next.fetch_add(1)) {
             const int i0 = c * chunk, m = std::min(chunk, n - i0);
             uint8_t *dsrc = (uint8_t *)(((uintptr_t)l->dev + 255) & ~(uintptr_t)255);
             uint8_t *dres = fres ? dsrc + fsrc * chunk : nullptr;
             uint8_t *dth = fth ? dsrc + (fsrc + fres) * chunk : nullptr;
             uint8_t *dwm = fwm ? dsrc + (fsrc + fres + fth) * chunk : nullptr;
-            int16_t *dcoef = (int16_t *)(dsrc + (fsrc + fres + fth + fwm) * chunk);
+            uint8_t *cbase = dsrc + (fsrc + fres + fth + fwm) * chunk;
             hipError_t e = hipSuccess;
             if (ysrc) {
                 // planes of the chunk: [m x Y][m x Cb][m x Cr]
@@ -307,13 +347,25 @@ static int run_host_jpeg_impl(ipx_ctx *ctx, const ipx_plan *pl, int n, const uin
             const Out outs[3] = {{dres, fres, pl->info.resize_w, pl->info.resize_h, resize_out},
                                  {dth, fth, pl->info.thumb_w, pl->info.thumb_h, thumb_out},
                                  {dwm, fwm, sw, sh, wm_out}};
-            for (int k = 0; k < 3 && !rc; k++) {
+            if (rc) break;
+            JpegEncSet sets[3];
+            const Out *who[3];
+            int K = 0;
+            size_t cat = 0;
+            for (int k = 0; k < 3; k++) {
                 const Out &o = outs[k];
-                if (!o.dev || o.w <= 0 || o.h <= 0) continue;
-                uint8_t *blob = nullptr;
-                rc = jpeg_encode_core(ctx, l->stream, dcoef, o.dev, o.w, o.h, o.w * 4, o.fs, m, quality, &blob, offs.data(), lens.data());
-                if (rc) break;
-                for (int i = 0; i < m; i++) { o.dst[i0 + i].data = blob + offs[i]; o.dst[i0 + i].len = lens[i]; }
+                if (o.dev && o.w > 0 && o.h > 0) {
+                    sets[K] = JpegEncSet{(int16_t *)(cbase + cat * chunk), o.dev, o.w, o.h, o.w * 4, o.fs, offs.data() + (size_t)K * chunk, lens.data() + (size_t)K * chunk};
+                    who[K++] = &o;
+                }
+                cat += ccoef[k];
+            }
+            uint8_t *blob = nullptr;
+            rc = jpeg_encode_sets(ctx, l->stream, sets, K, m, quality, &blob);
+            if (rc) break;
+            for (int k = 0; k < K; k++)
+                for (int i = 0; i < m; i++) { who[k]->dst[i0 + i].data = blob + sets[k].offs[i]; who[k]->dst[i0 + i].len = sets[k].lens[i]; }
+            if (blob) {
                 std::lock_guard<std::mutex> lk(res_mu);
                 res->blobs.push_back(blob);
             }
@@ -519,6 +571,19 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
     }
     std::vector<JpegParImage> par;
     const bool use_par = env_int("IPX_JPEG_PAR", 1) != 0;
+    // Sub-sequences of the scans that are decoded in parallel (ipx_jpeg_dec_par.hip): 1 KiB each for a large batch.  A lane walks its
+    // sub-sequence symbol by symbol, so a pass over a small batch takes as long as ONE sub-sequence takes while the chip idles (8
+    // files: 44 waves, 1.3 ms per pass, three passes); shorter ones until the batch fills about eight waves per CU.
+    int par_sub = jpeg_par_sub_bytes();
+    {
+        const int forced = env_int("IPX_JPEG_PAR_SUB", 0);
+        if (forced == 128 || forced == 256 || forced == 512 || forced == 1024) par_sub = forced;
+        else {
+            size_t total = 0;
+            for (int i = 0; i < n; i++) if (status[i] == IPX_OK && !info[i].host_scans) total += info[i].scan_len;
+            while (par_sub > 128 && total / (size_t)par_sub < (size_t)131072) par_sub >>= 1;
+        }
+    }
     for (int i = 0; i < n; i++) {
         if (status[i] == IPX_OK) {
             if (ref < 0 && (*w <= 0 || (info[i].w == *w && info[i].h == *h))) ref = i;
@@ -547,12 +612,12 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
         size_t start = 0;
         int mcu = 0;
         for (uint32_t k : marks[i]) { push(start, k, mcu, I.ri); items.back().strict_end = 1; mcu += I.ri; start = (size_t)k + 2; }
-        if (marks[i].empty() && use_par && I.scan_len >= (size_t)4 * jpeg_par_sub_bytes() && I.scan_len < ((size_t)1 << 28)) {
+        if (marks[i].empty() && use_par && I.scan_len >= (size_t)4 * jpeg_par_sub_bytes() && I.scan_len < ((size_t)1 << 28)) {   // (the same files whatever par_sub is)
             // a long scan without restart markers: decoded in parallel inside the scan (ipx_jpeg_dec_par.hip)
             JpegParImage pi;
             memset(&pi, 0, sizeof pi);
             pi.scan_off = blob_bytes; pi.scan_len = (uint32_t)I.scan_len; pi.img = (uint32_t)i;
-            pi.nsub = (uint32_t)((I.scan_len + jpeg_par_sub_bytes() - 1) / jpeg_par_sub_bytes());
+            pi.nsub = (uint32_t)((I.scan_len + par_sub - 1) / par_sub);
             memcpy(pi.td, I.td, 3); memcpy(pi.ta, I.ta, 3);
             par.push_back(pi);
         } else {
@@ -728,6 +793,7 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
         JpegParArgs P{};
         P.blob = d_blob; P.tab = d_tab; P.nimg = (int)par.size(); P.bpm = a.bpm; P.ybl = a.ybl; P.nblk = a.nblk;
         P.coefs = d_coefs; P.status = d_status; P.dcs = d_dcs;
+        P.sub = par_sub;
         P.stage_rows = env_int("IPX_JPEG_PAR_STAGE", 0);   // measured: 109 ms staged (2 waves per CU) against 49 ms through L1 / L2 (1024 x 1080p)
         for (auto &pi : par) P.max_nsub = std::max(P.max_nsub, (int)pi.nsub);
         for (size_t k = 0; k < par.size(); k++) par[k].sub_off = k * (size_t)P.max_nsub;
@@ -871,39 +937,50 @@ static int run_jpeg_jpeg_one(ipx_ctx *ctx, const ipx_plan *pl, int n, const ipx_
     const size_t cres = fres ? ipx_jpeg_coef_count(pl->info.resize_w, pl->info.resize_h) * 2 : 0;
     const size_t cth = fth ? ipx_jpeg_coef_count(pl->info.thumb_w, pl->info.thumb_h) * 2 : 0;
     const size_t cwm = fwm ? ipx_jpeg_coef_count(sw, sh) * 2 : 0;
-    const size_t ccoef = align256(std::max(cres, std::max(cth, cwm)));
-    const size_t per_frame = fres + fth + fwm + ccoef;
+    // (a coefficient buffer per output: the three encodes run stage by stage together, jpeg_encode_sets)
+    const size_t ccoef[3] = {align256(cres), align256(cth), align256(cwm)};
+    const size_t per_frame = fres + fth + fwm + ccoef[0] + ccoef[1] + ccoef[2];
     if (per_frame == 0) return IPX_OK;
     const int chunk = std::max(1, std::min(n, env_int("IPX_JPEG_JPEG_CHUNK", 256)));
     rc = lane_reserve(lane.get(), per_frame * chunk + 256);
     if (rc) return rc;
     const double t_res = ms_since(t0);
     std::unique_ptr<ipx_jpeg_result> res(new ipx_jpeg_result);
-    std::vector<size_t> offs(chunk), lens(chunk);
+    std::vector<size_t> offs(3 * (size_t)chunk), lens(3 * (size_t)chunk);
     for (int i0 = 0; i0 < n && !rc; i0 += chunk) {
         const int m = std::min(chunk, n - i0);
         uint8_t *base = (uint8_t *)(((uintptr_t)lane->dev + 255) & ~(uintptr_t)255);
         uint8_t *dres = fres ? base : nullptr, *dth = fth ? base + fres * chunk : nullptr, *dwm = fwm ? base + (fres + fth) * chunk : nullptr;
-        int16_t *dcoef = (int16_t *)(base + (fres + fth + fwm) * chunk);
+        uint8_t *cbase = base + (fres + fth + fwm) * chunk;
         ipx_ycbcr_batch d = planes;
         d.y += planes.y_frame_stride * i0;
         if (d.cb) { d.cb += planes.c_frame_stride * i0; d.cr += planes.c_frame_stride * i0; }
         if (planes.ratio == IPX_GRAY) rc = ipx_plan_run_dev_gray(ctx, s, pl, m, d.y, d.ystride, d.y_frame_stride, dres, fres, dth, fth, dwm, fwm);
         else rc = ipx_plan_run_dev_ycbcr(ctx, s, pl, m, &d, dres, fres, dth, fth, dwm, fwm);
+        if (rc) break;
         struct Out { uint8_t *dev; size_t fs; int w, h; ipx_bytes *dst; };
         const Out outs[3] = {{dres, fres, pl->info.resize_w, pl->info.resize_h, resize_out},
                              {dth, fth, pl->info.thumb_w, pl->info.thumb_h, thumb_out},
                              {dwm, fwm, sw, sh, wm_out}};
-        for (int k = 0; k < 3 && !rc; k++) {
+        JpegEncSet sets[3];
+        const Out *who[3];
+        int K = 0;
+        size_t cat = 0;
+        for (int k = 0; k < 3; k++) {
             const Out &o = outs[k];
-            if (!o.dev || o.w <= 0 || o.h <= 0) continue;
-            uint8_t *blob = nullptr;
-            rc = jpeg_encode_core(ctx, s, dcoef, o.dev, o.w, o.h, o.w * 4, o.fs, m, quality, &blob, offs.data(), lens.data());
-            if (rc) break;
-            res->blobs.push_back(blob);
-            for (int i = 0; i < m; i++)
-                if (status[i0 + i] == IPX_OK) { o.dst[i0 + i].data = blob + offs[i]; o.dst[i0 + i].len = lens[i]; }
+            if (o.dev && o.w > 0 && o.h > 0) {
+                sets[K] = JpegEncSet{(int16_t *)(cbase + cat * chunk), o.dev, o.w, o.h, o.w * 4, o.fs, offs.data() + (size_t)K * chunk, lens.data() + (size_t)K * chunk};
+                who[K++] = &o;
+            }
+            cat += ccoef[k];
         }
+        uint8_t *blob = nullptr;
+        rc = jpeg_encode_sets(ctx, s, sets, K, m, quality, &blob);
+        if (rc) break;
+        if (blob) res->blobs.push_back(blob);
+        for (int k = 0; k < K; k++)
+            for (int i = 0; i < m; i++)
+                if (status[i0 + i] == IPX_OK) { who[k]->dst[i0 + i].data = blob + sets[k].offs[i]; who[k]->dst[i0 + i].len = sets[k].lens[i]; }
     }
     (void)hipStreamSynchronize(s);
     if (dbg) fprintf(stderr, "[ipx] jpeg->jpeg part of %d files: lane after %.1f ms, decoded at %.1f, scratch at %.1f, done at %.1f\n", n, t_lane, t_dec, t_res, ms_since(t0));
