@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libipx.so")
 SOURCES = ["ipx_kernels.hip", "ipx_ks_generic.hip", "ipx_ks_fused.hip", "ipx_jpeg.hip", "ipx_jpeg_entropy.hip", "ipx_jpeg_dec.hip", "ipx_jpeg_dec_par.hip", "ipx_runtime.hip", "ipx_jpeg_runtime.hip", "ipx_pool.hip", "ipx_host.cpp", "ipx_ks_host.cpp", "ipx_batcher.cpp", "ipx_ops.cpp", "ipx_font.cpp", "ipx_jpeg_host.cpp", "ipx_jpeg_dec_host.cpp", "ipx_jpeg_dec_prog.cpp"]
-HEADERS = ["ipx_internal.h", "ipx_runtime_internal.h", "ipx_device.h", "ipx_ks.h", "ipx_threads.h", "ipx_batcher.h", os.path.join("..", "..", "include", "ipx.h")]
+HEADERS = ["ipx_internal.h", "ipx_runtime_internal.h", "ipx_device.h", "ipx_ks.h", "ipx_threads.h", "ipx_batcher.h", "ipx_pool_core.h", os.path.join("..", "..", "include", "ipx.h")]
 # -ffp-contract=off: the kernel scaler must round every float64 product before the add, as the
 # reference's GOAMD64=v1 build does (no FMA); the kernels also carry `#pragma clang fp contract(off)`.
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off",

@@ -4,6 +4,8 @@
 // independent, nothing is exchanged.  A Go worker binds this: it submits a job (a batch of equally sized frames, or of JPEG files) and
 // gets a ticket back at once, so no goroutine blocks an OS thread for the length of a batch; ipx_job_wait collects the result.
 //
+// The queue, the tickets and the feeder threads are ipx_pool_core.h (no GPU in it: tools/sanitize/pool_host_test.cpp runs it under
+// ThreadSanitizer); this file is what a chunk does on a GPU, and the ABI.
 // Inside: one ipx_ctx per pool slot (a device may be listed more than once), `lanes_per_device` feeder threads per slot, each with a
 // HIP stream and a grow-only device buffer of its own.  A job is cut into chunks; chunks wait in one priority queue ordered by cost
 // (bytes moved), and a feeder takes the most expensive chunk whenever it is free -- pull scheduling: a mixed batch balances itself
@@ -24,6 +26,7 @@
 #include <thread>
 #include <vector>
 
+#include "ipx_pool_core.h"
 #include "ipx_runtime_internal.h"
 
 namespace {
@@ -38,25 +41,10 @@ struct PoolOps {                 // a deep copy of ipx_pool_ops: the caller may 
 struct JobState {
     ipx_job job{};
     PoolOps ops;
-    uint64_t id = 0;
-    int chunks_left = 0;
-    int status = IPX_OK;
-    std::string error;
-    int frames_done = 0;
     std::vector<ipx_jpeg_result *> results;   // IPX_JOB_JPEG: pinned blocks the output streams live in, per slot that produced them
-    std::vector<ipx_ctx *> result_ctx;
-    bool waited = false;
+    std::vector<ipx_ctx *> result_ctx;        // (chunks append under the job's State::mu)
 };
-
-struct Chunk {
-    std::shared_ptr<JobState> job;
-    int i0 = 0, m = 0;
-    double cost = 0;
-    uint64_t seq = 0;
-};
-struct ChunkLess {   // the most expensive chunk first; submission order among equals
-    bool operator()(const Chunk &a, const Chunk &b) const { return a.cost != b.cost ? a.cost < b.cost : a.seq > b.seq; }
-};
+typedef ipx::PoolCore<JobState> Core;
 
 struct Slot {
     int device = 0;
@@ -71,15 +59,8 @@ struct Slot {
 
 struct ipx_pool {
     std::vector<std::unique_ptr<Slot>> slots;
-    std::vector<std::thread> feeders;
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::priority_queue<Chunk, std::vector<Chunk>, ChunkLess> queue;
-    std::map<uint64_t, std::shared_ptr<JobState>> jobs;
-    uint64_t next_id = 1, next_seq = 1;
-    bool stopping = false;
     size_t lane_bytes = (size_t)256 << 20;
-    std::atomic<long long> frames_by_slot[64];
+    Core core;                      // last: its feeders stop before the slots go
 };
 
 namespace {
@@ -130,11 +111,17 @@ int copy_ops(const ipx_pool_ops &in, PoolOps *out)
     return IPX_OK;
 }
 
-struct Feeder {
+struct Feeder {                     // what one feeder thread owns; made and destroyed on that thread
     hipStream_t stream = nullptr;
     hipEvent_t uploaded = nullptr;
     uint8_t *dev = nullptr;
     size_t dev_bytes = 0;
+    ~Feeder()
+    {
+        if (dev) (void)hipFree(dev);
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (uploaded) (void)hipEventDestroy(uploaded);
+    }
 };
 
 int feeder_reserve(Feeder &f, size_t bytes)
@@ -235,45 +222,30 @@ int run_chunk(Slot &s, Feeder &f, JobState &j, int i0, int m, ipx_jpeg_result **
     }
 }
 
-void feeder_main(ipx_pool *pool, int slot_index)
+// a feeder's chunk function, made on the feeder's own thread (bound next to the slot's GPU before it allocates anything)
+Core::ChunkFn make_feeder(ipx_pool *pool, int slot_index)
 {
     Slot &s = *pool->slots[slot_index];
     (void)hipSetDevice(s.device);
     bind_near_device(s.device);
-    Feeder f;
-    if (hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); f.stream = nullptr; }
-    if (hipEventCreateWithFlags(&f.uploaded, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); f.uploaded = nullptr; }
+    std::shared_ptr<Feeder> f(new Feeder);
+    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); f->stream = nullptr; }
+    if (hipEventCreateWithFlags(&f->uploaded, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); f->uploaded = nullptr; }
     {
         std::lock_guard<std::mutex> lk(s.up_mu);
         if (!s.up_stream && hipStreamCreateWithFlags(&s.up_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); s.up_stream = nullptr; }
     }
-    for (;;) {
-        Chunk c;
-        {
-            std::unique_lock<std::mutex> lk(pool->mu);
-            pool->cv_work.wait(lk, [&] { return pool->stopping || !pool->queue.empty(); });
-            if (pool->queue.empty()) break;          // stopping, and nothing left to drain
-            c = pool->queue.top();
-            pool->queue.pop();
-        }
-        JobState &j = *c.job;
+    return [&s, f](Core::State &st, int i0, int m, std::string *error) -> int {
         ipx_jpeg_result *res = nullptr;
-        const int rc = run_chunk(s, f, j, c.i0, c.m, &res);
-        const std::string text = rc ? ipx_last_error() : "";
-        bool finished = false;
-        {
-            std::lock_guard<std::mutex> lk(pool->mu);
-            if (rc && j.status == IPX_OK) { j.status = rc; j.error = text; }
-            if (!rc) j.frames_done += c.m;
-            if (res) { j.results.push_back(res); j.result_ctx.push_back(s.ctx); }
-            pool->frames_by_slot[slot_index] += c.m;
-            finished = --j.chunks_left == 0;
+        const int rc = run_chunk(s, *f, st.user, i0, m, &res);
+        if (rc) *error = ipx_last_error();
+        if (res) {
+            std::lock_guard<std::mutex> lk(st.mu);
+            st.user.results.push_back(res);
+            st.user.result_ctx.push_back(s.ctx);
         }
-        if (finished) pool->cv_done.notify_all();
-    }
-    if (f.dev) (void)hipFree(f.dev);
-    if (f.stream) { (void)hipStreamSynchronize(f.stream); (void)hipStreamDestroy(f.stream); }
-    if (f.uploaded) (void)hipEventDestroy(f.uploaded);
+        return rc;
+    };
 }
 
 int job_check(const ipx_job *job)
@@ -307,7 +279,6 @@ int ipx_pool_create(const int *devices, int n_devices, const ipx_pool_config *cf
     *out = nullptr;
     const int lanes = cfg && cfg->lanes_per_device > 0 ? cfg->lanes_per_device : 3;
     std::unique_ptr<ipx_pool> pool(new ipx_pool);
-    for (auto &c : pool->frames_by_slot) c = 0;
     if (cfg && cfg->lane_bytes) pool->lane_bytes = cfg->lane_bytes;
     for (int i = 0; i < n_devices; i++) {
         std::unique_ptr<Slot> s(new Slot);
@@ -321,8 +292,8 @@ int ipx_pool_create(const int *devices, int n_devices, const ipx_pool_config *cf
         }
         pool->slots.push_back(std::move(s));
     }
-    for (int i = 0; i < n_devices; i++)
-        for (int l = 0; l < lanes; l++) pool->feeders.emplace_back(feeder_main, pool.get(), i);
+    ipx_pool *raw = pool.get();
+    pool->core.start(n_devices, lanes, [raw](int slot) { return make_feeder(raw, slot); });
     *out = pool.release();
     return IPX_OK;
 }
@@ -331,14 +302,9 @@ IPX_CATCH_STATUS
 void ipx_pool_destroy(ipx_pool *pool)
 {
     if (!pool) return;
-    {
-        std::lock_guard<std::mutex> lk(pool->mu);
-        pool->stopping = true;
-    }
-    pool->cv_work.notify_all();
-    for (auto &t : pool->feeders) t.join();      // feeders drain the queue before they leave
-    for (auto &kv : pool->jobs)
-        for (size_t i = 0; i < kv.second->results.size(); i++) ipx_jpeg_result_free(kv.second->result_ctx[i], kv.second->results[i]);
+    pool->core.stop();                           // feeders drain the queue before they leave
+    for (auto &j : pool->core.leftovers())
+        for (size_t i = 0; i < j->user.results.size(); i++) ipx_jpeg_result_free(j->user.result_ctx[i], j->user.results[i]);
     for (auto &s : pool->slots) {
         if (s->up_stream) { (void)hipSetDevice(s->device); (void)hipStreamSynchronize(s->up_stream); (void)hipStreamDestroy(s->up_stream); }
         ipx_destroy(s->ctx);     // (with the plans its cache holds)
@@ -350,7 +316,7 @@ int ipx_pool_slots(const ipx_pool *pool) { return pool ? (int)pool->slots.size()
 
 long long ipx_pool_frames_done(const ipx_pool *pool, int slot)
 {
-    return pool && slot >= 0 && slot < (int)pool->slots.size() ? (long long)pool->frames_by_slot[slot] : -1;
+    return pool && slot >= 0 && slot < (int)pool->slots.size() ? pool->core.units_done(slot) : -1;
 }
 
 void *ipx_pool_host_alloc(ipx_pool *pool, int slot, size_t bytes) try
@@ -382,7 +348,8 @@ int ipx_job_submit(ipx_pool *pool, const ipx_job *job, ipx_ticket *ticket) try
     if (!pool || !ticket) { set_error("ipx_job_submit: bad argument"); return IPX_ERR_INVALID; }
     int rc = job_check(job);
     if (rc) return rc;
-    std::shared_ptr<JobState> j(new JobState);
+    std::shared_ptr<Core::State> st(new Core::State);
+    JobState *j = &st->user;
     j->job = *job;
     rc = copy_ops(job->ops, &j->ops);
     if (rc) return rc;
@@ -395,31 +362,23 @@ int ipx_job_submit(ipx_pool *pool, const ipx_job *job, ipx_ticket *ticket) try
     else {
         const size_t fb = (size_t)job->ops.sw * job->ops.sh * (4 + pixel_job_bpp(job->kind)) + ((size_t)4 << 20);
         per = (int)std::max<size_t>(1, pool->lane_bytes / fb);
-        const int want = 2 * (int)pool->feeders.size();
+        const int want = 2 * pool->core.feeders();
         per = std::max(1, std::min(per, (job->n + want - 1) / std::max(1, want)));
     }
-    std::vector<Chunk> chunks;
+    std::vector<Core::Piece> pieces;
     for (int i0 = 0; i0 < job->n; i0 += per) {
-        Chunk c;
-        c.job = j; c.i0 = i0; c.m = std::min(per, job->n - i0);
+        Core::Piece c;
+        c.i0 = i0; c.m = std::min(per, job->n - i0);
         if (job->kind == IPX_JOB_JPEG) {
             JobState tmp;            // cost of this slice: its own file sizes
             tmp.job = *job; tmp.job.files = job->files + i0; tmp.ops.p = job->ops;
             c.cost = chunk_cost(tmp, c.m);
         } else c.cost = chunk_cost(*j, c.m);
-        chunks.push_back(c);
+        pieces.push_back(c);
     }
-    {
-        std::lock_guard<std::mutex> lk(pool->mu);
-        if (pool->stopping) { set_error("ipx_job_submit: the pool is shutting down"); return IPX_ERR_INVALID; }
-        j->id = pool->next_id++;
-        j->chunks_left = (int)chunks.size();
-        pool->jobs[j->id] = j;
-        for (auto &c : chunks) { c.seq = pool->next_seq++; pool->queue.push(c); }
-        *ticket = j->id;
-    }
-    pool->cv_work.notify_all();
-    if (chunks.empty()) pool->cv_done.notify_all();
+    uint64_t t = 0;
+    if (!pool->core.submit(st, pieces, &t)) { set_error("ipx_job_submit: the pool is shutting down"); return IPX_ERR_INVALID; }
+    *ticket = t;
     return IPX_OK;
 }
 IPX_CATCH_STATUS
@@ -428,13 +387,9 @@ int ipx_job_wait(ipx_pool *pool, ipx_ticket ticket, int *frames_done) try
 {
     clear_error();
     if (!pool) { set_error("ipx_job_wait: null pool"); return IPX_ERR_INVALID; }
-    std::unique_lock<std::mutex> lk(pool->mu);
-    auto it = pool->jobs.find(ticket);
-    if (it == pool->jobs.end()) { set_error("ipx_job_wait: unknown ticket"); return IPX_ERR_INVALID; }
-    std::shared_ptr<JobState> j = it->second;
-    pool->cv_done.wait(lk, [&] { return j->chunks_left == 0; });
-    if (frames_done) *frames_done = j->frames_done;
-    j->waited = true;
+    std::shared_ptr<Core::State> j = pool->core.wait(ticket);
+    if (!j) { set_error("ipx_job_wait: unknown ticket"); return IPX_ERR_INVALID; }
+    if (frames_done) *frames_done = j->units_done;
     if (j->status) set_error("%s", j->error.c_str());
     return j->status;
 }
@@ -444,10 +399,9 @@ int ipx_job_poll(ipx_pool *pool, ipx_ticket ticket, int *done)
 {
     clear_error();
     if (!pool || !done) { set_error("ipx_job_poll: bad argument"); return IPX_ERR_INVALID; }
-    std::lock_guard<std::mutex> lk(pool->mu);
-    auto it = pool->jobs.find(ticket);
-    if (it == pool->jobs.end()) { set_error("ipx_job_poll: unknown ticket"); return IPX_ERR_INVALID; }
-    *done = it->second->chunks_left == 0;
+    const int d = pool->core.poll(ticket);
+    if (d < 0) { set_error("ipx_job_poll: unknown ticket"); return IPX_ERR_INVALID; }
+    *done = d;
     return IPX_OK;
 }
 
@@ -455,16 +409,9 @@ int ipx_job_release(ipx_pool *pool, ipx_ticket ticket) try
 {
     clear_error();
     if (!pool) { set_error("ipx_job_release: null pool"); return IPX_ERR_INVALID; }
-    std::shared_ptr<JobState> j;
-    {
-        std::unique_lock<std::mutex> lk(pool->mu);
-        auto it = pool->jobs.find(ticket);
-        if (it == pool->jobs.end()) { set_error("ipx_job_release: unknown ticket"); return IPX_ERR_INVALID; }
-        j = it->second;
-        pool->cv_done.wait(lk, [&] { return j->chunks_left == 0; });     // releasing a running job waits for it
-        pool->jobs.erase(it);
-    }
-    for (size_t i = 0; i < j->results.size(); i++) ipx_jpeg_result_free(j->result_ctx[i], j->results[i]);
+    std::shared_ptr<Core::State> j = pool->core.release(ticket);     // releasing a running job waits for it
+    if (!j) { set_error("ipx_job_release: unknown ticket"); return IPX_ERR_INVALID; }
+    for (size_t i = 0; i < j->user.results.size(); i++) ipx_jpeg_result_free(j->user.result_ctx[i], j->user.results[i]);
     return IPX_OK;
 }
 IPX_CATCH_STATUS
