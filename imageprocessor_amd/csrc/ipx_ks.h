@@ -106,7 +106,7 @@ struct KsFusedOut {
     int wcols;                 // columns per tap row of the LDS weight table (most destination columns any strip owns)
     const double *wx;          // [strip][ntap][wcols] horizontal weights
     const float *wxf;          // the float pass: float(w * invTotalWeightFFFF * 0xffff [* 0x101 where the tile holds bytes]), same layout
-    float feps;                // the float pass: a channel whose value / 256 has a fraction within feps of 0 or 1 is not decided
+    float feps;                // the float pass: a channel whose T = (value + 0.5) / 256 has a fraction within feps * T of 0 or 1 is not decided
     const double *itwf;        // [dw] invTotalWeightFFFF
     const int32_t *xlo;        // [dw] first tap, relative to the source rectangle
     const int32_t *colb;       // [nstrips + 1] first destination column owned by each strip
@@ -127,11 +127,12 @@ struct KsFusedArgs {
     unsigned long long *stamps; // diagnostic build (-DIPX_DIAG=1) only: per-phase cycle sums over all waves, else NULL
     int *redo;                 // speculative kernels (opaque, float): one int per item, 1 = the item met a pixel with alpha != 0xff or
                                // overflowed the frame's list and is to be redone; general kernel: only items with redo[item] != 0 run (NULL: all)
-    uint2 *fix; int *fix_count; int fix_cap;   // the float pass: per frame a list of (output << 31 | dy, dx) of the pixels it could not
-                               // decide, fix_cap entries each, and how many were appended
+    uint2 *fix; int *fix_count; int fix_cap[2], fix_stride;   // the float pass: per frame and output (of the plan: 0 resize, 1 thumbnail) a
+                               // list of (dy, dx) of the pixels it could not decide -- output k's at fix + frame * fix_stride + (k ? fix_cap[0] : 0),
+                               // fix_cap[k] entries -- and how many were appended, fix_count[2 * frame + k]
 };
 // what the exact per-pixel pass after the float pass needs per output: the axes in HBM (NULL list: no float pass)
-struct KsFix { uint2 *list = nullptr; int *count = nullptr; int cap = 0; KsAxisDev ax[2], ay[2]; };
+struct KsFix { uint2 *list = nullptr; int *count = nullptr; int cap[2] = {0, 0}; KsAxisDev ax[2], ay[2]; };
 // one segmentation of the frame's rows and the row tables cut for it
 struct KsFusedGeom { int nseg = 0; const KsSeg *segs = nullptr; const void *rows[2] = {nullptr, nullptr}; const int32_t *rowoff[2] = {nullptr, nullptr}; };
 struct KsFusedPlan {
@@ -158,7 +159,8 @@ void ks_fused_rebase(KsFusedPlan *p, const uint8_t *dev_blob);
 // *matched = false: nothing launched (shape, alignment or kind the kernel is not built for)
 // fix: lists for the float pass (RGBA with `redo`, YCbCr, Gray sources), or NULL: float64 throughout
 hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fix, int cus, hipStream_t s, bool *matched);
-// the exact pass over the float pass's lists: every listed pixel of output `k` (described by `g`, one frame per blockIdx.y) recomputed
-hipError_t launch_ks_fix(const KsGenArgs &g, const uint2 *list, const int *count, int cap, int k, hipStream_t s);
+// the exact pass over the float pass's lists: every listed pixel of one output (described by `g`, one frame per blockIdx.y) recomputed.
+// list / count: the output's list and counter of frame 0; frame f's are list + f * list_stride and count[f * count_stride]
+hipError_t launch_ks_fix(const KsGenArgs &g, const uint2 *list, size_t list_stride, const int *count, int count_stride, int cap, hipStream_t s);
 
 }  // namespace ipx

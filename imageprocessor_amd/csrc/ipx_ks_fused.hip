@@ -25,10 +25,10 @@
 //
 // The float pass (FAST = true; RGBA frames taken as opaque, YCbCr, Gray).  The float64 arithmetic above is what bounds the kernel, and a
 // byte of output needs almost none of it: the same sums in float -- taps are exact in float, one fused multiply-add per term, both
-// normalisations folded into the weights -- land within (nx + ny + 3) / 256 sixteen-bit units of the reference's value (derivation at
+// normalisations folded into the weights -- land within (nx + ny + 3) 2^-24 of the reference's value, relatively (derivation at
 // ks_float_eps, ipx_ks_host.cpp), and the byte is floor((V + 0.5) / 256): unless V + 0.5 lies that close to a multiple of 256, the
 // float result IS the reference's byte.  The pass checks exactly that for every channel it stores (the fraction of t / 256 against
-// feps); a pixel with a channel it cannot decide -- about one in a thousand -- goes on its frame's list, and ks_fix_kernel recomputes
+// feps times t / 256); a pixel with a channel it cannot decide -- about one in a thousand -- goes on its frame's list, and ks_fix_kernel recomputes
 // the listed pixels in float64, operation by operation as the reference does.  A frame whose list is full hands the item to the
 // float64 kernel through `redo`, like an item that is not opaque.  Results are the reference's bits either way; IPX_KS_FAST=0 runs
 // float64 throughout.
@@ -401,7 +401,6 @@ __device__ __forceinline__ void ks_column_fast(const uint8_t *lds, const uint8_t
 #pragma unroll
         for (int p = 0; p < NACC; p++) { rw[r][p] = row->wf[p]; remit[r][p] = row->emit[p]; }
     }
-    const float hi = 1.0f - feps;
 #pragma unroll
     for (int r = 0; r < B; r++) {
 #pragma unroll
@@ -416,8 +415,8 @@ __device__ __forceinline__ void ks_column_fast(const uint8_t *lds, const uint8_t
 #pragma unroll
                 for (int k = 0; k < NCH; k++) {
                     const float u = (c.q[p][k] + 0.5f) * (1.0f / 256.0f);
-                    const float fr = __builtin_amdgcn_fractf(u);
-                    open |= fr < feps || fr > hi;
+                    const float fr = __builtin_amdgcn_fractf(u), lim = feps * u;    // (1 - fr is exact wherever the second test can hold)
+                    open |= fr < lim || 1.0f - fr < lim;
                     b[k] = min((uint32_t)u, 255u);
                     c.q[p][k] = 0.f;
                 }
@@ -583,12 +582,12 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     issue(0);
     bool bad = false;
     KsOpen open;
-    uint32_t okey = 0;
+    const uint32_t okey = 0;
     if (FAST) {
+        const int pk = role >= 0 ? a.o[role].pk : 0;
         open.wave = (uint2 *)(lds + a.lds_open) + wv * kKsOpenPerWave;
         open.n = 0; open.full = false;
-        open.list = a.fix + (size_t)frame * a.fix_cap; open.count = a.fix_count + frame; open.cap = a.fix_cap;
-        okey = role >= 0 ? (uint32_t)a.o[role].pk << 31 : 0u;
+        open.list = a.fix + (size_t)frame * a.fix_stride + (pk ? a.fix_cap[0] : 0); open.count = a.fix_count + 2 * frame + pk; open.cap = a.fix_cap[pk];
     }
 #if IPX_DIAG
     unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
@@ -799,8 +798,10 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fi
                 a.nout > 1 ? a.o[1].waves : 0, a.nout > 1 ? a.o[1].cpl : 0, a.nout > 1 ? a.o[1].wcols : 0);
     // the float pass where the source type has one and the caller brought lists: float kernel, the listed pixels in float64, then the
     // float64 kernel on the items the float kernel gave up
-    const bool fast = fix && fix->list && a.redo && (src == KS_RGBA || src == KS_YCC || src == KS_GRAY);
-    a.fix = fast ? fix->list : nullptr; a.fix_count = fast ? fix->count : nullptr; a.fix_cap = fast ? fix->cap : 0;
+    bool fast = fix && fix->list && a.redo && (src == KS_RGBA || src == KS_YCC || src == KS_GRAY);
+    for (int i = 0; i < a.nout; i++) fast = fast && a.o[i].feps > 0.f;       // (an output with more taps than the margin's derivation covers)
+    a.fix = fast ? fix->list : nullptr; a.fix_count = fast ? fix->count : nullptr;
+    a.fix_cap[0] = fast ? fix->cap[0] : 0; a.fix_cap[1] = fast ? fix->cap[1] : 0; a.fix_stride = a.fix_cap[0] + a.fix_cap[1];
     auto exact_listed = [&]() {
         hipError_t e = hipSuccess;
         for (int i = 0; i < a.nout && e == hipSuccess; i++) {
@@ -812,7 +813,7 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fi
             g.src = a.src; g.sstride = a.sstride; g.src_fs = a.src_fs;
             g.cb = a.cb; g.cr = a.cr; g.cstride = a.cstride; g.ratio = a.ratio; g.c_fs = a.c_fs;
             g.nframes = a.nframes;
-            e = launch_ks_fix(g, fix->list, fix->count, fix->cap, o.pk, s);
+            e = launch_ks_fix(g, fix->list + (o.pk ? fix->cap[0] : 0), (size_t)a.fix_stride, fix->count + o.pk, 2, fix->cap[o.pk], s);
         }
         return e;
     };

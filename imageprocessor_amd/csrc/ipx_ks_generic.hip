@@ -124,9 +124,10 @@ __global__ __launch_bounds__(256) void ks_generic_kernel(KsGenArgs a)
 // source-row order, one after the other as scaleY does, in every lane of the group (the first one stores).  A thread per pixel would
 // walk nx * ny taps one after the other: 1936 dependent steps for an 8K frame's thumbnail, 0.7 ms for a batch of two frames.
 template <int KIND>
-__global__ __launch_bounds__(256) void ks_fix_kernel(KsGenArgs a, const uint2 *list, const int *count, int cap, int k, int R)
+__global__ __launch_bounds__(256) void ks_fix_kernel(KsGenArgs a, const uint2 *list, size_t list_stride, const int *count, int count_stride, int cap, int R)
 {
-    const int frame = (int)blockIdx.y, n = min(count[frame], cap);
+    const int frame = (int)blockIdx.y, n = min(count[(size_t)frame * count_stride], cap);
+    list += (size_t)frame * list_stride;
     a.dst += frame * a.dst_fs;
     a.src += frame * a.src_fs;
     if (KIND == IPX_SRC_YCBCR || KIND == IPX_SRC_YCBCR_CROP) { a.cb += frame * a.c_fs; a.cr += frame * a.c_fs; }
@@ -136,9 +137,9 @@ __global__ __launch_bounds__(256) void ks_fix_kernel(KsGenArgs a, const uint2 *l
     for (int i0 = (int)blockIdx.x * per_block; i0 < n; i0 += (int)gridDim.x * per_block) {
         const int i = i0 + wv * per_wave + sub;
         bool live = i < n;
-        const uint2 e = live ? list[(size_t)frame * cap + i] : make_uint2(0u, 0u);
-        const int dy = (int)(e.x & 0x7fffffffu), dx = (int)e.y;
-        live = live && (int)(e.x >> 31) == k && dx < a.adr_x1 && dy < a.adr_y1;
+        const uint2 e = live ? list[i] : make_uint2(0u, 0u);
+        const int dy = (int)e.x, dx = (int)e.y;
+        live = live && dx < a.adr_x1 && dy < a.adr_y1;
         const int xlo = live ? a.ax.lo[dx] : 0, xn = live ? a.ax.cnt[dx] : 0, ylo = live ? a.ay.lo[dy] : 0, yn = live ? a.ay.cnt[dy] : 0;
         const double *wx = a.ax.w + (size_t)(live ? dx : 0) * a.ax.ntap, *wy = a.ay.w + (size_t)(live ? dy : 0) * a.ay.ntap;
         const double xs = live ? a.ax.itwffff[dx] : 0.0;
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(256) void ks_fix_kernel(KsGenArgs a, const uint2 *l
             const int j = jb + sl;
             double pr = 0, pg = 0, pb = 0, pa = 0;
             if (j < yn)
-                for (int t = 0; t < xn; t++) {
+#pragma unroll 4
+                for (int t = 0; t < xn; t++) {                            // (the taps' loads do not wait for one another)
                     const Tap4 tp = ks_tap<KIND>(a, a.sr_x0 + xlo + t, a.sr_y0 + ylo + j);
                     const double w = wx[t];
                     pr += (double)tp.r * w;
@@ -199,19 +201,19 @@ hipError_t launch_ks_generic(const KsGenArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_ks_fix(const KsGenArgs &a, const uint2 *list, const int *count, int cap, int k, hipStream_t s)
+hipError_t launch_ks_fix(const KsGenArgs &a, const uint2 *list, size_t list_stride, const int *count, int count_stride, int cap, hipStream_t s)
 {
     if (a.nframes <= 0 || cap <= 0) return hipSuccess;
     const int R = a.ay.ntap <= 8 ? 8 : a.ay.ntap <= 16 ? 16 : 64;
-    // a few blocks per frame walk its list (a photograph leaves about a thousandth of its pixels there, the list holds forty times that)
-    // (more of them when the batch is small: about a thousand blocks in all)
+    // a few blocks per frame walk its list (a photograph leaves about a thousandth of the output's pixels there, the list holds forty
+    // times that); more of them when the batch is small: about eight thousand blocks in all
     const int per_block = 4 * (64 / R), most = (cap + per_block - 1) / per_block;
-    dim3 block(256), grid(std::max(1, std::min(most, std::max(8, 1024 / a.nframes))), a.nframes);
+    dim3 block(256), grid(std::max(1, std::min(most, std::max(8, 8192 / a.nframes))), a.nframes);
     switch (a.kind) {
-    case IPX_SRC_YCBCR: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_YCBCR>, grid, block, 0, s, a, list, count, cap, k, R); break;
-    case IPX_SRC_YCBCR_CROP: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_YCBCR_CROP>, grid, block, 0, s, a, list, count, cap, k, R); break;
-    case IPX_SRC_RGBA_CROP: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_RGBA_CROP>, grid, block, 0, s, a, list, count, cap, k, R); break;
-    case IPX_SRC_RGBA: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_RGBA>, grid, block, 0, s, a, list, count, cap, k, R); break;
+    case IPX_SRC_YCBCR: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_YCBCR>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
+    case IPX_SRC_YCBCR_CROP: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_YCBCR_CROP>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
+    case IPX_SRC_RGBA_CROP: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_RGBA_CROP>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
+    case IPX_SRC_RGBA: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_RGBA>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -99,19 +99,22 @@ void ks_axis_pack(const KsAxis &a, uint8_t *h, const uint8_t *d, KsAxisDev *out)
 // =====================================================================================================================================
 namespace ipx {
 
-// The float pass's margin (ipx_ks_fused.hip, "the float pass"), as a fraction of 256 sixteen-bit units.
+// The float pass's margin (ipx_ks_fused.hip, "the float pass"), relative to the value.
 // Reference, in real numbers: X_i = sum_j tap_ij a_j (a = horizontal weights over their total), V = sum_i X_i b_i, result
-// min(floor(V + 0.5), 0xffff) >> 8 = floor((V + 0.5) / 256) capped at 255; its float64 evaluation is within 1e-6 units of that for any
+// min(floor(V + 0.5), 0xffff) >> 8 = floor((V + 0.5) / 256) capped at 255; its float64 evaluation is within 1e-9 units of that for any
 // tap count below 10^4.  The float pass evaluates the same sums with taps exact in float (at most 16 bits), weights a' = fl(a), b' = fl(b)
-// (relative error u = 2^-24 each) and one fused multiply-add per term: every partial sum is at most 65537, so every rounding is at most
-// u * 65537 < 2^-8 (1 + 2e-5) units.
-//   |X'_i - X_i| <= nx roundings + 65535 u for the weights                      <= (nx + 1) 2^-8 (1 + 3e-5)
-//   |V' - V|     <= ny roundings + the X errors (sum b' <= 1 + u) + 65535 u     <= (nx + ny + 2) 2^-8 (1 + 4e-5)
-//   t = fl(V' + 0.5): one more rounding                                          <= (nx + ny + 3) 2^-8 (1 + 4e-5)
-// t / 256 and its fraction are exact.  So when that fraction is at least feps = (nx + ny + 4) 2^-16 away from 0 and from 1 (one spare
-// 2^-8 for the factors and the reference's own rounding), floor(t / 256) IS the reference's byte; a channel that is not goes on the
-// frame's list and is recomputed in float64, operation by operation as the reference does it (ks_fix_kernel).
-float ks_float_eps(int nx, int ny) { return std::nextafter((float)((nx + ny + 4) * (1.0 / 65536.0)), 1.0f); }
+// (relative error u = 2^-24 each) and one fused multiply-add per term.  Taps and weights are not negative, so partial sums only grow:
+// every rounding of a sum is at most u times the FINAL value of that sum.
+//   |X'_i - X_i| <= nx roundings of at most u X'_i + the weights' u X_i                      <= (nx + 1) u X_i (1 + 1e-5)
+//   |V' - V|     <= ny roundings of at most u V' + sum b'_i |X'_i - X_i| + the weights' u V  <= (nx + ny + 2) u V (1 + 1e-4)
+//   t = fl(V' + 0.5): one more rounding of at most u t                                        <= (nx + ny + 3) u t (1 + 1e-4)
+// (sum b_i X_i = V: a bright row's larger error enters with its weight.)  T = t / 256 and its fraction are exact.  So when that
+// fraction is at least (nx + ny + 4) u T away from 0 and from 1 -- one spare u T for the factors, the reference's own rounding
+// (t >= 0.5, so u t >= 3e-8) and the rounding of the product that forms the margin -- floor(T) IS the reference's byte; a channel
+// that is not goes on the frame's list and is recomputed in float64, operation by operation as the reference does it (ks_fix_kernel).
+// The margin grows with the value: a dark pixel is decided almost always, a white one has (nx + ny + 4) / 65536 of a byte on either side.
+// 0: too many taps for the factors above (a downscale by 250 and more): no float pass for such an output.
+float ks_float_eps(int nx, int ny) { return nx + ny > 1000 ? 0.f : std::nextafter((float)((nx + ny + 4) * (1.0 / 16777216.0)), 1.0f); }
 
 namespace {
 

@@ -1234,18 +1234,18 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
         const int fast_env = env_int("IPX_KS_FAST", 1);
         const bool fast = (spec || src.kind == IPX_SRC_YCBCR) && fast_env && (fast_env > 1 || (double)n * sw * sh >= 100e6);
         if (spec || fast) {
-            size_t px = 0;
-            for (int k = 0; k < 2; k++) if (outs[k]) px += (size_t)pl->sc[k].dw * pl->sc[k].dh;
             const int cap_env = env_int("IPX_KS_FIX_CAP", 0);     // test knob: tiny lists, so that frames fill them
-            const int cap = !fast ? 0 : cap_env > 0 ? cap_env : (int)std::min<size_t>(std::max<size_t>(px / 24, 1024), (size_t)1 << 20);
-            const size_t flags = align256((size_t)max_items * sizeof(int)), counts = fast ? align256((size_t)n * sizeof(int)) : 0;
-            IPX_HIP(hipMallocAsync((void **)&redo, flags + counts + (size_t)n * cap * sizeof(uint2), s));
+            int cap[2] = {0, 0};
+            for (int k = 0; k < 2; k++)
+                if (fast && outs[k]) cap[k] = cap_env > 0 ? cap_env : (int)std::min<size_t>(std::max<size_t>((size_t)pl->sc[k].dw * pl->sc[k].dh / 24, 256), (size_t)1 << 20);
+            const size_t flags = align256((size_t)max_items * sizeof(int)), counts = fast ? align256((size_t)n * 2 * sizeof(int)) : 0;
+            IPX_HIP(hipMallocAsync((void **)&redo, flags + counts + (size_t)n * (cap[0] + cap[1]) * sizeof(uint2), s));
             if (fast) {
                 fixv.count = (int *)((uint8_t *)redo + flags);
                 fixv.list = (uint2 *)((uint8_t *)redo + flags + counts);
-                fixv.cap = cap;
+                fixv.cap[0] = cap[0]; fixv.cap[1] = cap[1];
                 for (int k = 0; k < 2; k++) { fixv.ax[k] = pl->sc[k].ax[0]; fixv.ay[k] = pl->sc[k].ax[1]; }
-                IPX_HIP(hipMemsetAsync(fixv.count, 0, (size_t)n * sizeof(int), s));
+                IPX_HIP(hipMemsetAsync(fixv.count, 0, (size_t)n * 2 * sizeof(int), s));
                 fix = &fixv;
             }
         }
