@@ -288,11 +288,13 @@ def e2e_legs(ipx, device, n, sw, sh, resize, reps, lanes=5):
     synchronous host entries of the ABI: n frames in pinned host memory per call, chunks pipelined over `lanes` streams.  Never
     `value`: these are bound by the link, not by HBM.  Every repetition is reported, not the best."""
     from helpers import DEFAULT_COL, text_glyphs
+    pool = photo_like(4, sw, sh)
+    # the pool first, while the process holds no other context (an idle second one costs it 12 %: DESIGN.md section 5)
+    pool_result = pool_leg(ipx, n, sw, sh, resize, reps, pool)
     ctx = ipx.Context(device=device, lanes=lanes, lane_bytes=1 << 30)
     gs = ctx.glyphset(text_glyphs(sw, sh), DEFAULT_COL)
     plan = ctx.plan(sw, sh, resize=resize, thumbnail=(200, True), watermark=gs)
     i = plan.info
-    pool = photo_like(4, sw, sh)
     src = ctx.host_alloc((n, sh, sw, 4))
     for k in range(n):
         src[k] = pool[k % 4]
@@ -345,7 +347,7 @@ def e2e_legs(ipx, device, n, sw, sh, resize, reps, lanes=5):
     plan.close()
     gs.close()
     ctx.close()
-    legs["pool_pixels_to_pixels"] = pool_leg(ipx, n, sw, sh, resize, reps, pool)
+    legs["pool_pixels_to_pixels"] = pool_result
     return {"workload": "%d x %dx%d per call, photograph-like frames, %d lanes, pinned host memory" % (n, sw, sh, lanes),
             "link_GBps": dict(link, what="ipx_link_probe: 64 frames' worth of pinned memory up (8.3 MB each) and down (11.6 MB each), alone and at once, best of 3; copies in 32 MiB pieces, one stream per direction; at once = the better of copy engine / kernel stores for the way down"),
             "legs": legs}
