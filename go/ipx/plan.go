@@ -124,8 +124,18 @@ func (p *Plan) RunHost(n int, src, resizeOut, thumbOut, wmOut []byte) error {
 // RunHostYCbCr does the same for decoded JPEGs as image.Decode leaves them (*image.YCbCr planes of n frames, tightly packed per
 // plane): per operator the reference converts differently (16-bit per tap inside resize; RGBA8 first for the crop thumbnail and the
 // watermark), and the results are those of the reference's helpers on the *image.YCbCr itself.
+// The batch descriptor holds pointers into y, cb and cr and is itself passed by pointer: cgo refuses a Go pointer to memory that holds
+// unpinned Go pointers, so the planes' bases are pinned for the call (a no-op for Pinned / C memory).  Synchronous: nothing is read
+// after the return.
 func (p *Plan) RunHostYCbCr(n int, first *image.YCbCr, y, cb, cr, resizeOut, thumbOut, wmOut []byte) error {
 	cw, ch := first.CStride, len(first.Cb)/first.CStride
+	var pin runtimePinner
+	defer pin.Unpin()
+	for _, plane := range [][]byte{y, cb, cr} {
+		if len(plane) > 0 {
+			pin.Pin(&plane[0])
+		}
+	}
 	b := C.ipx_ycbcr_batch{y: ptr(y), cb: ptr(cb), cr: ptr(cr), ystride: C.int32_t(first.YStride), cstride: C.int32_t(cw),
 		y_frame_stride: C.size_t(first.YStride * p.h), c_frame_stride: C.size_t(cw * ch), ratio: C.int32_t(first.SubsampleRatio)}
 	i := p.Info

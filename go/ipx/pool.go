@@ -98,19 +98,29 @@ func (k PixelKind) bytesPerPixel() int {
 	return 4
 }
 
-// SubmitPixels queues n decoded RGBA8 frames of w x h (src and the outputs: Pinned memory, valid until Wait returns).
-func (p *Pool) SubmitPixels(w, h, n int, o Ops, src, resizeOut, thumbOut, wmOut []byte, resizeBytes, thumbBytes int) (*Job, error) {
+// SubmitPixels queues n decoded RGBA8 frames of w x h.  The job is ASYNCHRONOUS: feeder threads read src and write the outputs after
+// this call has returned, so all four are *Pinned (Pool.Pinned: C memory the garbage collector neither moves nor frees; nil = that
+// operator's output is not wanted) and must stay allocated until Wait has returned.  A Go slice here would be read after the call
+// that named it -- cgo cannot check that, hence the type.
+func (p *Pool) SubmitPixels(w, h, n int, o Ops, src, resizeOut, thumbOut, wmOut *Pinned, resizeBytes, thumbBytes int) (*Job, error) {
 	return p.SubmitPixelsOf(PixRGBA, w, h, n, o, src, resizeOut, thumbOut, wmOut, resizeBytes, thumbBytes)
 }
 
+func pinnedPtr(m *Pinned) *C.uint8_t {
+	if m == nil {
+		return nil
+	}
+	return ptr(m.Bytes)
+}
+
 // SubmitPixelsOf does the same for frames of any packed type image.Decode returns (rows packed without stride padding).
-func (p *Pool) SubmitPixelsOf(kind PixelKind, w, h, n int, o Ops, src, resizeOut, thumbOut, wmOut []byte, resizeBytes, thumbBytes int) (*Job, error) {
+func (p *Pool) SubmitPixelsOf(kind PixelKind, w, h, n int, o Ops, src, resizeOut, thumbOut, wmOut *Pinned, resizeBytes, thumbBytes int) (*Job, error) {
 	ops, free := p.ops(w, h, o)
 	defer free()
 	bpp := kind.bytesPerPixel()
-	j := C.ipx_job{kind: C.int32_t(kind), ops: ops, n: C.int32_t(n), src: ptr(src), sstride: C.int32_t(w * bpp), src_frame_stride: C.size_t(w * h * bpp),
-		resize_out: ptr(resizeOut), resize_frame_stride: C.size_t(resizeBytes), thumb_out: ptr(thumbOut), thumb_frame_stride: C.size_t(thumbBytes),
-		wm_out: ptr(wmOut), wm_frame_stride: C.size_t(w * h * 4)}
+	j := C.ipx_job{kind: C.int32_t(kind), ops: ops, n: C.int32_t(n), src: pinnedPtr(src), sstride: C.int32_t(w * bpp), src_frame_stride: C.size_t(w * h * bpp),
+		resize_out: pinnedPtr(resizeOut), resize_frame_stride: C.size_t(resizeBytes), thumb_out: pinnedPtr(thumbOut), thumb_frame_stride: C.size_t(thumbBytes),
+		wm_out: pinnedPtr(wmOut), wm_frame_stride: C.size_t(w * h * 4)}
 	job := &Job{p: p, n: n}
 	if err := call(func() C.int { return C.ipx_job_submit(p.c, &j, &job.ticket) }); err != nil {
 		return nil, err

@@ -63,9 +63,17 @@ for trial in range(trials):
     _, tw0, th0 = oracle.thumb_geometry(w, h, *thumb)
     if nw < 1 or nh < 1 or tw0 < 1 or th0 < 1 or max(nw, nh, tw0, th0) > 65535:      # (beyond 65535 pixels a side: IPX_ERR_UNSUPPORTED by design)
         continue
-    knobs = ("IPX_KS_STRIPS", "IPX_KS_SPLIT_ROWS", "IPX_KS_SPLIT", "IPX_KS_SPEC", "IPX_FUSED")
+    knobs = ("IPX_KS_STRIPS", "IPX_KS_SPLIT_ROWS", "IPX_KS_SPLIT", "IPX_KS_SPEC", "IPX_FUSED", "IPX_KS_FAST", "IPX_KS_FIX_CAP")
     for k in knobs:
         os.environ.pop(k, None)
+    # the arithmetic route: the float pass whatever the batch size (with lists that overflow now and then), or float64 throughout
+    pick = rng.random()
+    if pick < 0.6:
+        os.environ["IPX_KS_FAST"] = "2"
+        if rng.random() < 0.3:
+            os.environ["IPX_KS_FIX_CAP"] = str(int(rng.choice([1, 8, 100, 1000])))
+    elif pick < 0.8:
+        os.environ["IPX_KS_FAST"] = "0"
     if rng.random() < 0.4:
         os.environ["IPX_KS_STRIPS"] = str(int(rng.choice([1, 2, 3, 5, 9])))          # tilings of the one-pass kernel (read when the plan is made)
     if rng.random() < 0.4:
