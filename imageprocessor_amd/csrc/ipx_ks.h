@@ -122,6 +122,7 @@ struct KsFusedArgs {
     const KsStrip *strips; const KsSeg *segs;
     int nout; KsFusedOut o[2];
     int lds_w[2], lds_rows, lds_open;   // byte offsets in LDS: weight tables, staged row entries, the float pass's undecided pixels (the tile is at 0)
+    int open_per_wave;         // the float pass: entries of a wave's share of lds_open
     uint8_t wave_role[16];     // per wave: output index << 4 | index among that output's waves; 0xff = no role (stages pixels only).  The roles
                                // are interleaved so that the waves of one output spread over the SIMDs however the hardware deals waves out
     unsigned long long *stamps; // diagnostic build (-DIPX_DIAG=1) only: per-phase cycle sums over all waves, else NULL
@@ -139,6 +140,8 @@ struct KsFusedPlan {
     bool ok = false;
     int nacc = 2, rows = 4, pitch = 0, nstrips = 0, nthreads = 0, nstg = 0, dbuf = 0;   // dbuf: two tile buffers fit in LDS (one barrier per group)
     int lds_w[2] = {0, 0}, lds_rows = 0, lds_open = 0, lds_bytes = 0;
+    // the float pass's own layout: float weight tables are half the size, so two tile buffers fit where the float64 kernels have room for one
+    struct Lds { int dbuf = 0, lds_w[2] = {0, 0}, lds_rows = 0, lds_open = 0, open_per_wave = 0, lds_bytes = 0; } fast;
     const KsStrip *strips = nullptr;
     struct Out { int ntap = 0, waves = 0, cpl = 0, wcols = 0; const double *wx = nullptr, *itwf = nullptr; const int32_t *xlo = nullptr, *colb = nullptr;
                  const float *wxf = nullptr; float feps = 0; } o[2];
@@ -150,7 +153,7 @@ constexpr int kKsMaxStage = 3;    // 16-byte chunks a thread stages per group
 constexpr int kKsMaxWaves = 12;   // waves per workgroup (768 threads: three waves per SIMD, 168 registers each)
 constexpr int kKsMaxThreads = 64 * kKsMaxWaves;
 constexpr int kKsMaxCpl = 2;
-constexpr int kKsOpenPerWave = 128;   // the float pass: undecided pixels a wave collects in LDS before they go to the frame's list
+constexpr int kKsOpenPerWave = 128;   // the float pass: undecided pixels a wave collects in LDS before they go to the frame's list (64 or 32 where that lets a second tile buffer in)
 // cuts the frame into strips and segments, assigns wave roles and lays every table out in `blob` (appended, 16-byte aligned offsets;
 // the pointers in *out are OFFSETS into the blob until ks_fused_rebase adds the device address).  sc[k] = nullptr: output absent.
 struct KsFusedIn { int dw, dh, sr_x0, sr_y0; const KsAxis *hx, *hy; };

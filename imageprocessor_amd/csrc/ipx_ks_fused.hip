@@ -332,7 +332,7 @@ __device__ __forceinline__ void ks_column(const uint8_t *lds, const uint8_t *til
 // flight as well -- the next group's pixels.  One such wait per hundred pixels, not one per pixel.
 struct KsOpen {
     uint2 *wave;               // this wave's entries in LDS
-    int n;                     // how many (wave-uniform)
+    int n, room;               // how many (wave-uniform); how many fit
     uint2 *list; int *count; int cap;   // the frame's list in HBM
     bool full;                 // the list had no room for an entry of this lane
 };
@@ -426,7 +426,7 @@ __device__ __forceinline__ void ks_column_fast(const uint8_t *lds, const uint8_t
                 const unsigned long long m = __ballot(open);
                 if (m) {                                               // wave-uniform; about one store in fifteen
                     const int k = __popcll(m);
-                    if (op.n + k > kKsOpenPerWave) ks_open_flush(op);
+                    if (op.n + k > op.room) ks_open_flush(op);
                     const int slot = op.n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // open lanes below this one
                     if (open) op.wave[slot] = make_uint2(okey | (uint32_t)dy, (uint32_t)c.ooff >> 2);
                     op.n += k;
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     const uint32_t okey = 0;
     if (FAST) {
         const int pk = role >= 0 ? a.o[role].pk : 0;
-        open.wave = (uint2 *)(lds + a.lds_open) + wv * kKsOpenPerWave;
-        open.n = 0; open.full = false;
+        open.wave = (uint2 *)(lds + a.lds_open) + wv * a.open_per_wave;
+        open.n = 0; open.room = a.open_per_wave; open.full = false;
         open.list = a.fix + (size_t)frame * a.fix_stride + (pk ? a.fix_cap[0] : 0); open.count = a.fix_count + 2 * frame + pk; open.cap = a.fix_cap[pk];
     }
 #if IPX_DIAG
@@ -699,10 +699,11 @@ hipError_t launch_rag(const KsFusedPlan &p, const KsFusedArgs &a, int nitems, hi
     static KernelLaunchCache cache;
     auto fn = ks_fused_kernel<SRC, NCH, NACC, kKsRows, OPQ, RAG, FAST>;
     int resident = 0;
-    hipError_t e = cache.prepare((const void *)fn, p.nthreads, (size_t)p.lds_bytes, getenv("IPX_KS_DEBUG") ? &resident : nullptr);
+    const int lds_bytes = FAST ? p.fast.lds_bytes : p.lds_bytes;
+    hipError_t e = cache.prepare((const void *)fn, p.nthreads, (size_t)lds_bytes, getenv("IPX_KS_DEBUG") ? &resident : nullptr);
     if (e != hipSuccess) return e;
-    if (resident) fprintf(stderr, "[ipx ks] %d workgroups of %d threads with %d bytes of LDS resident per CU\n", resident, p.nthreads, p.lds_bytes);
-    hipLaunchKernelGGL(fn, dim3(nitems), dim3(p.nthreads), (size_t)p.lds_bytes, s, a);
+    if (resident) fprintf(stderr, "[ipx ks] %d workgroups of %d threads with %d bytes of LDS resident per CU\n", resident, p.nthreads, lds_bytes);
+    hipLaunchKernelGGL(fn, dim3(nitems), dim3(p.nthreads), (size_t)lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -764,9 +765,15 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fi
     const char *ev = getenv("IPX_KS_SPLIT");                       // test knob: 1 = always the split segmentation, 0 = never
     const bool whole = ev && *ev ? atoi(ev) == 0 : (long long)a.nframes * p.nstrips >= 2LL * cus;
     const KsFusedGeom &g = whole || p.split.nseg <= 1 ? p.whole : p.split;
-    a.nstrips = p.nstrips; a.nseg = g.nseg; a.nthreads = p.nthreads; a.pitch = p.pitch; a.dbuf = p.dbuf;
+    a.nstrips = p.nstrips; a.nseg = g.nseg; a.nthreads = p.nthreads; a.pitch = p.pitch;
     a.strips = p.strips; a.segs = g.segs;
-    a.lds_rows = p.lds_rows; a.lds_open = p.lds_open;
+    // where things live in LDS: the float64 kernels' layout, or the float pass's own (float weight tables, lists of undecided pixels)
+    auto layout = [&](bool fl) {
+        a.dbuf = fl ? p.fast.dbuf : p.dbuf;
+        a.lds_rows = fl ? p.fast.lds_rows : p.lds_rows;
+        a.lds_open = fl ? p.fast.lds_open : 0; a.open_per_wave = fl ? p.fast.open_per_wave : 0;
+        for (int i = 0; i < a.nout; i++) a.lds_w[i] = fl ? p.fast.lds_w[a.o[i].pk] : p.lds_w[a.o[i].pk];
+    };
     for (int i = 0; i < a.nout; i++) {                             // a.o[i].pk: which of the plan's outputs this is
         const int k = a.o[i].pk;
         const KsFusedPlan::Out &po = p.o[k];
@@ -774,7 +781,6 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fi
         o.ntap = po.ntap; o.waves = po.waves; o.cpl = po.cpl; o.wcols = po.wcols;
         o.wx = po.wx; o.itwf = po.itwf; o.xlo = po.xlo; o.colb = po.colb; o.wxf = po.wxf; o.feps = po.feps;
         o.rows = g.rows[k]; o.rowoff = g.rowoff[k];
-        a.lds_w[i] = p.lds_w[k];
     }
     // deal the roles out: the waves of the output with fewer waves are spread evenly among the others
     {
@@ -793,13 +799,15 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fi
     *matched = true;
     const int n = (int)nitems;
     if (getenv("IPX_KS_DEBUG"))
-        fprintf(stderr, "[ipx ks] src %d nacc %d frames %d strips %d segs %d threads %d pitch %d dbuf %d lds %d | out0 ntap %d waves %d cpl %d wcols %d | out1 ntap %d waves %d cpl %d wcols %d\n", src, p.nacc,
-                a.nframes, a.nstrips, a.nseg, a.nthreads, a.pitch, a.dbuf, p.lds_bytes, a.o[0].ntap, a.o[0].waves, a.o[0].cpl, a.o[0].wcols, a.nout > 1 ? a.o[1].ntap : 0,
+        fprintf(stderr, "[ipx ks] src %d nacc %d frames %d strips %d segs %d threads %d pitch %d dbuf %d lds %d (float pass: dbuf %d lds %d) | out0 ntap %d waves %d cpl %d wcols %d | out1 ntap %d waves %d cpl %d wcols %d\n", src, p.nacc,
+                a.nframes, a.nstrips, a.nseg, a.nthreads, a.pitch, p.dbuf, p.lds_bytes, p.fast.dbuf, p.fast.lds_bytes, a.o[0].ntap, a.o[0].waves, a.o[0].cpl, a.o[0].wcols, a.nout > 1 ? a.o[1].ntap : 0,
                 a.nout > 1 ? a.o[1].waves : 0, a.nout > 1 ? a.o[1].cpl : 0, a.nout > 1 ? a.o[1].wcols : 0);
     // the float pass where the source type has one and the caller brought lists: float kernel, the listed pixels in float64, then the
     // float64 kernel on the items the float kernel gave up
     bool fast = fix && fix->list && a.redo && (src == KS_RGBA || src == KS_YCC || src == KS_GRAY);
     for (int i = 0; i < a.nout; i++) fast = fast && a.o[i].feps > 0.f;       // (an output with more taps than the margin's derivation covers)
+    fast = fast && p.fast.lds_bytes > 0;
+    layout(false);
     a.fix = fast ? fix->list : nullptr; a.fix_count = fast ? fix->count : nullptr;
     a.fix_cap[0] = fast ? fix->cap[0] : 0; a.fix_cap[1] = fast ? fix->cap[1] : 0; a.fix_stride = a.fix_cap[0] + a.fix_cap[1];
     auto exact_listed = [&]() {
@@ -823,13 +831,17 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fi
     case KS_TAP64: a.redo = nullptr; return launch_src<KS_TAP64, 4>(p, a, n, s);
     case KS_YCC:
         if (!fast) { a.redo = nullptr; return launch_src<KS_YCC, 3>(p, a, n, s); }
+        layout(true);
         e = p.nacc == 2 ? launch_one<KS_YCC, 3, 2, false, true>(p, a, n, s) : launch_one<KS_YCC, 3, 4, false, true>(p, a, n, s);
+        layout(false);
         if (e == hipSuccess) e = exact_listed();
         if (e == hipSuccess) e = launch_src<KS_YCC, 3>(p, a, n, s);
         return e;
     case KS_GRAY:
         if (!fast) { a.redo = nullptr; return launch_src<KS_GRAY, 1>(p, a, n, s); }
+        layout(true);
         e = p.nacc == 2 ? launch_one<KS_GRAY, 1, 2, false, true>(p, a, n, s) : launch_one<KS_GRAY, 1, 4, false, true>(p, a, n, s);
+        layout(false);
         if (e == hipSuccess) e = exact_listed();
         if (e == hipSuccess) e = launch_src<KS_GRAY, 1>(p, a, n, s);
         return e;
@@ -838,7 +850,9 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fi
     if (!a.redo) return launch_src<KS_RGBA, 4>(p, a, n, s);        // the general kernel alone
     // the speculative opaque pass first; the general kernel then redoes the items that met a pixel with alpha != 0xff
     if (fast) {
+        layout(true);
         e = p.nacc == 2 ? launch_one<KS_RGBA, 3, 2, true, true>(p, a, n, s) : launch_one<KS_RGBA, 3, 4, true, true>(p, a, n, s);
+        layout(false);
         if (e == hipSuccess) e = exact_listed();
     } else e = p.nacc == 2 ? launch_one<KS_RGBA, 3, 2, true>(p, a, n, s) : launch_one<KS_RGBA, 3, 4, true>(p, a, n, s);
     if (e == hipSuccess) e = launch_src<KS_RGBA, 4>(p, a, n, s);

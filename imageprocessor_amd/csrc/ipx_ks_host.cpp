@@ -302,7 +302,6 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
         for (int k = 0; k < 2; k++)
             if (sc[k]) rest += (size_t)sc[k]->hx->ntap * wcols[k] * sizeof(double);
         rest += 2 * 2 * (size_t)B * row_bytes + 64;                // two buffers of row entries for two outputs (+ slack)
-        rest += (size_t)kKsMaxWaves * kKsOpenPerWave * sizeof(uint2);   // the float pass's undecided pixels, per wave
         int dbuf = 1;
         if (2 * (size_t)B * pitch + rest > lds_budget) dbuf = 0;
         if ((size_t)(dbuf + 1) * B * pitch + rest > lds_budget) continue;
@@ -313,14 +312,38 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
         }
         const int lds_rows = (int)lds;
         lds += 2 * 2 * (size_t)B * row_bytes + 64;
-        lds = (lds + 15) & ~(size_t)15;
-        const int lds_open = (int)lds;
-        lds += (size_t)kKsMaxWaves * kKsOpenPerWave * sizeof(uint2);
+        // the float pass's layout: float weights, the waves' lists of undecided pixels behind the row entries; two tile buffers where
+        // they fit in the CU's 160 KB with lists of 128, 64 or 32 entries per wave, else one
+        KsFusedPlan::Lds F;
+        {
+            size_t wf = 0;
+            for (int k = 0; k < 2; k++) if (sc[k]) wf += ((size_t)sc[k]->hx->ntap * wcols[k] * sizeof(float) + 15) & ~(size_t)15;
+            const size_t rows_b = 2 * 2 * (size_t)B * row_bytes + 64, cu = ((size_t)160 << 10) - 512;
+            F.dbuf = 0; F.open_per_wave = kKsOpenPerWave;
+            for (int per : {kKsOpenPerWave, 64, 32})
+                if (2 * (size_t)B * pitch + wf + rows_b + 16 + (size_t)kKsMaxWaves * per * sizeof(uint2) <= cu) { F.dbuf = 1; F.open_per_wave = per; break; }
+            size_t at = (size_t)(F.dbuf + 1) * B * pitch;
+            for (int k = 0; k < 2; k++) {
+                F.lds_w[k] = (int)at;
+                if (sc[k]) at += ((size_t)sc[k]->hx->ntap * wcols[k] * sizeof(float) + 15) & ~(size_t)15;
+            }
+            F.lds_rows = (int)at;
+            at += rows_b;
+            at = (at + 15) & ~(size_t)15;
+            F.lds_open = (int)at;
+            at += (size_t)kKsMaxWaves * F.open_per_wave * sizeof(uint2);
+            F.lds_bytes = (int)at;
+            if (at > cu) { F = KsFusedPlan::Lds(); }            // (cannot happen while the float64 layout fits: it is larger)
+        }
 
         // ---- accepted: lay the tables out ----
         P.nstrips = ns; P.pitch = pitch; P.nthreads = nthreads; P.dbuf = dbuf;
         P.nstg = (chunks + nthreads - 1) / nthreads;
-        P.lds_w[0] = lds_w[0]; P.lds_w[1] = lds_w[1]; P.lds_rows = lds_rows; P.lds_open = lds_open; P.lds_bytes = (int)lds;
+        P.lds_w[0] = lds_w[0]; P.lds_w[1] = lds_w[1]; P.lds_rows = lds_rows; P.lds_bytes = (int)lds;
+        P.fast = F;
+        if (const char *e = getenv("IPX_KS_FAST_DBUF")) if (atoi(e) == 0 && P.fast.dbuf) {   // test knob: the float pass with one tile buffer
+            P.fast.dbuf = 0;
+        }
         P.strips = as_off<KsStrip>(blob_put(blob, strips.data(), strips.size() * sizeof(KsStrip)));
         for (int k = 0; k < 2; k++) {
             if (!sc[k]) continue;
