@@ -1260,6 +1260,17 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
 #endif
         bool matched = false;
         hipError_t e = launch_ks_fused(fp, a, fix, ctx->cus, s, &matched);
+        if (fix && matched && e == hipSuccess && env_int("IPX_KS_STATS", 0)) {   // diagnostic: how full the float pass's lists got, how many items went to float64
+            std::vector<int> cnt((size_t)n * 2), flags((size_t)max_items);
+            (void)hipMemcpyAsync(cnt.data(), fixv.count, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, s);
+            (void)hipMemcpyAsync(flags.data(), redo, flags.size() * sizeof(int), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            long long tot[2] = {0, 0}; int mx[2] = {0, 0}, nredo = 0;
+            for (int i = 0; i < n; i++) for (int k = 0; k < 2; k++) { tot[k] += cnt[2 * i + k]; mx[k] = std::max(mx[k], cnt[2 * i + k]); }
+            for (int f : flags) nredo += f != 0;
+            fprintf(stderr, "[ipx ks stats] %d frames: undecided pixels per frame resize mean %.1f max %d (room %d), thumbnail mean %.1f max %d (room %d); %d of %d items redone in float64\n", n,
+                    (double)tot[0] / n, mx[0], fixv.cap[0], (double)tot[1] / n, mx[1], fixv.cap[1], nredo, max_items);
+        }
         if (redo) (void)hipFreeAsync(redo, s);
 #if IPX_DIAG
         if (a.stamps && matched) {
