@@ -350,48 +350,68 @@ __device__ __forceinline__ void ks_open_flush(KsOpen &o)
     o.n = 0;
 }
 
-// The float pass's column: the same walk with float sums.
-template <int SRC, int NCH, int NACC, int B, int MODE>
-__device__ __forceinline__ void ks_column_fast(const uint8_t *lds, const uint8_t *tile, KsCol<NCH, NACC, float> &c, int ntap, int wstride, int pitch,
-                                               const uint8_t *rows, __amdgpu_buffer_rsrc_t ors, int ostride, float feps, uint32_t okey, KsOpen &op)
+// The float pass's columns: the same walk with float sums, for the NC columns of a lane TOGETHER -- their LDS reads are issued in one
+// batch (twice as many in flight per wait: with three waves per SIMD it is the LDS round trips that the arithmetic waits for) and the
+// group's row entries are read once for both.
+template <int SRC, int NCH, int NACC, int B, int MODE, int NC>
+__device__ __forceinline__ void ks_columns_fast(const uint8_t *lds, const uint8_t *tile, KsCol<NCH, NACC, float> *c, int ntap, int wstride, int pitch,
+                                                const uint8_t *rows, __amdgpu_buffer_rsrc_t ors, int ostride, float feps, uint32_t okey, KsOpen &op
+#if IPX_DIAG
+                                                , unsigned long long *tsum, unsigned long long &tlast
+#endif
+                                                )
 {
     constexpr int PXB = KsPx<SRC>::bytes;
-    float acc[B][NCH];
+    static_assert(B % 2 == 0, "rows are summed in pairs");
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc[NC][B / 2][NCH];          // rows r and r + 1 of a channel side by side: one v_pk_fma_f32 adds a tap to both
+    const uint8_t *tap[NC], *wp[NC];
 #pragma unroll
-    for (int r = 0; r < B; r++)
+    for (int j = 0; j < NC; j++) {
 #pragma unroll
-        for (int k = 0; k < NCH; k++) acc[r][k] = 0.f;
-    const uint8_t *tap = tile + c.xb;
-    const uint8_t *wp = lds + c.wofs;
+        for (int r = 0; r < B / 2; r++)
+#pragma unroll
+            for (int k = 0; k < NCH; k++) acc[j][r][k] = f32x2{0.f, 0.f};
+        tap[j] = tile + c[j].xb;
+        wp[j] = lds + c[j].wofs;
+    }
     typedef typename KsTapRaw<SRC>::type Raw;
     auto taps = [&](auto nt) {
         constexpr int NT = decltype(nt)::value;
-        float w[NT];
-        Raw px[NT][B];
+        float w[NC][NT];
+        Raw px[NC][NT][B];
 #pragma unroll
-        for (int i = 0; i < NT; i++) {
-            w[i] = *(const float *)(wp + i * wstride);
+        for (int j = 0; j < NC; j++)
 #pragma unroll
-            for (int r = 0; r < B; r++) px[i][r] = *(const Raw *)(tap + r * pitch + i * PXB);
-        }
+            for (int i = 0; i < NT; i++) {
+                w[j][i] = *(const float *)(wp[j] + i * wstride);
+#pragma unroll
+                for (int r = 0; r < B; r++) px[j][i][r] = *(const Raw *)(tap[j] + r * pitch + i * PXB);
+            }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < NT; i++)
+        for (int j = 0; j < NC; j++) {
 #pragma unroll
-            for (int r = 0; r < B; r++) {
-                float v[NCH];
-                ks_fetchf<SRC, NCH, MODE>(px[i][r], v);
+            for (int i = 0; i < NT; i++)
 #pragma unroll
-                for (int k = 0; k < NCH; k++) acc[r][k] = __builtin_fmaf(v[k], w[i], acc[r][k]);
-            }
-        tap += NT * PXB;
-        wp += NT * wstride;
+                for (int r = 0; r < B; r += 2) {
+                    float v0[NCH], v1[NCH];
+                    ks_fetchf<SRC, NCH, MODE>(px[j][i][r], v0);
+                    ks_fetchf<SRC, NCH, MODE>(px[j][i][r + 1], v1);
+                    const f32x2 ww{w[j][i], w[j][i]};
+#pragma unroll
+                    for (int k = 0; k < NCH; k++) acc[j][r / 2][k] = __builtin_elementwise_fma(f32x2{v0[k], v1[k]}, ww, acc[j][r / 2][k]);
+                }
+            tap[j] += NT * PXB;
+            wp[j] += NT * wstride;
+        }
     };
     int t = 0;
-    constexpr int TU = SRC == KS_RGBA || SRC == KS_GRAY ? 4 : 2;
+    constexpr int TU = SRC == KS_RGBA || SRC == KS_GRAY ? 4 : 2;   // (8-byte taps: two at a time keep the registers)
     for (; t + TU <= ntap; t += TU) taps(std::integral_constant<int, TU>());
     if (TU > 2 && t + 2 <= ntap) { taps(std::integral_constant<int, 2>()); t += 2; }
-    if (t < ntap) taps(std::integral_constant<int, 1>());
+    for (; t < ntap; t++) taps(std::integral_constant<int, 1>());
+    KS_STAMP(4);                                         // scaleX of the group's rows for these columns
     typedef KsRowT<NACC> Row;
     float rw[B][NACC];
     int remit[B][NACC];
@@ -407,29 +427,37 @@ __device__ __forceinline__ void ks_column_fast(const uint8_t *lds, const uint8_t
         for (int p = 0; p < NACC; p++) {
             const float w = rw[r][p];
 #pragma unroll
-            for (int k = 0; k < NCH; k++) c.q[p][k] = __builtin_fmaf(acc[r][k], w, c.q[p][k]);
+            for (int j = 0; j < NC; j++)
+#pragma unroll
+                for (int k = 0; k < NCH; k++) c[j].q[p][k] = __builtin_fmaf(acc[j][r / 2][k][r & 1], w, c[j].q[p][k]);
             const int dy = __builtin_amdgcn_readfirstlane(remit[r][p]);
             if (dy >= 0) {                                             // wave-uniform
-                uint32_t b[NCH];
-                bool open = false;                                     // a channel too close to a multiple of 256 to call
 #pragma unroll
-                for (int k = 0; k < NCH; k++) {
-                    const float u = (c.q[p][k] + 0.5f) * (1.0f / 256.0f);
-                    const float fr = __builtin_amdgcn_fractf(u), lim = feps * u;    // (1 - fr is exact wherever the second test can hold)
-                    open |= fr < lim || 1.0f - fr < lim;
-                    b[k] = min((uint32_t)u, 255u);
-                    c.q[p][k] = 0.f;
-                }
-                const uint32_t px = NCH == 1 ? b[0] * 0x010101u | 0xff000000u : b[0] | b[1 % NCH] << 8 | b[2 % NCH] << 16 | 0xff000000u;
-                __builtin_amdgcn_raw_buffer_store_b32(px, ors, c.ooff, dy * ostride, 0);
-                open = open && c.ooff != kOOB;
-                const unsigned long long m = __ballot(open);
-                if (m) {                                               // wave-uniform; about one store in fifteen
-                    const int k = __popcll(m);
-                    if (op.n + k > op.room) ks_open_flush(op);
-                    const int slot = op.n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // open lanes below this one
-                    if (open) op.wave[slot] = make_uint2(okey | (uint32_t)dy, (uint32_t)c.ooff >> 2);
-                    op.n += k;
+                for (int j = 0; j < NC; j++) {
+                    // T = (V' + 0.5) / 256 in one rounding (scaling by 2^-8 is exact); the byte is floor(T) -- below 256 for every tap count
+                    // the float pass takes (ks_float_eps) -- and the channel is open when T lies within feps * T of an integer (T - rint(T)
+                    // is exact).  v_cvt_pk_u8_f32 converts an integer-valued float and drops it into its byte of the pixel.
+                    uint32_t px = 0xff000000u;
+                    bool open = false;                                 // a channel too close to a multiple of 256 to call
+#pragma unroll
+                    for (int k = 0; k < NCH; k++) {
+                        const float u = __builtin_fmaf(c[j].q[p][k], 1.0f / 256.0f, 0.5f / 256.0f);
+                        const float d = u - __builtin_rintf(u);
+                        open |= __builtin_fabsf(d) < feps * u;
+                        px = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(u), (uint32_t)k, px);
+                        c[j].q[p][k] = 0.f;
+                    }
+                    if (NCH == 1) px = (px & 0xffu) * 0x010101u | 0xff000000u;
+                    __builtin_amdgcn_raw_buffer_store_b32(px, ors, c[j].ooff, dy * ostride, 0);
+                    open = open && c[j].ooff != kOOB;
+                    const unsigned long long m = __ballot(open);
+                    if (m) {                                           // wave-uniform; about one store in thirty
+                        const int k = __popcll(m);
+                        if (op.n + k > op.room) ks_open_flush(op);
+                        const int slot = op.n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // open lanes below this one
+                        if (open) op.wave[slot] = make_uint2(okey | (uint32_t)dy, (uint32_t)c[j].ooff >> 2);
+                        op.n += k;
+                    }
                 }
             }
         }
@@ -647,8 +675,10 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     _Pragma("unroll") for (int j = 0; j < CPLM; j++)                                                                                 \
         if (j < cpl) ks_column<SRC, NCH, NACC, B, MODE, AONE>(lds, tile, col[j], ntap, wstride, pitch, rws, ors, ostride KS_DIAG_ARGS)
 #define KS_COLSF(MODE)                                                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < CPLM; j++)                                                                                 \
-        if (j < cpl) ks_column_fast<SRC, NCH, NACC, B, MODE>(lds, tile, col[j], ntap, wstride, pitch, rws, ors, ostride, feps, okey, open)
+    do {                                                                                                                                 \
+        if (CPLM > 1 && cpl > 1) ks_columns_fast<SRC, NCH, NACC, B, MODE, CPLM>(lds, tile, col, ntap, wstride, pitch, rws, ors, ostride, feps, okey, open KS_DIAG_ARGS); \
+        else if (cpl > 0) ks_columns_fast<SRC, NCH, NACC, B, MODE, 1>(lds, tile, col, ntap, wstride, pitch, rws, ors, ostride, feps, okey, open KS_DIAG_ARGS);          \
+    } while (0)
             if constexpr (FAST) {
                 // (the alpha of these sources never reaches the sums: opaque RGBA, YCbCr and Gray store 0xff)
                 if constexpr (SRC == KS_YCC) {

@@ -113,8 +113,9 @@ namespace ipx {
 // (t >= 0.5, so u t >= 3e-8) and the rounding of the product that forms the margin -- floor(T) IS the reference's byte; a channel
 // that is not goes on the frame's list and is recomputed in float64, operation by operation as the reference does it (ks_fix_kernel).
 // The margin grows with the value: a dark pixel is decided almost always, a white one has (nx + ny + 4) / 65536 of a byte on either side.
-// 0: too many taps for the factors above (a downscale by 250 and more): no float pass for such an output.
-float ks_float_eps(int nx, int ny) { return nx + ny > 1000 ? 0.f : std::nextafter((float)((nx + ny + 4) * (1.0 / 16777216.0)), 1.0f); }
+// 0: no float pass for an output with more than 100 taps per pixel (a downscale by 25 and more on both axes; 8K to a 200-pixel thumbnail
+// has 88).  The factors above hold far beyond that, but V' <= 65535 (1 + 104 u) keeps T below 256: the kernel needs no clamp.
+float ks_float_eps(int nx, int ny) { return nx + ny > 100 ? 0.f : std::nextafter((float)((nx + ny + 4) * (1.0 / 16777216.0)), 1.0f); }
 
 namespace {
 

@@ -1223,7 +1223,8 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
         }
         // RGBA frames: the speculative opaque pass first (IPX_KS_SPEC=0: the general kernel alone), one flag per item.  RGBA, YCbCr and
         // Gray frames: the float pass (IPX_KS_FAST=0: float64 throughout) with a list per frame for the pixels it cannot decide --
-        // 1 / 24 of the output pixels each, thirty times what photographs put there; a frame that fills its list is redone in float64.
+        // 1 / 96 of the output's pixels each, twenty times what photographs put there (IPX_KS_STATS=1 prints the fill); a frame that fills
+        // its list is redone in float64.
         // One stream-ordered block: [flags][counts][lists].
         int *redo = nullptr;
         KsFix fixv, *fix = nullptr;
@@ -1237,7 +1238,7 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
             const int cap_env = env_int("IPX_KS_FIX_CAP", 0);     // test knob: tiny lists, so that frames fill them
             int cap[2] = {0, 0};
             for (int k = 0; k < 2; k++)
-                if (fast && outs[k]) cap[k] = cap_env > 0 ? cap_env : (int)std::min<size_t>(std::max<size_t>((size_t)pl->sc[k].dw * pl->sc[k].dh / 24, 256), (size_t)1 << 20);
+                if (fast && outs[k]) cap[k] = cap_env > 0 ? cap_env : (int)std::min<size_t>(std::max<size_t>((size_t)pl->sc[k].dw * pl->sc[k].dh / 96, 256), (size_t)1 << 20);
             const size_t flags = align256((size_t)max_items * sizeof(int)), counts = fast ? align256((size_t)n * 2 * sizeof(int)) : 0;
             IPX_HIP(hipMallocAsync((void **)&redo, flags + counts + (size_t)n * (cap[0] + cap[1]) * sizeof(uint2), s));
             if (fast) {
