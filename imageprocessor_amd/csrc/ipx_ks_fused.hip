@@ -216,6 +216,27 @@ struct KsCol {                 // one destination column of a lane
     int xb;                    // LDS byte offset of the column's first tap within a tile row
     int wofs;                  // LDS byte offset of the column's first weight
     int ooff;                  // byte offset of the column in a destination row; kOOB = the lane has no such column
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int p = 0; p < NACC; p++)
+#pragma unroll
+            for (int k = 0; k < NCH; k++) q[p][k] = 0;
+    }
+};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NCH, int NACC>
+struct KsCol<NCH, NACC, float> {   // the float pass: accumulators 2p and 2p + 1 of a channel side by side (one v_pk_fma_f32 feeds both)
+    f32x2 q2[NCH][NACC / 2];
+    double itwf;
+    int xb, wofs, ooff;
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int k = 0; k < NCH; k++)
+#pragma unroll
+            for (int h = 0; h < NACC / 2; h++) q2[k][h] = f32x2{0.f, 0.f};
+    }
 };
 
 // scaleX on the B rows of the tile for one column, then scaleY's accumulation and, where a destination row completes, its store.
@@ -362,8 +383,7 @@ __device__ __forceinline__ void ks_columns_fast(const uint8_t *lds, const uint8_
                                                 )
 {
     constexpr int PXB = KsPx<SRC>::bytes;
-    static_assert(B % 2 == 0, "rows are summed in pairs");
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    static_assert(B % 2 == 0 && NACC % 2 == 0, "rows and accumulators go in pairs");
     f32x2 acc[NC][B / 2][NCH];          // rows r and r + 1 of a channel side by side: one v_pk_fma_f32 adds a tap to both
     const uint8_t *tap[NC], *wp[NC];
 #pragma unroll
@@ -413,23 +433,29 @@ __device__ __forceinline__ void ks_columns_fast(const uint8_t *lds, const uint8_
     for (; t < ntap; t++) taps(std::integral_constant<int, 1>());
     KS_STAMP(4);                                         // scaleX of the group's rows for these columns
     typedef KsRowT<NACC> Row;
-    float rw[B][NACC];
+    f32x2 rw[B][NACC / 2];
     int remit[B][NACC];
 #pragma unroll
     for (int r = 0; r < B; r++) {
         const Row *row = (const Row *)(rows + r * sizeof(Row));
 #pragma unroll
-        for (int p = 0; p < NACC; p++) { rw[r][p] = row->wf[p]; remit[r][p] = row->emit[p]; }
+        for (int p = 0; p < NACC; p++) remit[r][p] = row->emit[p];
+#pragma unroll
+        for (int h = 0; h < NACC / 2; h++) rw[r][h] = f32x2{row->wf[2 * h], row->wf[2 * h + 1]};
     }
 #pragma unroll
     for (int r = 0; r < B; r++) {
 #pragma unroll
-        for (int p = 0; p < NACC; p++) {
-            const float w = rw[r][p];
+        for (int h = 0; h < NACC / 2; h++)                             // the row's value into both accumulators of a pair
 #pragma unroll
             for (int j = 0; j < NC; j++)
 #pragma unroll
-                for (int k = 0; k < NCH; k++) c[j].q[p][k] = __builtin_fmaf(acc[j][r / 2][k][r & 1], w, c[j].q[p][k]);
+                for (int k = 0; k < NCH; k++) {
+                    const float v = acc[j][r / 2][k][r & 1];
+                    c[j].q2[k][h] = __builtin_elementwise_fma(f32x2{v, v}, rw[r][h], c[j].q2[k][h]);
+                }
+#pragma unroll
+        for (int p = 0; p < NACC; p++) {
             const int dy = __builtin_amdgcn_readfirstlane(remit[r][p]);
             if (dy >= 0) {                                             // wave-uniform
 #pragma unroll
@@ -441,11 +467,11 @@ __device__ __forceinline__ void ks_columns_fast(const uint8_t *lds, const uint8_
                     bool open = false;                                 // a channel too close to a multiple of 256 to call
 #pragma unroll
                     for (int k = 0; k < NCH; k++) {
-                        const float u = __builtin_fmaf(c[j].q[p][k], 1.0f / 256.0f, 0.5f / 256.0f);
+                        const float u = __builtin_fmaf(c[j].q2[k][p / 2][p & 1], 1.0f / 256.0f, 0.5f / 256.0f);
                         const float d = u - __builtin_rintf(u);
                         open |= __builtin_fabsf(d) < feps * u;
                         px = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(u), (uint32_t)k, px);
-                        c[j].q[p][k] = 0.f;
+                        c[j].q2[k][p / 2][p & 1] = 0.f;
                     }
                     if (NCH == 1) px = (px & 0xffu) * 0x010101u | 0xff000000u;
                     __builtin_amdgcn_raw_buffer_store_b32(px, ors, c[j].ooff, dy * ostride, 0);
@@ -555,10 +581,7 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
         for (int j = 0; j < CPLM; j++) {
             const int slot = wk * 64 + lane + j * 64 * o.waves, dx = cb + slot;
             const bool has = j < o.cpl && dx < ce;
-#pragma unroll
-            for (int p = 0; p < NACC; p++)
-#pragma unroll
-                for (int k = 0; k < NCH; k++) col[j].q[p][k] = 0;
+            col[j].clear();
             col[j].itwf = has ? o.itwf[dx] : 0.0;
             col[j].xb = has ? (o.sr_x0 + o.xlo[dx] - st.t0) * PXB : 0;
             col[j].wofs = a.lds_w[role] + (has ? slot : 0) * (FAST ? 4 : 8);
