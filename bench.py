@@ -543,12 +543,12 @@ def main():
                 "wm": "watermark only (copy + 16 glyphs)", "thumb": "thumbnail 200 crop only",
                 "resize-wm": "resize 1024x768 + watermark"}[args.workload]),
                 "frames_per_gpu": F, "sharding": "independent frames, round-robin by rank, no collective",
-                "arithmetic": "u8 pixels in, u8 pixels out, every byte the reference's: x/image's kernel scaler is evaluated in f32 with a proven error margin, and each value that margin cannot separate from a rounding boundary (about 0.1 % of the pixels) is recomputed in f64, every product rounded before it is added as in the reference's amd64 build (IPX_KS_FAST=0: f64 throughout, 5.7 ms per launch); composite in u32"},
+                "arithmetic": "u8 pixels in, u8 pixels out, every byte the reference's: x/image's kernel scaler is evaluated in f32 with a proven error margin, and each value that margin cannot separate from a rounding boundary (about 0.1 % of the pixels) is recomputed in f64, every product rounded before it is added as in the reference's amd64 build (IPX_KS_FAST=0: f64 throughout, 5.7 ms per launch against 4.4); composite in u32"},
             "checked": checked,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "ks_fused_kernel<RGBA, 3 channels, float pass> (frames taken as opaque; ks_fix_kernel recomputes the listed pixels in float64, the 4-channel float64 kernel redoes items that meet alpha != 0xff or fill their list); avg_launch_ms covers all of a call's kernels",
-                         "in_practice": "HBM streaming: the launch moves the algorithmic minimum at 0.82 - 0.88 of what ipx_stream_copy reaches on the same box (copy_ceiling); with float64 throughout it was float64 VALU issue (DESIGN.md 4.1)",
+                         "in_practice": "HBM streaming: the launch moves the algorithmic minimum at 0.84 - 0.88 of what ipx_stream_copy reaches on the same box (copy_ceiling); with float64 throughout it was float64 VALU issue (DESIGN.md 4.1)",
                          "algorithmic_bytes_per_launch": alg,
                          "avg_launch_ms": round(avg_ms, 4), "traffic_source": traffic_src,
                          "buffer_sets": nsets,
