@@ -148,6 +148,8 @@ int run_pixel_chunk(Slot &s, Feeder &f, const JobState &j, ipx_plan *plan, int i
     // outputs in pinned memory are written by the kernels themselves, over the link (run_host_packed in ipx_runtime.hip has the why)
     uint8_t *vres = nullptr, *vth = nullptr, *vwm = nullptr;
     bool direct = env_int("IPX_HOST_DIRECT", 1) != 0;
+    if (((uintptr_t)q.resize_out | (uintptr_t)q.thumb_out | (uintptr_t)q.wm_out | (fres ? q.resize_frame_stride : 0) | (fth ? q.thumb_frame_stride : 0) |
+         (fwm ? q.wm_frame_stride : 0)) & 15) direct = false;      // (16-byte stores: other strides go through the feeder's scratch)
     if (direct && fres) direct = (vres = pinned_device_view(q.resize_out + (size_t)i0 * q.resize_frame_stride, q.resize_frame_stride * (m - 1) + info.resize_bytes)) != nullptr;
     if (direct && fth) direct = (vth = pinned_device_view(q.thumb_out + (size_t)i0 * q.thumb_frame_stride, q.thumb_frame_stride * (m - 1) + info.thumb_bytes)) != nullptr;
     if (direct && fwm) direct = (vwm = pinned_device_view(q.wm_out + (size_t)i0 * q.wm_frame_stride, q.wm_frame_stride * (m - 1) + info.wm_bytes)) != nullptr;

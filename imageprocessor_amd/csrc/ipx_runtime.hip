@@ -1430,6 +1430,9 @@ static int run_host_packed(ipx_ctx *ctx, const ipx_plan *pl, int n, int kind, co
     // in flight, so the two directions cannot land on one engine, and a chunk has two stages instead of three.
     uint8_t *vres = nullptr, *vth = nullptr, *vwm = nullptr;
     bool direct = !bounce && env_int("IPX_HOST_DIRECT", 1) != 0;
+    // (the kernels store 16 bytes per lane: frames whose stride would break that alignment go through the lane's scratch, which pads)
+    if (((uintptr_t)resize_out | (uintptr_t)thumb_out | (uintptr_t)wm_out | (resize_out ? resize_frame_stride : 0) | (thumb_out ? thumb_frame_stride : 0) |
+         (wm_out ? wm_frame_stride : 0)) & 15) direct = false;
     if (direct && resize_out) direct = (vres = pinned_device_view(resize_out, resize_frame_stride * (n - 1) + pl->info.resize_bytes)) != nullptr;
     if (direct && thumb_out) direct = (vth = pinned_device_view(thumb_out, thumb_frame_stride * (n - 1) + pl->info.thumb_bytes)) != nullptr;
     if (direct && wm_out) direct = (vwm = pinned_device_view(wm_out, wm_frame_stride * (n - 1) + pl->info.wm_bytes)) != nullptr;

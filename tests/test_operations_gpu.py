@@ -358,3 +358,41 @@ def test_plan_cache_replaces_the_least_recently_used_plan(ipx, monkeypatch):
         c.sync()
         np.testing.assert_array_equal(out_d.download((16, 16, 4)), oracle.scale_bilinear(frames[0], 16, 16))
         L.ipx_plan_release(c.handle, p, cached)
+
+
+@pytest.mark.parametrize("shape", [(640, 360, 9, (1024, 768, True), (200, True)),      # every stride a multiple of 16: the kernels store into the pinned outputs
+                                   (333, 251, 5, (201, 99, False), (63, False)),       # odd strides: through the lane's scratch and copy engines
+                                   (1280, 720, 7, (500, 333, False), (64, True))],
+                         ids=lambda c: "%dx%d" % (c[0], c[1]))
+@pytest.mark.parametrize("direct", ["1", "0"], ids=["kernel-stored", "copied"])
+def test_pinned_outputs_of_the_host_entries(ctx, shape, direct, monkeypatch):
+    """ipx_plan_run_host with frames and outputs in pinned memory (ipx_host_alloc): the kernels store the outputs over the link
+    themselves when every pointer and stride is 16-byte aligned (IPX_HOST_DIRECT=0: the copy path), several chunks per call, the text
+    composite reading and writing the pinned watermark frames; the same bytes as the oracle, and nothing written beside the outputs."""
+    from helpers import DEFAULT_COL, rgba_frames, text_glyphs
+    monkeypatch.setenv("IPX_HOST_DIRECT", direct)
+    monkeypatch.setenv("IPX_HOST_CHUNK", "2")
+    sw, sh, n, resize, thumb = shape
+    frames = rgba_frames(n, sw, sh, seed=sw + n)
+    glyphs = text_glyphs(sw, sh, n=6, width_px=min(150, sw), height_px=min(30, sh))
+    gs = ctx.glyphset(glyphs, DEFAULT_COL)
+    plan = ctx.plan(sw, sh, resize=resize, thumbnail=thumb, watermark=gs)
+    i = plan.info
+    src = ctx.host_alloc((n, sh, sw, 4))
+    src[:] = frames
+    # one guard frame behind each output: it must stay untouched
+    outs = {"resize": ctx.host_alloc((n + 1, i.resize_h, i.resize_w, 4)), "thumbnail": ctx.host_alloc((n + 1, i.thumb_h, i.thumb_w, 4)),
+            "watermark": ctx.host_alloc((n + 1, i.wm_h, i.wm_w, 4))}
+    for a in outs.values():
+        a[:] = 0xA5
+    got = plan.run_host(src, out={k: v[:n] for k, v in outs.items()})
+    for k in range(n):
+        want = oracle.process(frames[k], resize=resize, thumb=thumb, glyphs=glyphs, col=DEFAULT_COL)
+        for key in ("resize", "thumbnail", "watermark"):
+            np.testing.assert_array_equal(got[key][k], want[key], err_msg="%s frame %d" % (key, k))
+    for key, a in outs.items():
+        assert (a[n] == 0xA5).all(), key
+    for a in [src] + list(outs.values()):
+        ctx.host_free(a)
+    plan.close()
+    gs.close()
