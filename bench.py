@@ -228,14 +228,14 @@ def run_mixed(args, ipx, shard, rank, local_rank, world):
             "metric": "images/sec (resize+thumb+watermark) on mixed-size batch (480p-8K), work stealing",
             "value": round(frames_done / wall_max, 1), "unit": "images/sec", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(wall_max / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32+f64",
             "data": "synthetic: one seeded opaque RGBA8 frame per size tiled over each chunk, resident in HBM",
             "config": {"workload": "%d frames per step of sizes %s drawn uniformly (seed 0x51), full pipeline keep_aspect=true (BASELINE config 5)"
                                    % (total, sizes), "items_per_step": len(items), "frames_per_rank": counts,
                        "sharding": "pull scheduling, largest first, atomic counter in the store; two chunks in flight per rank"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "ks_fused_kernel, one launch group per chunk of equal-size frames (the float pass for chunks of 100 megapixels and more)",
+                         "kernel": "ks_fused_kernel (float pass + exact pass), one launch group per chunk of equal-size frames",
                          "algorithmic_bytes": alg,
                          "basis": "sum of algorithmic bytes of the frames rank 0 processed / rank 0's device timeline from the first launch "
                                   "to the last completion (HIP events on the two streams the kernels run on): %.3f ms" % dev_ms,

@@ -1230,10 +1230,8 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
         KsFix fixv, *fix = nullptr;
         const int max_items = n * fp.nstrips * std::max(fp.whole.nseg, fp.split.nseg);
         const bool spec = src.kind == IPX_SRC_RGBA && env_int("IPX_KS_SPEC", 1);
-        // (the float pass costs three more launches and a memset, about 0.1 ms: batches under 100 megapixels of source -- 48 frames
-        // of 1080p, 3 of 8K -- stay with float64; IPX_KS_FAST=2 takes it whatever the size)
-        const int fast_env = env_int("IPX_KS_FAST", 1);
-        const bool fast = (spec || src.kind == IPX_SRC_YCBCR) && fast_env && (fast_env > 1 || (double)n * sw * sh >= 100e6);
+        // (three more launches and a memset; measured faster than float64 throughout at every size from one 640x360 frame to 8K frames)
+        const bool fast = (spec || src.kind == IPX_SRC_YCBCR) && env_int("IPX_KS_FAST", 1) != 0;
         if (spec || fast) {
             const int cap_env = env_int("IPX_KS_FIX_CAP", 0);     // test knob: tiny lists, so that frames fill them
             int cap[2] = {0, 0};

@@ -8,11 +8,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The one-pass kernel's float pass is taken for batches of 100 megapixels and more (ipx_runtime.hip, run_dev_any); the tests' batches
-# are a few frames, so they ask for it whatever the size.  The float64 kernels are the "IPX_KS_FAST=0" variants of the same tests.
-os.environ.setdefault("IPX_KS_FAST", "2")
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

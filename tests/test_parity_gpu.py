@@ -237,7 +237,7 @@ def test_random_geometries_vs_oracle(ctx, monkeypatch):
         thumb = (int(rng.integers(1, 300)), bool(rng.integers(0, 2)))
         for k in ("IPX_KS_STRIPS", "IPX_KS_SPLIT_ROWS", "IPX_KS_SPLIT", "IPX_KS_SPEC", "IPX_KS_FIX_CAP"):
             monkeypatch.delenv(k, raising=False)
-        monkeypatch.setenv("IPX_KS_FAST", "2")                      # the float pass whatever the batch size (conftest.py)
+        monkeypatch.delenv("IPX_KS_FAST", raising=False)            # the float pass (the default)
         if rng.random() < 0.5:
             monkeypatch.setenv("IPX_KS_STRIPS", str(int(rng.choice([1, 2, 3, 5, 9]))))
         if rng.random() < 0.5:
@@ -248,7 +248,7 @@ def test_random_geometries_vs_oracle(ctx, monkeypatch):
             monkeypatch.setenv("IPX_KS_SPEC", "0")
         pick = rng.random()
         if pick < 0.25:
-            monkeypatch.setenv("IPX_KS_FAST", "0")
+            monkeypatch.setenv("IPX_KS_FAST", "0")                  # float64 throughout
         elif pick < 0.5:
             monkeypatch.setenv("IPX_KS_FIX_CAP", str(int(rng.choice([1, 5, 40, 400]))))
         n = int(rng.integers(1, 4))
