@@ -156,7 +156,9 @@ constexpr int kKsMaxCpl = 2;
 constexpr int kKsOpenPerWave = 128;   // the float pass: undecided pixels a wave collects in LDS before they go to the frame's list (64 or 32 where that lets a second tile buffer in)
 // cuts the frame into strips and segments, assigns wave roles and lays every table out in `blob` (appended, 16-byte aligned offsets;
 // the pointers in *out are OFFSETS into the blob until ks_fused_rebase adds the device address).  sc[k] = nullptr: output absent.
-struct KsFusedIn { int dw, dh, sr_x0, sr_y0; const KsAxis *hx, *hy; };
+// top_taps: this output's taps on a tile of 16-bit values are top bytes times 0x101 (the crop thumbnail of YCbCr frames): the float
+// pass reads the byte and its weights carry the 0x101
+struct KsFusedIn { int dw, dh, sr_x0, sr_y0; const KsAxis *hx, *hy; int top_taps = 0; };
 bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, int px_bytes, std::vector<uint8_t> *blob, KsFusedPlan *out);
 void ks_fused_rebase(KsFusedPlan *p, const uint8_t *dev_blob);
 // *matched = false: nothing launched (shape, alignment or kind the kernel is not built for)

@@ -198,9 +198,8 @@ __device__ __forceinline__ void ks_fetchf(typename KsTapRaw<SRC>::type raw, floa
     } else {
         const uint2 t = raw;
         uint32_t c[4];
-        if (MODE == KS_TAP_TOP) {
-            c[0] = __builtin_amdgcn_perm(0u, t.x, 0x0c0c0101u); c[1] = __builtin_amdgcn_perm(0u, t.x, 0x0c0c0303u);
-            c[2] = __builtin_amdgcn_perm(0u, t.y, 0x0c0c0101u); c[3] = 0;
+        if (MODE == KS_TAP_TOP) {                          // the top bytes themselves (v_cvt_f32_ubyte1 / 3): this output's weights carry the 0x101
+            c[0] = (t.x >> 8) & 0xffu; c[1] = t.x >> 24; c[2] = (t.y >> 8) & 0xffu; c[3] = 0;
         } else {
             c[0] = t.x & 0xffffu; c[1] = t.x >> 16; c[2] = t.y & 0xffffu; c[3] = t.y >> 16;
         }

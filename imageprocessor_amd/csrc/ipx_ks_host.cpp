@@ -359,7 +359,7 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
             o.wx = as_off<double>(blob_put(blob, wx.data(), wx.size() * sizeof(double)));
             // the float pass: weights with both normalisations folded in, in the unit of the 16-bit result (a byte tile's taps are bytes)
             std::vector<float> wxf(wx.size(), 0.f);
-            const double unit = px_bytes == 4 ? 65535.0 * 257.0 : 65535.0;
+            const double unit = px_bytes == 4 || (px_bytes == 8 && sc[k]->top_taps) ? 65535.0 * 257.0 : 65535.0;
             for (int c = 0; c < ns; c++)
                 for (int i = 0; i < colb[k][c + 1] - colb[k][c]; i++)
                     for (int t = 0; t < hx.ntap; t++)

@@ -1037,6 +1037,7 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
         const int px_bytes[3] = {4, 8, 2};
         for (int f = 0; f < 3; f++) {
             std::vector<uint8_t> fblob;
+            fin[1].top_taps = f == 1 && pl->p.crop_to_fit;       // (of this tile only the YCbCr source takes the float pass: IPX_SRC_YCBCR_CROP taps)
             if (ks_fused_plan(sw, sh, have[0] ? &fin[0] : nullptr, have[1] ? &fin[1] : nullptr, px_bytes[f], &fblob, &pl->fused[f])) {
                 fused_off[f] = put(fblob.size());
                 memcpy(blob.data() + fused_off[f], fblob.data(), fblob.size());
