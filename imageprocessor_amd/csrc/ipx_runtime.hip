@@ -1037,7 +1037,7 @@ int ipx_plan_create(ipx_ctx *ctx, const ipx_plan_params *p, ipx_plan **out) try
         const int px_bytes[3] = {4, 8, 2};
         for (int f = 0; f < 3; f++) {
             std::vector<uint8_t> fblob;
-            fin[1].top_taps = f == 1 && pl->p.crop_to_fit;       // (of this tile only the YCbCr source takes the float pass: IPX_SRC_YCBCR_CROP taps)
+            fin[1].top_taps = f == 1 && pl->p.crop_to_fit;       // (the YCbCr and NRGBA sources' crop thumbnails: IPX_SRC_YCBCR_CROP / IPX_SRC_NRGBA_CROP taps)
             if (ks_fused_plan(sw, sh, have[0] ? &fin[0] : nullptr, have[1] ? &fin[1] : nullptr, px_bytes[f], &fblob, &pl->fused[f])) {
                 fused_off[f] = put(fblob.size());
                 memcpy(blob.data() + fused_off[f], fblob.data(), fblob.size());
@@ -1232,7 +1232,7 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
         const int max_items = n * fp.nstrips * std::max(fp.whole.nseg, fp.split.nseg);
         const bool spec = src.kind == IPX_SRC_RGBA && env_int("IPX_KS_SPEC", 1);
         // (three more launches and a memset; measured faster than float64 throughout at every size from one 640x360 frame to 8K frames)
-        const bool fast = (spec || src.kind == IPX_SRC_YCBCR) && env_int("IPX_KS_FAST", 1) != 0;
+        const bool fast = (spec || src.kind == IPX_SRC_YCBCR || src.kind == IPX_SRC_NRGBA) && env_int("IPX_KS_FAST", 1) != 0;
         if (spec || fast) {
             const int cap_env = env_int("IPX_KS_FIX_CAP", 0);     // test knob: tiny lists, so that frames fill them
             int cap[2] = {0, 0};

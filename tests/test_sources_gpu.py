@@ -170,7 +170,7 @@ def test_ycbcr_batch_plan(ctx, case, fused, monkeypatch):
 @pytest.mark.parametrize("case", [(640, 360, 3, (1024, 768, True), (200, True)), (333, 251, 2, (200, 100, False), (64, False)),
                                   (200, 200, 2, (200, 200, False), (100, True)), (1920, 1080, 2, (1024, 768, False), (200, False)),
                                   (1280, 720, 2, (500, 333, False), (200, True))], ids=lambda c: "%dx%d" % (c[0], c[1]))
-@pytest.mark.parametrize("fused", ["conv", "split", "0"], ids=["one-pass", "one-pass-split-strips", "per-output"])
+@pytest.mark.parametrize("fused", ["conv", "split", "0", "f64", "cap"], ids=["one-pass", "one-pass-split-strips", "per-output", "one-pass-float64", "one-pass-short-lists"])
 def test_nrgba_batch_plan(ctx, case, fused, monkeypatch):
     """ipx_plan_run_dev_nrgba: a batch of *image.NRGBA frames (PNGs with alpha), per operator as the reference's helpers treat the
     type: 16-bit premultiplied taps for resizeImage, drawNRGBA* first for the crop thumbnail and the watermark.  The converted-tile
@@ -180,6 +180,10 @@ def test_nrgba_batch_plan(ctx, case, fused, monkeypatch):
     monkeypatch.setenv("IPX_FUSED", "0" if fused == "0" else "1")
     if fused == "split":
         monkeypatch.setenv("IPX_KS_STRIPS", "2"); monkeypatch.setenv("IPX_KS_SPLIT", "1"); monkeypatch.setenv("IPX_KS_SPLIT_ROWS", "31")
+    if fused == "f64":
+        monkeypatch.setenv("IPX_KS_FAST", "0")          # no float pass (all four channels are sums here: the alpha too)
+    if fused == "cap":
+        monkeypatch.setenv("IPX_KS_FIX_CAP", "11")      # the float pass's lists fill up: the frames' items are redone in float64
     w, h, n, resize, thumb = case
     rng = np.random.default_rng(w)
     frames = rng.integers(0, 256, (n, h, w, 4), dtype=np.uint8)          # non-premultiplied: colour may exceed alpha
