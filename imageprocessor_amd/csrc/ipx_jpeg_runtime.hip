@@ -125,6 +125,8 @@ static int jpeg_encode_sets(ipx_ctx *ctx, hipStream_t s, const JpegEncSet *sets,
 {
     *blob = nullptr;
     if (K <= 0 || K > 3 || n <= 0) return IPX_OK;
+    // every way out of this function waits for the stream: the queued copies read and write the vectors below
+    struct SyncOnExit { hipStream_t s; ~SyncOnExit() { (void)hipStreamSynchronize(s); } } sync_on_exit{s};
     const bool trace = env_int("IPX_DEBUG_J2J", 0) != 0;
     const auto te0 = std::chrono::steady_clock::now();
     auto ems = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te0).count(); };

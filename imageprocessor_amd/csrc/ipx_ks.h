@@ -153,7 +153,7 @@ constexpr int kKsMaxStage = 3;    // 16-byte chunks a thread stages per group
 constexpr int kKsMaxWaves = 12;   // waves per workgroup (768 threads: three waves per SIMD, 168 registers each)
 constexpr int kKsMaxThreads = 64 * kKsMaxWaves;
 constexpr int kKsMaxCpl = 2;
-constexpr int kKsOpenPerWave = 128;   // the float pass: undecided pixels a wave collects in LDS before they go to the frame's list (64 or 32 where that lets a second tile buffer in)
+constexpr int kKsOpenPerWave = 128;   // the float pass: undecided pixels a wave collects in LDS before they go to the frame's list (64 where that lets a second tile buffer in; at least one entry per lane)
 // cuts the frame into strips and segments, assigns wave roles and lays every table out in `blob` (appended, 16-byte aligned offsets;
 // the pointers in *out are OFFSETS into the blob until ks_fused_rebase adds the device address).  sc[k] = nullptr: output absent.
 // top_taps: this output's taps on a tile of 16-bit values are top bytes times 0x101 (the crop thumbnail of YCbCr frames): the float

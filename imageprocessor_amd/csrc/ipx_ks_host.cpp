@@ -314,14 +314,14 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
         const int lds_rows = (int)lds;
         lds += 2 * 2 * (size_t)B * row_bytes + 64;
         // the float pass's layout: float weights, the waves' lists of undecided pixels behind the row entries; two tile buffers where
-        // they fit in the CU's 160 KB with lists of 128, 64 or 32 entries per wave, else one
+        // they fit in the CU's 160 KB with lists of 128 or 64 entries per wave, else one
         KsFusedPlan::Lds F;
         {
             size_t wf = 0;
             for (int k = 0; k < 2; k++) if (sc[k]) wf += ((size_t)sc[k]->hx->ntap * wcols[k] * sizeof(float) + 15) & ~(size_t)15;
             const size_t rows_b = 2 * 2 * (size_t)B * row_bytes + 64, cu = ((size_t)160 << 10) - 512;
             F.dbuf = 0; F.open_per_wave = kKsOpenPerWave;
-            for (int per : {kKsOpenPerWave, 64, 32})
+            for (int per : {kKsOpenPerWave, 64})                   // (never under 64: one ballot may add an entry per lane)
                 if (2 * (size_t)B * pitch + wf + rows_b + 16 + (size_t)kKsMaxWaves * per * sizeof(uint2) <= cu) { F.dbuf = 1; F.open_per_wave = per; break; }
             size_t at = (size_t)(F.dbuf + 1) * B * pitch;
             for (int k = 0; k < 2; k++) {

@@ -515,11 +515,21 @@ def test_values_exactly_on_a_rounding_boundary(ctx, env, monkeypatch):
     oracle's."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    frames = rgba_frames(2, 1920, 1080, seed=0xB0DA)
+    frames = rgba_frames(3, 1920, 1080, seed=0xB0DA)
+    # frame 2: EVERY interior value of the 2:1 output on a boundary.  With a source of period 2 in x and y the 16 taps weigh each of the
+    # four tile values by 16 / 64, so sum(tap * weight) = 257 * (a + b + c + d) / 4, and tiles that sum to 510 give 32767.5: + 0.5 is
+    # 128 * 256 exactly.  All 64 lanes of a wave are undecided at once, every frame's list overflows, every item is redone in float64.
+    rng = np.random.default_rng(0xA11)
+    for ch in range(3):
+        a = rng.integers(100, 156, (540, 960)); b = rng.integers(100, 156, (540, 960)); c = rng.integers(100, 156, (540, 960))
+        d = 510 - a - b - c
+        tile = np.empty((1080, 1920), np.int64)
+        tile[0::2, 0::2] = a[0, 0]; tile[0::2, 1::2] = b[0, 0]; tile[1::2, 0::2] = c[0, 0]; tile[1::2, 1::2] = d[0, 0]   # one tile, repeated
+        frames[2, :, :, ch] = tile.astype(np.uint8)
     plan = ctx.plan(1920, 1080, resize=(960, 540, False), thumbnail=(270, True), watermark=None)
     got = plan.run_host(frames)
     on_boundary = 0
-    for i in range(2):
+    for i in range(3):
         want = oracle.process(frames[i], resize=(960, 540, False), thumb=(270, True), want=("resize", "thumbnail"))
         for k in ("resize", "thumbnail"):
             np.testing.assert_array_equal(got[k][i], want[k], err_msg="%s frame %d %s" % (k, i, env))
@@ -530,5 +540,5 @@ def test_values_exactly_on_a_rounding_boundary(ctx, env, monkeypatch):
         cols = sum(wy[k] * np.pad(rows, ((0, 0), (1, 1), (0, 0)), mode="edge")[:, k:k + 1920:2] for k in range(4))[:, :960]
         inner = cols[1:-1, 1:-1]                                     # (edge rows and columns have their own, renormalised weights)
         on_boundary += int(np.count_nonzero((257 * inner + 32) % (256 * 64) == 0))
-    assert on_boundary > 100, on_boundary                            # the case is really there
+    assert on_boundary > 100 + 3 * 900 * 500, on_boundary            # the case is really there: hundreds in the random frames, all of frame 2
     plan.close()

@@ -11,6 +11,12 @@ from helpers import DEFAULT_COL, text_glyphs
 n, sw, sh = int(os.environ.get("N", 256)), 1920, 1080
 lanes, lane_mb = int(os.environ.get("POOL_LANES", 0)), int(os.environ.get("POOL_LANE_MB", 0))
 glyphs = text_glyphs(sw, sh)
+if os.environ.get("PRE_CTX"):            # a context that lived (and was closed) before the pool is made
+    c0 = ipx.Context(device=0)
+    if os.environ["PRE_CTX"] == "plan":
+        p0 = c0.plan(sw, sh, resize=(1024, 768, False), thumbnail=(200, True), watermark=True)
+        p0.close()
+    c0.close()
 with ipx.Pool(devices=(0,), lanes_per_device=lanes, lane_bytes=lane_mb << 20) as pool:
     src = pool.host_alloc(0, (n, sh, sw, 4))
     src[:] = np.random.default_rng(1).integers(0, 256, (1, sh, sw, 4), dtype=np.uint8)
