@@ -360,13 +360,13 @@ def pool_leg(ipx, n, sw, sh, resize, reps, frames4):
     from helpers import DEFAULT_COL, text_glyphs
     ndev = max(1, ipx.device_count())
     glyphs = text_glyphs(sw, sh)
+    tmp = ipx.Context(device=0)                           # (the output sizes; gone before the pool exists)
+    info = tmp.plan(sw, sh, resize=resize, thumbnail=(200, True), watermark=True).info
+    rb, tb = (info.resize_h, info.resize_w, 4), (info.thumb_h, info.thumb_w, 4)
+    tmp.close()
     with ipx.Pool(devices=tuple(range(ndev))) as pool:
         per = (n + ndev - 1) // ndev
         jobs, keep = [], []
-        tmp = ipx.Context(device=0)
-        info = tmp.plan(sw, sh, resize=resize, thumbnail=(200, True), watermark=True).info
-        rb, tb = (info.resize_h, info.resize_w, 4), (info.thumb_h, info.thumb_w, 4)
-        tmp.close()
         for d in range(ndev):
             src = pool.host_alloc(d, (per, sh, sw, 4))
             for k in range(per):

@@ -497,7 +497,7 @@ void ipx_jpeg_planes_free(ipx_ctx *ctx, ipx_jpeg_planes *owner);
  * until ipx_job_wait has returned; the operator description and its glyph masks are copied at submit. */
 typedef struct ipx_pool ipx_pool;
 typedef struct {
-    int32_t lanes_per_device;   /* feeder threads (one stream each) per listed device; 0 = 3, the reference's WORKER_CONCURRENCY */
+    int32_t lanes_per_device;   /* feeder threads (one stream each) per listed device; 0 = 4 (the reference's WORKER_CONCURRENCY is 3; four chunks in flight keep the host link busy) */
     size_t lane_bytes;          /* frames per chunk are sized to about this many bytes; 0 = 256 MiB */
 } ipx_pool_config;
 int ipx_pool_create(const int *devices, int n_devices, const ipx_pool_config *cfg, ipx_pool **out);
