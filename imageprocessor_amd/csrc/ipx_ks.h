@@ -116,6 +116,7 @@ struct KsFusedOut {
 struct KsFusedArgs {
     const uint8_t *src; size_t src_fs; int sstride, sw, sh;   // pixels, or the luma plane
     int src_kind;              // IPX_SRC_*: how `src` is laid out
+    int taps_le_alpha;         // IPX_SRC_TAP64: no colour tap exceeds its alpha tap, so the reference's clamp never fires (the float pass asks)
     const uint8_t *cb, *cr; int cstride, ratio; size_t c_fs;   // IPX_SRC_YCBCR: the chroma planes (cstride 0: a Gray frame)
     uint8_t *wm; size_t wm_fs; int wm_stride;
     int nframes, nstrips, nseg, nthreads, pitch, dbuf;

@@ -23,7 +23,7 @@
 // alpha, term by term), so the clamp never fires and the stored alpha is 0xff: the alpha channel costs nothing.  The kernel checks
 // the assumption on every pixel it stages; an item that meets alpha != 0xff gives up and is redone by the NCH = 4 kernel (`redo`).
 //
-// The float pass (FAST = true; RGBA frames taken as opaque, YCbCr, Gray, NRGBA).  The float64 arithmetic above is what bounds the kernel, and a
+// The float pass (FAST = true; RGBA frames taken as opaque, YCbCr, Gray, NRGBA, and the 16-bit / CMYK types whose colours stay under their alpha).  The float64 arithmetic above is what bounds the kernel, and a
 // byte of output needs almost none of it: the same sums in float -- taps are exact in float, one fused multiply-add per term, both
 // normalisations folded into the weights -- land within (nx + ny + 3) 2^-24 of the reference's value, relatively (derivation at
 // ks_float_eps, ipx_ks_host.cpp), and the byte is floor((V + 0.5) / 256): unless V + 0.5 lies that close to a multiple of 256, the
@@ -706,6 +706,10 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
                 if constexpr (SRC == KS_YCC) {
                     if (!aone) { KS_COLSF(KS_TAP_TOP); }
                     else { KS_COLSF(KS_TAP_PLAIN); }
+                } else if constexpr (SRC == KS_TAP64) {
+                    // (only for taps whose colours never exceed their alpha: then min(c, a) is c and the crop copy's tap is the top byte)
+                    if (mode == KS_TAP_MINTOP) { KS_COLSF(KS_TAP_TOP); }
+                    else { KS_COLSF(KS_TAP_PLAIN); }
                 } else if constexpr (SRC == KS_NRGBA) {
                     // (a colour tap of an NRGBA pixel, c * a16 / 0xff, never exceeds its alpha tap: the reference's clamp of a colour
                     // sum to the alpha sum never fires, and all four channels are plain sums)
@@ -861,7 +865,7 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fi
                 a.nout > 1 ? a.o[1].waves : 0, a.nout > 1 ? a.o[1].cpl : 0, a.nout > 1 ? a.o[1].wcols : 0);
     // the float pass where the source type has one and the caller brought lists: float kernel, the listed pixels in float64, then the
     // float64 kernel on the items the float kernel gave up
-    bool fast = fix && fix->list && a.redo && (src == KS_RGBA || src == KS_YCC || src == KS_GRAY || src == KS_NRGBA);
+    bool fast = fix && fix->list && a.redo && (src == KS_RGBA || src == KS_YCC || src == KS_GRAY || src == KS_NRGBA || (src == KS_TAP64 && a.taps_le_alpha));
     for (int i = 0; i < a.nout; i++) fast = fast && a.o[i].feps > 0.f;       // (an output with more taps than the margin's derivation covers)
     fast = fast && p.fast.lds_bytes > 0;
     layout(false);
@@ -892,7 +896,14 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fi
         if (e == hipSuccess) e = exact_listed();
         if (e == hipSuccess) e = launch_src<KS_NRGBA, 4>(p, a, n, s);
         return e;
-    case KS_TAP64: a.redo = nullptr; return launch_src<KS_TAP64, 4>(p, a, n, s);
+    case KS_TAP64:
+        if (!fast) { a.redo = nullptr; return launch_src<KS_TAP64, 4>(p, a, n, s); }
+        layout(true);
+        e = p.nacc == 2 ? launch_one<KS_TAP64, 4, 2, false, true>(p, a, n, s) : launch_one<KS_TAP64, 4, 4, false, true>(p, a, n, s);
+        layout(false);
+        if (e == hipSuccess) e = exact_listed();
+        if (e == hipSuccess) e = launch_src<KS_TAP64, 4>(p, a, n, s);
+        return e;
     case KS_YCC:
         if (!fast) { a.redo = nullptr; return launch_src<KS_YCC, 3>(p, a, n, s); }
         layout(true);

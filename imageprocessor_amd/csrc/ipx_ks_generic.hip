@@ -216,6 +216,8 @@ hipError_t launch_ks_fix(const KsGenArgs &a, const uint2 *list, size_t list_stri
     case IPX_SRC_RGBA: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_RGBA>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
     case IPX_SRC_NRGBA: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_NRGBA>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
     case IPX_SRC_NRGBA_CROP: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_NRGBA_CROP>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
+    case IPX_SRC_TAP64: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_TAP64>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
+    case IPX_SRC_TAP64_CROP: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_TAP64_CROP>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

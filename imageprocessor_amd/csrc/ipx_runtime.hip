@@ -86,6 +86,7 @@ struct DevSrc {
     int w = 0, h = 0;
     int nframes = 1;                // a batch: frames frame_stride / c_frame_stride bytes apart
     size_t frame_stride = 0, c_frame_stride = 0;
+    bool le_alpha = false;          // IPX_SRC_TAP64: no colour tap exceeds its alpha tap (NRGBA64, Gray16, CMYK after the expansion; not RGBA64)
 };
 
 int dev_draw_src(hipStream_t s, uint8_t *dst, int dw, int dh, int dstride, Rect r, const DevSrc &src, int spx,
@@ -1214,6 +1215,7 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
         a.src_kind = src.kind; a.cb = src.cb; a.cr = src.cr; a.cstride = src.cstride; a.ratio = src.ratio; a.c_fs = src.c_frame_stride;
         a.wm = wm; a.wm_fs = wm_frame_stride; a.wm_stride = sw * 4;
         a.nframes = n;
+        a.taps_le_alpha = src.le_alpha;
         for (int k = 0; k < 2; k++) {
             if (!outs[k]) continue;
             const PlanScale &ps = pl->sc[k];
@@ -1232,7 +1234,8 @@ static int run_dev_any(ipx_ctx *ctx, hipStream_t s, const ipx_plan *pl, int n, c
         const int max_items = n * fp.nstrips * std::max(fp.whole.nseg, fp.split.nseg);
         const bool spec = src.kind == IPX_SRC_RGBA && env_int("IPX_KS_SPEC", 1);
         // (three more launches and a memset; measured faster than float64 throughout at every size from one 640x360 frame to 8K frames)
-        const bool fast = (spec || src.kind == IPX_SRC_YCBCR || src.kind == IPX_SRC_NRGBA) && env_int("IPX_KS_FAST", 1) != 0;
+        const bool fast = (spec || src.kind == IPX_SRC_YCBCR || src.kind == IPX_SRC_NRGBA || (src.kind == IPX_SRC_TAP64 && src.le_alpha)) &&
+                          env_int("IPX_KS_FAST", 1) != 0;
         if (spec || fast) {
             const int cap_env = env_int("IPX_KS_FIX_CAP", 0);     // test knob: tiny lists, so that frames fill them
             int cap[2] = {0, 0};
@@ -1665,6 +1668,7 @@ int ipx_plan_run_dev_deep(ipx_ctx *ctx, void *stream, const ipx_plan *pl, int n,
     DevSrc d;
     d.kind = IPX_SRC_TAP64; d.pix = taps; d.stride = sw * 8; d.w = sw; d.h = sh;
     d.nframes = n; d.frame_stride = tfs;
+    d.le_alpha = kind != IPX_DEEP_RGBA64;     // (a premultiplied RGBA64 file may hold a colour above its alpha; the others cannot)
     return run_dev_any(ctx, s, pl, n, d, resize_out, resize_frame_stride, thumb_out, thumb_frame_stride, wm_out, wm_frame_stride);
 }
 IPX_CATCH_STATUS

@@ -55,7 +55,7 @@ def _expect(pix, kind, w, h, resize, thumb, glyphs, col):
 @pytest.mark.parametrize("case", [(640, 360, 3, (1024, 768, True), (200, True)), (333, 251, 2, (200, 100, False), (64, False)),
                                   (200, 200, 2, (200, 200, False), (100, True)), (1280, 720, 2, (500, 333, False), (200, True))],
                          ids=lambda c: "%dx%d" % (c[0], c[1]))
-@pytest.mark.parametrize("path", ["taps", "split", "three"], ids=["one-pass", "one-pass-split-strips", "per-output"])
+@pytest.mark.parametrize("path", ["taps", "split", "three", "f64", "cap"], ids=["one-pass", "one-pass-split-strips", "per-output", "one-pass-float64", "one-pass-short-lists"])
 def test_deep_batch_plan(ctx, kind, case, path, monkeypatch):
     """The three ways a batch can go: the converted-tile kernel reading Go's Pix (16-byte aligned frames, widths that are multiples of
     4), the same kernel on the expanded frames of taps, and expansion + the three-kernel path (any shape)."""
@@ -63,6 +63,10 @@ def test_deep_batch_plan(ctx, kind, case, path, monkeypatch):
     monkeypatch.setenv("IPX_FUSED", "0" if path == "three" else "1")
     if path == "split":
         monkeypatch.setenv("IPX_KS_STRIPS", "2"); monkeypatch.setenv("IPX_KS_SPLIT", "1"); monkeypatch.setenv("IPX_KS_SPLIT_ROWS", "29")
+    if path == "f64":
+        monkeypatch.setenv("IPX_KS_FAST", "0")          # no float pass (NRGBA64, Gray16 and CMYK take it by default; RGBA64 never)
+    if path == "cap":
+        monkeypatch.setenv("IPX_KS_FIX_CAP", "13")      # the float pass's lists fill up: the frames' items are redone in float64
     w, h, n, resize, thumb = case
     pix = _frames(kind, n, h, w, seed=w + kind)
     glyphs = text_glyphs(w, h, n=6, width_px=min(150, w), height_px=min(30, h))
