@@ -92,12 +92,13 @@ struct Reader {
     }
 };
 
-// checkpoints per sub-sequence, 512 bits apart.  A re-decode ends at the first checkpoint where it meets its previous trajectory, and a
+// checkpoints per sub-sequence, a sixteenth of it apart (512 bits for 1 KiB).  A re-decode ends at the first checkpoint where it meets its previous trajectory, and a
 // wave waits for its slowest lane: with three checkpoints (512, 1536, 4096 bits) round 1 took 1.7 ms per 1024 1080p files against
 // 2.65 for the full speculative round, with fifteen 1.12 (the slowest of 64 lanes needs ~3000 bits as a rule)
 constexpr int kCk = 15;
 constexpr unsigned long long kNoState = ~0ull;           // no packed state has its upper 16 bits set
-__device__ __forceinline__ uint32_t ck_bits(int k) { return 512u * (uint32_t)(k + 1); }
+// (512 bits apart in a 1 KiB sub-sequence, 128 in a 256-byte one: sixteen intervals whatever the length)
+__device__ __forceinline__ uint32_t ck_bits(int k, int sub_bytes) { return (uint32_t)(sub_bytes >> 1) * (uint32_t)(k + 1); }
 
 struct NoSink {
     __device__ __forceinline__ void dc(int) {}
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(64) void par_sync_kernel(JpegParArgs a, int round)
             bool ended = false;
             out = entry;
             for (; k < kCk; k++) {
-                const uint32_t limit = ustart + ck_bits(k);
+                const uint32_t limit = ustart + ck_bits(k, a.sub);
                 if (limit >= uend) break;                               // the remaining checkpoints lie beyond this sub-sequence
                 if (p >= limit) { ck[k] = kNoState; continue; }         // entered beyond it: not on this trajectory
                 uint32_t e1;
