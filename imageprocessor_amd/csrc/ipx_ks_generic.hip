@@ -158,11 +158,13 @@ __global__ __launch_bounds__(256) void ks_fix_kernel(KsGenArgs a, const uint2 *l
                     if (!alpha_one) pa += (double)tp.a * w;
                 }
             const double tr = pr * xs, tg = pg * xs, tb = pb * xs, ta = alpha_one ? 1.0 : pa * xs;
+            const double wl = j < yn ? wy[j] : 0.0;                       // the row's vertical weight travels with its sums (a load per
+                                                                          // step of the loop below was a memory round trip per row)
             for (int jj = 0; jj < R; jj++) {                              // every lane of the group adds the group's rows in order
                 const int from = sub * R + jj;
                 const double vr = __shfl(tr, from), vg = __shfl(tg, from), vb = __shfl(tb, from), va = __shfl(ta, from);
+                const double w = __shfl(wl, from);
                 if (jb + jj < yn) {
-                    const double w = wy[jb + jj];
                     qr += vr * w;
                     qg += vg * w;
                     qb += vb * w;
