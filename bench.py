@@ -145,7 +145,8 @@ def cpu_baseline(pool, glyphs, col, resize, thumb, want, seconds):
 def run_mixed(args, ipx, shard, rank, local_rank, world):
     """Config 5: args.mixed frames per GPU, sizes drawn uniformly from six (854x480 ... 7680x4320, seed 0x51), full pipeline with the
     product-default keep_aspect=true.  Every rank holds one plan, one pool of source frames and two sets of outputs per size in HBM
-    (shard.MixedBatch); work items are chunks of equal-size frames (~256 MB of source), ordered largest first and claimed with an
+    (shard.MixedBatch); work items are chunks of equal-size frames (~1 GiB of source, at most 128 frames: an 8K chunk of 2 frames fills half
+    the chip, one of 8 all of it -- 42 k images/s with 256 MB chunks, 51 k with 1 GiB), ordered largest first and claimed with an
     atomic counter in the rendezvous store, so a rank that finishes early claims more (work stealing).  A rank keeps two chunks in
     flight on two streams: the next chunk is claimed and launched while the previous one runs.  A step = one pass over the batch."""
     import ctypes
@@ -161,7 +162,8 @@ def run_mixed(args, ipx, shard, rank, local_rank, world):
 
     def make_frames(si, w, h, k):
         return rgba_frames(k, w, h, seed=0x1F00D + si)
-    mb = shard.MixedBatch(ctx, make_frames, text_glyphs, DEFAULT_COL, resize=(1024, 768, True), thumbnail=(200, True))
+    mb = shard.MixedBatch(ctx, make_frames, text_glyphs, DEFAULT_COL, resize=(1024, 768, True), thumbnail=(200, True),
+                          chunk_bytes=int(os.environ.get("IPX_MIXED_CHUNK_MB", "1024")) << 20, max_chunk=int(os.environ.get("IPX_MIXED_MAX_CHUNK", "128")))
     items = mb.items_for(draw)
     store = shard.default_store()
 
