@@ -151,6 +151,7 @@ static int jpeg_encode_sets(ipx_ctx *ctx, hipStream_t s, const JpegEncSet *sets,
     uint32_t *d_tot, *d_fftot;                    // [K][n]
     IPX_HIP(mem.get(&d_tot, (size_t)K * n * 4));
     IPX_HIP(mem.get(&d_fftot, (size_t)K * n * 4));
+    if (trace) fprintf(stderr, "[ipx]   tables queued at %.2f ms\n", ems());
     for (int k = 0; k < K; k++) {
         const JpegEncSet &o = sets[k];
         Dev &d = dv[k];
@@ -175,6 +176,7 @@ static int jpeg_encode_sets(ipx_ctx *ctx, hipStream_t s, const JpegEncSet *sets,
             IPX_HIP(launch_jpeg_len(o.dcoefs, d.nblk, n, d_tab, d.d_len, s));     // the earlier separate pass over the coefficients
         }
         IPX_HIP(launch_scan(d.d_len, d.nblk, n, d_tot + (size_t)k * n, s));
+        if (trace) fprintf(stderr, "[ipx]   set %d (%dx%d) transform and sizes queued at %.2f ms\n", k, o.w, o.h, ems());
     }
     std::vector<uint32_t> tot((size_t)K * n), ubytes((size_t)K * n), ff((size_t)K * n);
     IPX_HIP(hipMemcpyAsync(tot.data(), d_tot, (size_t)K * n * 4, hipMemcpyDeviceToHost, s));

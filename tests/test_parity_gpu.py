@@ -542,3 +542,21 @@ def test_values_exactly_on_a_rounding_boundary(ctx, env, monkeypatch):
         on_boundary += int(np.count_nonzero((257 * inner + 32) % (256 * 64) == 0))
     assert on_boundary > 100 + 3 * 900 * 500, on_boundary            # the case is really there: hundreds in the random frames, all of frame 2
     plan.close()
+
+
+def test_the_float_pass_is_what_runs_by_default(ctx, monkeypatch, capfd):
+    """IPX_KS_STATS=1 makes the runtime report the float pass's lists after a launch: by default opaque RGBA frames take the float pass
+    (a few undecided pixels in ten thousand, nothing redone in float64), with IPX_KS_FAST=0 there is no such report."""
+    import re
+    frames = rgba_frames(2, 1280, 720, seed=5)
+    plan = ctx.plan(1280, 720, resize=(1024, 768, True), thumbnail=(200, True), watermark=None)
+    monkeypatch.setenv("IPX_KS_STATS", "1")
+    plan.run_host(frames)
+    err = capfd.readouterr().err
+    m = re.search(r"\[ipx ks stats\] \d+ frames: undecided pixels per frame resize mean ([0-9.]+) max (\d+) \(room (\d+)\).*; (\d+) of (\d+) items redone", err)
+    assert m, err[-400:]
+    assert 0 < float(m.group(1)) < 0.004 * 1024 * 576 and int(m.group(2)) < int(m.group(3)) and int(m.group(4)) == 0
+    monkeypatch.setenv("IPX_KS_FAST", "0")
+    plan.run_host(frames)
+    assert "ks stats" not in capfd.readouterr().err
+    plan.close()
