@@ -124,12 +124,28 @@ __device__ __forceinline__ u32x4 ks_convert(const KsStageRegs &s, uint8_t *dst, 
         px.z = __builtin_amdgcn_perm(t[5], t[4], 0x07050301u); px.w = __builtin_amdgcn_perm(t[7], t[6], 0x07050301u);
     } else {   // KS_YCC: v[0] = four luma bytes, v[1] / v[2] = the Cb / Cr bytes of their samples (two when hs, else four)
         uint32_t t[8];
+        // the chroma terms once per SAMPLE: two pixels share one where the planes are subsampled horizontally (hs is uniform; with the
+        // sample index computed per pixel the compiler multiplied every pixel's terms anew: 6.8 multiplies per pixel instead of 3)
+        int rt[4], gt[4], bt[4];
+        if (hs) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int cb1 = (int)((s.v[1] >> (8 * c)) & 0xffu) - 128, cr1 = (int)((s.v[2] >> (8 * c)) & 0xffu) - 128;
+                rt[2 * c] = rt[2 * c + 1] = 91881 * cr1;
+                gt[2 * c] = gt[2 * c + 1] = -22554 * cb1 - 46802 * cr1;
+                bt[2 * c] = bt[2 * c + 1] = 116130 * cb1;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int cb1 = (int)((s.v[1] >> (8 * c)) & 0xffu) - 128, cr1 = (int)((s.v[2] >> (8 * c)) & 0xffu) - 128;
+                rt[c] = 91881 * cr1; gt[c] = -22554 * cb1 - 46802 * cr1; bt[c] = 116130 * cb1;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int ci = hs ? i >> 1 : i;
-            const int cb1 = (int)((s.v[1] >> (8 * ci)) & 0xffu) - 128, cr1 = (int)((s.v[2] >> (8 * ci)) & 0xffu) - 128;
             uint32_t r, g, b;
-            ks_ycc16((s.v[0] >> (8 * i)) & 0xffu, 91881 * cr1, -22554 * cb1 - 46802 * cr1, 116130 * cb1, r, g, b);
+            ks_ycc16((s.v[0] >> (8 * i)) & 0xffu, rt[i], gt[i], bt[i], r, g, b);
             t[2 * i] = r | g << 16; t[2 * i + 1] = b | 0xffff0000u;
         }
         *(u32x4 *)dst = u32x4{t[0], t[1], t[2], t[3]};
