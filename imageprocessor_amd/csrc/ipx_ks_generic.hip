@@ -9,6 +9,7 @@
 // is that a tmp value is computed by every destination row that uses it (two for a downscale).  Bound: FP64 VALU and L2 gathers; this
 // is not the throughput path.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ipx_ks.h"
 
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void ks_fix_kernel(KsGenArgs a, const uint2 *l
     a.src += frame * a.src_fs;
     if (KIND == IPX_SRC_YCBCR || KIND == IPX_SRC_YCBCR_CROP) { a.cb += frame * a.c_fs; a.cr += frame * a.c_fs; }
     const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
-    const int per_wave = 64 / R, sub = lane / R, sl = lane - sub * R, per_block = 4 * per_wave;
+    const int per_wave = 64 / R, sub = lane / R, sl = lane - sub * R, per_block = ((int)blockDim.x >> 6) * per_wave;
     constexpr bool alpha_one = KIND == IPX_SRC_YCBCR;
     for (int i0 = (int)blockIdx.x * per_block; i0 < n; i0 += (int)gridDim.x * per_block) {
         const int i = i0 + wv * per_wave + sub;
@@ -207,10 +208,12 @@ hipError_t launch_ks_fix(const KsGenArgs &a, const uint2 *list, size_t list_stri
 {
     if (a.nframes <= 0 || cap <= 0) return hipSuccess;
     const int R = a.ay.ntap <= 8 ? 8 : a.ay.ntap <= 16 ? 16 : 64;
-    // a few blocks per frame walk its list (a photograph leaves about a thousandth of the output's pixels there, the list holds forty
-    // times that); more of them when the batch is small: about eight thousand blocks in all
-    const int per_block = 4 * (64 / R), most = (cap + per_block - 1) / per_block;
-    dim3 block(256), grid(std::max(1, std::min(most, std::max(8, 8192 / a.nframes))), a.nframes);
+    // about two thousand blocks in all: two per frame for a batch of 1024 (a photograph leaves a few hundred pixels of an output on
+    // its frame's list: a block takes 32 or 16 per pass), more per frame when the batch is small.  Measured per 1024 x 1080p
+    // (tools/fix_grid.sh): 8192 blocks 113 + 96 us (most of them find nothing to do), 2048 105 + 63, 1024-thread blocks 108 - 250.
+    constexpr int threads = 256, budget = 2048;
+    const int per_block = (threads / 64) * (64 / R), most = (cap + per_block - 1) / per_block;
+    dim3 block(threads), grid(std::max(1, std::min(most, std::max(1, budget / a.nframes))), a.nframes);
     switch (a.kind) {
     case IPX_SRC_YCBCR: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_YCBCR>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
     case IPX_SRC_YCBCR_CROP: hipLaunchKernelGGL(ks_fix_kernel<IPX_SRC_YCBCR_CROP>, grid, block, 0, s, a, list, list_stride, count, count_stride, cap, R); break;
