@@ -105,7 +105,9 @@ struct KsFusedOut {
     int waves, cpl;            // wave roles: `waves` waves of 64 lanes, `cpl` columns per lane
     int wcols;                 // columns per tap row of the LDS weight table (most destination columns any strip owns)
     const double *wx;          // [strip][ntap][wcols] horizontal weights
-    const float *wxf;          // the float pass: float(w * invTotalWeightFFFF * 0xffff [* 0x101 where the tile holds bytes]), same layout
+    const float *wxf;          // the float pass: float(w * invTotalWeightFFFF * 0xffff [* 0x101 where the tile holds bytes]), [strip][ntapf][wcols]
+    int split, ntapf;          // the float pass: lanes per column (1, or 2: adjacent lanes sum half of a column's taps each -- float sums need
+                               // no order -- and add the halves), and the tap rows of wxf (ntap rounded up to a multiple of split, zero padded)
     float feps;                // the float pass: a channel whose T = (value + 0.5) / 256 has a fraction within feps * T of 0 or 1 is not decided
     const double *itwf;        // [dw] invTotalWeightFFFF
     const int32_t *xlo;        // [dw] first tap, relative to the source rectangle
@@ -145,7 +147,7 @@ struct KsFusedPlan {
     struct Lds { int dbuf = 0, lds_w[2] = {0, 0}, lds_rows = 0, lds_open = 0, open_per_wave = 0, lds_bytes = 0; } fast;
     const KsStrip *strips = nullptr;
     struct Out { int ntap = 0, waves = 0, cpl = 0, wcols = 0; const double *wx = nullptr, *itwf = nullptr; const int32_t *xlo = nullptr, *colb = nullptr;
-                 const float *wxf = nullptr; float feps = 0; } o[2];
+                 const float *wxf = nullptr; float feps = 0; int split = 1, ntapf = 0; } o[2];
     KsFusedGeom whole, split;   // one segment per frame (large batches) / segments of about kKsSplitRows rows (small ones)
 };
 constexpr int kKsSplitRows = 96;
@@ -154,6 +156,7 @@ constexpr int kKsMaxStage = 3;    // 16-byte chunks a thread stages per group
 constexpr int kKsMaxWaves = 12;   // waves per workgroup (768 threads: three waves per SIMD, 168 registers each)
 constexpr int kKsMaxThreads = 64 * kKsMaxWaves;
 constexpr int kKsMaxCpl = 2;
+constexpr int kKsSplitTaps = 16;      // horizontal taps per column from which the float pass may give a column to two lanes
 constexpr int kKsOpenPerWave = 128;   // the float pass: undecided pixels a wave collects in LDS before they go to the frame's list (64 where that lets a second tile buffer in; at least one entry per lane)
 // cuts the frame into strips and segments, assigns wave roles and lays every table out in `blob` (appended, 16-byte aligned offsets;
 // the pointers in *out are OFFSETS into the blob until ks_fused_rebase adds the device address).  sc[k] = nullptr: output absent.

@@ -391,7 +391,7 @@ __device__ __forceinline__ void ks_open_flush(KsOpen &o)
 // group's row entries are read once for both.
 template <int SRC, int NCH, int NACC, int B, int MODE, int NC>
 __device__ __forceinline__ void ks_columns_fast(const uint8_t *lds, const uint8_t *tile, KsCol<NCH, NACC, float> *c, int ntap, int wstride, int pitch,
-                                                const uint8_t *rows, __amdgpu_buffer_rsrc_t ors, int ostride, float feps, uint32_t okey, KsOpen &op
+                                                const uint8_t *rows, __amdgpu_buffer_rsrc_t ors, int ostride, float feps, bool split2, KsOpen &op
 #if IPX_DIAG
                                                 , unsigned long long *tsum, unsigned long long &tlast
 #endif
@@ -446,6 +446,18 @@ __device__ __forceinline__ void ks_columns_fast(const uint8_t *lds, const uint8_
     for (; t + TU <= ntap; t += TU) taps(std::integral_constant<int, TU>());
     if (TU > 2 && t + 2 <= ntap) { taps(std::integral_constant<int, 2>()); t += 2; }
     for (; t < ntap; t++) taps(std::integral_constant<int, 1>());
+    if (NC == 1 && split2) {
+        // two lanes per column: each summed half of the taps (the order of a float sum is free), the halves meet here -- v_add with a
+        // DPP operand, quad_perm [1, 0, 3, 2]; both lanes go on with the total, the even one owns the column's stores
+        auto other = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); };
+#pragma unroll
+        for (int r = 0; r < B / 2; r++)
+#pragma unroll
+            for (int k = 0; k < NCH; k++) {
+                acc[0][r][k].x += other(acc[0][r][k].x);
+                acc[0][r][k].y += other(acc[0][r][k].y);
+            }
+    }
     KS_STAMP(4);                                         // scaleX of the group's rows for these columns
     typedef KsRowT<NACC> Row;
     f32x2 rw[B][NACC / 2];
@@ -496,7 +508,7 @@ __device__ __forceinline__ void ks_columns_fast(const uint8_t *lds, const uint8_
                         const int k = __popcll(m);
                         if (op.n + k > op.room) ks_open_flush(op);
                         const int slot = op.n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // open lanes below this one
-                        if (open) op.wave[slot] = make_uint2(okey | (uint32_t)dy, (uint32_t)c[j].ooff >> 2);
+                        if (open) op.wave[slot] = make_uint2((uint32_t)dy, (uint32_t)c[j].ooff >> 2);
                         op.n += k;
                     }
                 }
@@ -568,6 +580,7 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void *)nullptr, 0, 0, 0x00020000);
     int ntap = 0, wstride = 0, ostride = 0, cpl = 0, mode = KS_TAP_PLAIN;
     float feps = 0.f;
+    bool split2 = false;                                 // the float pass: two lanes per column of this wave's output
     bool aone = false;
     const uint8_t *rows_lds = lds + a.lds_rows;
     const int dbuf = a.dbuf;
@@ -575,15 +588,17 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     if (role >= 0) {
         const KsFusedOut &o = a.o[role];
         ors = __builtin_amdgcn_make_buffer_rsrc((void *)(o.out + (size_t)frame * o.frame_stride), 0, o.obytes, 0x00020000);
-        ntap = o.ntap; wstride = o.wcols * (FAST ? 4 : 8); ostride = o.ostride; cpl = o.cpl; feps = o.feps;
+        split2 = FAST && o.split == 2;
+        ntap = FAST ? (split2 ? o.ntapf >> 1 : o.ntapf) : o.ntap;      // taps per LANE
+        wstride = o.wcols * (FAST ? 4 : 8); ostride = o.ostride; cpl = o.cpl; feps = o.feps;
         mode = o.mode; aone = o.aone != 0;
         rows_lds += role * B * (int)sizeof(Row);
         const int cb = o.colb[strip], ce = o.colb[strip + 1];
         // the strip's weight table -> LDS (every wave of the role copies a share)
         {
-            const int n = o.ntap * o.wcols;
+            const int n = (FAST ? o.ntapf : o.ntap) * o.wcols;
             if (FAST) {
-                const float *wsrc = o.wxf + (size_t)strip * o.ntap * o.wcols;
+                const float *wsrc = o.wxf + (size_t)strip * o.ntapf * o.wcols;
                 float *wdst = (float *)(lds + a.lds_w[role]);
                 for (int i = wk * 64 + lane; i < n; i += o.waves * 64) wdst[i] = wsrc[i];
             } else {
@@ -594,13 +609,14 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
         }
 #pragma unroll
         for (int j = 0; j < CPLM; j++) {
-            const int slot = wk * 64 + lane + j * 64 * o.waves, dx = cb + slot;
+            const int slot = wk * 64 + lane + j * 64 * o.waves;
+            const int part = split2 ? slot & 1 : 0, cslot = split2 ? slot >> 1 : slot, dx = cb + cslot;   // (two lanes per column: which half of the taps)
             const bool has = j < o.cpl && dx < ce;
             col[j].clear();
             col[j].itwf = has ? o.itwf[dx] : 0.0;
-            col[j].xb = has ? (o.sr_x0 + o.xlo[dx] - st.t0) * PXB : 0;
-            col[j].wofs = a.lds_w[role] + (has ? slot : 0) * (FAST ? 4 : 8);
-            col[j].ooff = has ? dx * 4 : kOOB;
+            col[j].xb = has ? (o.sr_x0 + o.xlo[dx] - st.t0 + part * ntap) * PXB : 0;
+            col[j].wofs = a.lds_w[role] + (has ? cslot : 0) * (FAST ? 4 : 8) + part * ntap * wstride;
+            col[j].ooff = has && part == 0 ? dx * 4 : kOOB;
         }
     }
 
@@ -648,7 +664,6 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
     issue(0);
     bool bad = false;
     KsOpen open;
-    const uint32_t okey = 0;
     if (FAST) {
         const int pk = role >= 0 ? a.o[role].pk : 0;
         open.wave = (uint2 *)(lds + a.lds_open) + wv * a.open_per_wave;
@@ -714,8 +729,8 @@ __global__ __launch_bounds__(kKsMaxThreads) void ks_fused_kernel(KsFusedArgs a)
         if (j < cpl) ks_column<SRC, NCH, NACC, B, MODE, AONE>(lds, tile, col[j], ntap, wstride, pitch, rws, ors, ostride KS_DIAG_ARGS)
 #define KS_COLSF(MODE)                                                                                                                   \
     do {                                                                                                                                 \
-        if (CPLM > 1 && cpl > 1) ks_columns_fast<SRC, NCH, NACC, B, MODE, CPLM>(lds, tile, col, ntap, wstride, pitch, rws, ors, ostride, feps, okey, open KS_DIAG_ARGS); \
-        else if (cpl > 0) ks_columns_fast<SRC, NCH, NACC, B, MODE, 1>(lds, tile, col, ntap, wstride, pitch, rws, ors, ostride, feps, okey, open KS_DIAG_ARGS);          \
+        if (CPLM > 1 && cpl > 1) ks_columns_fast<SRC, NCH, NACC, B, MODE, CPLM>(lds, tile, col, ntap, wstride, pitch, rws, ors, ostride, feps, false, open KS_DIAG_ARGS); \
+        else if (cpl > 0) ks_columns_fast<SRC, NCH, NACC, B, MODE, 1>(lds, tile, col, ntap, wstride, pitch, rws, ors, ostride, feps, split2, open KS_DIAG_ARGS);          \
     } while (0)
             if constexpr (FAST) {
                 // (the alpha of these sources never reaches the sums: opaque RGBA, YCbCr and Gray store 0xff)
@@ -856,7 +871,7 @@ hipError_t launch_ks_fused(const KsFusedPlan &p, KsFusedArgs &a, const KsFix *fi
         const KsFusedPlan::Out &po = p.o[k];
         KsFusedOut &o = a.o[i];
         o.ntap = po.ntap; o.waves = po.waves; o.cpl = po.cpl; o.wcols = po.wcols;
-        o.wx = po.wx; o.itwf = po.itwf; o.xlo = po.xlo; o.colb = po.colb; o.wxf = po.wxf; o.feps = po.feps;
+        o.wx = po.wx; o.itwf = po.itwf; o.xlo = po.xlo; o.colb = po.colb; o.wxf = po.wxf; o.feps = po.feps; o.split = po.split; o.ntapf = po.ntapf;
         o.rows = g.rows[k]; o.rowoff = g.rowoff[k];
     }
     // deal the roles out: the waves of the output with fewer waves are spread evenly among the others

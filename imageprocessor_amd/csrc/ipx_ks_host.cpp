@@ -252,7 +252,7 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
                 const int n = colb[k][c + 1] - colb[k][c];
                 wcols[k] = std::max(wcols[k], n);
                 if (n > 0) {
-                    const int first = sc[k]->sr_x0 + hx.lo[colb[k][c]], last = sc[k]->sr_x0 + hx.lo[colb[k][c + 1] - 1] + hx.ntap;   // padded taps stay in the tile
+                    const int first = sc[k]->sr_x0 + hx.lo[colb[k][c]], last = sc[k]->sr_x0 + hx.lo[colb[k][c + 1] - 1] + hx.ntap + (hx.ntap >= kKsSplitTaps ? 1 : 0);   // padded taps stay in the tile (one more where the float pass may halve an odd count)
                     const int t1 = std::max(strips[c].t0 + strips[c].tw, last);
                     strips[c].t0 = std::min(strips[c].t0, first & ~3);
                     strips[c].tw = t1 - strips[c].t0;
@@ -263,29 +263,43 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
         const int pitch = twmax * px_bytes;
 
         // wave roles: W_k waves for output k, each lane cpl_k columns; the busiest SIMD (waves dealt round-robin) decides
-        int bestW[2] = {0, 0}, bestcpl[2] = {0, 0};
+        int bestW[2] = {0, 0}, bestcpl[2] = {0, 0}, bestS[2] = {1, 1};
         double bestT = 1e300;
-        double percol[2] = {0, 0};
-        for (int k = 0; k < 2; k++) if (sc[k]) percol[k] = 12.0 * sc[k]->hx->ntap + 30.0;
         const bool two = sc[0] && sc[1] && wcols[0] > 0 && wcols[1] > 0;
-        for (int nw = 1; nw <= kKsMaxWaves; nw++) {
-            for (int w0 = two ? 1 : (sc[0] && wcols[0] > 0 ? nw : 0); w0 <= (two ? nw - 1 : (sc[0] && wcols[0] > 0 ? nw : 0)); w0++) {
-                const int W[2] = {w0, nw - w0};
-                int cpl[2] = {0, 0};
-                bool ok = true;
-                for (int k = 0; k < 2; k++) {
-                    if (!sc[k] || wcols[k] <= 0) { ok = ok && W[k] == 0; continue; }
-                    if (W[k] <= 0) { ok = false; continue; }
-                    cpl[k] = (wcols[k] + 64 * W[k] - 1) / (64 * W[k]);
-                    if (cpl[k] > (P.nacc == 2 ? kKsMaxCpl : 1)) ok = false;   // four accumulators per column: one column per lane
+        // An output with many taps per column (a thumbnail from 4K: 22, from 8K: 44) makes one lane's tap loop the workgroup's longest
+        // chain while most lanes idle: the float pass may give such a column to TWO adjacent lanes, half of the taps each (S = 2; then
+        // one column pair per lane pair: cpl = 1).  The float64 kernels keep one lane per column on the same waves.
+        static const int split_knob = [] { const char *e = getenv("IPX_KS_TAPSPLIT"); return e ? atoi(e) : -1; }();   // test knob: 0 never, 1 wherever allowed
+        for (int s0 = 1; s0 <= 2; s0++)
+        for (int s1 = 1; s1 <= 2; s1++) {
+            const int S[2] = {s0, s1};
+            bool allowed = true;
+            double percol[2] = {0, 0};
+            for (int k = 0; k < 2; k++) {
+                if (S[k] == 2 && (!sc[k] || sc[k]->hx->ntap < kKsSplitTaps || split_knob == 0)) allowed = false;
+                if (S[k] == 1 && sc[k] && sc[k]->hx->ntap >= kKsSplitTaps && split_knob == 1) allowed = false;
+                if (sc[k]) percol[k] = 12.0 * ((sc[k]->hx->ntap + S[k] - 1) / S[k]) + 30.0 + (S[k] == 2 ? 8.0 : 0.0);
+            }
+            if (!allowed) continue;
+            for (int nw = 1; nw <= kKsMaxWaves; nw++) {
+                for (int w0 = two ? 1 : (sc[0] && wcols[0] > 0 ? nw : 0); w0 <= (two ? nw - 1 : (sc[0] && wcols[0] > 0 ? nw : 0)); w0++) {
+                    const int W[2] = {w0, nw - w0};
+                    int cpl[2] = {0, 0};
+                    bool ok = true;
+                    for (int k = 0; k < 2; k++) {
+                        if (!sc[k] || wcols[k] <= 0) { ok = ok && W[k] == 0; continue; }
+                        if (W[k] <= 0) { ok = false; continue; }
+                        cpl[k] = (wcols[k] * S[k] + 64 * W[k] - 1) / (64 * W[k]);
+                        if (cpl[k] > (P.nacc == 2 && S[k] == 1 ? kKsMaxCpl : 1)) ok = false;   // four accumulators per column, or two lanes per column: one column per lane
+                    }
+                    if (!ok) continue;
+                    double simd[4] = {0, 0, 0, 0};
+                    for (int i = 0; i < nw; i++) { const int k = i < W[0] ? 0 : 1; simd[i & 3] += cpl[k] * percol[k]; }
+                    // (a workgroup whose waves do not divide by the four SIMDs loads them unevenly, and two such workgroups on a CU stack
+                    // their surplus on the same SIMDs: measured 30 % slower with 6 waves than with 12)
+                    const double T = (std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3])) + 1e-3 * nw) * (nw % 4 ? 1.25 : 1.0);
+                    if (T < bestT) { bestT = T; bestW[0] = W[0]; bestW[1] = W[1]; bestcpl[0] = cpl[0]; bestcpl[1] = cpl[1]; bestS[0] = S[0]; bestS[1] = S[1]; }
                 }
-                if (!ok) continue;
-                double simd[4] = {0, 0, 0, 0};
-                for (int i = 0; i < nw; i++) { const int k = i < W[0] ? 0 : 1; simd[i & 3] += cpl[k] * percol[k]; }
-                // (a workgroup whose waves do not divide by the four SIMDs loads them unevenly, and two such workgroups on a CU stack
-                // their surplus on the same SIMDs: measured 30 % slower with 6 waves than with 12)
-                const double T = (std::max(std::max(simd[0], simd[1]), std::max(simd[2], simd[3])) + 1e-3 * nw) * (nw % 4 ? 1.25 : 1.0);
-                if (T < bestT) { bestT = T; bestW[0] = W[0]; bestW[1] = W[1]; bestcpl[0] = cpl[0]; bestcpl[1] = cpl[1]; }
             }
         }
         const bool any_cols = (sc[0] && wcols[0] > 0) || (sc[1] && wcols[1] > 0);
@@ -318,7 +332,7 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
         KsFusedPlan::Lds F;
         {
             size_t wf = 0;
-            for (int k = 0; k < 2; k++) if (sc[k]) wf += ((size_t)sc[k]->hx->ntap * wcols[k] * sizeof(float) + 15) & ~(size_t)15;
+            for (int k = 0; k < 2; k++) if (sc[k]) wf += ((size_t)(sc[k]->hx->ntap + 1) * wcols[k] * sizeof(float) + 15) & ~(size_t)15;   // (+ 1: a split output's padded tap row)
             const size_t rows_b = 2 * 2 * (size_t)B * row_bytes + 64, cu = ((size_t)160 << 10) - 512;
             F.dbuf = 0; F.open_per_wave = kKsOpenPerWave;
             for (int per : {kKsOpenPerWave, 64})                   // (never under 64: one ballot may add an entry per lane)
@@ -326,7 +340,7 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
             size_t at = (size_t)(F.dbuf + 1) * B * pitch;
             for (int k = 0; k < 2; k++) {
                 F.lds_w[k] = (int)at;
-                if (sc[k]) at += ((size_t)sc[k]->hx->ntap * wcols[k] * sizeof(float) + 15) & ~(size_t)15;
+                if (sc[k]) at += ((size_t)(sc[k]->hx->ntap + 1) * wcols[k] * sizeof(float) + 15) & ~(size_t)15;
             }
             F.lds_rows = (int)at;
             at += rows_b;
@@ -358,12 +372,13 @@ bool ks_fused_plan(int sw, int sh, const KsFusedIn *sc0, const KsFusedIn *sc1, i
                         wx[((size_t)c * hx.ntap + t) * wcols[k] + i] = hx.w[(size_t)(colb[k][c] + i) * hx.ntap + t];
             o.wx = as_off<double>(blob_put(blob, wx.data(), wx.size() * sizeof(double)));
             // the float pass: weights with both normalisations folded in, in the unit of the 16-bit result (a byte tile's taps are bytes)
-            std::vector<float> wxf(wx.size(), 0.f);
+            o.split = bestS[k]; o.ntapf = (hx.ntap + o.split - 1) / o.split * o.split;
+            std::vector<float> wxf((size_t)ns * o.ntapf * std::max(1, wcols[k]), 0.f);
             const double unit = px_bytes == 4 || (px_bytes == 8 && sc[k]->top_taps) ? 65535.0 * 257.0 : 65535.0;
             for (int c = 0; c < ns; c++)
                 for (int i = 0; i < colb[k][c + 1] - colb[k][c]; i++)
                     for (int t = 0; t < hx.ntap; t++)
-                        wxf[((size_t)c * hx.ntap + t) * wcols[k] + i] = (float)(hx.w[(size_t)(colb[k][c] + i) * hx.ntap + t] * hx.itwffff[colb[k][c] + i] * unit);
+                        wxf[((size_t)c * o.ntapf + t) * wcols[k] + i] = (float)(hx.w[(size_t)(colb[k][c] + i) * hx.ntap + t] * hx.itwffff[colb[k][c] + i] * unit);
             o.wxf = as_off<float>(blob_put(blob, wxf.data(), wxf.size() * sizeof(float)));
             o.feps = ks_float_eps(hx.ntap, sc[k]->hy->ntap);
             o.itwf = as_off<double>(blob_put(blob, hx.itwffff.data(), hx.itwffff.size() * sizeof(double)));
