@@ -560,3 +560,20 @@ def test_the_float_pass_is_what_runs_by_default(ctx, monkeypatch, capfd):
     plan.run_host(frames)
     assert "ks stats" not in capfd.readouterr().err
     plan.close()
+
+
+@pytest.mark.parametrize("split", ["1", "0"], ids=["two-lanes-per-column", "one-lane-per-column"])
+def test_many_taps_per_column(ctx, split, monkeypatch):
+    """Large reductions: 39 and 43 horizontal taps per column (odd counts: the second lane's half ends in a zero-weight tap).  The float
+    pass may give such a column to two adjacent lanes (IPX_KS_TAPSPLIT=1: wherever 16 taps and more allow it; 0: never); the bytes are
+    the oracle's either way, for RGBA and for decoded-JPEG planes."""
+    monkeypatch.setenv("IPX_KS_TAPSPLIT", split)
+    for sw, sh, resize, thumb in ((1920, 1080, (100, 60, False), (50, True)), (1600, 900, (96, 54, True), (40, False))):
+        frames = rgba_frames(2, sw, sh, seed=sw + int(split))
+        plan = ctx.plan(sw, sh, resize=resize, thumbnail=thumb, watermark=None)
+        got = plan.run_host(frames)
+        for i in range(2):
+            want = oracle.process(frames[i], resize=resize, thumb=thumb, want=("resize", "thumbnail"))
+            for k in ("resize", "thumbnail"):
+                np.testing.assert_array_equal(got[k][i], want[k], err_msg="%s frame %d %dx%d" % (k, i, sw, sh))
+        plan.close()
