@@ -77,12 +77,12 @@ func (b *Batcher) Process(file []byte, w, h int, o Ops) (*Objects, error) {
 }
 
 // Stats: how the files were grouped so far.
-type BatcherStats struct{ Files, Batches, BySize, ByTimer, Largest, Pending int64 }
+type BatcherStats struct{ Files, Batches, BySize, ByTimer, Largest, Pending, WhenIdle int64 }
 
 func (b *Batcher) Stats() BatcherStats {
 	var s C.ipx_batcher_stats
 	C.ipx_batcher_get_stats(b.c, &s)
-	return BatcherStats{int64(s.files), int64(s.batches), int64(s.flushed_by_size), int64(s.flushed_by_timer), int64(s.largest_batch), int64(s.pending_files)}
+	return BatcherStats{int64(s.files), int64(s.batches), int64(s.flushed_by_size), int64(s.flushed_by_timer), int64(s.largest_batch), int64(s.pending_files), int64(s.flushed_when_idle)}
 }
 
 var _ = unsafe.Pointer(nil)

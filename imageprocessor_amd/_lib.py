@@ -116,7 +116,7 @@ class BatchResult(C.Structure):
 
 
 class BatcherStats(C.Structure):
-    _fields_ = [(k, C.c_longlong) for k in ("files", "batches", "flushed_by_size", "flushed_by_timer", "largest_batch", "pending_files")]
+    _fields_ = [(k, C.c_longlong) for k in ("files", "batches", "flushed_by_size", "flushed_by_timer", "largest_batch", "pending_files", "flushed_when_idle")]
 
 
 _P = C.c_void_p

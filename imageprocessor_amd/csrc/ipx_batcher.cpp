@@ -3,13 +3,16 @@
 // a submitter gets its result back on its own ticket and commits itself).
 #include "ipx_batcher.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 
 namespace ipx {
 
-Batcher::Batcher(const BatchBackend &be, int max_batch, int max_wait_us, int quality)
-    : be_(be), max_batch_(std::max(1, max_batch)), quality_(quality), max_wait_(std::max(0, max_wait_us))
+Batcher::Batcher(const BatchBackend &be, int max_batch, int max_wait_us, int quality, int idle_jobs)
+    : be_(be), max_batch_(std::max(1, max_batch)), quality_(quality), max_wait_(std::max(0, max_wait_us)), idle_jobs_(std::max(0, idle_jobs))
 {
+    if (const char *e = getenv("IPX_BATCHER_IDLE_FLUSH")) idle_jobs_ = std::max(0, atoi(e));
     timer_ = std::thread([this] { timer_loop(); });
 }
 
@@ -24,7 +27,7 @@ Batcher::~Batcher()
     }
     cv_timer_.notify_all();
     if (timer_.joinable()) timer_.join();
-    for (auto &b : rest) flush(b, true);
+    for (auto &b : rest) { { std::lock_guard<std::mutex> lk(mu_); running_++; } flush(b, ByTimer); }
     // every job still held: wait for it and hand its blocks back (tickets nobody collected)
     std::vector<std::shared_ptr<Batch>> all;
     {
@@ -81,6 +84,7 @@ int Batcher::submit(const ipx_bytes &file, const ipx_pool_ops &ops, uint64_t *ti
     const int rc = copy_ops(ops, &oc, &key, err);
     if (rc) return rc;
     std::shared_ptr<Batch> full;
+    Why why = BySize;
     {
         std::lock_guard<std::mutex> lk(mu_);
         if (stop_) { *err = "ipx_batcher_submit: the batcher is shutting down"; return IPX_ERR_INVALID; }
@@ -104,12 +108,17 @@ int Batcher::submit(const ipx_bytes &file, const ipx_pool_ops &ops, uint64_t *ti
         b.unreleased++;
         stats_.files++;
         if ((int)b.files.size() >= max_batch_) { full = it->second; pending_.erase(it); }
+        // Nothing of this batcher runs on the GPU: waiting for company would only add the wait to the file's latency.  Under load
+        // jobs are running, files gather while they do, and the group leaves when the last running job has been seen to finish
+        // (job_seen_done), by size or by the timer -- batches form by themselves exactly when there is something to wait for.
+        else if (running_ < idle_jobs_) { full = it->second; pending_.erase(it); why = WhenIdle; }
+        if (full) running_++;                                   // (counted before the lock goes: a second submitter must not see "idle")
     }
-    if (full) flush(full, false);
+    if (full) flush(full, why);
     return IPX_OK;
 }
 
-void Batcher::flush(const std::shared_ptr<Batch> &b, bool by_timer)
+void Batcher::flush(const std::shared_ptr<Batch> &b, Why why)
 {
     const int n = (int)b->files.size();
     b->res.assign(n, ipx_bytes{nullptr, 0}); b->th.assign(n, ipx_bytes{nullptr, 0}); b->wm.assign(n, ipx_bytes{nullptr, 0});
@@ -135,9 +144,11 @@ void Batcher::flush(const std::shared_ptr<Batch> &b, bool by_timer)
         b->submit_failed = rc != IPX_OK;
         b->error = text;
         b->flushed = true;
+        if (b->submit_failed) { b->done = true; running_--; }     // (the caller counted it as running)
         stats_.batches++;
-        if (by_timer) stats_.flushed_by_timer++;
-        else stats_.flushed_by_size++;
+        if (why == ByTimer) stats_.flushed_by_timer++;
+        else if (why == BySize) stats_.flushed_by_size++;
+        else stats_.flushed_when_idle++;
         stats_.largest_batch = std::max<long long>(stats_.largest_batch, n);
     }
     b->cv.notify_all();
@@ -165,8 +176,9 @@ void Batcher::timer_loop()
         }
         std::shared_ptr<Batch> b = first->second;
         pending_.erase(first);
+        running_++;
         lk.unlock();
-        flush(b, true);
+        flush(b, ByTimer);
         lk.lock();
     }
 }
@@ -184,6 +196,7 @@ int Batcher::wait(uint64_t ticket, ipx_batch_result *res, std::string *err)
         if (b->submit_failed) { *err = b->error; return b->rc; }
     }
     const int rc = be_.wait(be_.self, b->job);          // the pool lets any number of threads wait for one job
+    job_seen_done(b);
     if (res) {
         res->status = rc ? rc : b->status[idx];
         res->resize = b->res[idx]; res->thumb = b->th[idx]; res->wm = b->wm[idx];
@@ -208,9 +221,25 @@ int Batcher::release(uint64_t ticket, std::string *err)
     }
     // a file's bytes are read until its batch has run: whoever lets go of a ticket -- with or without having waited for it -- may free
     // the file once this returns
-    if (!b->submit_failed) (void)be_.wait(be_.self, b->job);
+    if (!b->submit_failed) { (void)be_.wait(be_.self, b->job); job_seen_done(b); }
     if (last) return be_.release(be_.self, b->job);     // the batch's output blocks are shared: they go back with its last file
     return IPX_OK;
+}
+
+void Batcher::job_seen_done(const std::shared_ptr<Batch> &b)
+{
+    std::vector<std::shared_ptr<Batch>> go;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (b->done) return;
+        b->done = true;
+        running_--;
+        if (running_ >= idle_jobs_ || stop_) return;
+        for (auto &kv : pending_) go.push_back(kv.second);      // what gathered while the jobs ran leaves now
+        pending_.clear();
+        running_ += (int)go.size();
+    }
+    for (auto &g : go) flush(g, WhenIdle);
 }
 
 void Batcher::stats(ipx_batcher_stats *out)
@@ -247,7 +276,8 @@ int ipx_batcher_create(ipx_pool *pool, const ipx_batcher_config *cfg, ipx_batche
     ipx_batcher *b = new ipx_batcher;
     b->pool = pool;
     b->b = new ipx::Batcher(be, cfg && cfg->max_batch > 0 ? cfg->max_batch : 256, cfg && cfg->max_wait_us > 0 ? cfg->max_wait_us : 2000,
-                            cfg && cfg->quality > 0 ? cfg->quality : 85);
+                            cfg && cfg->quality > 0 ? cfg->quality : 85,
+                            4 * std::max(1, ipx_pool_slots(pool)));   // (the pool's default: four feeders per device)
     *out = b;
     return IPX_OK;
 }

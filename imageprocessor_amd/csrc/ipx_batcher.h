@@ -35,7 +35,9 @@ struct BatchBackend {
 
 class Batcher {
 public:
-    Batcher(const BatchBackend &be, int max_batch, int max_wait_us, int quality);
+    // idle_jobs: a group leaves at once while fewer jobs than this are running (what the backend can run side by side: the pool's
+    // feeders); 0 = size and timer only
+    Batcher(const BatchBackend &be, int max_batch, int max_wait_us, int quality, int idle_jobs = 1);
     ~Batcher();                                     // flushes what is pending, waits for every job, releases them
     int submit(const ipx_bytes &file, const ipx_pool_ops &ops, uint64_t *ticket, std::string *err);
     int wait(uint64_t ticket, ipx_batch_result *res, std::string *err);
@@ -56,7 +58,7 @@ private:
         std::vector<ipx_bytes> res, th, wm;
         std::vector<int32_t> status;
         // guarded by Batcher::mu_
-        bool flushed = false, submit_failed = false, job_released = false;
+        bool flushed = false, submit_failed = false, job_released = false, done = false;   // done: some waiter has seen the job finish
         int rc = IPX_OK;
         std::string error;
         ipx_ticket job = 0;
@@ -64,7 +66,9 @@ private:
         std::condition_variable cv;                 // flushed
     };
     static int copy_ops(const ipx_pool_ops &in, OpsCopy *out, std::string *key, std::string *err);
-    void flush(const std::shared_ptr<Batch> &b, bool by_timer);
+    enum Why { BySize, ByTimer, WhenIdle };
+    void flush(const std::shared_ptr<Batch> &b, Why why);
+    void job_seen_done(const std::shared_ptr<Batch> &b);   // the first waiter back from the backend: perhaps nothing runs any more
     void timer_loop();
 
     BatchBackend be_;
@@ -76,6 +80,8 @@ private:
     std::map<uint64_t, std::pair<std::shared_ptr<Batch>, int>> tickets_;
     uint64_t next_ticket_ = 1;
     bool stop_ = false;
+    int idle_jobs_ = 1;                             // a group leaves at once while fewer jobs than this run (IPX_BATCHER_IDLE_FLUSH: 0 = size and timer only)
+    int running_ = 0;                               // jobs handed to the backend that nobody has seen finish yet
     ipx_batcher_stats stats_{};
     std::thread timer_;
 };

@@ -575,7 +575,7 @@ int ipx_pool_run_host(ipx_pool *pool, const ipx_job *jobs, int n_jobs);
 typedef struct ipx_batcher ipx_batcher;
 typedef struct {
     int32_t max_batch;      /* files per job; 0 = 256 (a part of ipx_plan_run_jpeg_jpeg) */
-    int32_t max_wait_us;    /* how long the first file of a group may wait for company; 0 = 2000 */
+    int32_t max_wait_us;    /* how long the first file of a group may wait for company WHILE other jobs of this batcher run; 0 = 2000 */
     int32_t quality;        /* jpeg.Options.Quality of the outputs; 0 = 85 (domain.DefaultJPEGQuality, task.go:57) */
 } ipx_batcher_config;
 typedef uint64_t ipx_batch_ticket;
@@ -585,6 +585,8 @@ typedef struct {
 } ipx_batch_result;
 typedef struct {
     long long files, batches, flushed_by_size, flushed_by_timer, largest_batch, pending_files;
+    long long flushed_when_idle;   /* groups that left at once because nothing of this batcher was running (a job finishing releases what
+                                    * gathered while it ran): a lone file does not wait max_wait_us for company that is not coming */
 } ipx_batcher_stats;
 int ipx_batcher_create(ipx_pool *pool, const ipx_batcher_config *cfg, ipx_batcher **out);
 void ipx_batcher_destroy(ipx_batcher *b);     /* flushes what is pending, waits for it, frees what was not released */

@@ -124,7 +124,7 @@ int main()
     std::atomic<long long> ok_files{0}, refused{0}, unsupported{0};
     std::vector<std::deque<std::vector<uint8_t>>> all_files(nthreads);   // outlive the batcher: some tickets are never collected
     {
-        std::unique_ptr<Batcher> b_owner(new Batcher(be, pool.max_batch, 1500, 85));
+        std::unique_ptr<Batcher> b_owner(new Batcher(be, pool.max_batch, 1500, 85, 3));   // (groups leave at once while fewer than three jobs run)
         Batcher &b = *b_owner;
         std::vector<std::thread> ts;
         for (int th = 0; th < nthreads; th++)
@@ -184,9 +184,10 @@ int main()
         for (auto &t : ts) t.join();
         ipx_batcher_stats st;
         b.stats(&st);
-        printf("batcher: %lld files in %lld batches (%lld by size, %lld by timer), largest %lld; verified %lld, refused %lld, unsupported %lld\n", st.files, st.batches,
-               st.flushed_by_size, st.flushed_by_timer, st.largest_batch, (long long)ok_files, (long long)refused, (long long)unsupported);
-        if (st.files != (long long)nthreads * per_thread || st.largest_batch > pool.max_batch || st.flushed_by_timer == 0 || st.flushed_by_size == 0) return 2;
+        printf("batcher: %lld files in %lld batches (%lld by size, %lld by timer, %lld when idle), largest %lld; verified %lld, refused %lld, unsupported %lld\n", st.files, st.batches,
+               st.flushed_by_size, st.flushed_by_timer, st.flushed_when_idle, st.largest_batch, (long long)ok_files, (long long)refused, (long long)unsupported);
+        if (st.files != (long long)nthreads * per_thread || st.largest_batch > pool.max_batch || st.flushed_by_timer + st.flushed_when_idle == 0 || st.flushed_by_size == 0 ||
+            st.batches != st.flushed_by_size + st.flushed_by_timer + st.flushed_when_idle) return 2;
     }   // ~Batcher: pending files flushed, uncollected tickets' jobs waited for and released
     {
         std::lock_guard<std::mutex> lk(pool.mu);
