@@ -58,6 +58,7 @@ with ipx.Pool(devices=(0,)) as pool, ipx.Batcher(pool, max_batch=max_batch, max_
         lat.sort()
         st = b.stats()
         nb = st["batches"] - before["batches"]
-        print("%3d submitters x %d files: %7.0f images/s; latency p50 %.2f ms, p99 %.2f ms; %d batches (mean %.1f files; %d by size, %d by timer)"
+        print("%3d submitters x %d files: %7.0f images/s; latency p50 %.2f ms, p99 %.2f ms; %d batches (mean %.1f files; %d by size, %d by timer, %d when idle)"
               % (S, per, S * per / dt, lat[len(lat) // 2] * 1e3, lat[min(len(lat) - 1, int(len(lat) * 0.99))] * 1e3, nb, S * per / max(1, nb),
-                 st["flushed_by_size"] - before["flushed_by_size"], st["flushed_by_timer"] - before["flushed_by_timer"]), flush=True)
+                 st["flushed_by_size"] - before["flushed_by_size"], st["flushed_by_timer"] - before["flushed_by_timer"],
+                 st["flushed_when_idle"] - before["flushed_when_idle"]), flush=True)
