@@ -202,7 +202,7 @@ struct JpegParArgs {
     const uint8_t *blob; const JpegDecTables *tab; const JpegParImage *img;
     uint8_t *ublob;                        // the scans without stuffing, same offsets as blob, zero filled
     int nimg, max_nsub, bpm, ybl, nblk;
-    int stage_rows;                        // 1: the workgroup's sub-sequences are staged in LDS (64 KiB, two waves per CU; 1 KiB sub-sequences only); 0: read through L1 / L2
+    int stage_rows;                        // 1: the workgroup's 64 sub-sequences are staged in LDS (rows of sub + 4 bytes: small batches); 0: read through L1 / L2; 2: diagnostic, see CoefSink::drop
     int sub;                               // bytes of scan per sub-sequence: 128, 256, 512 or 1024 (jpeg_par_sub_bytes(): the largest)
     uint32_t *stuffed;                     // [nimg][max_nsub] stuffed zeros before each sub-sequence's chunk (after the scan)
     uint32_t *scan_end, *ulen;             // per image: first marker in the stuffed scan; bytes of the unstuffed scan

@@ -20,8 +20,10 @@
 //   4. dc      per image and component, the running sum of the DC differences (F.2.1.3.1).
 // After that the coefficient array is what jpeg_huff_kernel would have left, and jpeg_idct_kernel finishes the job.
 // A workgroup is one wave = 64 consecutive sub-sequences of ONE image, with that image's Huffman tables in LDS.  The scan
-// words are read through L1 / L2 (a lane walks its own KiB sequentially); staging the 64 KiB in LDS (IPX_JPEG_PAR_STAGE=1,
-// row stride 1028 bytes against bank aliasing) leaves two waves per CU and is 2.2x slower than the occupancy it costs.
+// words of a large batch are read through L1 / L2 (a lane walks its own sub-sequence sequentially): staging 64 KiB-rows in LDS
+// (IPX_JPEG_PAR_STAGE=1, row stride sub + 4 bytes against bank aliasing) leaves two waves per CU and is 2.2x slower than the occupancy
+// it costs.  A small batch (every wave resident at once, 256-byte rows) is staged: its waves sit alone on their SIMDs and would wait
+// for a global load almost every symbol (ipx_jpeg_runtime.hip, where stage_rows is set).
 #include <algorithm>
 #include <cstdlib>
 
@@ -32,7 +34,7 @@ namespace ipx {
 namespace {
 
 constexpr int kSub = 1024;            // bytes of scan per sub-sequence at most (JpegParArgs::sub: 256 and 512 for small batches)
-constexpr int kRow = kSub + 4;        // LDS bytes per staged sub-sequence
+constexpr int kRowPad = 4;            // a staged sub-sequence takes sub + 4 LDS bytes: lanes at the same depth of their rows hit different banks
 constexpr uint32_t kEnd = 0xffffffffu;
 
 __constant__ uint8_t c_unzig_par[64] = {
@@ -52,6 +54,7 @@ struct Reader {
     const uint8_t *lds;      // staged rows of this workgroup's 64 sub-sequences (+ 16 bytes)
     const uint8_t *g;        // the unstuffed scan in global memory (zero padded), for the words outside the staged window
     uint32_t wg_base, wg_bytes;
+    uint32_t sub_shift = 10, sub_mask = kSub - 1, row = kSub + kRowPad;   // staged rows: sub-sequence i >> sub_shift starts at LDS byte (i >> sub_shift) * row
     uint32_t ubits;          // length of the unstuffed scan in bits
     uint32_t widx = 0;       // next 32-bit word
     unsigned long long acc = 0;
@@ -65,7 +68,7 @@ struct Reader {
     {
         const uint32_t i = wi * 4 - wg_base;
         uint32_t wv;
-        if (i < wg_bytes) wv = *(const uint32_t *)(lds + (i >> 10) * kRow + (i & (kSub - 1)));
+        if (i < wg_bytes) wv = *(const uint32_t *)(lds + (i >> sub_shift) * row + (i & sub_mask));
         else {
             if ((wi >> 2) != buf_q) { buf_q = wi >> 2; buf = *(const uint4 *)(g + (size_t)buf_q * 16); }
             const uint32_t k = wi & 3u;
@@ -209,11 +212,12 @@ __device__ __forceinline__ Tables stage(uint8_t *lds, const JpegParArgs &a, cons
     const uint8_t *scan = a.ublob + im.scan_off;           // unstuffed copy: same offsets as the packed scans, zero padded
     const uint32_t base = (uint32_t)first_sub * (uint32_t)a.sub;
     const uint32_t cap = (im.scan_len + 15u) & ~15u;       // the unstuffed scan is no longer than the stuffed one
-    const uint32_t avail = a.stage_rows == 1 && a.sub == kSub && cap > base ? min(cap - base, (uint32_t)(64 * kSub + 16)) : 0u;
+    const uint32_t avail = a.stage_rows == 1 && cap > base ? min(cap - base, (uint32_t)(64 * a.sub + 16)) : 0u;
+    r.sub_shift = 31u - (uint32_t)__builtin_clz((uint32_t)a.sub); r.sub_mask = (uint32_t)a.sub - 1u; r.row = (uint32_t)a.sub + kRowPad;
     for (uint32_t ch = lane; ch < (avail >> 4); ch += 64) {
         const uint4 v = *(const uint4 *)(scan + base + ch * 16);
         const uint32_t i = ch * 16;
-        uint32_t *d = (uint32_t *)(rows + (i >> 10) * kRow + (i & (kSub - 1)));   // 16-byte pieces never straddle a row; rows are only 4-byte aligned
+        uint32_t *d = (uint32_t *)(rows + (i >> r.sub_shift) * r.row + (i & r.sub_mask));   // 16-byte pieces never straddle a row; rows are only 4-byte aligned
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
@@ -221,7 +225,9 @@ __device__ __forceinline__ Tables stage(uint8_t *lds, const JpegParArgs &a, cons
     return Tables{(const uint16_t *)tb, mc, vo, vl, unz, (const uint4 *)bd};
 }
 
-constexpr size_t kParLds = 4096 + (size_t)65 * kRow + 64;
+// tables, 64 rows and the 16 bytes of look-ahead in a 65th
+constexpr size_t par_lds(int sub) { return 4096 + (size_t)65 * (size_t)(sub + kRowPad) + 64; }
+constexpr size_t kParLds = par_lds(kSub);
 
 // step 0a: stuffed zeros per 1 KiB chunk of the scan, and where the scan ends (the first 0xff not followed by 0x00)
 __global__ __launch_bounds__(256) void par_count_kernel(JpegParArgs a)
@@ -633,7 +639,7 @@ hipError_t launch_par_sync(const JpegParArgs &a, int round, hipStream_t s)
     hipError_t e = sync_cache.prepare((const void *)par_sync_kernel, 64, kParLds, nullptr);
     if (e == hipSuccess) e = write_cache.prepare((const void *)par_write_kernel, 64, kParLds, nullptr);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(par_sync_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows == 1 ? kParLds : 4096, s, a, round);
+    hipLaunchKernelGGL(par_sync_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows == 1 ? par_lds(a.sub) : 4096, s, a, round);
     return hipGetLastError();
 }
 hipError_t launch_par_write(const JpegParArgs &a, hipStream_t s)
@@ -642,7 +648,7 @@ hipError_t launch_par_write(const JpegParArgs &a, hipStream_t s)
     // 128-byte line each in flight, and with 2048 lanes per CU those lines do not fit the XCD's 4 MiB L2 -- every line is then written
     // back (and read for the merge) several times
     static const int write_lds = [] { const char *e = getenv("IPX_JPEG_WRITE_LDS"); return e ? atoi(e) : 16384; }();   // measured per 1024 x 1080p files: 4 KiB 8.7 ms, 10 KiB 8.4, 16 KiB 7.9, 20 KiB 8.1, 40 KiB 11.7
-    hipLaunchKernelGGL(par_write_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows == 1 ? kParLds : (size_t)std::max(4096, write_lds), s, a);
+    hipLaunchKernelGGL(par_write_kernel, dim3((a.max_nsub + 63) / 64, a.nimg), dim3(64), a.stage_rows == 1 ? std::max(par_lds(a.sub), (size_t)write_lds) : (size_t)std::max(4096, write_lds), s, a);
     return hipGetLastError();
 }
 hipError_t launch_par_dc(const JpegParArgs &a, hipStream_t s)

@@ -798,10 +798,16 @@ static int decode_batch(ipx_ctx *ctx, hipStream_t s, Lane *lane, bool planes_in_
         P.blob = d_blob; P.tab = d_tab; P.nimg = (int)par.size(); P.bpm = a.bpm; P.ybl = a.ybl; P.nblk = a.nblk;
         P.coefs = d_coefs; P.status = d_status; P.dcs = d_dcs;
         P.sub = par_sub;
-        P.stage_rows = env_int("IPX_JPEG_PAR_STAGE", 0);   // measured: 109 ms staged (2 waves per CU) against 49 ms through L1 / L2 (1024 x 1080p)
         for (auto &pi : par) P.max_nsub = std::max(P.max_nsub, (int)pi.nsub);
         for (size_t k = 0; k < par.size(); k++) par[k].sub_off = k * (size_t)P.max_nsub;
         const size_t nsubs = par.size() * (size_t)P.max_nsub;
+        // The scan bytes of a wave's 64 sub-sequences staged in LDS, or read through L1 / L2.  A big batch hides the latency of the global
+        // reads behind its other waves and loses more to the occupancy the rows cost (1024 x 1080p, 1 KiB rows: 109 ms staged against
+        // 49); in a small one a SIMD has one wave, and that wave waits for a global load nearly every symbol, because some lane of the 64
+        // crosses a 16-byte group each step.  tools/par_stage.sh, 1080p files: 1 file 2.8 -> 2.6 ms, 8 files 3.5 -> 3.4, 64 files (86 k
+        // sub-sequences) 7.4 -> 6.9; 256 files (345 k) 17.7 -> 20.0.  Staged while every wave of the batch is resident at once.
+        P.stage_rows = env_int("IPX_JPEG_PAR_STAGE", -1);
+        if (P.stage_rows < 0) P.stage_rows = nsubs <= (size_t)env_int("IPX_JPEG_PAR_STAGE_SUBS", 98304) ? 1 : 0;
         JpegParImage *d_par = nullptr; uint32_t *d_tot = nullptr;
         if (e == hipSuccess) e = mem.get(&d_par, sizeof(JpegParImage) * par.size());
         if (e == hipSuccess) e = mem.get(&P.stuffed, nsubs * 4);

@@ -141,6 +141,19 @@ def test_gpu_decode_matches_oracle(ctx, sub):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stage", ["0", "1"], ids=["scan-through-l2", "scan-rows-in-lds"])
+@pytest.mark.parametrize("sub_bytes", ["128", "256", "512", "1024"])
+def test_parallel_huffman_passes_at_every_sub_sequence_size(ctx, monkeypatch, sub_bytes, stage):
+    """The decoder that is parallel inside a scan, with each sub-sequence length it may choose for a batch and with the scan bytes of a
+    wave read through L1 / L2 or staged as LDS rows (what small batches get): the same planes as the oracle either way."""
+    monkeypatch.setenv("IPX_JPEG_PAR_SUB", sub_bytes)
+    monkeypatch.setenv("IPX_JPEG_PAR_STAGE", stage)
+    files = [pil_jpeg(picture(1920, 1080, seed=20 + i, noise=3.0 + 9 * i), subsampling=2, quality=(85, 100, 40)[i], optimize=(i == 1)) for i in range(3)]
+    files += [pil_jpeg(picture(1920, 1080, seed=29, noise=1.0), subsampling=2, quality=10)]     # a short scan: few sub-sequences, the last one ragged
+    _check_batch(ctx, files)
+
+
+@pytest.mark.gpu
 def test_gpu_decode_of_go_style_streams_and_440(ctx):
     """Streams as Go's own encoder writes them (no JFIF, both tables, 4:2:0), and 4:4:0 built by transposing a 4:2:2 file's role:
     Pillow cannot write 4:4:0, so the sampling bytes of a 4:2:2 file are swapped -- a valid 4:4:0 stream of other content."""
