@@ -71,8 +71,9 @@ struct Reader {
         if (i < wg_bytes) wv = *(const uint32_t *)(lds + (i >> sub_shift) * row + (i & sub_mask));
         else {
             if ((wi >> 2) != buf_q) { buf_q = wi >> 2; buf = *(const uint4 *)(g + (size_t)buf_q * 16); }
-            const uint32_t k = wi & 3u;
-            wv = k == 0 ? buf.x : (k == 1 ? buf.y : (k == 2 ? buf.z : buf.w));
+            // (two selects and a shift: as a chain of ternaries this became two levels of exec-mask branches)
+            const unsigned long long half = wi & 2u ? ((unsigned long long)buf.w << 32 | buf.z) : ((unsigned long long)buf.y << 32 | buf.x);
+            wv = (uint32_t)(half >> ((wi & 1u) * 32u));
         }
         return __builtin_bswap32(wv);
     }
@@ -117,11 +118,18 @@ struct NoSink {
 // Huffman table slots of the three components as scalars (arrays indexed by the component would live in scratch memory: a global-memory
 // round trip per symbol -- measured on the first piece kernel: 12.5 ms instead of 3)
 struct Slots {
-    int td0, td1, td2, ta0, ta1, ta2;
+    uint32_t packed;     // four bits per slot: DC tables of the three components, then their AC tables
     template <class Im>
-    __device__ __forceinline__ static Slots of(const Im &im) { return Slots{im.td[0], im.td[1], im.td[2], im.ta[0], im.ta[1], im.ta[2]}; }
+    __device__ __forceinline__ static Slots of(const Im &im)
+    {
+        return Slots{(uint32_t)im.td[0] | (uint32_t)im.td[1] << 4 | (uint32_t)im.td[2] << 8 | (uint32_t)im.ta[0] << 12 | (uint32_t)im.ta[1] << 16 | (uint32_t)im.ta[2] << 20};
+    }
 };
 
+// The 64 lanes of a wave are in 64 different states (DC or AC, short or long code, refill or not, end of block or not), so the wave
+// walks every arm of this loop on every step and what a step costs is the loop's instruction count, not its memory accesses (a wave
+// alone on its SIMD: ~0.8 us per symbol with the first, branchy form -- 350 instructions, 40 branches, half of them exec-mask
+// bookkeeping).  Hence one arm for DC and AC with selects, and branches only where memory is touched (refill, the long codes, the sink).
 template <class Sink>
 __device__ __forceinline__ unsigned long long run(Reader &r, const Tables &T, const Slots im, int bpm, int ybl, int c, int z, uint32_t uend,
                                                   Sink &sink, uint32_t *ends)
@@ -132,8 +140,9 @@ __device__ __forceinline__ unsigned long long run(Reader &r, const Tables &T, co
     for (;;) {
         const uint32_t p = r.upos();
         if (p >= uend) { out = p >= r.ubits ? kOut : pack_state(p, c, z); break; }
+        const bool dcs = z == 0;
         const int comp = c < ybl ? 0 : c - ybl + 1;
-        const int slot = z == 0 ? (comp == 0 ? im.td0 : (comp == 1 ? im.td1 : im.td2)) : (comp == 0 ? im.ta0 : (comp == 1 ? im.ta1 : im.ta2));
+        const int slot = (int)((im.packed >> (comp * 4 + (dcs ? 0 : 12))) & 15u);
         r.refill();
         const uint32_t bits = (uint32_t)(r.acc >> (r.cnt - 32));        // cnt >= 33 after the refill; past the end the buffer holds zeros
         const uint32_t e = T.lut[slot * 256 + (bits >> 24)];
@@ -144,44 +153,29 @@ __device__ __forceinline__ unsigned long long run(Reader &r, const Tables &T, co
             const uint32_t x = bits >> 16;
             const uint4 b0 = T.bound[slot * 2], b1 = T.bound[slot * 2 + 1];
             len = 9 + (int)(x >= b0.x) + (int)(x >= b0.y) + (int)(x >= b0.z) + (int)(x >= b0.w) + (int)(x >= b1.x) + (int)(x >= b1.y) + (int)(x >= b1.z);
-            sym = -1;
-            if (x < b1.w) sym = (int)T.vals[slot * 256 + ((T.valoff[slot * 18 + len] + (int)(bits >> (32 - len))) & 255)];
-            if (sym < 0) {                                               // no such code: a speculative decoder just moves on by one bit
-                r.cnt -= 1;
-                if (r.upos() > r.ubits) { out = kOut; break; }
-                sink.bad();
-                continue;
-            }
+            const int at = slot * 256 + ((T.valoff[slot * 18 + len] + (int)(bits >> (32 - len))) & 255);
+            sym = x < b1.w ? (int)T.vals[at] : -1;
         }
-        bool block_done = false;
-        int nbits = 0;                                                   // value bits after the code (receiveExtend)
-        if (z == 0) {
-            if (sym <= 16) nbits = sym;
-        } else if ((sym & 15) && z + (sym >> 4) <= 63) nbits = sym & 15;   // Go: zig += val0; if zig > zigEnd { break } -- the value bits stay unread
+        const bool nocode = sym < 0;                                     // no such code: a speculative decoder just moves on by one bit
+        const int run_ = sym >> 4, sz = sym & 15;
+        // value bits after the code (receiveExtend).  AC: Go does zig += val0; if zig > zigEnd { break } -- the value bits stay unread
+        int nbits = dcs ? (sym <= 16 ? sym : 0) : (sz && z + run_ <= 63 ? sz : 0);
+        nbits = nocode ? 0 : nbits;
+        len = nocode ? 1 : len;
         r.cnt -= len + nbits;
         if (r.upos() > r.ubits) { out = kOut; break; }                   // the data ended inside this symbol
-        const uint32_t v = nbits ? (bits << len) >> (32 - nbits) : 0u;
-        const int val = nbits ? ((int)v < (1 << (nbits - 1)) ? (int)v + (int)(0xffffffffu << nbits) + 1 : (int)v) : 0;
-        if (z == 0) {
-            if (sym > 16) { sink.bad(); continue; }
-            sink.dc(val);
-            z = 1;
-        } else {
-            const int run_ = sym >> 4, sz = sym & 15;
-            if (sz) {
-                z += run_;
-                if (z > 63) block_done = true;
-                else {
-                    sink.ac(z, val);
-                    z++;
-                    if (z > 63) block_done = true;
-                }
-            } else if (run_ != 15) {
-                block_done = true;                   // EOB
-            } else {
-                z += 16;
-                if (z > 63) block_done = true;
-            }
+        const uint32_t v = ((bits << len) >> 1) >> (31 - nbits);         // nbits == 0: 0
+        const int val = v < ((1u << nbits) >> 1) ? (int)v + 1 - (1 << nbits) : (int)v;
+        const bool bad = nocode || (dcs && sym > 16);
+        bool block_done = false;
+        if (bad) sink.bad();                                             // (the state stays as it is)
+        else if (dcs) { sink.dc(val); z = 1; }
+        else {
+            // sz != 0: skip run_ zeros and store; (15, 0): sixteen zeros; (r, 0): end of block
+            const int zz = z + (sz ? run_ : (run_ == 15 ? 16 : 64));
+            if (sz && zz <= 63) sink.ac(zz, val);
+            z = zz + (sz ? 1 : 0);
+            block_done = z > 63;
         }
         if (block_done) {
             nend++;
@@ -590,7 +584,7 @@ __global__ __launch_bounds__(64) void piece_decode_kernel(JpegDecArgs a, const u
     const JpegDecImage *ip = a.img + item;
     const uint32_t n_mcu = ip->n_mcu, first_mcu = ip->first_mcu, img = ip->img;
     if (!ip->valid || n_mcu == 0) return;
-    const Slots slots{ip->td[0], ip->td[1], ip->td[2], ip->ta[0], ip->ta[1], ip->ta[2]};
+    const Slots slots = Slots::of(*ip);
     const bool strict_end = ip->strict_end != 0;
     const Tables T{(const uint16_t *)tb, mc, vo, vl, unz, (const uint4 *)bd};
     Reader r;
