@@ -180,27 +180,43 @@ __global__ __launch_bounds__(256) void jpeg_bits_kernel(const int16_t *coefs, in
     s.flush();
 }
 
-// exclusive scan of one frame's array per workgroup, in place; sum -> total[frame]
+// exclusive scan of one frame's array per workgroup, in place; sum -> total[frame].
+// Tiles of 4096 values, four consecutive ones per thread: wave scan by shuffles, the sixteen wave sums through LDS, the next tile's
+// loads in flight while this one is scanned.  (The first form gave every thread n / 1024 CONSECUTIVE values and walked them twice, one
+// dependent strided load after the other: 78 us for the 48 600 blocks of one 1080p frame -- a sixth of a small call's encode.)
 __global__ __launch_bounds__(1024) void scan_kernel(uint32_t *v, int n, uint32_t *total)
 {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t wsum[2][16];
     uint32_t *a = v + (size_t)blockIdx.x * n;
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int i0 = min(n, t * per), i1 = min(n, i0 + per);
-    uint32_t s = 0;
-    for (int i = i0; i < i1; i++) s += a[i];
-    part[t] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t add = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += add;
-        __syncthreads();
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    auto load = [&](int i, uint32_t (&x)[4]) {
+        for (int k = 0; k < 4; k++) x[k] = i + k < n ? a[i + k] : 0u;
+    };
+    uint32_t carry = 0, nxt[4];
+    load(4 * t, nxt);
+    int flip = 0;
+    for (int base = 0; base < n; base += 4096, flip ^= 1) {
+        const int i = base + 4 * t;
+        const uint32_t x0 = nxt[0], x1 = nxt[1], x2 = nxt[2], x3 = nxt[3];
+        if (base + 4096 < n) load(i + 4096, nxt);
+        const uint32_t mine = x0 + x1 + x2 + x3;
+        uint32_t inc = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(inc, d);
+            if (lane >= d) inc += y;
+        }
+        if (lane == 63) wsum[flip][wave] = inc;
+        __syncthreads();                       // (two copies of wsum: a fast wave may write the next tile's sum while a slow one still reads this tile's)
+        uint32_t before = 0, all = 0;
+        for (int w = 0; w < 16; w++) { const uint32_t q = wsum[flip][w]; before += w < wave ? q : 0u; all += q; }
+        uint32_t run = carry + before + inc - mine;
+        if (i < n) a[i] = run;
+        run += x0; if (i + 1 < n) a[i + 1] = run;
+        run += x1; if (i + 2 < n) a[i + 2] = run;
+        run += x2; if (i + 3 < n) a[i + 3] = run;
+        carry += all;
     }
-    uint32_t run = part[t] - s;
-    for (int i = i0; i < i1; i++) { const uint32_t x = a[i]; a[i] = run; run += x; }
-    if (t == 1023) total[blockIdx.x] = part[1023];
+    if (t == 0) total[blockIdx.x] = carry;
 }
 
 constexpr int kChunk = 64;    // unstuffed bytes per thread in the stuffing passes
