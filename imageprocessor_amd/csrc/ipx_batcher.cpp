@@ -76,6 +76,32 @@ int Batcher::copy_ops(const ipx_pool_ops &in, OpsCopy *out, std::string *key, st
     return IPX_OK;
 }
 
+// Components and luma sampling factors of a JPEG file's frame header (B.2.2), zeros for anything else.  A batch is one shape --
+// ipx_plan_run_jpeg_jpeg takes the shape of its first decodable file and hands the others back with a status -- so the shape is part of
+// the grouping key: a Gray upload among colour ones gets a batch of its own kind (the reference decodes each message by itself,
+// image_processor.go:47) instead of being handed back or, arriving first, having its neighbours handed back.
+static void jpeg_shape(const ipx_bytes &f, uint8_t out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+    const uint8_t *p = (const uint8_t *)f.data;
+    const size_t n = f.len;
+    if (n < 4 || p[0] != 0xff || p[1] != 0xd8) return;
+    size_t i = 2;
+    while (i + 4 <= n && p[i] == 0xff) {
+        const uint8_t m = p[i + 1];
+        if (m == 0xff) { i++; continue; }                                          // fill byte
+        if (m == 0x01 || (m >= 0xd0 && m <= 0xd8)) { i += 2; continue; }            // markers without a segment
+        if (m == 0xd9 || m == 0xda) return;                                        // no frame header before the scan
+        const size_t len = (size_t)p[i + 2] << 8 | p[i + 3];
+        if (len < 2 || i + 2 + len > n) return;
+        if (m >= 0xc0 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {        // SOFn
+            if (len >= 11 && p[i + 9] >= 1) { out[0] = p[i + 9]; out[1] = p[i + 11] >> 4; out[2] = p[i + 11] & 15; }
+            return;
+        }
+        i += 2 + len;
+    }
+}
+
 int Batcher::submit(const ipx_bytes &file, const ipx_pool_ops &ops, uint64_t *ticket, std::string *err)
 {
     if (!ticket || !file.data || !file.len) { *err = "ipx_batcher_submit: bad argument"; return IPX_ERR_INVALID; }
@@ -83,6 +109,9 @@ int Batcher::submit(const ipx_bytes &file, const ipx_pool_ops &ops, uint64_t *ti
     std::string key;
     const int rc = copy_ops(ops, &oc, &key, err);
     if (rc) return rc;
+    uint8_t shape[3];
+    jpeg_shape(file, shape);
+    key.append((const char *)shape, 3);
     std::shared_ptr<Batch> full;
     Why why = BySize;
     {

@@ -2,7 +2,8 @@
 //
 // The reference pulls ONE message per goroutine (internal/worker/worker.go:112-149) from a channel of concurrency * 2 (:88); a GPU
 // wants hundreds of files per launch.  The batcher stands between: every goroutine hands over its one file and waits for its ticket;
-// files are grouped by frame size and operator content (parameters, colour, every glyph's rectangle and mask bytes), a group goes to
+// files are grouped by frame size, JPEG shape (components, luma sampling: a batch is one shape) and operator content (parameters,
+// colour, every glyph's rectangle and mask bytes), a group goes to
 // the pool as one JPEG job when it holds max_batch files or when its first file has waited max_wait_us, and every file gets its own
 // status -- a file the GPU path cannot decode does not fail its neighbours (the worker runs its own image.Decode path for it).
 //

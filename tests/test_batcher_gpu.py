@@ -34,11 +34,13 @@ def test_single_files_from_many_threads_equal_the_batch_entry():
     files[7] = (320, 200, files[7][2][:200])               # a truncated upload: its own status, the neighbours unharmed
     files[8] = (320, 200, _jpeg(rgba_frames(1, 320, 200, seed=5)[0][..., 0]))   # a Gray file among colour files: not in this batch's shape
     ops = {s: dict(resize=(64, 48, False), thumbnail=(32, True), glyphs=text_glyphs(s[0], s[1], n=4, width_px=60, height_px=16), col=DEFAULT_COL) for s in sizes}
-    # what the batch entry gives for each file (one call per size; statuses per file)
+    # what the batch entry gives for each file (one call per size and JPEG shape -- the batcher groups by both; statuses per file)
     want = {}
     with ipx.Context(device=0) as ctx:
-        for s in sizes:
-            idx = [i for i, f in enumerate(files) if f[:2] == s]
+        for s, gray in [(s, g) for s in sizes for g in (False, True)]:
+            idx = [i for i, f in enumerate(files) if f[:2] == s and (i == 8) == gray]
+            if not idx:
+                continue
             gs = ctx.glyphset(ops[s]["glyphs"], DEFAULT_COL)
             plan = ctx.plan(s[0], s[1], resize=ops[s]["resize"], thumbnail=ops[s]["thumbnail"], watermark=gs)
             out, st = plan.run_jpeg_jpeg([files[i][2] for i in idx], 85)
@@ -75,4 +77,5 @@ def test_single_files_from_many_threads_equal_the_batch_entry():
             assert got[i][1] == want[i][1], "file %d: streams differ from ipx_plan_run_jpeg_jpeg's" % i
         else:
             assert got[i][1] == {"resize": None, "thumbnail": None, "watermark": None}
-    assert want[7][0] != 0 and want[8][0] != 0 and sum(1 for i in want if want[i][0] == 0) >= 490
+    # the truncated file has its own status; the Gray file, in a batch of its own shape whenever it arrives, is processed like any other
+    assert want[7][0] != 0 and want[8][0] == 0 and sum(1 for i in want if want[i][0] == 0) >= 490

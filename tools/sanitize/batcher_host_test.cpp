@@ -40,6 +40,8 @@ int fake_submit(void *self, const ipx_job *j, ipx_ticket *t)
     assert(j->kind == IPX_JOB_JPEG && j->n >= 1 && j->n <= p->max_batch);
     for (int i = 1; i < j->n; i++) assert(j->files[i].data[0] == j->files[0].data[0]);   // byte 0 of a test file is its key: one key per batch
     assert(j->ops.sw == 100 + j->files[0].data[0]);
+    if (j->files[0].data[0] == 0xff)                      // files with a JPEG frame header: one shape (components, luma sampling) per batch
+        for (int i = 1; i < j->n; i++) assert(j->files[i].data[11] == j->files[0].data[11] && j->files[i].data[13] == j->files[0].data[13]);
     std::lock_guard<std::mutex> lk(p->mu);
     const ipx_ticket id = p->next++;
     if (id % 9 == 0) { g_err = "fake: submit refused"; return IPX_ERR_NOMEM; }
@@ -194,6 +196,29 @@ int main()
         if (!pool.jobs.empty()) { fprintf(stderr, "%zu jobs were never released\n", pool.jobs.size()); return 3; }
     }
     if (ok_files < 1000 || refused == 0 || unsupported == 0) return 4;
+    {
+        // the same operators, three JPEG shapes: three batches (fake_submit asserts one shape per job)
+        FakePool pool2;
+        pool2.max_batch = 16;
+        BatchBackend be2 = be;
+        be2.self = &pool2;
+        std::vector<std::vector<uint8_t>> fs;
+        const uint8_t shapes[3][2] = {{1, 0x11}, {3, 0x22}, {3, 0x11}};
+        for (int i = 0; i < 9; i++) fs.push_back({0xff, 0xd8, 0xff, 0xc0, 0x00, 0x0b, 0x08, 0x00, 0x32, 0x01, 0x63, shapes[i % 3][0], 0x01, shapes[i % 3][1], 0x00, (uint8_t)i});
+        {
+            Batcher b2(be2, pool2.max_batch, 50000, 85, 0);
+            ipx_pool_ops ops;
+            memset(&ops, 0, sizeof ops);
+            ops.sw = 100 + 0xff; ops.sh = 50; ops.do_resize = 1; ops.resize_w = 10; ops.resize_h = 10;
+            for (auto &f : fs) {
+                uint64_t t = 0;
+                std::string err;
+                const int rc = b2.submit(ipx_bytes{f.data(), f.size()}, ops, &t, &err);
+                assert(rc == IPX_OK);
+            }
+        }   // ~Batcher flushes the three groups
+        if (pool2.submitted != 3 || pool2.files != 9 || pool2.largest != 3) { fprintf(stderr, "shapes: %lld jobs, %lld files\n", (long long)pool2.submitted, (long long)pool2.files); return 5; }
+    }
     printf("batcher ok: %lld jobs submitted, %lld released\n", (long long)pool.submitted, (long long)pool.released);
     return 0;
 }
