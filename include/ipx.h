@@ -563,7 +563,8 @@ int ipx_pool_run_host(ipx_pool *pool, const ipx_job *jobs, int n_jobs);
  * turns those single files into GPU batches has to sit between the goroutines and the pool, and it sits here, below the ABI, so that
  * its policy is the library's (and tested) rather than every binding's.  ipx_batcher_submit takes ONE uploaded JPEG file with the
  * operators of its task (ops->sw x ops->sh = the frame size from the file's header, image.DecodeConfig) and returns a ticket at once;
- * files are grouped by frame size and operator content (parameters, colour, every glyph's rectangle and mask bytes); a group goes to the
+ * files are grouped by frame size, JPEG shape (components and luma sampling of the frame header: a batch is one shape) and operator
+ * content (parameters, colour, every glyph's rectangle and mask bytes); a group goes to the
  * pool as one IPX_JOB_JPEG when it holds max_batch files or when its first file has waited max_wait_us.  ipx_batcher_wait blocks until
  * the ticket's group is done and fills the file's own result: status IPX_OK and three streams (NULL for operators the task did not ask
  * for), or IPX_ERR_UNSUPPORTED / IPX_ERR_INVALID for a file the GPU path does not decode -- its neighbours are not affected, the worker
