@@ -93,6 +93,9 @@ int jpeg_parse(const uint8_t *d, size_t len, JpegDecInfo *info, JpegDecTables *t
                 cid[c] = s[6 + 3 * c]; ch[c] = s[7 + 3 * c] >> 4; cv[c] = s[7 + 3 * c] & 15; ctq[c] = s[8 + 3 * c];
                 if (ctq[c] > 3 || ch[c] < 1 || ch[c] > 4 || cv[c] < 1 || cv[c] > 4) return IPX_ERR_INVALID;
                 for (int j = 0; j < c; j++) if (cid[j] == cid[c]) return IPX_ERR_INVALID;   // "repeated component identifier"
+                // processSOF refuses a factor of 3 for every component, a single one included -- before it sets that one's (h, v) to (1, 1)
+                // (found by tools/fuzz_corrupt.py: a Gray file whose V_1 a bit flip had made 3 decoded here and fails in Go)
+                if (ch[c] == 3 || cv[c] == 3) return IPX_ERR_UNSUPPORTED;
             }
             if (ncomp == 1) { ch[0] = cv[0] = 1; break; }   // processSOF: a single component is non-interleaved, its (h, v) is effectively (1, 1)
             if (ch[1] != 1 || cv[1] != 1 || ch[2] != 1 || cv[2] != 1 || ch[0] > 2 || cv[0] > 2) return IPX_ERR_UNSUPPORTED;

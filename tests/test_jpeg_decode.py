@@ -170,6 +170,25 @@ def test_gpu_decode_of_go_style_streams_and_440(ctx):
 
 
 @pytest.mark.gpu
+def test_a_sampling_factor_of_three_is_refused_for_a_single_component_too(ctx):
+    """processSOF returns errUnsupportedSubsamplingRatio for h == 3 or v == 3 BEFORE it sets a single component's (h, v) to (1, 1): a Gray
+    file whose V_1 is 3 fails in Go although its data would decode (tools/fuzz_corrupt.py found the host parser accepting it)."""
+    good = pil_jpeg(picture(96, 64)[..., 0])
+    i = good.index(b"\xff\xc0")
+    assert good[i + 9] == 1 and good[i + 11] == 0x11
+    for hv in (0x13, 0x31, 0x33):
+        f = bytearray(good)
+        f[i + 11] = hv
+        with pytest.raises(ValueError, match="unsupported"):
+            oracle.jpeg_decode(bytes(f))
+        info, st = ctx.jpeg_decode_batch([good, bytes(f)])
+        assert st == [0, -4]
+    f = bytearray(good)
+    f[i + 11] = 0x42                                      # any other factor of a single component is as good as (1, 1)
+    _check_batch(ctx, [good, bytes(f)])
+
+
+@pytest.mark.gpu
 def test_gpu_decode_statuses(ctx):
     """A batch is one size and one sampling; the odd ones out, Gray files and broken files get a status and the rest still decode."""
     good = [pil_jpeg(picture(96, 64, seed=i), quality=85) for i in range(4)]
