@@ -64,3 +64,24 @@ time.sleep(0.05)
 run("single calls while host batches run")
 state["go"] = False
 th.join()
+
+# the same beside batches that never touch the link (frames and outputs resident in HBM): what of the above is contention for CUs
+dsrc = ctx.alloc(n * h * w * 4)
+dsrc.upload(frames)
+dres, dth, dwm = ctx.alloc(n * 576 * 1024 * 4), ctx.alloc(n * 200 * 200 * 4), ctx.alloc(n * h * w * 4)
+st = ctx.stream()
+state["go"] = True
+
+
+def dev_batches():
+    while state["go"]:
+        plan.run_dev(n, dsrc.ptr, dres.ptr, dth.ptr, dwm.ptr, stream=st)
+        ctx.sync(st)
+
+
+th = threading.Thread(target=dev_batches)
+th.start()
+time.sleep(0.05)
+run("single calls while device batches run")
+state["go"] = False
+th.join()
