@@ -28,7 +28,7 @@ ctx = ipx.Context(device=0)
 ip = ops.ImageProcessor(ctx, font)
 
 
-def run(label):
+def run(label, src=src):
     lat = []
     for _ in range(calls):
         t0 = time.perf_counter()
@@ -62,6 +62,9 @@ th = threading.Thread(target=batches)
 th.start()
 time.sleep(0.05)
 run("single calls while host batches run")
+pinned_src = ctx.host_alloc((h, w, 4))
+pinned_src[:] = src
+run("... with the call's source frame in pinned memory", pinned_src)
 state["go"] = False
 th.join()
 
