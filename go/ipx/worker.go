@@ -23,7 +23,8 @@ type Batcher struct {
 }
 
 // NewBatcher: maxBatch files per job (0 = 256), maxWaitMicros how long the first file of a group waits for company while the pool is
-// busy (0 = 2000; with WORKER_CONCURRENCY = 3 goroutines a file leaves at once: 3.0 ms p50 per message on one MI355X),
+// busy (0 = 2000; with WORKER_CONCURRENCY = 3 goroutines a file leaves at once: 2.4 ms p50 per message on one MI355X),
+// a group = files of one frame size, one JPEG shape (components, luma sampling) and one operator content;
 // quality = domain.DefaultJPEGQuality (task.go:57; 0 = 85).
 func NewBatcher(p *Pool, maxBatch, maxWaitMicros, quality int) (*Batcher, error) {
 	cfg := C.ipx_batcher_config{max_batch: C.int32_t(maxBatch), max_wait_us: C.int32_t(maxWaitMicros), quality: C.int32_t(quality)}
